@@ -1,0 +1,41 @@
+import pathlib
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+  sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / 'tests' / 'golden'
+
+
+def pytest_configure(config):
+  config.addinivalue_line(
+      'markers', 'gpu: needs a real MI355X (run on the GPU box with -m gpu)')
+  config.addinivalue_line(
+      'markers', 'reference: needs /root/reference (build container only)')
+
+
+def load_golden(name):
+  with np.load(GOLDEN / f'{name}.npz') as f:
+    return {k.replace('__', '/'): f[k] for k in f.files}
+
+
+def assert_same(got, want, name=''):
+  """Bit-exact for integer/byte/bool arrays, exact for floats that are pure
+  copies (replay payloads)."""
+  assert set(got) == set(want), (name, sorted(set(got) ^ set(want)))
+  for key in want:
+    a, b = np.asarray(got[key]), np.asarray(want[key])
+    assert a.shape == b.shape, (name, key, a.shape, b.shape)
+    assert a.dtype == b.dtype, (name, key, a.dtype, b.dtype)
+    if not np.array_equal(a, b, equal_nan=a.dtype.kind == 'f'):
+      bad = np.argwhere(a != b)[:5]
+      raise AssertionError(f'{name}:{key} differs at {bad.tolist()}')
+
+
+@pytest.fixture(scope='session')
+def golden():
+  return load_golden

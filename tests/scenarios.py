@@ -1,0 +1,409 @@
+"""Scripted scenarios shared by the golden generator, the oracle tests and the
+product (HIP) parity tests.
+
+Each scenario is a function of a namespace `ns` exposing the reference-shaped
+API (`Replay`, `Uniform`, `Prioritized`, `Mixture`, `SampleTree`, `Consec`,
+`Driver`, `tonp`) and returns `{name: ndarray}`.  `oracle/gen_golden.py` runs
+them against the real reference (build container only) and commits the result
+under `tests/golden/`; tests run them against `oracle/np_oracle.py` and against
+`embodied_amd` and compare with those files.
+"""
+import numpy as np
+
+
+class Spec:
+  """Minimal space: what Driver reads from `act_space` (driver.py:35-37)."""
+
+  def __init__(self, dtype, shape=()):
+    self.dtype = np.dtype(dtype)
+    self.shape = tuple(shape)
+
+
+class ScriptEnv:
+  """Deterministic fixture env modelled on the reference's Dummy
+  (embodied/envs/dummy.py:38-59): episode of `length` steps, reset on request
+  or after the terminal step; observations are functions of (env id, count)."""
+
+  def __init__(self, ident, length, image=(4, 4, 2)):
+    self.ident = ident
+    self.length = length
+    self.image = image
+    self.count = 0
+    self.done = False
+    self.total = 0
+
+  @property
+  def act_space(self):
+    return {
+        'reset': Spec(bool),
+        'act_disc': Spec(np.int32),
+        'act_cont': Spec(np.float32, (3,)),
+    }
+
+  @property
+  def obs_space(self):
+    return {
+        'image': Spec(np.uint8, self.image),
+        'count': Spec(np.float32),
+        'reward': Spec(np.float32),
+        'is_first': Spec(bool),
+        'is_last': Spec(bool),
+        'is_terminal': Spec(bool),
+    }
+
+  def step(self, action):
+    action = dict(action)
+    self.total += 1
+    if action.pop('reset') or self.done:
+      self.count = 0
+      self.done = False
+      return self._obs(0.0, is_first=True)
+    self.count += 1
+    self.done = self.count >= self.length
+    rew = float(action['act_disc']) + 0.5 * self.ident
+    return self._obs(rew, is_last=self.done, is_terminal=self.done and self.ident % 2 == 0)
+
+  def _obs(self, reward, is_first=False, is_last=False, is_terminal=False):
+    n = int(np.prod(self.image))
+    image = ((np.arange(n) * 3 + self.count * 7 + self.ident * 31) % 256)
+    return {
+        'image': image.astype(np.uint8).reshape(self.image),
+        'count': np.float32(self.count),
+        'reward': np.float32(reward),
+        'is_first': is_first,
+        'is_last': is_last,
+        'is_terminal': is_terminal,
+        'log/total': np.float32(self.total),
+    }
+
+  def close(self):
+    pass
+
+
+def synth_step(t, w, image=(6, 5, 3)):
+  """A replay step whose every byte is a function of (t, w)."""
+  n = int(np.prod(image))
+  return {
+      'image': ((np.arange(n) + 13 * t + 101 * w) % 251).astype(np.uint8).reshape(image),
+      'step': np.int32(t),
+      'worker': np.int32(w),
+      'reward': np.float32(0.25 * t - w),
+      'vec': (np.arange(5) * 0.5 + t + 100 * w).astype(np.float32),
+      'is_first': np.bool_(t % 11 == 0),
+      'is_last': np.bool_(t % 11 == 10),
+      'is_terminal': np.bool_(t % 22 == 10),
+  }
+
+
+# ---------------------------------------------------------------- selectors --
+
+
+def sel_uniform(ns):
+  out = {}
+  u = ns.Uniform(0)
+  for k in range(10):
+    u[k] = None
+  out['draws_a'] = np.array([u() for _ in range(16)])
+  del u[3]
+  out['draws_b'] = np.array([u() for _ in range(8)])
+  # capacity churn: FIFO-evict the oldest while inserting, as Replay does.
+  u = ns.Uniform(7)
+  live, draws = [], []
+  for k in range(200):
+    if len(live) >= 37:
+      del u[live.pop(0)]
+    u[k] = None
+    live.append(k)
+    if k % 3 == 0:
+      draws.append(u())
+  out['draws_churn'] = np.array(draws)
+  # n == 1 consumes no randomness, then mixed sizes (numpy Lemire path).
+  u = ns.Uniform(123)
+  u[100] = None
+  draws = [u() for _ in range(3)]
+  for k in range(1, 300):
+    u[100 + k] = None
+    draws.append(u())
+  out['draws_grow'] = np.array(draws)
+  return out
+
+
+def sel_sampletree(ns):
+  out = {}
+  for branching in (2, 3, 16):
+    tree = ns.SampleTree(branching, seed=0)
+    for k in range(40):
+      tree.insert(k, float(k % 5))
+    a = [tree.sample() for _ in range(16)]
+    for k in range(0, 40, 3):
+      tree.remove(k)
+    b = [tree.sample() for _ in range(16)]
+    for k in range(40, 60):
+      tree.insert(k, 0.1 * (k % 7) + 1e-3)
+    for k in range(1, 40, 6):
+      tree.update(k, 2.5 + k / 7)
+    c = [tree.sample() for _ in range(32)]
+    out[f'b{branching}'] = np.array(a + b + c)
+  tree = ns.SampleTree(16, seed=5)
+  for k in range(100):
+    tree.insert(k, np.inf if k % 3 == 0 else 1.0)
+  out['inf'] = np.array([tree.sample() for _ in range(32)])
+  tree = ns.SampleTree(4, seed=6)
+  for k in range(30):
+    tree.insert(k, 0.0)
+  out['zero'] = np.array([tree.sample() for _ in range(32)])
+  rng = np.random.default_rng(11)
+  tree = ns.SampleTree(5, seed=9)
+  live, draws = [], []
+  for k in range(400):
+    op = rng.integers(0, 4)
+    if op <= 1 or len(live) < 3:
+      tree.insert(k, float(rng.random() * 3))
+      live.append(k)
+    elif op == 2:
+      victim = live.pop(int(rng.integers(0, len(live))))
+      tree.remove(victim)
+    else:
+      tree.update(live[int(rng.integers(0, len(live)))], float(rng.random()))
+    draws.append(tree.sample())
+  out['random_ops'] = np.array(draws)
+  return out
+
+
+def _sid(k):
+  return np.frombuffer(int(k).to_bytes(20, 'big'), np.uint8)
+
+
+def sel_prioritized(ns):
+  out = {}
+  for name, kw in {
+      'plain': dict(exponent=1.0, initial=1.0, maxfrac=0.0, seed=0),
+      'expmax': dict(exponent=0.8, initial=1.0, maxfrac=0.5, seed=0),
+      'infzero': dict(exponent=0.8, initial=np.inf, maxfrac=0.5,
+                      zero_on_sample=True, seed=3),
+  }.items():
+    sel = ns.Prioritized(**kw)
+    length, draws = 4, []
+    for k in range(24):           # item k covers steps k..k+3 (overlapping)
+      sel[k] = np.stack([_sid(s) for s in range(k, k + length)])
+    draws += [sel() for _ in range(12)]
+    steps = np.stack([_sid(s) for s in range(3, 19)])
+    sel.prioritize(steps, np.linspace(0.1, 4.0, len(steps)))
+    draws += [sel() for _ in range(12)]
+    for k in range(0, 8):
+      del sel[k]
+    for k in range(24, 30):
+      sel[k] = np.stack([_sid(s) for s in range(k, k + length)])
+    sel.prioritize(np.stack([_sid(s) for s in (25, 26, 9)]), np.array([7.0, 0.0, 2.0]))
+    draws += [sel() for _ in range(24)]
+    out[name] = np.array(draws)
+  return out
+
+
+def sel_mixture(ns):
+  uni = ns.Uniform(1)
+  pri = ns.Prioritized(exponent=0.8, initial=1.0, maxfrac=0.5, seed=2)
+  mix = ns.Mixture(
+      dict(uniform=uni, priority=pri), dict(uniform=0.5, priority=0.5), seed=3)
+  for k in range(8):
+    mix[k] = np.stack([_sid(s) for s in range(k, k + 3)])
+  a = [mix() for _ in range(16)]
+  mix.prioritize(np.stack([_sid(s) for s in range(2, 6)]), np.array([5.0, 0.5, 3.0, 0.0]))
+  del mix[0]
+  b = [mix() for _ in range(16)]
+  return {'draws': np.array(a + b)}
+
+
+# ------------------------------------------------------------------- replay --
+
+
+def _dump(ns, batch, prefix, out):
+  for k, v in batch.items():
+    out[f'{prefix}/{k}'] = ns.tonp(v)
+
+
+def replay_basic(ns):
+  """SURVEY Appendix C capture: length 5, capacity 50, chunksize 8, 3 workers."""
+  out = {}
+  rep = ns.Replay(length=5, capacity=50, chunksize=8, seed=0)
+  lens = []
+  for t in range(30):
+    for w in range(3):
+      rep.add(synth_step(t, w), worker=w)
+    lens.append(len(rep))
+  out['lens'] = np.array(lens)
+  _dump(ns, rep.sample(4), 's0', out)
+  _dump(ns, rep.sample(7, 'report'), 's1', out)
+  stats = rep.stats()
+  out['stats'] = np.array(
+      [stats[k] for k in ('items', 'chunks', 'streams', 'inserts', 'samples', 'updates')],
+      np.float64)
+  return out
+
+
+def replay_chunk_spans(ns):
+  """chunksize smaller than length: windows span several chunks
+  (tests/test_replay.py:58-73 uses chunksize=4, length=7)."""
+  out = {}
+  rep = ns.Replay(length=7, capacity=27, chunksize=4, seed=1)
+  for t in range(40):
+    for w in range(2):
+      rep.add(synth_step(t, w), worker=w)
+    if t in (9, 20, 39):
+      _dump(ns, rep.sample(5), f't{t}', out)
+  out['len'] = np.array(len(rep))
+  return out
+
+
+def replay_uneven_workers(ns):
+  """Workers advance at different rates (tests/test_replay.py:119-135)."""
+  out = {}
+  rng = np.random.default_rng(0)
+  rep = ns.Replay(length=4, capacity=30, chunksize=6, seed=2)
+  clock = [0, 0, 0, 0]
+  lens = []
+  for n in range(160):
+    w = int(rng.integers(0, 4))
+    rep.add(synth_step(clock[w], w), worker=w)
+    clock[w] += 1
+    lens.append(len(rep))
+    if n in (40, 100, 159):
+      _dump(ns, rep.sample(6), f'n{n}', out)
+  out['lens'] = np.array(lens)
+  return out
+
+
+def replay_online(ns):
+  """Online queue (replay.py:114-118,158-160): train drains fresh windows in
+  order, report never touches the queue."""
+  out = {}
+  rep = ns.Replay(length=4, capacity=20, chunksize=5, online=True, seed=0)
+  for t in range(14):
+    rep.add(synth_step(t, 0), worker=0)
+  _dump(ns, rep.sample(2, 'report'), 'report', out)
+  _dump(ns, rep.sample(3, 'train'), 'train_a', out)
+  _dump(ns, rep.sample(2, 'train'), 'train_b', out)
+  for t in range(14, 60):
+    for w in range(2):
+      rep.add(synth_step(t, w), worker=w)
+  # capacity 20 evicted most queued windows: stale entries are skipped.
+  _dump(ns, rep.sample(6, 'train'), 'train_c', out)
+  return out
+
+
+def replay_update(ns):
+  """Write-back across chunk boundaries and onto evicted rows
+  (replay.py:129-149, 216-235)."""
+  out = {}
+  rep = ns.Replay(length=6, capacity=12, chunksize=4, seed=4)
+  for t in range(20):
+    rep.add(synth_step(t, 0), worker=0)
+  batch = rep.sample(5)
+  stale = {k: ns.tonp(v).copy() for k, v in batch.items()}
+  sid = ns.tonp(batch['stepid'])
+  upd = {
+      'stepid': ns.like(batch['stepid'], sid[:, :4]),
+      'vec': ns.like(batch['vec'], -np.arange(5 * 4 * 5, dtype=np.float32).reshape(5, 4, 5)),
+      'reward': ns.like(batch['reward'], 100 + np.arange(20, dtype=np.float32).reshape(5, 4)),
+  }
+  rep.update(upd)
+  for t in range(20, 26):
+    rep.add(synth_step(t, 0), worker=0)
+  _dump(ns, rep.sample(8), 'after', out)
+  # update aimed at rows whose first chunk is long gone: silently skipped.
+  for t in range(26, 60):
+    rep.add(synth_step(t, 0), worker=0)
+  rep.update({
+      'stepid': ns.like(batch['stepid'], stale['stepid']),
+      'reward': ns.like(batch['reward'], np.full((5, 6), -7, np.float32)),
+  })
+  _dump(ns, rep.sample(8), 'late', out)
+  return out
+
+
+def replay_prioritized(ns):
+  """Replay driving a Prioritized selector with priority feedback.  (The
+  reference's Mixture has no __len__, so Replay.sample raises with it —
+  replay.py:123 vs selectors.py:200-228 — Mixture is pinned standalone above.)"""
+  out = {}
+  sel = ns.Prioritized(
+      exponent=0.8, initial=np.inf, maxfrac=0.5, zero_on_sample=True, seed=6)
+  rep = ns.Replay(length=3, capacity=16, chunksize=5, selector=sel, seed=0)
+  for t in range(12):
+    for w in range(2):
+      rep.add(synth_step(t, w), worker=w)
+  for r in range(6):
+    batch = rep.sample(4)
+    out[f'r{r}/step'] = ns.tonp(batch['step'])
+    out[f'r{r}/worker'] = ns.tonp(batch['worker'])
+    prio = (ns.tonp(batch['step']) % 5 + 0.5 * r).astype(np.float32)
+    rep.update({'stepid': batch['stepid'], 'priority': ns.like(batch['reward'], prio)})
+    for w in range(2):
+      rep.add(synth_step(12 + r, w), worker=w)
+  return out
+
+
+def stream_consec(ns):
+  out = {}
+  rep = ns.Replay(length=7, capacity=40, chunksize=8, seed=3)
+  for t in range(30):
+    rep.add(synth_step(t, 0), worker=0)
+  stream = ns.consec(rep, batch=2, length=3, consec=2, prefix=1)
+  for n in range(5):
+    _dump(ns, next(stream), f'w{n}', out)
+  return out
+
+
+# ------------------------------------------------------------------- driver --
+
+
+def driver_script(ns):
+  out = {}
+  envs = [ScriptEnv(i, length=3 + i) for i in range(3)]
+  driver = ns.Driver(envs)
+  seen, carries, log = [], [], []
+
+  def policy(carry, obs, **kw):
+    seen.append({k: ns.tonp(v).copy() for k, v in obs.items()})
+    carries.append(carry)
+    n = len(ns.tonp(obs['is_first']))
+    tick = (carry or 0)
+    act = {
+        'act_disc': (np.arange(n) + tick + 1).astype(np.int32),
+        'act_cont': (np.arange(n * 3).reshape(n, 3) * 0.5 + tick + 1).astype(np.float32),
+    }
+    outs = {'logp': (np.arange(n) * -0.1 - tick).astype(np.float32)}
+    return tick + 1, act, outs
+
+  driver.on_step(lambda tran, worker, **kw: log.append(
+      (worker, {k: np.array(ns.tonp(v)) for k, v in tran.items()})))
+  driver.reset(lambda n: 0)
+  driver(policy, steps=30)
+  out['n_calls'] = np.array(len(seen))
+  out['workers'] = np.array([w for w, _ in log])
+  for key in sorted(log[0][1]):
+    out[f'tran/{key}'] = np.stack([t[key] for _, t in log])
+  for key in sorted(seen[0]):
+    out[f'obs/{key}'] = np.stack([o[key] for o in seen])
+  out['carries'] = np.array(carries)
+  log.clear()
+  driver(policy, episodes=4)
+  out['episodes_len'] = np.array(len(log))
+  out['episodes_last'] = np.stack([t['is_last'] for _, t in log])
+  return out
+
+
+SCENARIOS = {
+    'sel_uniform': sel_uniform,
+    'sel_sampletree': sel_sampletree,
+    'sel_prioritized': sel_prioritized,
+    'sel_mixture': sel_mixture,
+    'replay_basic': replay_basic,
+    'replay_chunk_spans': replay_chunk_spans,
+    'replay_uneven_workers': replay_uneven_workers,
+    'replay_online': replay_online,
+    'replay_update': replay_update,
+    'replay_prioritized': replay_prioritized,
+    'stream_consec': stream_consec,
+    'driver_script': driver_script,
+}
