@@ -1,0 +1,10 @@
+"""embodied_amd — MI355X-native Driver / Replay / return-scan hot path behind
+the reference's Python interfaces."""
+__version__ = '0.1.0'
+
+from . import _lib  # raises if libembodied_hip.so is missing: no CPU fallback
+
+from .space import Space
+from .core.base import Agent, Env, Stream
+from .core import limiters
+from .core import selectors

@@ -1,0 +1,187 @@
+"""ctypes binding of libembodied_hip.so (include/embodied_hip.h).
+
+There is no CPU fallback: if the library is missing or fails to load, importing
+this module raises.  Build it with `python -m embodied_amd.build`.
+"""
+import ctypes as C
+import pathlib
+
+HERE = pathlib.Path(__file__).resolve().parent
+PATH = HERE / 'libembodied_hip.so'
+
+OK, ERR_INVALID, ERR_HIP, ERR_EMPTY, ERR_POOL_FULL, ERR_NOT_FOUND, ERR_INTERNAL = (
+    0, -1, -2, -3, -4, -5, -6)
+STEPID_BYTES = 20
+
+U8, I8, I16, I32, I64, F16, BF16, F32, F64, BOOL = range(10)
+LAYOUT_SAME, LAYOUT_CHANNELS_FIRST = 0, 1
+MODES = {'train': 0, 'report': 1, 'eval': 2}
+
+
+class EmbError(RuntimeError):
+
+  def __init__(self, code, message):
+    super().__init__(f'libembodied_hip: {message} (status {code})')
+    self.code = code
+
+
+class PoolFull(EmbError):
+  pass
+
+
+class ReplayConfig(C.Structure):
+  _fields_ = [
+      ('length', C.c_int64), ('capacity', C.c_int64), ('chunksize', C.c_int64),
+      ('n_slots', C.c_int64), ('online', C.c_int32), ('reserved', C.c_int32),
+      ('uid_hi', C.c_uint64)]
+
+
+SAMPLE_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p)
+SIZE_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p)
+INSERT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.POINTER(C.c_uint8), C.c_int32)
+REMOVE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
+PRIORITIZE_FN = C.CFUNCTYPE(
+    None, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.c_int64)
+
+
+class SelectorCallbacks(C.Structure):
+  _fields_ = [
+      ('user', C.c_void_p), ('sample', SAMPLE_FN), ('size', SIZE_FN),
+      ('insert', INSERT_FN), ('remove', REMOVE_FN),
+      ('prioritize', PRIORITIZE_FN)]
+
+
+def _load():
+  if not PATH.exists():
+    raise ImportError(
+        f'{PATH} is missing. embodied_amd has no CPU fallback: build the HIP '
+        'library with `python -m embodied_amd.build` (needs hipcc, gfx950).')
+  try:
+    return C.CDLL(str(PATH))
+  except OSError as e:
+    raise ImportError(f'cannot load {PATH}: {e}') from e
+
+
+lib = _load()
+
+p, i32, i64, u64, f32, f64 = (
+    C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double)
+pp = C.POINTER(C.c_void_p)
+
+# name -> argtypes; every function returns int32 status unless listed below.
+SIGNATURES = {
+    'emb_device_count': [p],
+    'emb_rng_create': [p, i32, pp],
+    'emb_rng_integers': [p, i64, i64, p],
+    'emb_rng_random': [p, i64, p],
+    'emb_rng_choice': [p, p, i32, i64, p],
+    'emb_rng_destroy': [p],
+    'emb_np_sum': [p, i64, p],
+    'emb_tree_create': [i32, u64, pp],
+    'emb_tree_insert': [p, i64, f64],
+    'emb_tree_remove': [p, i64],
+    'emb_tree_update': [p, i64, f64],
+    'emb_tree_sample': [p, p],
+    'emb_tree_len': [p, p],
+    'emb_tree_root_sum': [p, p],
+    'emb_tree_shape': [p, i64, p, p, p],
+    'emb_tree_destroy': [p],
+    'emb_selector_create_fifo': [pp],
+    'emb_selector_create_uniform': [u64, pp],
+    'emb_selector_create_prioritized': [f64, f64, i32, f64, i32, u64, pp],
+    'emb_selector_create_mixture': [p, p, i32, u64, pp],
+    'emb_selector_create_callback': [p, pp],
+    'emb_selector_insert': [p, i64, p, i32],
+    'emb_selector_remove': [p, i64],
+    'emb_selector_sample': [p, p],
+    'emb_selector_len': [p, p],
+    'emb_selector_prioritize': [p, p, p, i64],
+    'emb_selector_destroy': [p],
+    'emb_replay_create': [p, p, u64, pp],
+    'emb_replay_destroy': [p],
+    'emb_replay_set_keys': [p, i32, p, p, p],
+    'emb_replay_grow': [p, i64, p],
+    'emb_replay_add_index': [p, i64, p, p, p],
+    'emb_replay_sample_index': [p, i64, i32, p, p],
+    'emb_replay_resolve': [p, i64, p, i64, p, p],
+    'emb_replay_prioritize': [p, p, p, i64],
+    'emb_replay_len': [p, p],
+    'emb_replay_sampler_len': [p, p],
+    'emb_replay_free_slots': [p, p],
+    'emb_replay_stats': [p, p, i32],
+    'emb_replay_add': [p, i64, p, p, p],
+    'emb_replay_sample': [p, i64, i32, p, p, p],
+    'emb_replay_update': [p, i64, i64, p, i32, p, p, p],
+    'emb_replay_gather_rows': [p, p, i64, i64, p, p],
+    'emb_replay_scatter_rows': [p, p, i64, i32, p, p, p],
+    'emb_replay_profile': [p, i32],
+    'emb_replay_profile_read': [p, p, p, i32],
+    'emb_replay_complete_all': [p],
+    'emb_replay_chunks': [p, i64, p, p, p, p, p],
+    'emb_replay_load_chunk': [p, u64, u64, i64, p],
+    'emb_replay_load_items': [p, u64, i64],
+    'emb_obs_stack': [p, p, i64, i64, i64, i32, i32, f32, f32, p, p],
+    'emb_mask_actions': [p, i64, i64, i32, p, p],
+    'emb_rows_gather': [p, i64, p, i64, p, p],
+    'emb_rows_scatter': [p, i64, p, i64, p, p],
+    'emb_window': [p, p, i64, i64, i64, i64, i64, p],
+    'emb_scan_gae': [p, p, p, p, i64, i64, f32, f32, p, p, p],
+    'emb_scan_lambda': [p, p, p, p, i64, i64, f32, f32, p, p],
+    'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],
+    'emb_synth_env_step': [p, p, p, p, p, i64, i64, i64, i64, p, p, p],
+}
+
+lib.emb_last_error.restype = C.c_char_p
+lib.emb_last_error.argtypes = []
+lib.emb_abi_version.restype = i32
+lib.emb_abi_version.argtypes = []
+
+
+def check(status):
+  if status == OK:
+    return
+  message = (lib.emb_last_error() or b'').decode('utf8', 'replace')
+  if status == ERR_POOL_FULL:
+    raise PoolFull(status, message)
+  if status == ERR_NOT_FOUND:
+    raise KeyError(message)
+  if status == ERR_EMPTY:
+    raise IndexError(message)
+  if status == ERR_INVALID:
+    raise ValueError(f'libembodied_hip: {message}')
+  raise EmbError(status, message)
+
+
+class _Api:
+  """`api.emb_xxx(...)` calls the C function and raises on a bad status."""
+
+  def __init__(self):
+    for name, argtypes in SIGNATURES.items():
+      fn = getattr(lib, name)          # AttributeError if the .so is stale
+      fn.argtypes = argtypes
+      fn.restype = i32
+      setattr(self, name, self._wrap(fn))
+    self.raw = lib
+
+  @staticmethod
+  def _wrap(fn):
+    def call(*args):
+      status = fn(*args)
+      if status:
+        check(status)
+    call.raw = fn
+    return call
+
+
+api = _Api()
+
+
+def ptr(array):
+  """Address of a numpy array's buffer (None -> NULL)."""
+  return None if array is None else array.ctypes.data
+
+
+def device_count():
+  n = C.c_int32(0)
+  api.emb_device_count(C.byref(n))
+  return n.value

@@ -1,0 +1,70 @@
+"""Build libembodied_hip.so in-tree with hipcc for gfx950.
+
+    python -m embodied_amd.build [--force]
+
+One hipcc invocation per translation unit (parallel), then a link.  The .so is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import concurrent.futures
+import os
+import pathlib
+import shutil
+import subprocess
+import sys
+
+HERE = pathlib.Path(__file__).resolve().parent
+CSRC = HERE / 'csrc'
+OUT = HERE / 'libembodied_hip.so'
+OBJ = HERE / 'build'
+SOURCES = ['kernels.hip', 'abi.cpp']
+ARCH = 'gfx950'
+
+
+def hipcc():
+  for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+    if cand and pathlib.Path(cand).exists():
+      return cand
+  raise RuntimeError('hipcc not found: cannot build libembodied_hip.so')
+
+
+def stale():
+  if not OUT.exists():
+    return True
+  built = OUT.stat().st_mtime
+  deps = list(CSRC.glob('*')) + [HERE.parent / 'include' / 'embodied_hip.h']
+  return any(p.stat().st_mtime > built for p in deps)
+
+
+def build(force=False, verbose=True):
+  if not force and not stale():
+    return OUT
+  cc = hipcc()
+  OBJ.mkdir(exist_ok=True)
+  flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall',
+           '-Wno-unused-function', '-x', 'hip']
+
+  def compile_one(name):
+    obj = OBJ / (name + '.o')
+    cmd = [cc, *flags, '-c', str(CSRC / name), '-o', str(obj)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode:
+      raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
+    if verbose and res.stderr.strip():
+      print(res.stderr, file=sys.stderr)
+    return obj
+
+  with concurrent.futures.ThreadPoolExecutor(len(SOURCES)) as pool:
+    objs = list(pool.map(compile_one, SOURCES))
+  tmp = OUT.with_suffix('.so.tmp')
+  cmd = [cc, f'--offload-arch={ARCH}', '-shared', '-fPIC', *map(str, objs), '-o', str(tmp)]
+  res = subprocess.run(cmd, capture_output=True, text=True)
+  if res.returncode:
+    raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
+  os.replace(tmp, OUT)
+  if verbose:
+    print(f'built {OUT}')
+  return OUT
+
+
+if __name__ == '__main__':
+  build(force='--force' in sys.argv)

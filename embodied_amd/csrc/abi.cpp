@@ -1,0 +1,826 @@
+// extern "C" surface of libembodied_hip.so — see include/embodied_hip.h.
+#include "../../include/embodied_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "np_random.h"
+#include "replay_index.h"
+#include "selectors.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int32_t fail(int32_t code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+struct HipFailure : std::runtime_error {
+  explicit HipFailure(hipError_t e, const char* what)
+      : std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)) {}
+};
+
+#define HIP_OK(expr)                                   \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) throw HipFailure(e_, #expr); \
+  } while (0)
+
+template <typename Fn>
+int32_t guarded(Fn&& fn) {
+  try {
+    fn();
+    return EMB_OK;
+  } catch (const emb::PoolFull& e) {
+    return fail(EMB_ERR_POOL_FULL, e.what());
+  } catch (const HipFailure& e) {
+    return fail(EMB_ERR_HIP, e.what());
+  } catch (const std::out_of_range& e) {
+    return fail(EMB_ERR_NOT_FOUND, e.what());
+  } catch (const std::invalid_argument& e) {
+    return fail(EMB_ERR_INVALID, e.what());
+  } catch (const std::runtime_error& e) {
+    const std::string msg = e.what();
+    return fail(msg.find("empty") != std::string::npos ? EMB_ERR_EMPTY : EMB_ERR_INVALID, msg);
+  } catch (const std::exception& e) {
+    return fail(EMB_ERR_INTERNAL, e.what());
+  } catch (...) {
+    return fail(EMB_ERR_INTERNAL, "unknown C++ exception");
+  }
+}
+
+void need(bool ok, const char* msg) {
+  if (!ok) throw std::invalid_argument(msg);
+}
+
+// Row tables travel host -> device through a small ring of pinned slots.  The
+// kernel reads the device copy; a slot is reused only after the launch that
+// read it has finished (event per slot).
+class TableRing {
+ public:
+  struct Lease {
+    int slot;
+    uint8_t* host;
+    uint8_t* device;
+  };
+
+  ~TableRing() { release_all(); }
+
+  Lease acquire(size_t bytes, hipStream_t stream) {
+    if (bytes > cap_) regrow(bytes, stream);
+    if (events_.empty()) regrow(cap_ ? cap_ : 4096, stream);
+    const int slot = next_;
+    next_ = (next_ + 1) % kSlots;
+    if (busy_[slot]) {
+      HIP_OK(hipEventSynchronize(events_[slot]));
+      busy_[slot] = false;
+    }
+    return {slot, host_ + slot * cap_, dev_ + slot * cap_};
+  }
+
+  void upload(const Lease& l, size_t bytes, hipStream_t stream) {
+    HIP_OK(hipMemcpyAsync(l.device, l.host, bytes, hipMemcpyHostToDevice, stream));
+  }
+
+  void retire(const Lease& l, hipStream_t stream) {
+    HIP_OK(hipEventRecord(events_[l.slot], stream));
+    busy_[l.slot] = true;
+  }
+
+ private:
+  static constexpr int kSlots = 32;
+
+  void regrow(size_t bytes, hipStream_t stream) {
+    size_t cap = 4096;
+    while (cap < bytes) cap *= 2;
+    for (int s = 0; s < static_cast<int>(events_.size()); ++s)
+      if (busy_[s]) HIP_OK(hipEventSynchronize(events_[s]));
+    (void)stream;
+    if (host_) HIP_OK(hipHostFree(host_));
+    if (dev_) HIP_OK(hipFree(dev_));
+    host_ = dev_ = nullptr;
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&host_), cap * kSlots, hipHostMallocDefault));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&dev_), cap * kSlots));
+    if (events_.empty()) {
+      events_.resize(kSlots);
+      for (auto& e : events_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    busy_.assign(kSlots, false);
+    cap_ = cap;
+  }
+
+  void release_all() {
+    for (auto& e : events_) (void)hipEventDestroy(e);
+    if (host_) (void)hipHostFree(host_);
+    if (dev_) (void)hipFree(dev_);
+  }
+
+  size_t cap_ = 0;
+  uint8_t* host_ = nullptr;
+  uint8_t* dev_ = nullptr;
+  std::vector<hipEvent_t> events_;
+  std::vector<bool> busy_;
+  int next_ = 0;
+};
+
+struct KeyInfo {
+  std::string name;
+  int64_t rowbytes;
+  uint8_t* pool;
+};
+
+// HIP-event pairs around gather launches (bench.py's roofline leg).
+class LaunchTimer {
+ public:
+  ~LaunchTimer() {
+    for (auto& p : pairs_) {
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+  }
+  bool enabled = false;
+  void begin(hipStream_t s) {
+    if (!enabled) return;
+    if (used_ == pairs_.size()) {
+      if (pairs_.size() >= 8192) collect();
+      if (used_ == pairs_.size()) {
+        hipEvent_t a, b;
+        HIP_OK(hipEventCreate(&a));
+        HIP_OK(hipEventCreate(&b));
+        pairs_.emplace_back(a, b);
+      }
+    }
+    HIP_OK(hipEventRecord(pairs_[used_].first, s));
+  }
+  void end(hipStream_t s) {
+    if (!enabled) return;
+    HIP_OK(hipEventRecord(pairs_[used_].second, s));
+    ++used_;
+  }
+  void collect() {
+    for (size_t i = 0; i < used_; ++i) {
+      HIP_OK(hipEventSynchronize(pairs_[i].second));
+      float ms = 0;
+      HIP_OK(hipEventElapsedTime(&ms, pairs_[i].first, pairs_[i].second));
+      total_ms_ += ms;
+      ++launches_;
+    }
+    used_ = 0;
+  }
+  void read(int64_t* launches, double* ms, bool reset) {
+    collect();
+    *launches = launches_;
+    *ms = total_ms_;
+    if (reset) {
+      launches_ = 0;
+      total_ms_ = 0;
+    }
+  }
+
+ private:
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs_;
+  size_t used_ = 0;
+  int64_t launches_ = 0;
+  double total_ms_ = 0;
+};
+
+std::mutex g_ring_mu;
+TableRing& global_ring() {
+  static TableRing* ring = new TableRing();  // leaked on purpose: HIP may be gone at exit
+  return *ring;
+}
+
+}  // namespace
+
+struct emb_rng {
+  std::mutex mu;
+  emb::NpRandom impl;
+  explicit emb_rng(const std::vector<uint32_t>& w) : impl(w) {}
+};
+
+struct emb_tree {
+  std::mutex mu;
+  emb::SampleTree impl;
+  emb_tree(int b, uint64_t s) : impl(b, s) {}
+};
+
+struct emb_selector {
+  std::shared_ptr<std::mutex> mu = std::make_shared<std::mutex>();
+  std::shared_ptr<emb::Selector> impl;
+};
+
+struct emb_replay {
+  std::mutex mu;
+  std::unique_ptr<emb::ReplayIndex> index;
+  std::shared_ptr<emb::Selector> selector;
+  std::vector<KeyInfo> keys;
+  int key_stepid = -1, key_is_first = -1, key_is_last = -1;
+  TableRing ring;
+  LaunchTimer timer;
+  std::vector<int32_t> rows;
+  std::vector<emb::StepId> ids;
+};
+
+extern "C" {
+
+const char* emb_last_error(void) { return g_error.c_str(); }
+int32_t emb_abi_version(void) { return EMB_ABI_VERSION; }
+
+int32_t emb_device_count(int32_t* count) {
+  return guarded([&] {
+    need(count, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+  });
+}
+
+// ---------------------------------------------------------------------- rng --
+
+int32_t emb_rng_create(const uint32_t* words, int32_t n_words, emb_rng_t** out) {
+  return guarded([&] {
+    need(words && n_words > 0 && out, "rng: bad arguments");
+    *out = new emb_rng(std::vector<uint32_t>(words, words + n_words));
+  });
+}
+
+int32_t emb_rng_integers(emb_rng_t* rng, int64_t high, int64_t count, int64_t* out) {
+  return guarded([&] {
+    need(rng && out && high >= 1 && count >= 0, "rng_integers: bad arguments");
+    std::lock_guard<std::mutex> lock(rng->mu);
+    for (int64_t i = 0; i < count; ++i) out[i] = rng->impl.integers(high);
+  });
+}
+
+int32_t emb_rng_random(emb_rng_t* rng, int64_t count, double* out) {
+  return guarded([&] {
+    need(rng && out && count >= 0, "rng_random: bad arguments");
+    std::lock_guard<std::mutex> lock(rng->mu);
+    for (int64_t i = 0; i < count; ++i) out[i] = rng->impl.random();
+  });
+}
+
+int32_t emb_rng_choice(emb_rng_t* rng, const double* p, int32_t k, int64_t count, int64_t* out) {
+  return guarded([&] {
+    need(rng && p && out && k >= 1 && count >= 0, "rng_choice: bad arguments");
+    std::lock_guard<std::mutex> lock(rng->mu);
+    std::vector<double> cdf(k);
+    for (int64_t i = 0; i < count; ++i) out[i] = rng->impl.choice(p, k, cdf.data());
+  });
+}
+
+int32_t emb_rng_destroy(emb_rng_t* rng) {
+  delete rng;
+  return EMB_OK;
+}
+
+int32_t emb_np_sum(const double* values, int64_t n, double* out) {
+  return guarded([&] {
+    need(values && out && n >= 0, "np_sum: bad arguments");
+    *out = emb::np_pairwise_sum(values, n);
+  });
+}
+
+// --------------------------------------------------------------------- tree --
+
+int32_t emb_tree_create(int32_t branching, uint64_t seed, emb_tree_t** out) {
+  return guarded([&] {
+    need(out, "tree: out is null");
+    *out = new emb_tree(branching, seed);
+  });
+}
+
+#define TREE_OP(...)                                  \
+  return guarded([&] {                                \
+    need(tree, "tree handle is null");                \
+    std::lock_guard<std::mutex> lock(tree->mu);       \
+    __VA_ARGS__;                                      \
+  })
+
+int32_t emb_tree_insert(emb_tree_t* tree, int64_t key, double uprob) { TREE_OP(tree->impl.insert(key, uprob)); }
+int32_t emb_tree_remove(emb_tree_t* tree, int64_t key) { TREE_OP(tree->impl.remove(key)); }
+int32_t emb_tree_update(emb_tree_t* tree, int64_t key, double uprob) { TREE_OP(tree->impl.update(key, uprob)); }
+int32_t emb_tree_sample(emb_tree_t* tree, int64_t* key) { TREE_OP(*key = tree->impl.sample()); }
+int32_t emb_tree_len(emb_tree_t* tree, int64_t* n) { TREE_OP(*n = tree->impl.size()); }
+int32_t emb_tree_root_sum(emb_tree_t* tree, double* total) { TREE_OP(*total = tree->impl.root_mass()); }
+
+int32_t emb_tree_shape(emb_tree_t* tree, int64_t cap, int64_t* depths, int64_t* n_leaves,
+                       int64_t* n_nodes) {
+  TREE_OP({
+    int64_t leaves = 0, nodes = 0;
+    std::vector<std::pair<const emb::SampleTree::Node*, int64_t>> stack;
+    stack.emplace_back(tree->impl.root(), 0);
+    while (!stack.empty()) {
+      auto [node, depth] = stack.back();
+      stack.pop_back();
+      ++nodes;
+      if (node->leaf) {
+        if (depths && leaves < cap) depths[leaves] = depth;
+        ++leaves;
+      }
+      for (auto* kid : node->kids) stack.emplace_back(kid, depth + 1);
+    }
+    if (n_leaves) *n_leaves = leaves;
+    if (n_nodes) *n_nodes = nodes;
+  });
+}
+
+int32_t emb_tree_destroy(emb_tree_t* tree) {
+  delete tree;
+  return EMB_OK;
+}
+
+// ---------------------------------------------------------------- selectors --
+
+static int32_t make_selector(emb_selector_t** out, std::shared_ptr<emb::Selector> impl) {
+  auto* h = new emb_selector();
+  h->impl = std::move(impl);
+  *out = h;
+  return EMB_OK;
+}
+
+int32_t emb_selector_create_fifo(emb_selector_t** out) {
+  return guarded([&] { need(out, "out is null"); make_selector(out, std::make_shared<emb::Fifo>()); });
+}
+
+int32_t emb_selector_create_uniform(uint64_t seed, emb_selector_t** out) {
+  return guarded([&] { need(out, "out is null"); make_selector(out, std::make_shared<emb::Uniform>(seed)); });
+}
+
+int32_t emb_selector_create_prioritized(double exponent, double initial, int32_t zero_on_sample,
+                                        double maxfrac, int32_t branching, uint64_t seed,
+                                        emb_selector_t** out) {
+  return guarded([&] {
+    need(out, "out is null");
+    make_selector(out, std::make_shared<emb::Prioritized>(exponent, initial, zero_on_sample != 0,
+                                                          maxfrac, branching, seed));
+  });
+}
+
+int32_t emb_selector_create_mixture(emb_selector_t* const* members, const float* fractions,
+                                    int32_t n, uint64_t seed, emb_selector_t** out) {
+  return guarded([&] {
+    need(members && fractions && n >= 1 && out, "mixture: bad arguments");
+    std::vector<std::shared_ptr<emb::Selector>> impls;
+    for (int i = 0; i < n; ++i) {
+      need(members[i], "mixture: null member");
+      impls.push_back(members[i]->impl);
+    }
+    make_selector(out, std::make_shared<emb::Mixture>(
+                           std::move(impls), std::vector<float>(fractions, fractions + n), seed));
+  });
+}
+
+int32_t emb_selector_create_callback(const emb_selector_callbacks_t* cb, emb_selector_t** out) {
+  return guarded([&] {
+    need(cb && cb->sample && cb->size && cb->insert && cb->remove && out, "callback selector: bad arguments");
+    emb::SelectorCallbacks c{cb->user, cb->sample, cb->size, cb->insert, cb->remove, cb->prioritize};
+    make_selector(out, std::make_shared<emb::CallbackSelector>(c));
+  });
+}
+
+#define SEL_OP(...)                                   \
+  return guarded([&] {                                \
+    need(sel, "selector handle is null");             \
+    std::lock_guard<std::mutex> lock(*sel->mu);       \
+    __VA_ARGS__;                                      \
+  })
+
+int32_t emb_selector_insert(emb_selector_t* sel, int64_t key, const uint8_t* stepids, int32_t n_steps) {
+  SEL_OP(sel->impl->insert(key, reinterpret_cast<const emb::StepId*>(stepids), stepids ? n_steps : 0));
+}
+int32_t emb_selector_remove(emb_selector_t* sel, int64_t key) { SEL_OP(sel->impl->remove(key)); }
+int32_t emb_selector_sample(emb_selector_t* sel, int64_t* key) { SEL_OP(*key = sel->impl->sample()); }
+int32_t emb_selector_len(emb_selector_t* sel, int64_t* n) { SEL_OP(*n = sel->impl->size()); }
+int32_t emb_selector_prioritize(emb_selector_t* sel, const uint8_t* stepids, const double* prios, int64_t n) {
+  SEL_OP(sel->impl->prioritize(reinterpret_cast<const emb::StepId*>(stepids), prios, n));
+}
+int32_t emb_selector_destroy(emb_selector_t* sel) {
+  delete sel;
+  return EMB_OK;
+}
+
+// ------------------------------------------------------------------- replay --
+
+int32_t emb_replay_create(const emb_replay_config_t* cfg, emb_selector_t* selector, uint64_t seed,
+                          emb_replay_t** out) {
+  return guarded([&] {
+    need(cfg && out, "replay_create: bad arguments");
+    emb::ReplayConfig c;
+    c.length = cfg->length;
+    c.capacity = cfg->capacity;
+    c.chunksize = cfg->chunksize;
+    c.n_slots = cfg->n_slots;
+    c.online = cfg->online != 0;
+    c.uid_hi = cfg->uid_hi;
+    auto rep = std::make_unique<emb_replay>();
+    rep->selector = selector ? selector->impl : std::make_shared<emb::Uniform>(seed);
+    rep->index = std::make_unique<emb::ReplayIndex>(c, rep->selector);
+    *out = rep.release();
+  });
+}
+
+int32_t emb_replay_destroy(emb_replay_t* rep) {
+  delete rep;
+  return EMB_OK;
+}
+
+#define REP_OP(...)                                   \
+  return guarded([&] {                                \
+    need(rep, "replay handle is null");               \
+    std::lock_guard<std::mutex> lock(rep->mu);        \
+    __VA_ARGS__;                                      \
+  })
+
+int32_t emb_replay_set_keys(emb_replay_t* rep, int32_t n_keys, const char* const* names,
+                            const int64_t* rowbytes, void* const* pools) {
+  REP_OP({
+    need(n_keys >= 1 && n_keys <= emb::kMaxKeys && names && rowbytes, "set_keys: bad arguments");
+    rep->keys.clear();
+    rep->key_stepid = rep->key_is_first = rep->key_is_last = -1;
+    for (int k = 0; k < n_keys; ++k) {
+      need(names[k] && rowbytes[k] > 0, "set_keys: bad key");
+      KeyInfo info{names[k], rowbytes[k], pools ? static_cast<uint8_t*>(pools[k]) : nullptr};
+      if (info.name == "stepid") {
+        need(rowbytes[k] == EMB_STEPID_BYTES, "set_keys: stepid must be 20 bytes");
+        rep->key_stepid = k;
+      } else if (info.name == "is_first" && rowbytes[k] == 1) {
+        rep->key_is_first = k;
+      } else if (info.name == "is_last" && rowbytes[k] == 1) {
+        rep->key_is_last = k;
+      }
+      rep->keys.push_back(info);
+    }
+  });
+}
+
+int32_t emb_replay_grow(emb_replay_t* rep, int64_t n_slots, void* const* pools) {
+  REP_OP({
+    rep->index->grow(n_slots);
+    if (pools)
+      for (size_t k = 0; k < rep->keys.size(); ++k) rep->keys[k].pool = static_cast<uint8_t*>(pools[k]);
+  });
+}
+
+static void add_index_locked(emb_replay* rep, int64_t n, const int64_t* workers, int32_t* rows,
+                             emb::StepId* ids) {
+  if (rep->index->slots_needed(workers, n) > rep->index->free_slots()) throw emb::PoolFull();
+  for (int64_t i = 0; i < n; ++i)
+    rows[i] = static_cast<int32_t>(rep->index->add(workers[i], &ids[i]));
+}
+
+static void sample_index_locked(emb_replay* rep, int64_t batch, int32_t mode, int32_t* rows,
+                                uint8_t* online) {
+  need(mode >= EMB_MODE_TRAIN && mode <= EMB_MODE_EVAL, "sample: bad mode");
+  const int64_t L = rep->index->config().length;
+  for (int64_t b = 0; b < batch; ++b) {
+    bool from_online = false;
+    const auto pos = rep->index->draw(mode == EMB_MODE_TRAIN, &from_online);
+    if (!rep->index->rows(pos, L, rows + b * L))
+      throw std::logic_error("replay: sampled window vanished");
+    if (online) online[b] = from_online ? 1 : 0;
+  }
+}
+
+int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                             int32_t* rows_out, uint8_t* stepids_out) {
+  REP_OP({
+    need(n >= 0 && workers && rows_out, "add_index: bad arguments");
+    rep->ids.resize(n);
+    add_index_locked(rep, n, workers, rows_out, rep->ids.data());
+    if (stepids_out) std::memcpy(stepids_out, rep->ids.data(), n * EMB_STEPID_BYTES);
+  });
+}
+
+int32_t emb_replay_sample_index(emb_replay_t* rep, int64_t batch, int32_t mode, int32_t* rows_out,
+                                uint8_t* online_out) {
+  REP_OP({
+    need(batch >= 0 && rows_out, "sample_index: bad arguments");
+    sample_index_locked(rep, batch, mode, rows_out, online_out);
+  });
+}
+
+int32_t emb_replay_resolve(emb_replay_t* rep, int64_t n, const uint8_t* stepids, int64_t count,
+                           int32_t* rows_out, uint8_t* found_out) {
+  REP_OP({
+    need(n >= 0 && stepids && count >= 0 && rows_out, "resolve: bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+      emb::ReplayIndex::Pos pos;
+      bool ok = rep->index->parse_stepid(stepids + i * EMB_STEPID_BYTES, &pos);
+      if (ok) ok = rep->index->rows(pos, count, rows_out + i * count);
+      else for (int64_t j = 0; j < count; ++j) rows_out[i * count + j] = -1;
+      if (found_out) found_out[i] = ok ? 1 : 0;
+    }
+  });
+}
+
+int32_t emb_replay_prioritize(emb_replay_t* rep, const uint8_t* stepids, const double* prios, int64_t n) {
+  REP_OP({
+    need(stepids && prios && n >= 0, "prioritize: bad arguments");
+    if (!rep->selector->can_prioritize())
+      throw std::invalid_argument("replay: selector has no prioritize()");  // AttributeError in replay.py:137
+    rep->selector->prioritize(reinterpret_cast<const emb::StepId*>(stepids), prios, n);
+  });
+}
+
+int32_t emb_replay_len(emb_replay_t* rep, int64_t* items) { REP_OP(*items = rep->index->size()); }
+int32_t emb_replay_sampler_len(emb_replay_t* rep, int64_t* n) { REP_OP(*n = rep->selector->size()); }
+int32_t emb_replay_free_slots(emb_replay_t* rep, int64_t* n) { REP_OP(*n = rep->index->free_slots()); }
+int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset) { REP_OP(rep->index->stats(out, reset != 0)); }
+
+static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, int64_t n_rows,
+                     const emb::StepId* ids, int stepid_plan_slot, bool gather, hipStream_t stream) {
+  // Table layout in the ring slot: int32 rows[n_rows] | (16-aligned) stepids.
+  const size_t rows_bytes = static_cast<size_t>(n_rows) * sizeof(int32_t);
+  const size_t ids_off = (rows_bytes + 15) & ~size_t(15);
+  const size_t total = ids ? ids_off + static_cast<size_t>(n_rows) * EMB_STEPID_BYTES : rows_bytes;
+  auto lease = rep->ring.acquire(total, stream);
+  std::memcpy(lease.host, rows, rows_bytes);
+  if (ids) {
+    std::memcpy(lease.host + ids_off, ids, static_cast<size_t>(n_rows) * EMB_STEPID_BYTES);
+    plan.key[stepid_plan_slot].batch = lease.device + ids_off;
+  }
+  rep->ring.upload(lease, total, stream);
+  plan.rows = reinterpret_cast<const int32_t*>(lease.device);
+  plan.n_rows = static_cast<int32_t>(n_rows);
+  if (gather) rep->timer.begin(stream);
+  HIP_OK(gather ? emb::launch_gather(plan, stream) : emb::launch_scatter(plan, stream));
+  if (gather) rep->timer.end(stream);
+  rep->ring.retire(lease, stream);
+}
+
+int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers, const void* const* src,
+                       void* stream) {
+  REP_OP({
+    need(n >= 0 && workers && src, "add: bad arguments");
+    need(!rep->keys.empty(), "add: call emb_replay_set_keys first");
+    if (n == 0) return;
+    emb::MovePlan plan;
+    int sid_slot = -1;
+    for (size_t k = 0; k < rep->keys.size(); ++k) {
+      need(rep->keys[k].pool, "add: key has no pool");
+      if (static_cast<int>(k) == rep->key_stepid) {
+        sid_slot = plan.n_keys;
+        plan.key[plan.n_keys++] = {rep->keys[k].pool, nullptr, rep->keys[k].rowbytes};
+        continue;
+      }
+      need(src[k], "add: null source buffer");
+      plan.key[plan.n_keys++] = {rep->keys[k].pool,
+                                 const_cast<uint8_t*>(static_cast<const uint8_t*>(src[k])),
+                                 rep->keys[k].rowbytes};
+    }
+    rep->rows.resize(n);
+    rep->ids.resize(n);
+    add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());
+    run_move(rep, plan, rep->rows.data(), n, sid_slot >= 0 ? rep->ids.data() : nullptr, sid_slot,
+             false, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
+                          uint8_t* online_out, void* stream) {
+  REP_OP({
+    need(batch >= 0 && dst, "sample: bad arguments");
+    need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
+    if (batch == 0) return;
+    const int64_t L = rep->index->config().length;
+    emb::MovePlan plan;
+    for (size_t k = 0; k < rep->keys.size(); ++k) {
+      need(dst[k] && rep->keys[k].pool, "sample: null buffer");
+      if (static_cast<int>(k) == rep->key_is_first) plan.key_is_first = plan.n_keys;
+      if (static_cast<int>(k) == rep->key_is_last) plan.key_is_last = plan.n_keys;
+      plan.key[plan.n_keys++] = {rep->keys[k].pool, static_cast<uint8_t*>(dst[k]), rep->keys[k].rowbytes};
+    }
+    plan.seq_len = static_cast<int32_t>(L);
+    rep->rows.resize(batch * L);
+    sample_index_locked(rep, batch, mode, rep->rows.data(), online_out);
+    run_move(rep, plan, rep->rows.data(), batch * L, nullptr, -1, true, static_cast<hipStream_t>(stream));
+  });
+}
+
+static emb::MovePlan plan_subset(emb_replay* rep, int32_t n_keys, const int32_t* key_ids,
+                                 const void* const* bufs) {
+  emb::MovePlan plan;
+  need(n_keys >= 1 && key_ids && bufs, "bad key subset");
+  for (int j = 0; j < n_keys; ++j) {
+    need(key_ids[j] >= 0 && key_ids[j] < static_cast<int>(rep->keys.size()), "key id out of range");
+    const KeyInfo& info = rep->keys[key_ids[j]];
+    need(bufs[j] && info.pool, "null buffer");
+    plan.key[plan.n_keys++] = {info.pool, const_cast<uint8_t*>(static_cast<const uint8_t*>(bufs[j])),
+                               info.rowbytes};
+  }
+  return plan;
+}
+
+int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t* stepids,
+                          int32_t n_keys, const int32_t* key_ids, const void* const* src,
+                          void* stream) {
+  REP_OP({
+    need(B >= 0 && T >= 1 && stepids, "update: bad arguments");
+    if (B == 0) return;
+    emb::MovePlan plan = plan_subset(rep, n_keys, key_ids, src);
+    rep->rows.resize(B * T);
+    for (int64_t i = 0; i < B; ++i) {
+      emb::ReplayIndex::Pos pos;
+      if (rep->index->parse_stepid(stepids + i * EMB_STEPID_BYTES, &pos))
+        rep->index->rows(pos, T, rep->rows.data() + i * T);
+      else
+        for (int64_t j = 0; j < T; ++j) rep->rows[i * T + j] = -1;
+    }
+    run_move(rep, plan, rep->rows.data(), B * T, nullptr, -1, false, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n_rows,
+                               int64_t seq_len, void* const* dst, void* stream) {
+  REP_OP({
+    need(rows && n_rows >= 0 && dst && seq_len >= 1, "gather_rows: bad arguments");
+    if (n_rows == 0) return;
+    emb::MovePlan plan;
+    for (size_t k = 0; k < rep->keys.size(); ++k) {
+      need(dst[k] && rep->keys[k].pool, "gather_rows: null buffer");
+      if (static_cast<int>(k) == rep->key_is_first) plan.key_is_first = plan.n_keys;
+      if (static_cast<int>(k) == rep->key_is_last) plan.key_is_last = plan.n_keys;
+      plan.key[plan.n_keys++] = {rep->keys[k].pool, static_cast<uint8_t*>(dst[k]), rep->keys[k].rowbytes};
+    }
+    plan.seq_len = static_cast<int32_t>(seq_len);
+    run_move(rep, plan, rows, n_rows, nullptr, -1, true, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t n_rows,
+                                int32_t n_keys, const int32_t* key_ids, const void* const* src,
+                                void* stream) {
+  REP_OP({
+    need(rows && n_rows >= 0, "scatter_rows: bad arguments");
+    if (n_rows == 0) return;
+    emb::MovePlan plan = plan_subset(rep, n_keys, key_ids, src);
+    run_move(rep, plan, rows, n_rows, nullptr, -1, false, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) { REP_OP(rep->timer.enabled = enable != 0); }
+
+int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* total_ms, int32_t reset) {
+  REP_OP({
+    need(launches && total_ms, "profile_read: bad arguments");
+    rep->timer.read(launches, total_ms, reset != 0);
+  });
+}
+
+int32_t emb_replay_complete_all(emb_replay_t* rep) { REP_OP(rep->index->complete_all()); }
+
+int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_t* succ,
+                          int64_t* fill, int64_t* slot, int64_t* n) {
+  REP_OP({
+    need(n, "chunks: n is null");
+    int64_t i = 0;
+    for (const auto& kv : rep->index->chunks()) {
+      if (i < cap) {
+        if (uid) uid[i] = kv.second.uid;
+        if (succ) succ[i] = kv.second.succ;
+        if (fill) fill[i] = kv.second.fill;
+        if (slot) slot[i] = kv.second.slot;
+      }
+      ++i;
+    }
+    *n = i;
+  });
+}
+
+int32_t emb_replay_load_chunk(emb_replay_t* rep, uint64_t uid, uint64_t succ, int64_t fill, int64_t* slot) {
+  REP_OP({
+    need(slot, "load_chunk: slot is null");
+    *slot = rep->index->load_chunk(uid, succ, fill);
+  });
+}
+
+int32_t emb_replay_load_items(emb_replay_t* rep, uint64_t uid, int64_t amount) {
+  REP_OP(rep->index->load_items(uid, amount));
+}
+
+// ------------------------------------------------------------------ kernels --
+
+int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_t pixels,
+                      int64_t channels, int32_t layout, int32_t out_dtype, float scale,
+                      float offset, void* dst, void* stream) {
+  return guarded([&] {
+    need(src && dst && n >= 0 && pixels > 0 && channels > 0, "obs_stack: bad arguments");
+    need(layout == EMB_LAYOUT_SAME || layout == EMB_LAYOUT_CHANNELS_FIRST, "obs_stack: bad layout");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!env_ids) {
+      HIP_OK(emb::launch_obs_stack(static_cast<const uint8_t*>(src), nullptr, dst, n, pixels,
+                                   channels, layout, out_dtype, scale, offset, s));
+      return;
+    }
+    std::lock_guard<std::mutex> lock(g_ring_mu);
+    auto lease = global_ring().acquire(n * sizeof(int32_t), s);
+    std::memcpy(lease.host, env_ids, n * sizeof(int32_t));
+    global_ring().upload(lease, n * sizeof(int32_t), s);
+    HIP_OK(emb::launch_obs_stack(static_cast<const uint8_t*>(src),
+                                 reinterpret_cast<const int32_t*>(lease.device), dst, n, pixels,
+                                 channels, layout, out_dtype, scale, offset, s));
+    global_ring().retire(lease, s);
+  });
+}
+
+int32_t emb_mask_actions(void* act, int64_t n, int64_t row_elems, int32_t dtype,
+                         const void* is_last, void* stream) {
+  return guarded([&] {
+    need(act && is_last && n >= 0 && row_elems >= 0, "mask_actions: bad arguments");
+    HIP_OK(emb::launch_mask_rows(act, n, row_elems, dtype, static_cast<const uint8_t*>(is_last),
+                                 static_cast<hipStream_t>(stream)));
+  });
+}
+
+static void rows_move(void* table, int64_t rowbytes, const int32_t* ids, int64_t n, void* batch,
+                      bool gather, hipStream_t s) {
+  need(table && batch && ids && rowbytes > 0 && n >= 0, "rows_gather/scatter: bad arguments");
+  if (n == 0) return;
+  std::lock_guard<std::mutex> lock(g_ring_mu);
+  auto lease = global_ring().acquire(n * sizeof(int32_t), s);
+  std::memcpy(lease.host, ids, n * sizeof(int32_t));
+  global_ring().upload(lease, n * sizeof(int32_t), s);
+  emb::MovePlan plan;
+  plan.n_keys = 1;
+  plan.key[0] = {static_cast<uint8_t*>(table), static_cast<uint8_t*>(batch), rowbytes};
+  plan.n_rows = static_cast<int32_t>(n);
+  plan.rows = reinterpret_cast<const int32_t*>(lease.device);
+  HIP_OK(gather ? emb::launch_gather(plan, s) : emb::launch_scatter(plan, s));
+  global_ring().retire(lease, s);
+}
+
+int32_t emb_rows_gather(const void* table, int64_t rowbytes, const int32_t* ids, int64_t n, void* dst,
+                        void* stream) {
+  return guarded([&] { rows_move(const_cast<void*>(table), rowbytes, ids, n, dst, true, static_cast<hipStream_t>(stream)); });
+}
+
+int32_t emb_rows_scatter(void* table, int64_t rowbytes, const int32_t* ids, int64_t n, const void* src,
+                         void* stream) {
+  return guarded([&] { rows_move(table, rowbytes, ids, n, const_cast<void*>(src), false, static_cast<hipStream_t>(stream)); });
+}
+
+int32_t emb_window(const void* src, void* dst, int64_t batch, int64_t total, int64_t start,
+                   int64_t count, int64_t rowbytes, void* stream) {
+  return guarded([&] {
+    need(src && dst && batch >= 0 && start >= 0 && count >= 0 && start + count <= total && rowbytes > 0,
+         "window: bad arguments");
+    HIP_OK(emb::launch_window(static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), batch,
+                              total, start, count, rowbytes, static_cast<hipStream_t>(stream)));
+  });
+}
+
+int32_t emb_scan_gae(const void* rew, const void* val, const void* last, const void* term, int64_t B,
+                     int64_t T, float live_scale, float lam, void* adv, void* tar, void* stream) {
+  return guarded([&] {
+    need(rew && val && last && term && adv && tar && B >= 0 && T >= 1, "scan_gae: bad arguments");
+    HIP_OK(emb::launch_gae(static_cast<const float*>(rew), static_cast<const float*>(val),
+                           static_cast<const uint8_t*>(last), static_cast<const uint8_t*>(term), B, T,
+                           live_scale, lam, static_cast<float*>(adv), static_cast<float*>(tar),
+                           static_cast<hipStream_t>(stream)));
+  });
+}
+
+int32_t emb_scan_lambda(const void* last, const void* term, const void* rew, const void* boot,
+                        int64_t B, int64_t T, float disc, float lam, void* ret, void* stream) {
+  return guarded([&] {
+    need(last && term && rew && boot && ret && B >= 0 && T >= 1, "scan_lambda: bad arguments");
+    HIP_OK(emb::launch_lambda_return(static_cast<const uint8_t*>(last), static_cast<const uint8_t*>(term),
+                                     static_cast<const float*>(rew), static_cast<const float*>(boot), B, T,
+                                     disc, lam, static_cast<float*>(ret), static_cast<hipStream_t>(stream)));
+  });
+}
+
+int32_t emb_scan_director(const void* rew, const void* cont, const void* value, int64_t T, int64_t B,
+                          float discount, float lam, void* ret, void* stream) {
+  return guarded([&] {
+    need(rew && cont && value && ret && B >= 0 && T >= 1, "scan_director: bad arguments");
+    HIP_OK(emb::launch_director_score(static_cast<const float*>(rew), static_cast<const float*>(cont),
+                                      static_cast<const float*>(value), T, B, discount, lam,
+                                      static_cast<float*>(ret), static_cast<hipStream_t>(stream)));
+  });
+}
+
+int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_last, void* is_terminal,
+                           int64_t n, int64_t frame_bytes, int64_t env0, int64_t episode_len,
+                           const void* reset, void* counters, void* stream) {
+  return guarded([&] {
+    need(image && reward && is_first && is_last && is_terminal && counters && n >= 0 && episode_len >= 1,
+         "synth_env_step: bad arguments");
+    HIP_OK(emb::launch_synth_env(static_cast<uint8_t*>(image), static_cast<float*>(reward),
+                                 static_cast<uint8_t*>(is_first), static_cast<uint8_t*>(is_last),
+                                 static_cast<uint8_t*>(is_terminal), n, frame_bytes, env0, 0, episode_len,
+                                 static_cast<const uint8_t*>(reset), static_cast<int32_t*>(counters),
+                                 static_cast<hipStream_t>(stream)));
+  });
+}
+
+}  // extern "C"

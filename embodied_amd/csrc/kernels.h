@@ -1,0 +1,79 @@
+// Launchers for the gfx950 kernels in kernels.hip (host-callable, no torch).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace emb {
+
+constexpr int kMaxKeys = 32;
+
+// One replay column: its chunk pool in HBM and the batch-side buffer.
+struct KeyDesc {
+  uint8_t* pool;       // (n_slots * chunksize, rowbytes)
+  uint8_t* batch;      // (n_rows, rowbytes) contiguous
+  int64_t rowbytes;
+};
+
+struct MovePlan {
+  int32_t n_keys = 0;
+  KeyDesc key[kMaxKeys];
+  int32_t n_rows = 0;        // rows moved per key
+  int32_t seq_len = 1;       // rows per sequence (annotate uses t = r % seq_len)
+  int32_t key_is_first = -1; // gather only: fuse replay.py:277-292
+  int32_t key_is_last = -1;
+  const int32_t* rows = nullptr;  // device-visible table of pool rows (-1 = skip)
+};
+
+// pool[rows[r]] -> batch[r]   (Replay.sample: replay.py:255-292 on device)
+hipError_t launch_gather(const MovePlan& plan, hipStream_t stream);
+// batch[r] -> pool[rows[r]]   (Replay.add / Replay.update: chunk.py:41-58)
+hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream);
+
+// (B, total, rowbytes) -> (B, count, rowbytes) window starting at `start`
+// (streams.py:133-138).
+hipError_t launch_window(const uint8_t* src, uint8_t* dst, int64_t batch,
+                         int64_t total, int64_t start, int64_t count,
+                         int64_t rowbytes, hipStream_t stream);
+
+enum ObsLayout { kLayoutSame = 0, kLayoutChannelsFirst = 1 };
+enum DType {
+  kU8 = 0, kI8 = 1, kI16 = 2, kI32 = 3, kI64 = 4,
+  kF16 = 5, kBF16 = 6, kF32 = 7, kF64 = 8, kBool = 9,
+};
+
+// Per-env uint8 frames (N, P, C) [env e at src + env_ids[e] * P*C, or e if
+// env_ids is null] -> policy batch (N, P, C) or (N, C, P) in u8/f16/bf16/f32,
+// value * scale + offset for float outputs (driver.py:65 + jax/agent.py:230).
+hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* dst,
+                            int64_t n, int64_t pixels, int64_t channels,
+                            int layout, int out_dtype, float scale, float offset,
+                            hipStream_t stream);
+
+// act[n, :] *= !is_last[n] in the action's own dtype (driver.py:72-74,84-87).
+hipError_t launch_mask_rows(void* act, int64_t n, int64_t row_elems, int dtype,
+                            const uint8_t* is_last, hipStream_t stream);
+
+// Return scans (float32).  Batch-major (B, T) unless stated.
+hipError_t launch_gae(const float* rew, const float* val, const uint8_t* last,
+                      const uint8_t* term, int64_t B, int64_t T, float live_scale,
+                      float lam, float* adv, float* tar, hipStream_t stream);
+hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term,
+                                const float* rew, const float* boot, int64_t B,
+                                int64_t T, float disc, float lam, float* ret,
+                                hipStream_t stream);
+// Time-major: rew (T-1, B), cont/value (T, B) -> ret (T-1, B).
+hipError_t launch_director_score(const float* rew, const float* cont,
+                                 const float* value, int64_t T, int64_t B,
+                                 float discount, float lam, float* ret,
+                                 hipStream_t stream);
+
+// Synthetic vector env (bench/test input): counter-hash frames written straight
+// into HBM, SURVEY.md 8d.
+hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first,
+                            uint8_t* is_last, uint8_t* is_terminal, int64_t n,
+                            int64_t frame_bytes, int64_t env0, int64_t tick,
+                            int64_t episode_len, const uint8_t* reset,
+                            int32_t* counters, hipStream_t stream);
+
+}  // namespace emb

@@ -1,0 +1,586 @@
+// gfx950 (CDNA4, wave64) kernels for the Driver / Replay / return-scan hot path.
+//
+// Everything here is HBM-bound byte movement or a short recurrence: no MFMA.
+// What matters (cdna_hip_programming.md G2, G11, G13): 16-byte accesses per
+// lane with consecutive lanes on consecutive addresses, several independent
+// loads in flight per lane, and far more than 256 workgroups per launch.
+#include "kernels.h"
+
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+namespace emb {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one dwordx4
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 8;                       // 16-byte loads in flight per lane
+constexpr int kTileVec = kThreads * kUnroll;     // 2048 x 16 B = 32 KiB per workgroup
+
+// Per-launch plan in kernel-argument memory (< 4 KiB).
+struct MoveArgs {
+  KeyDesc key[kMaxKeys];
+  int32_t first_block[kMaxKeys + 1];
+  int32_t unit[kMaxKeys];           // 0: tiled 16-byte path; else bytes per lane
+  int32_t tiles_per_row[kMaxKeys];
+  int32_t n_keys, n_rows, seq_len, key_is_first, key_is_last;
+  const int32_t* rows;
+};
+
+__device__ __forceinline__ int find_key(const MoveArgs& a, int block) {
+  int k = 0;
+  while (k + 1 < a.n_keys && block >= a.first_block[k + 1]) ++k;
+  return k;
+}
+
+template <typename T>
+__device__ __forceinline__ void copy_unit(const uint8_t* s, uint8_t* d) {
+  *reinterpret_cast<T*>(d) = *reinterpret_cast<const T*>(s);
+}
+
+__device__ __forceinline__ void copy_bytes(const uint8_t* s, uint8_t* d, int unit) {
+  switch (unit) {
+    case 16: copy_unit<uint4>(s, d); break;
+    case 8: copy_unit<uint2>(s, d); break;
+    case 4: copy_unit<uint32_t>(s, d); break;
+    case 2: copy_unit<uint16_t>(s, d); break;
+    default: *d = *s; break;
+  }
+}
+
+// One workgroup moves one 32 KiB tile of one row: every lane issues up to
+// kUnroll independent 16-byte loads before the first store.
+template <bool kGather>
+__device__ __forceinline__ void move_tile(const KeyDesc& key, int64_t pool_row,
+                                          int64_t batch_row, int tile) {
+  const int64_t nvec = key.rowbytes >> 4;
+  const int64_t v0 = static_cast<int64_t>(tile) * kTileVec;
+  const u32x4* pool = reinterpret_cast<const u32x4*>(key.pool + pool_row * key.rowbytes);
+  const u32x4* batch = reinterpret_cast<const u32x4*>(key.batch + batch_row * key.rowbytes);
+  const u32x4* src = kGather ? pool : batch;
+  u32x4* dst = const_cast<u32x4*>(kGather ? batch : pool);
+  u32x4 buf[kUnroll];
+#pragma unroll
+  for (int u = 0; u < kUnroll; ++u) {
+    const int64_t i = v0 + threadIdx.x + u * kThreads;
+    if (i < nvec) buf[u] = __builtin_nontemporal_load(src + i);
+  }
+#pragma unroll
+  for (int u = 0; u < kUnroll; ++u) {
+    const int64_t i = v0 + threadIdx.x + u * kThreads;
+    if (i < nvec) dst[i] = buf[u];
+  }
+}
+
+// pool[rows[r]] -> batch[r] for every key of the replay in ONE launch, with
+// the is_first / is_last annotation of replay.py:277-292 applied in flight.
+__global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
+  const int k = find_key(a, blockIdx.x);
+  const KeyDesc key = a.key[k];
+  const int local = blockIdx.x - a.first_block[k];
+  const int unit = a.unit[k];
+  if (unit == 0) {
+    const int tpr = a.tiles_per_row[k];
+    const int r = local / tpr;
+    move_tile<true>(key, a.rows[r], r, local - r * tpr);
+    return;
+  }
+  const int64_t upr = key.rowbytes / unit;
+  const int64_t u = static_cast<int64_t>(local) * kThreads + threadIdx.x;
+  if (u >= upr * a.n_rows) return;
+  const int64_t r = u / upr;
+  const int64_t off = (u - r * upr) * unit;
+  const int64_t row = a.rows[r];
+  const uint8_t* src = key.pool + row * key.rowbytes + off;
+  uint8_t* dst = key.batch + r * key.rowbytes + off;
+  if (key.rowbytes == 1 && (k == a.key_is_first || k == a.key_is_last)) {
+    const int t = static_cast<int>(r % a.seq_len);
+    uint8_t v = *src;
+    if (k == a.key_is_first) {
+      if (t == 0) v = 1;
+    } else if (a.key_is_first >= 0 && t + 1 < a.seq_len) {
+      v |= a.key[a.key_is_first].pool[a.rows[r + 1]];
+    }
+    *dst = v;
+    return;
+  }
+  copy_bytes(src, dst, unit);
+}
+
+// batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
+__global__ __launch_bounds__(kThreads) void scatter_kernel(const MoveArgs a) {
+  const int k = find_key(a, blockIdx.x);
+  const KeyDesc key = a.key[k];
+  const int local = blockIdx.x - a.first_block[k];
+  const int unit = a.unit[k];
+  if (unit == 0) {
+    const int tpr = a.tiles_per_row[k];
+    const int r = local / tpr;
+    const int row = a.rows[r];
+    if (row < 0) return;
+    move_tile<false>(key, row, r, local - r * tpr);
+    return;
+  }
+  const int64_t upr = key.rowbytes / unit;
+  const int64_t u = static_cast<int64_t>(local) * kThreads + threadIdx.x;
+  if (u >= upr * a.n_rows) return;
+  const int64_t r = u / upr;
+  const int64_t off = (u - r * upr) * unit;
+  const int64_t row = a.rows[r];
+  if (row < 0) return;
+  copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
+}
+
+int pick_unit(const KeyDesc& key) {
+  const uint64_t mix = reinterpret_cast<uint64_t>(key.pool) |
+                       reinterpret_cast<uint64_t>(key.batch) |
+                       static_cast<uint64_t>(key.rowbytes);
+  if (mix % 16 == 0) return key.rowbytes >= 2048 ? 0 : 16;
+  if (mix % 8 == 0) return 8;
+  if (mix % 4 == 0) return 4;
+  if (mix % 2 == 0) return 2;
+  return 1;
+}
+
+hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream) {
+  if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || !plan.rows)
+    return hipErrorInvalidValue;
+  if (plan.n_rows == 0) return hipSuccess;
+  MoveArgs a;
+  a.n_keys = plan.n_keys;
+  a.n_rows = plan.n_rows;
+  a.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;
+  a.key_is_first = plan.key_is_first;
+  a.key_is_last = plan.key_is_last;
+  a.rows = plan.rows;
+  int64_t blocks = 0;
+  for (int k = 0; k < plan.n_keys; ++k) {
+    a.key[k] = plan.key[k];
+    a.unit[k] = pick_unit(plan.key[k]);
+    a.first_block[k] = static_cast<int32_t>(blocks);
+    if (a.unit[k] == 0) {
+      const int64_t nvec = plan.key[k].rowbytes >> 4;
+      a.tiles_per_row[k] = static_cast<int32_t>((nvec + kTileVec - 1) / kTileVec);
+      blocks += static_cast<int64_t>(plan.n_rows) * a.tiles_per_row[k];
+    } else {
+      a.tiles_per_row[k] = 0;
+      const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes / a.unit[k]);
+      blocks += (units + kThreads - 1) / kThreads;
+    }
+    if (blocks > INT32_MAX) return hipErrorInvalidValue;
+  }
+  a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
+  if (gather)
+    hipLaunchKernelGGL(gather_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(kThreads), 0, stream, a);
+  else
+    hipLaunchKernelGGL(scatter_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- windowing --
+
+__global__ __launch_bounds__(kThreads) void window_kernel(
+    const uint8_t* src, uint8_t* dst, int64_t total, int64_t start, int64_t count,
+    int64_t rowbytes, int unit, int64_t units_per_seq) {
+  const int64_t b = blockIdx.y;
+  const uint8_t* s = src + (b * total + start) * rowbytes;
+  uint8_t* d = dst + b * count * rowbytes;
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+       u < units_per_seq; u += static_cast<int64_t>(gridDim.x) * kThreads)
+    copy_bytes(s + u * unit, d + u * unit, unit);
+}
+
+// ---------------------------------------------------------------- obs stack --
+
+template <typename Out>
+__device__ __forceinline__ Out cvt(uint8_t v, float scale, float offset);
+template <> __device__ __forceinline__ uint8_t cvt<uint8_t>(uint8_t v, float, float) { return v; }
+template <> __device__ __forceinline__ float cvt<float>(uint8_t v, float s, float o) { return fmaf(static_cast<float>(v), s, o); }
+template <> __device__ __forceinline__ __half cvt<__half>(uint8_t v, float s, float o) { return __float2half(fmaf(static_cast<float>(v), s, o)); }
+template <> __device__ __forceinline__ __hip_bfloat16 cvt<__hip_bfloat16>(uint8_t v, float s, float o) { return __float2bfloat16(fmaf(static_cast<float>(v), s, o)); }
+
+template <typename Out>
+struct alignas(4 * sizeof(Out)) Quad { Out v[4]; };
+
+// Each lane owns 4 consecutive pixels of one frame: it reads their 4*C bytes as
+// C dwords (coalesced across lanes) and writes, per channel, one 4-element
+// vector.  Output is (N, C, P) channels-first or (N, P, C) as stored.
+template <typename Out, int C, bool kChannelsFirst>
+__global__ __launch_bounds__(kThreads) void obs_stack_kernel(
+    const uint8_t* src, const int32_t* env_ids, Out* dst, int64_t pixels,
+    float scale, float offset) {
+  const int64_t n = blockIdx.y;
+  const int64_t e = env_ids ? env_ids[n] : n;
+  const int64_t quads = pixels >> 2;
+  const uint32_t* frame = reinterpret_cast<const uint32_t*>(src + e * pixels * C);
+  Out* out = dst + n * pixels * C;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; q < quads;
+       q += static_cast<int64_t>(gridDim.x) * kThreads) {
+    uint32_t w[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[c] = frame[q * C + c];
+    auto byte_at = [&w](int idx) {
+      return static_cast<uint8_t>((w[idx >> 2] >> ((idx & 3) * 8)) & 0xFFu);
+    };
+    if (kChannelsFirst) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        Quad<Out> o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o.v[p] = cvt<Out>(byte_at(p * C + c), scale, offset);
+        *reinterpret_cast<Quad<Out>*>(out + c * pixels + q * 4) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        Quad<Out> o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o.v[p] = cvt<Out>(byte_at(j * 4 + p), scale, offset);
+        *reinterpret_cast<Quad<Out>*>(out + (q * C + j) * 4) = o;
+      }
+    }
+  }
+}
+
+// Any channel count / pixel tail: one element per lane.
+template <typename Out>
+__global__ __launch_bounds__(kThreads) void obs_stack_generic_kernel(
+    const uint8_t* src, const int32_t* env_ids, Out* dst, int64_t pixels,
+    int64_t channels, int layout, float scale, float offset) {
+  const int64_t n = blockIdx.y;
+  const int64_t e = env_ids ? env_ids[n] : n;
+  const int64_t elems = pixels * channels;
+  const uint8_t* frame = src + e * elems;
+  Out* out = dst + n * elems;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < elems;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    int64_t s = i;
+    if (layout == kLayoutChannelsFirst) {
+      const int64_t c = i / pixels, p = i - c * pixels;
+      s = p * channels + c;
+    }
+    out[i] = cvt<Out>(frame[s], scale, offset);
+  }
+}
+
+template <typename Out>
+hipError_t obs_stack_typed(const uint8_t* src, const int32_t* env_ids, void* dst,
+                           int64_t n, int64_t pixels, int64_t channels, int layout,
+                           float scale, float offset, hipStream_t stream) {
+  Out* out = static_cast<Out*>(dst);
+  const bool fast = pixels % 4 == 0 && channels >= 1 && channels <= 4 &&
+                    reinterpret_cast<uint64_t>(src) % 4 == 0 &&
+                    (pixels * channels) % 4 == 0 &&
+                    reinterpret_cast<uint64_t>(dst) % (4 * sizeof(Out)) == 0;
+  if (!fast) {
+    const int64_t elems = pixels * channels;
+    dim3 grid(static_cast<uint32_t>(std::min<int64_t>((elems + kThreads - 1) / kThreads, 64)),
+              static_cast<uint32_t>(n));
+    hipLaunchKernelGGL(obs_stack_generic_kernel<Out>, grid, dim3(kThreads), 0, stream,
+                       src, env_ids, out, pixels, channels, layout, scale, offset);
+    return hipGetLastError();
+  }
+  const int64_t quads = pixels / 4;
+  dim3 grid(static_cast<uint32_t>(std::min<int64_t>((quads + kThreads - 1) / kThreads, 32)),
+            static_cast<uint32_t>(n));
+  const bool cf = layout == kLayoutChannelsFirst && channels > 1;
+#define EMB_OBS(C)                                                                         \
+  if (cf) hipLaunchKernelGGL((obs_stack_kernel<Out, C, true>), grid, dim3(kThreads), 0,   \
+                             stream, src, env_ids, out, pixels, scale, offset);           \
+  else hipLaunchKernelGGL((obs_stack_kernel<Out, C, false>), grid, dim3(kThreads), 0,     \
+                          stream, src, env_ids, out, pixels, scale, offset);
+  switch (channels) {
+    case 1: EMB_OBS(1) break;
+    case 2: EMB_OBS(2) break;
+    case 3: EMB_OBS(3) break;
+    default: EMB_OBS(4) break;
+  }
+#undef EMB_OBS
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------- action mask --
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mask_rows_kernel(
+    T* act, int64_t n, int64_t row_elems, const uint8_t* is_last) {
+  const int64_t total = n * row_elems;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t r = i / row_elems;
+    // value * mask.astype(value.dtype): a real multiply, so -x -> -0.0 and
+    // NaN stays NaN exactly as numpy does (driver.py:84-87).
+    act[i] = act[i] * static_cast<T>(is_last[r] ? 0 : 1);
+  }
+}
+
+template <>
+__global__ __launch_bounds__(kThreads) void mask_rows_kernel<__half>(
+    __half* act, int64_t n, int64_t row_elems, const uint8_t* is_last) {
+  const int64_t total = n * row_elems;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads)
+    act[i] = __float2half(__half2float(act[i]) * (is_last[i / row_elems] ? 0.f : 1.f));
+}
+
+template <>
+__global__ __launch_bounds__(kThreads) void mask_rows_kernel<__hip_bfloat16>(
+    __hip_bfloat16* act, int64_t n, int64_t row_elems, const uint8_t* is_last) {
+  const int64_t total = n * row_elems;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads)
+    act[i] = __float2bfloat16(__bfloat162float(act[i]) * (is_last[i / row_elems] ? 0.f : 1.f));
+}
+
+// ------------------------------------------------------------ return scans --
+//
+// y_t = a_t + b_t * y_{t+1}.  A segment of W lanes owns one row; lane = time
+// step.  Reverse inclusive Kogge-Stone over the affine maps
+// (a1,b1) o (a2,b2) = (a1 + b1*a2, b1*b2) with __shfl_down inside the segment,
+// rows longer than W are walked right-to-left in W-wide pieces with the
+// running y carried in a register.  Episode boundaries need no flags: b_t = 0.
+
+template <int W>
+__device__ __forceinline__ float affine_suffix_scan(float a, float b, int sl, float carry) {
+#pragma unroll
+  for (int off = 1; off < W; off <<= 1) {
+    const float ap = __shfl_down(a, off, W);
+    const float bp = __shfl_down(b, off, W);
+    if (sl + off < W) {
+      a = fmaf(b, ap, a);
+      b = b * bp;
+    }
+  }
+  return fmaf(b, carry, a);
+}
+
+template <int W>
+__global__ __launch_bounds__(kThreads) void gae_kernel(
+    const float* __restrict__ rew, const float* __restrict__ val,
+    const uint8_t* __restrict__ last, const uint8_t* __restrict__ term, int64_t B,
+    int64_t T, float live_scale, float lam, float* __restrict__ adv,
+    float* __restrict__ tar) {
+  const int sl = threadIdx.x % W;
+  const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
+  const bool row_ok = b < B;
+  const int64_t n = T - 1;
+  const int64_t in = b * T, on = b * n;
+  float carry = 0.f;
+  for (int64_t base = ((n - 1) / W) * W; base >= 0; base -= W) {
+    const int64_t t = base + sl;
+    const bool ok = row_ok && t < n;
+    float a = 0.f, bc = 1.f, v0 = 0.f;
+    if (ok) {
+      const bool tm = term[in + t + 1] != 0;
+      const bool ls = last[in + t + 1] != 0;
+      const float live = tm ? 0.f : live_scale;
+      const float cont = (ls || tm) ? 0.f : lam;
+      v0 = val[in + t];
+      a = rew[in + t + 1] + live * val[in + t + 1] - v0;
+      bc = live * cont;
+    }
+    const float y = affine_suffix_scan<W>(a, bc, sl, carry);
+    if (ok) {
+      adv[on + t] = y;
+      tar[on + t] = y + v0;
+    }
+    carry = __shfl(y, 0, W);
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(kThreads) void lambda_return_kernel(
+    const uint8_t* __restrict__ last, const uint8_t* __restrict__ term,
+    const float* __restrict__ rew, const float* __restrict__ boot, int64_t B, int64_t T,
+    float disc, float lam, float* __restrict__ ret) {
+  const int sl = threadIdx.x % W;
+  const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
+  const bool row_ok = b < B;
+  const int64_t n = T - 1;
+  const int64_t in = b * T, on = b * n;
+  float carry = row_ok ? boot[in + T - 1] : 0.f;
+  for (int64_t base = ((n - 1) / W) * W; base >= 0; base -= W) {
+    const int64_t t = base + sl;
+    const bool ok = row_ok && t < n;
+    float a = 0.f, bc = 1.f;
+    if (ok) {
+      const float live = (1.f - static_cast<float>(term[in + t + 1] != 0)) * disc;
+      const float cont = (1.f - static_cast<float>(last[in + t + 1] != 0)) * lam;
+      a = rew[in + t + 1] + (1.f - cont) * live * boot[in + t + 1];
+      bc = live * cont;
+    }
+    const float y = affine_suffix_scan<W>(a, bc, sl, carry);
+    if (ok) ret[on + t] = y;
+    carry = __shfl(y, 0, W);
+  }
+}
+
+// Time-major: lane = batch column (coalesced), the T-step recurrence runs
+// sequentially in the reference's own order.
+__global__ __launch_bounds__(kThreads) void director_score_kernel(
+    const float* __restrict__ rew, const float* __restrict__ cont,
+    const float* __restrict__ value, int64_t T, int64_t B, float discount, float lam,
+    float* __restrict__ ret) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (b >= B) return;
+  float v = value[(T - 1) * B + b];
+  for (int64_t t = T - 2; t >= 0; --t) {
+    const float d = cont[(t + 1) * B + b] * discount;
+    const float interm = rew[t * B + b] + d * value[(t + 1) * B + b] * (1.f - lam);
+    v = interm + d * lam * v;
+    ret[t * B + b] = v;
+  }
+}
+
+// ------------------------------------------------------------ synthetic env --
+
+// Device-resident stand-in for N simulators: the episode logic
+// of envs/dummy.py:38-48 with counter-hash frames, so gathers are verifiable.
+__global__ __launch_bounds__(kThreads) void synth_env_kernel(
+    uint8_t* image, float* reward, uint8_t* is_first, uint8_t* is_last,
+    uint8_t* is_terminal, int64_t frame_bytes, int64_t env0, int64_t episode_len,
+    const uint8_t* reset, int32_t* counters) {
+  const int64_t e = blockIdx.y;
+  __shared__ int32_t s_count;
+  if (threadIdx.x == 0) s_count = counters[2 * e];
+  __syncthreads();
+  int32_t count = s_count;
+  const bool was_done = counters[2 * e + 1] != 0;
+  const bool restart = (reset && reset[e]) || was_done;
+  const int64_t length = episode_len + ((env0 + e) % 8) * 13;
+  count = restart ? 0 : count + 1;
+  const bool done = !restart && count >= length;
+  const uint32_t salt = static_cast<uint32_t>((env0 + e) * 131 + static_cast<int64_t>(count) * 7);
+  // byte i of the frame = (salt + i) & 0xFF, written 16 bytes per lane.
+  uint4* out = reinterpret_cast<uint4*>(image + e * frame_bytes);
+  const int64_t vecs = frame_bytes >> 4;
+  auto word = [salt](int64_t byte0) {
+    const uint32_t x = salt + static_cast<uint32_t>(byte0);
+    return (x & 0xFF) | (((x + 1) & 0xFF) << 8) | (((x + 2) & 0xFF) << 16) | (((x + 3) & 0xFF) << 24);
+  };
+  for (int64_t i = threadIdx.x; i < vecs; i += kThreads)
+    out[i] = make_uint4(word(i * 16), word(i * 16 + 4), word(i * 16 + 8), word(i * 16 + 12));
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    counters[2 * e] = count;
+    counters[2 * e + 1] = done ? 1 : 0;
+    reward[e] = restart ? 0.f : static_cast<float>(count % 7);
+    is_first[e] = restart ? 1 : 0;
+    is_last[e] = done ? 1 : 0;
+    is_terminal[e] = done ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_gather(const MovePlan& plan, hipStream_t stream) {
+  return plan_and_launch(plan, true, stream);
+}
+
+hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream) {
+  return plan_and_launch(plan, false, stream);
+}
+
+hipError_t launch_window(const uint8_t* src, uint8_t* dst, int64_t batch, int64_t total,
+                         int64_t start, int64_t count, int64_t rowbytes,
+                         hipStream_t stream) {
+  if (batch <= 0 || count <= 0) return hipSuccess;
+  const uint64_t mix = reinterpret_cast<uint64_t>(src) | reinterpret_cast<uint64_t>(dst) |
+                       static_cast<uint64_t>(rowbytes);
+  const int unit = mix % 16 == 0 ? 16 : mix % 8 == 0 ? 8 : mix % 4 == 0 ? 4 : mix % 2 == 0 ? 2 : 1;
+  const int64_t units = count * rowbytes / unit;
+  const int64_t bx = std::min<int64_t>((units + kThreads - 1) / kThreads, 1024);
+  hipLaunchKernelGGL(window_kernel, dim3(static_cast<uint32_t>(bx), static_cast<uint32_t>(batch)),
+                     dim3(kThreads), 0, stream, src, dst, total, start, count, rowbytes, unit, units);
+  return hipGetLastError();
+}
+
+hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* dst, int64_t n,
+                            int64_t pixels, int64_t channels, int layout, int out_dtype,
+                            float scale, float offset, hipStream_t stream) {
+  if (n <= 0 || pixels <= 0 || channels <= 0) return hipSuccess;
+  switch (out_dtype) {
+    case kU8: return obs_stack_typed<uint8_t>(src, env_ids, dst, n, pixels, channels, layout, scale, offset, stream);
+    case kF16: return obs_stack_typed<__half>(src, env_ids, dst, n, pixels, channels, layout, scale, offset, stream);
+    case kBF16: return obs_stack_typed<__hip_bfloat16>(src, env_ids, dst, n, pixels, channels, layout, scale, offset, stream);
+    case kF32: return obs_stack_typed<float>(src, env_ids, dst, n, pixels, channels, layout, scale, offset, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_mask_rows(void* act, int64_t n, int64_t row_elems, int dtype,
+                            const uint8_t* is_last, hipStream_t stream) {
+  const int64_t total = n * row_elems;
+  if (total <= 0) return hipSuccess;
+  const dim3 grid(static_cast<uint32_t>(std::min<int64_t>((total + kThreads - 1) / kThreads, 2048)));
+#define EMB_MASK(T) hipLaunchKernelGGL(mask_rows_kernel<T>, grid, dim3(kThreads), 0, stream, static_cast<T*>(act), n, row_elems, is_last)
+  switch (dtype) {
+    case kU8: case kBool: EMB_MASK(uint8_t); break;
+    case kI8: EMB_MASK(int8_t); break;
+    case kI16: EMB_MASK(int16_t); break;
+    case kI32: EMB_MASK(int32_t); break;
+    case kI64: EMB_MASK(int64_t); break;
+    case kF16: EMB_MASK(__half); break;
+    case kBF16: EMB_MASK(__hip_bfloat16); break;
+    case kF32: EMB_MASK(float); break;
+    case kF64: EMB_MASK(double); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef EMB_MASK
+  return hipGetLastError();
+}
+
+namespace {
+inline int scan_width(int64_t n) { return n <= 16 ? 16 : n <= 32 ? 32 : 64; }
+inline dim3 scan_grid(int64_t B, int W) {
+  const int64_t rows_per_block = kThreads / W;
+  return dim3(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
+}
+}  // namespace
+
+hipError_t launch_gae(const float* rew, const float* val, const uint8_t* last,
+                      const uint8_t* term, int64_t B, int64_t T, float live_scale, float lam,
+                      float* adv, float* tar, hipStream_t stream) {
+  if (B <= 0 || T < 2) return hipSuccess;
+  const int W = scan_width(T - 1);
+#define EMB_GAE(W_) hipLaunchKernelGGL(gae_kernel<W_>, scan_grid(B, W_), dim3(kThreads), 0, stream, rew, val, last, term, B, T, live_scale, lam, adv, tar)
+  if (W == 16) EMB_GAE(16); else if (W == 32) EMB_GAE(32); else EMB_GAE(64);
+#undef EMB_GAE
+  return hipGetLastError();
+}
+
+hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term, const float* rew,
+                                const float* boot, int64_t B, int64_t T, float disc, float lam,
+                                float* ret, hipStream_t stream) {
+  if (B <= 0 || T < 2) return hipSuccess;
+  const int W = scan_width(T - 1);
+#define EMB_LAM(W_) hipLaunchKernelGGL(lambda_return_kernel<W_>, scan_grid(B, W_), dim3(kThreads), 0, stream, last, term, rew, boot, B, T, disc, lam, ret)
+  if (W == 16) EMB_LAM(16); else if (W == 32) EMB_LAM(32); else EMB_LAM(64);
+#undef EMB_LAM
+  return hipGetLastError();
+}
+
+hipError_t launch_director_score(const float* rew, const float* cont, const float* value,
+                                 int64_t T, int64_t B, float discount, float lam, float* ret,
+                                 hipStream_t stream) {
+  if (B <= 0 || T < 2) return hipSuccess;
+  hipLaunchKernelGGL(director_score_kernel, dim3(static_cast<uint32_t>((B + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, stream, rew, cont, value, T, B, discount, lam, ret);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, uint8_t* is_last,
+                            uint8_t* is_terminal, int64_t n, int64_t frame_bytes, int64_t env0,
+                            int64_t tick, int64_t episode_len, const uint8_t* reset,
+                            int32_t* counters, hipStream_t stream) {
+  (void)tick;
+  if (n <= 0) return hipSuccess;
+  if (frame_bytes % 16 != 0 || reinterpret_cast<uint64_t>(image) % 16 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(synth_env_kernel, dim3(1, static_cast<uint32_t>(n)), dim3(kThreads), 0, stream,
+                     image, reward, is_first, is_last, is_terminal, frame_bytes, env0,
+                     episode_len, reset, counters);
+  return hipGetLastError();
+}
+
+}  // namespace emb

@@ -1,0 +1,322 @@
+// Host-side integer bookkeeping of the replay buffer: which device row every
+// step lives in, which windows are sampleable items, FIFO eviction, chunk
+// reference counts and the online queue.  Mirrors embodied/core/replay.py
+// (add :77-118, _sample :151-169, _insert :171-179, _remove :181-191,
+// _getseq :193-214, _complete :362-370) and chunk.py's fixed-size chunks, with
+// one change of representation: a chunk's payload is not a numpy dict but one
+// slot of a device pool laid out (n_slots, chunksize, rowbytes) per key, so a
+// step is addressed by the global row  slot * chunksize + index.
+#pragma once
+
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <stdexcept>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "selectors.h"
+
+namespace emb {
+
+struct PoolFull : std::runtime_error {
+  PoolFull() : std::runtime_error("replay chunk pool is full") {}
+};
+
+struct ReplayConfig {
+  int64_t length = 1;
+  int64_t capacity = 0;   // items; 0 = unbounded
+  int64_t chunksize = 1024;
+  int64_t n_slots = 0;    // chunk slots in the device pool
+  bool online = false;
+  uint64_t uid_hi = 0;    // high 64 bits of every chunk uid (replica id)
+};
+
+class ReplayIndex {
+ public:
+  struct Chunk {
+    uint64_t uid = 0;
+    uint64_t succ = 0;
+    int64_t fill = 0;
+    int64_t refs = 0;
+    int64_t slot = -1;
+  };
+  struct Span { uint64_t uid; int64_t slot; int64_t index; int64_t count; };
+  using Pos = std::pair<uint64_t, int64_t>;  // (chunk uid, row in chunk)
+
+  ReplayIndex(const ReplayConfig& cfg, std::shared_ptr<Selector> selector)
+      : cfg_(cfg), selector_(std::move(selector)) {
+    if (cfg_.length < 1 || cfg_.chunksize < 1 || cfg_.n_slots < 1 || cfg_.capacity < 0)
+      throw std::invalid_argument("replay: bad length/chunksize/n_slots/capacity");
+    if (cfg_.n_slots * cfg_.chunksize > INT32_MAX)
+      throw std::invalid_argument("replay: more than 2^31 rows in the pool");
+    for (int64_t s = cfg_.n_slots - 1; s >= 0; --s) free_.push_back(s);
+  }
+
+  const ReplayConfig& config() const { return cfg_; }
+  Selector& selector() { return *selector_; }
+  int64_t size() const { return static_cast<int64_t>(items_.size()); }
+  int64_t free_slots() const { return static_cast<int64_t>(free_.size()); }
+  int64_t next_item() const { return next_item_; }
+
+  void grow(int64_t n_slots) {
+    if (n_slots < cfg_.n_slots) throw std::invalid_argument("replay: pool cannot shrink");
+    if (n_slots * cfg_.chunksize > INT32_MAX)
+      throw std::invalid_argument("replay: more than 2^31 rows in the pool");
+    for (int64_t s = n_slots - 1; s >= cfg_.n_slots; --s) free_.insert(free_.begin(), s);
+    cfg_.n_slots = n_slots;
+  }
+
+  // Upper bound on the chunk slots `add` may take for these workers; lets the
+  // caller fail (PoolFull) before any state changes.
+  int64_t slots_needed(const int64_t* workers, int64_t n) const {
+    int64_t need = 0;
+    std::unordered_map<int64_t, int64_t> seen;  // worker -> simulated index
+    for (int64_t i = 0; i < n; ++i) {
+      auto s = seen.find(workers[i]);
+      int64_t index;
+      if (s != seen.end()) {
+        index = s->second;
+      } else {
+        auto c = cursor_.find(workers[i]);
+        if (c == cursor_.end()) { ++need; index = 0; }
+        else index = c->second.second;
+      }
+      ++index;
+      if (index >= cfg_.chunksize) { ++need; index = 0; }
+      seen[workers[i]] = index;
+    }
+    return need;
+  }
+
+  // replay.py:77-118.  Returns the device row the step's payload goes to.
+  int64_t add(int64_t worker, StepId* stepid) {
+    auto cur = cursor_.find(worker);
+    if (cur == cursor_.end()) {
+      Chunk& c = new_chunk(1);
+      cur = cursor_.emplace(worker, Pos(c.uid, 0)).first;
+    }
+    const uint64_t uid = cur->second.first;
+    int64_t index = cur->second.second;
+    Chunk& chunk = chunks_.at(uid);
+    if (chunk.fill != index) throw std::logic_error("replay: chunk cursor out of sync");
+    *stepid = make_stepid(uid, index);
+    const int64_t row = chunk.slot * cfg_.chunksize + index;
+    chunk.fill += 1;
+    auto& stream = pending_[worker];
+    stream.emplace_back(uid, index);
+    chunk.refs += 1;
+    index += 1;
+    if (index < cfg_.chunksize) cur->second.second = index;
+    else rotate(chunk, worker);
+    if (static_cast<int64_t>(stream.size()) >= cfg_.length) {
+      metrics_[kInserts] += 1;
+      const Pos start = stream.front();
+      stream.pop_front();
+      insert_item(start);
+      if (cfg_.online && steps_seen_[worker] % cfg_.length == 0) fresh_.push_back(start);
+    }
+    if (cfg_.online) steps_seen_[worker] += 1;
+    return row;
+  }
+
+  // replay.py:151-169: one sequence start.  Stale online entries (first chunk
+  // evicted) are dropped and the draw repeated, as the KeyError retry does.
+  Pos draw(int mode_train, bool* from_online) {
+    if (mode_train) metrics_[kSamples] += 1;
+    for (;;) {
+      Pos pos;
+      if (cfg_.online && !fresh_.empty() && mode_train) {
+        pos = fresh_.front();
+        fresh_.pop_front();
+        *from_online = true;
+      } else {
+        pos = items_.at(selector_->sample());
+        *from_online = false;
+      }
+      if (chunks_.count(pos.first)) return pos;
+    }
+  }
+
+  // replay.py:193-214.  False if the first chunk is gone.
+  bool spans(const Pos& pos, int64_t count, std::vector<Span>* out) const {
+    out->clear();
+    auto it = chunks_.find(pos.first);
+    if (it == chunks_.end()) return false;
+    const Chunk* chunk = &it->second;
+    const int64_t have = chunk->fill - pos.second;
+    if (have < 0) return false;
+    if (have >= count) {
+      out->push_back({chunk->uid, chunk->slot, pos.second, count});
+      return true;
+    }
+    out->push_back({chunk->uid, chunk->slot, pos.second, have});
+    int64_t left = count - have;
+    while (left > 0) {
+      auto nx = chunks_.find(chunk->succ);
+      if (nx == chunks_.end()) return false;
+      chunk = &nx->second;
+      const int64_t used = left < chunk->fill ? left : chunk->fill;
+      if (used == 0) return false;
+      out->push_back({chunk->uid, chunk->slot, 0, used});
+      left -= used;
+    }
+    return true;
+  }
+
+  // Device rows of `count` consecutive steps from `pos`; false if evicted (rows
+  // are then filled with -1, which the scatter kernel skips).
+  bool rows(const Pos& pos, int64_t count, int32_t* out) const {
+    if (!spans(pos, count, &scratch_)) {
+      for (int64_t i = 0; i < count; ++i) out[i] = -1;
+      return false;
+    }
+    int64_t at = 0;
+    for (const Span& s : scratch_)
+      for (int64_t i = 0; i < s.count; ++i)
+        out[at++] = static_cast<int32_t>(s.slot * cfg_.chunksize + s.index + i);
+    return true;
+  }
+
+  StepId make_stepid(uint64_t uid, int64_t index) const {
+    StepId s;
+    for (int i = 0; i < 8; ++i) s.b[i] = static_cast<uint8_t>(cfg_.uid_hi >> (56 - 8 * i));
+    for (int i = 0; i < 8; ++i) s.b[8 + i] = static_cast<uint8_t>(uid >> (56 - 8 * i));
+    for (int i = 0; i < 4; ++i) s.b[16 + i] = static_cast<uint8_t>(static_cast<uint32_t>(index) >> (24 - 8 * i));
+    return s;
+  }
+
+  // replay.py:141-144.  False when the id was not issued by this replay.
+  bool parse_stepid(const uint8_t* b, Pos* pos) const {
+    uint64_t hi = 0, lo = 0;
+    uint32_t idx = 0;
+    for (int i = 0; i < 8; ++i) hi = (hi << 8) | b[i];
+    for (int i = 0; i < 8; ++i) lo = (lo << 8) | b[8 + i];
+    for (int i = 0; i < 4; ++i) idx = (idx << 8) | b[16 + i];
+    *pos = Pos(lo, static_cast<int64_t>(idx));
+    return hi == cfg_.uid_hi;
+  }
+
+  void count_updates(int64_t n) { metrics_[kUpdates] += n; }
+
+  // replay.py:58-74 (ram_gb is the caller's: it owns the device pool).
+  void stats(int64_t out[6], bool reset) {
+    out[0] = size();
+    out[1] = static_cast<int64_t>(chunks_.size());
+    out[2] = static_cast<int64_t>(pending_.size());
+    out[3] = metrics_[kInserts];
+    out[4] = metrics_[kSamples];
+    out[5] = metrics_[kUpdates];
+    if (reset) metrics_[0] = metrics_[1] = metrics_[2] = 0;
+  }
+
+  const std::unordered_map<uint64_t, Chunk>& chunks() const { return chunks_; }
+  const std::unordered_map<int64_t, Pos>& cursors() const { return cursor_; }
+
+  // Checkpoint support (replay.py:295-359): close every worker's open chunk.
+  void complete_all() {
+    std::vector<int64_t> workers;
+    for (auto& kv : cursor_)
+      if (chunks_.at(kv.second.first).fill > 0) workers.push_back(kv.first);
+    for (int64_t w : workers) rotate(chunks_.at(cursor_.at(w).first), w);
+  }
+
+  // Re-create a saved chunk (replay.py:347-359): returns its slot.
+  int64_t load_chunk(uint64_t uid, uint64_t succ, int64_t fill) {
+    if (chunks_.count(uid)) throw std::runtime_error("replay: chunk already loaded");
+    if (free_.empty()) throw PoolFull();
+    Chunk c;
+    c.uid = uid;
+    c.succ = succ;
+    c.fill = fill;
+    c.refs = 0;
+    c.slot = free_.back();
+    free_.pop_back();
+    chunks_[uid] = c;
+    if (uid >= next_uid_) next_uid_ = uid + 1;
+    return c.slot;
+  }
+
+  void load_items(uint64_t uid, int64_t amount) {
+    Chunk& c = chunks_.at(uid);
+    c.refs += amount;
+    auto nx = chunks_.find(c.succ);
+    if (nx != chunks_.end()) nx->second.refs += 1;
+    for (int64_t i = 0; i < amount; ++i) insert_item(Pos(uid, i));
+  }
+
+ private:
+  enum { kInserts = 0, kSamples = 1, kUpdates = 2 };
+
+  Chunk& new_chunk(int64_t refs) {
+    if (free_.empty()) throw PoolFull();
+    Chunk c;
+    c.uid = next_uid_++;
+    c.refs = refs;
+    c.slot = free_.back();
+    free_.pop_back();
+    return chunks_[c.uid] = c;
+  }
+
+  // replay.py:362-370
+  void rotate(Chunk& chunk, int64_t worker) {
+    const uint64_t old = chunk.uid;
+    Chunk& succ = new_chunk(2);      // may rehash: re-find `chunk` below
+    Chunk& prev = chunks_.at(old);
+    prev.refs -= 1;
+    prev.succ = succ.uid;
+    cursor_[worker] = Pos(succ.uid, 0);
+  }
+
+  // replay.py:171-179
+  void insert_item(const Pos& start) {
+    while (cfg_.capacity && size() >= cfg_.capacity) evict();
+    const int64_t key = next_item_++;
+    items_[key] = start;
+    if (!spans(start, cfg_.length, &scratch_))
+      throw std::logic_error("replay: inserted window is incomplete");
+    ids_.clear();
+    for (const Span& s : scratch_)
+      for (int64_t i = 0; i < s.count; ++i) ids_.push_back(make_stepid(s.uid, s.index + i));
+    selector_->insert(key, ids_.data(), static_cast<int>(ids_.size()));
+    fifo_.push_back(key);
+  }
+
+  // replay.py:181-191
+  void evict() {
+    const int64_t key = fifo_.front();
+    fifo_.pop_front();
+    selector_->remove(key);
+    auto it = items_.find(key);
+    const uint64_t uid = it->second.first;
+    items_.erase(it);
+    Chunk& chunk = chunks_.at(uid);
+    chunk.refs -= 1;
+    if (chunk.refs < 1) {
+      const uint64_t succ = chunk.succ;
+      free_.push_back(chunk.slot);
+      chunks_.erase(uid);
+      auto nx = chunks_.find(succ);
+      if (nx != chunks_.end()) nx->second.refs -= 1;
+    }
+  }
+
+  ReplayConfig cfg_;
+  std::shared_ptr<Selector> selector_;
+  std::unordered_map<uint64_t, Chunk> chunks_;
+  std::vector<int64_t> free_;
+  std::unordered_map<int64_t, Pos> items_;
+  std::deque<int64_t> fifo_;
+  int64_t next_item_ = 0;
+  uint64_t next_uid_ = 1;
+  std::unordered_map<int64_t, Pos> cursor_;
+  std::unordered_map<int64_t, std::deque<Pos>> pending_;
+  std::unordered_map<int64_t, int64_t> steps_seen_;
+  std::deque<Pos> fresh_;
+  int64_t metrics_[3] = {0, 0, 0};
+  mutable std::vector<Span> scratch_;
+  std::vector<StepId> ids_;
+};
+
+}  // namespace emb

@@ -1,0 +1,257 @@
+/* embodied_hip.h — C ABI of libembodied_hip.so (MI355X / gfx950).
+ *
+ * The reference (danijar/embodied) has no FFI: its boundary is a set of
+ * duck-typed Python protocols (embodied/core/base.py:1-73) implemented in numpy.
+ * This library is the native layer the MI355X build puts UNDER the same Python
+ * classes (embodied_amd.Driver / Replay / selectors / streams / scans).  Every
+ * entry point below names the reference code whose work it takes over.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 ok, <0 error; the message of the
+ *     last error on the calling thread is emb_last_error();
+ *   - no exceptions and no C++/torch types cross the ABI: plain pointers, sizes;
+ *   - device pointers are caller-owned (hipMalloc / torch storage); every launch
+ *     goes to the caller's `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream);
+ *   - handles are internally locked: add / sample / update may be called from
+ *     different host threads (reference: tests/test_replay.py:306-357);
+ *   - "host" arrays are ordinary CPU memory, "device" arrays are HBM;
+ *   - step ids are 20 bytes: 16-byte big-endian chunk uid || 4-byte big-endian
+ *     row-in-chunk (embodied/core/replay.py:90-91).
+ */
+#ifndef EMBODIED_HIP_H_
+#define EMBODIED_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMB_ABI_VERSION 1
+
+#define EMB_OK 0
+#define EMB_ERR_INVALID (-1)   /* bad argument / state                         */
+#define EMB_ERR_HIP (-2)       /* a HIP runtime call failed                     */
+#define EMB_ERR_EMPTY (-3)     /* sampling from an empty selector               */
+#define EMB_ERR_POOL_FULL (-4) /* chunk pool exhausted: grow it and retry       */
+#define EMB_ERR_NOT_FOUND (-5) /* unknown key                                   */
+#define EMB_ERR_INTERNAL (-6)
+
+#define EMB_STEPID_BYTES 20
+
+/* dtype codes (emb_mask_actions, emb_obs_stack) */
+#define EMB_U8 0
+#define EMB_I8 1
+#define EMB_I16 2
+#define EMB_I32 3
+#define EMB_I64 4
+#define EMB_F16 5
+#define EMB_BF16 6
+#define EMB_F32 7
+#define EMB_F64 8
+#define EMB_BOOL 9
+
+#define EMB_LAYOUT_SAME 0           /* (N, P, C) as stored by the envs          */
+#define EMB_LAYOUT_CHANNELS_FIRST 1 /* (N, C, P)                                */
+
+#define EMB_MODE_TRAIN 0
+#define EMB_MODE_REPORT 1
+#define EMB_MODE_EVAL 2
+
+typedef struct emb_rng emb_rng_t;
+typedef struct emb_tree emb_tree_t;
+typedef struct emb_selector emb_selector_t;
+typedef struct emb_replay emb_replay_t;
+
+const char* emb_last_error(void);
+int32_t emb_abi_version(void);
+int32_t emb_device_count(int32_t* count);
+
+/* ---- numpy-compatible PRNG ------------------------------------------------
+ * Replaces numpy.random.default_rng as used by selectors.py:34,42,240,305,212
+ * and the per-batch seeds of embodied/jax/agent.py:405-408.  `words` is the
+ * SeedSequence entropy: a Python int seed split into little-endian u32 words
+ * (a list seed concatenates its elements' words).                            */
+int32_t emb_rng_create(const uint32_t* words, int32_t n_words, emb_rng_t** out);
+int32_t emb_rng_integers(emb_rng_t* rng, int64_t high, int64_t count, int64_t* out);
+int32_t emb_rng_random(emb_rng_t* rng, int64_t count, double* out);
+int32_t emb_rng_choice(emb_rng_t* rng, const double* p, int32_t k, int64_t count, int64_t* out);
+int32_t emb_rng_destroy(emb_rng_t* rng);
+/* ndarray.sum() of a contiguous float64 vector (pairwise), selectors.py:296. */
+int32_t emb_np_sum(const double* values, int64_t n, double* out);
+
+/* ---- SampleTree (selectors.py:231-354) ------------------------------------ */
+int32_t emb_tree_create(int32_t branching, uint64_t seed, emb_tree_t** out);
+int32_t emb_tree_insert(emb_tree_t* tree, int64_t key, double uprob);
+int32_t emb_tree_remove(emb_tree_t* tree, int64_t key);
+int32_t emb_tree_update(emb_tree_t* tree, int64_t key, double uprob);
+int32_t emb_tree_sample(emb_tree_t* tree, int64_t* key);
+int32_t emb_tree_len(emb_tree_t* tree, int64_t* n);
+int32_t emb_tree_root_sum(emb_tree_t* tree, double* total);
+/* leaf depths (root = 0) and node count incl. leaves: what the reference's
+ * tests/test_sampletree.py:18-58 inspect.                                    */
+int32_t emb_tree_shape(emb_tree_t* tree, int64_t cap, int64_t* depths, int64_t* n_leaves,
+                       int64_t* n_nodes);
+int32_t emb_tree_destroy(emb_tree_t* tree);
+
+/* ---- selectors (selectors.py:7-228): __call__/__len__/__setitem__/__delitem__
+ * /prioritize.  Item keys are int64 (Replay's itemid counter).              */
+int32_t emb_selector_create_fifo(emb_selector_t** out);
+int32_t emb_selector_create_uniform(uint64_t seed, emb_selector_t** out);
+int32_t emb_selector_create_prioritized(double exponent, double initial, int32_t zero_on_sample,
+                                        double maxfrac, int32_t branching, uint64_t seed,
+                                        emb_selector_t** out);
+/* members: name-sorted, zero fractions already dropped (selectors.py:205-211);
+ * the mixture shares the members, which stay valid handles of their own.     */
+int32_t emb_selector_create_mixture(emb_selector_t* const* members, const float* fractions,
+                                    int32_t n, uint64_t seed, emb_selector_t** out);
+/* a caller-implemented selector (any Python object with the protocol).       */
+typedef struct {
+  void* user;
+  int64_t (*sample)(void* user);
+  int64_t (*size)(void* user);
+  void (*insert)(void* user, int64_t key, const uint8_t* stepids, int32_t n_steps);
+  void (*remove)(void* user, int64_t key);
+  void (*prioritize)(void* user, const uint8_t* stepids, const double* prios, int64_t n); /* may be NULL */
+} emb_selector_callbacks_t;
+int32_t emb_selector_create_callback(const emb_selector_callbacks_t* cb, emb_selector_t** out);
+int32_t emb_selector_insert(emb_selector_t* sel, int64_t key, const uint8_t* stepids, int32_t n_steps);
+int32_t emb_selector_remove(emb_selector_t* sel, int64_t key);
+int32_t emb_selector_sample(emb_selector_t* sel, int64_t* key);
+int32_t emb_selector_len(emb_selector_t* sel, int64_t* n);
+int32_t emb_selector_prioritize(emb_selector_t* sel, const uint8_t* stepids, const double* prios, int64_t n);
+int32_t emb_selector_destroy(emb_selector_t* sel);
+
+/* ---- Replay (embodied/core/replay.py, chunk.py) ---------------------------
+ * Payload lives in a caller-owned device chunk pool: for key k a buffer of
+ * (n_slots * chunksize) rows of rowbytes[k] bytes.  The library keeps the
+ * integer state (items, FIFO, chunk refcounts, online queue, selector) on the
+ * host and moves rows with HIP kernels.                                      */
+typedef struct {
+  int64_t length;     /* Replay(length=...)                replay.py:16-21     */
+  int64_t capacity;   /* in items; 0 = unbounded                              */
+  int64_t chunksize;  /*                                    chunk.py:13        */
+  int64_t n_slots;    /* chunk slots in the device pool                       */
+  int32_t online;     /*                                    replay.py:39-42    */
+  int32_t reserved;
+  uint64_t uid_hi;    /* high 64 bits of chunk uids (replica id)              */
+} emb_replay_config_t;
+
+/* selector may be NULL: Uniform(seed), as replay.py:26.                      */
+int32_t emb_replay_create(const emb_replay_config_t* cfg, emb_selector_t* selector,
+                          uint64_t seed, emb_replay_t** out);
+int32_t emb_replay_destroy(emb_replay_t* rep);
+/* Column schema, discovered from the first add (chunk.py:43-47).  Keys named
+ * "stepid" (20 B), "is_first", "is_last" (1 B) get their reference meaning.  */
+int32_t emb_replay_set_keys(emb_replay_t* rep, int32_t n_keys, const char* const* names,
+                            const int64_t* rowbytes, void* const* pools);
+/* After the caller re-allocated a larger pool (rows copied by the caller).   */
+int32_t emb_replay_grow(emb_replay_t* rep, int64_t n_slots, void* const* pools);
+
+/* Host-only index steps (no GPU needed; bit-exact with the reference):
+ * add_index    = bookkeeping of Replay.add for n steps, one per workers[i], in
+ *                order (replay.py:77-118); rows_out[i] = pool row to write,
+ *                stepids_out = n x 20 bytes.
+ * sample_index = `batch` sequence draws (replay.py:121-127,151-169,193-214):
+ *                rows_out[batch*length] pool rows, online_out[batch] flags.
+ * resolve      = Replay.update's decode of stepid[i,0] -> `count` pool rows
+ *                (replay.py:139-149,216-235); evicted -> rows -1, found 0.   */
+int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                             int32_t* rows_out, uint8_t* stepids_out);
+int32_t emb_replay_sample_index(emb_replay_t* rep, int64_t batch, int32_t mode,
+                                int32_t* rows_out, uint8_t* online_out);
+int32_t emb_replay_resolve(emb_replay_t* rep, int64_t n, const uint8_t* stepids, int64_t count,
+                           int32_t* rows_out, uint8_t* found_out);
+int32_t emb_replay_prioritize(emb_replay_t* rep, const uint8_t* stepids, const double* prios,
+                              int64_t n);
+int32_t emb_replay_len(emb_replay_t* rep, int64_t* items);
+int32_t emb_replay_sampler_len(emb_replay_t* rep, int64_t* n);
+int32_t emb_replay_free_slots(emb_replay_t* rep, int64_t* n);
+/* out = {items, chunks, streams, inserts, samples, updates} (replay.py:58-74) */
+int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset);
+
+/* Fused device steps: index + row table upload + ONE kernel launch.
+ * add:    src[k] = device (n, rowbytes[k]) for every key except "stepid",
+ *         which the library synthesises (entry ignored).   Replay.add
+ * sample: dst[k] = device (batch, length, rowbytes[k]); is_first / is_last are
+ *         annotated in flight (replay.py:277-292).         Replay.sample
+ * update: stepids = host (B, 20) first step of each row; key_ids/src select the
+ *         columns to overwrite, src[j] = device (B, T, rowbytes).  Replay.update */
+int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                       const void* const* src, void* stream);
+int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
+                          uint8_t* online_out, void* stream);
+int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t* stepids,
+                          int32_t n_keys, const int32_t* key_ids, const void* const* src,
+                          void* stream);
+/* Move rows given an explicit host row table (multi-GPU owner-side gather,
+ * load from disk).                                                           */
+int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n_rows,
+                               int64_t seq_len, void* const* dst, void* stream);
+int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t n_rows,
+                                int32_t n_keys, const int32_t* key_ids, const void* const* src,
+                                void* stream);
+
+/* HIP-event timing of the gather launches issued through this handle (on their
+ * own stream): total milliseconds and launch count since the last reset.     */
+int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable);
+int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* total_ms,
+                                int32_t reset);
+
+/* Checkpoint support (replay.py:294-388): chunk table in/out.                */
+int32_t emb_replay_complete_all(emb_replay_t* rep);
+int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_t* succ,
+                          int64_t* fill, int64_t* slot, int64_t* n);
+int32_t emb_replay_load_chunk(emb_replay_t* rep, uint64_t uid, uint64_t succ, int64_t fill,
+                              int64_t* slot);
+int32_t emb_replay_load_items(emb_replay_t* rep, uint64_t uid, int64_t amount);
+
+/* ---- Driver-side kernels (embodied/core/driver.py:55-87) ------------------ */
+/* np.stack of per-env frames into the policy batch (driver.py:65) fused with
+ * the layout/dtype change the agent applies next (jax/agent.py:230):
+ * src = device (n_envs_total, pixels, channels) u8 slab; batch row j reads env
+ * env_ids[j] (host int32[n], NULL = identity).                               */
+int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_t pixels,
+                      int64_t channels, int32_t layout, int32_t out_dtype, float scale,
+                      float offset, void* dst, void* stream);
+/* acts zeroed where is_last (driver.py:72-74,84-87): act (n, row_elems).     */
+int32_t emb_mask_actions(void* act, int64_t n, int64_t row_elems, int32_t dtype,
+                         const void* is_last, void* stream);
+/* Per-env policy carry rows by env id (embodied/jax/agent.py:173-181,
+ * run/parallel.py:94-104): dst[j] = table[ids[j]] / table[ids[j]] = src[j].  */
+int32_t emb_rows_gather(const void* table, int64_t rowbytes, const int32_t* ids, int64_t n,
+                        void* dst, void* stream);
+int32_t emb_rows_scatter(void* table, int64_t rowbytes, const int32_t* ids, int64_t n,
+                         const void* src, void* stream);
+/* Sequence windowing (streams.py:133-138): src (B, total, rowbytes) ->
+ * dst (B, count, rowbytes) = src[:, start:start+count].                      */
+int32_t emb_window(const void* src, void* dst, int64_t batch, int64_t total, int64_t start,
+                   int64_t count, int64_t rowbytes, void* stream);
+
+/* ---- return scans, float32 on device ------------------------------------- */
+/* PPO GAE (ppo/agent.py:188-201): rew,val (B,T) f32; last,term (B,T) u8 ->
+ * adv,tar (B,T-1).  live_scale = 1 - 1/hor.                                  */
+int32_t emb_scan_gae(const void* rew, const void* val, const void* last, const void* term,
+                     int64_t B, int64_t T, float live_scale, float lam, void* adv, void* tar,
+                     void* stream);
+/* DreamerV3 lambda-return (dreamerv3/agent.py:482-490) -> ret (B,T-1).       */
+int32_t emb_scan_lambda(const void* last, const void* term, const void* rew, const void* boot,
+                        int64_t B, int64_t T, float disc, float lam, void* ret, void* stream);
+/* Director critic target, time-major (director/agent.py:430-445): rew (T-1,B),
+ * cont,value (T,B) -> ret (T-1,B).  discount = 1 - 1/horizon.                */
+int32_t emb_scan_director(const void* rew, const void* cont, const void* value, int64_t T,
+                          int64_t B, float discount, float lam, void* ret, void* stream);
+
+/* ---- synthetic vector env (benchmark / test input) ---------- */
+/* Episode logic of embodied/envs/dummy.py:38-48 for n device-resident envs;
+ * counters = device int32[2n] state; reset = device u8[n] or NULL.           */
+int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_last,
+                           void* is_terminal, int64_t n, int64_t frame_bytes, int64_t env0,
+                           int64_t episode_len, const void* reset, void* counters,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMBODIED_HIP_H_ */

@@ -1,0 +1,202 @@
+"""Host index core of libembodied_hip.so (selectors, SampleTree, ReplayIndex)
+against the golden vectors recorded from the reference and against the oracle.
+No GPU: payload bytes are kept in numpy by a test-side pool so that only the
+C++ integer/float64 bookkeeping is under test here."""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+
+from embodied_amd import _lib, selectors
+from embodied_amd._lib import api
+from oracle import np_oracle
+from tests import adapters, scenarios
+from tests.conftest import assert_same, load_golden
+
+
+class HostReplay:
+  """Drives emb_replay_*_index and mirrors rows into numpy (TEST stand-in for
+  the device pool; the product's Replay moves rows with HIP kernels)."""
+
+  def __init__(self, length, capacity=None, chunksize=1024, online=False,
+               selector=None, seed=0, n_slots=64):
+    self.length, self.chunksize, self.n_slots = length, chunksize, n_slots
+    cfg = _lib.ReplayConfig(length, capacity or 0, chunksize, n_slots, int(online), 0, 0)
+    self.selector = selector
+    self.h = C.c_void_p()
+    api.emb_replay_create(
+        C.byref(cfg), selector._handle if selector is not None else None,
+        seed, C.byref(self.h))
+    self.pool = None
+
+  def __del__(self):
+    api.raw.emb_replay_destroy(self.h)
+
+  def __len__(self):
+    n = C.c_int64()
+    api.emb_replay_len(self.h, C.byref(n))
+    return n.value
+
+  def add(self, step, worker=0):
+    step = {k: np.asarray(v) for k, v in step.items() if not k.startswith('log/')}
+    workers = np.array([worker], np.int64)
+    rows = np.zeros(1, np.int32)
+    sid = np.zeros((1, 20), np.uint8)
+    api.emb_replay_add_index(self.h, 1, _lib.ptr(workers), _lib.ptr(rows), _lib.ptr(sid))
+    step['stepid'] = sid[0]
+    if self.pool is None:
+      self.pool = {k: np.zeros((self.n_slots * self.chunksize, *v.shape), v.dtype)
+                   for k, v in step.items()}
+    for k, v in step.items():
+      self.pool[k][rows[0]] = v
+
+  def sample_rows(self, batch, mode='train'):
+    rows = np.zeros((batch, self.length), np.int32)
+    online = np.zeros(batch, np.uint8)
+    api.emb_replay_sample_index(
+        self.h, batch, _lib.MODES[mode], _lib.ptr(rows), _lib.ptr(online))
+    return rows, online
+
+  def sample(self, batch, mode='train'):
+    rows, _ = self.sample_rows(batch, mode)
+    return np_oracle.annotate({k: v[rows] for k, v in self.pool.items()})
+
+  def update(self, data):
+    data = dict(data)
+    stepid = np.ascontiguousarray(data.pop('stepid'))
+    priority = data.pop('priority', None)
+    if priority is not None:
+      flat = np.ascontiguousarray(stepid.reshape(-1, 20))
+      prios = np.ascontiguousarray(priority, np.float64).reshape(-1)
+      api.emb_replay_prioritize(self.h, _lib.ptr(flat), _lib.ptr(prios), len(prios))
+    if not data:
+      return
+    B = len(stepid)
+    T = len(next(iter(data.values()))[0])
+    first = np.ascontiguousarray(stepid[:, 0])
+    rows = np.zeros((B, T), np.int32)
+    found = np.zeros(B, np.uint8)
+    api.emb_replay_resolve(self.h, B, _lib.ptr(first), T, _lib.ptr(rows), _lib.ptr(found))
+    for b in range(B):
+      if found[b]:
+        for k, v in data.items():
+          self.pool[k][rows[b]] = np.asarray(v)[b]
+
+  def stats(self):
+    out = np.zeros(6, np.int64)
+    api.emb_replay_stats(self.h, _lib.ptr(out), 1)
+    names = ('items', 'chunks', 'streams', 'inserts', 'samples', 'updates')
+    return dict(zip(names, out.tolist()))
+
+
+def host_ns():
+  ns = adapters.oracle_ns()
+  ns.name = 'host-index'
+  ns.Replay = HostReplay
+  ns.Uniform = selectors.Uniform
+  ns.Prioritized = selectors.Prioritized
+  ns.Mixture = selectors.Mixture
+  ns.SampleTree = selectors.SampleTree
+  ns.consec = lambda rep, batch, length, consec, prefix: iter(np_oracle.Consec(
+      lambda: rep.sample(batch, 'train'), length, consec, prefix))
+  return ns
+
+
+HOST_SCENARIOS = [n for n in sorted(scenarios.SCENARIOS) if n != 'driver_script']
+
+
+@pytest.mark.parametrize('name', HOST_SCENARIOS)
+def test_host_index_matches_reference_golden(name):
+  got = scenarios.SCENARIOS[name](host_ns())
+  assert_same(got, load_golden(name), name)
+
+
+def test_foreign_selector_through_callbacks():
+  """Any Python object with the selector protocol can drive the native index."""
+  native = HostReplay(length=3, capacity=9, chunksize=4, seed=5)
+  foreign = HostReplay(length=3, capacity=9, chunksize=4,
+                       selector=selectors.Foreign(np_oracle.Uniform(5)))
+  for t in range(40):
+    for w in range(2):
+      native.add({'t': np.int32(t)}, w)
+      foreign.add({'t': np.int32(t)}, w)
+    assert len(native) == len(foreign)
+  a, _ = native.sample_rows(16)
+  b, _ = foreign.sample_rows(16)
+  assert (a == b).all()
+  foreign.selector.reraise()
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_random_histories_against_oracle(seed):
+  """Fuzz: random worker interleavings, capacities and chunk sizes; every
+  sampled row table must address exactly the steps the oracle returns."""
+  gen = np.random.default_rng(seed)
+  length = int(gen.integers(1, 9))
+  chunksize = int(gen.integers(1, 12))
+  capacity = int(gen.integers(1, 40))
+  online = bool(gen.integers(0, 2))
+  workers = int(gen.integers(1, 6))
+  ours = HostReplay(length, capacity, chunksize, online, seed=seed, n_slots=256)
+  ref = np_oracle.Replay(length, capacity, chunksize, online, seed=seed)
+  clock = [0] * workers
+  for n in range(600):
+    w = int(gen.integers(0, workers))
+    step = {'t': np.int32(clock[w]), 'w': np.int32(w)}
+    clock[w] += 1
+    ours.add(step, w)
+    ref.add(step, w)
+    assert len(ours) == len(ref)
+    if len(ref) and n % 7 == 0:
+      mode = ('train', 'report')[int(gen.integers(0, 2))]
+      got = ours.sample(3, mode)
+      want = ref.sample(3, mode)
+      assert_same(got, want, f'seed{seed} n{n}')
+  got, want = ours.stats(), ref.stats()
+  for k in got:
+    assert got[k] == want[k], k
+
+
+def test_pool_full_is_reported_before_any_change():
+  rep = HostReplay(length=2, capacity=None, chunksize=2, n_slots=2)
+  for t in range(2):
+    rep.add({'t': np.int32(t)}, 0)      # fills slot 0, opens slot 1
+  rep.add({'t': np.int32(2)}, 0)
+  before = len(rep)
+  with pytest.raises(_lib.PoolFull):
+    rep.add({'t': np.int32(3)}, 0)      # would need a third slot
+  assert len(rep) == before
+  api.emb_replay_grow(rep.h, 4, None)
+  rep.pool = {k: np.concatenate([v, np.zeros_like(v)]) for k, v in rep.pool.items()}
+  rep.n_slots = 4
+  rep.add({'t': np.int32(3)}, 0)
+  assert len(rep) == before + 1
+
+
+def test_sampletree_shape_like_reference_tests():
+  """tests/test_sampletree.py:18-58 re-expressed against the native tree."""
+  for branching in (2, 3, 5, 10):
+    for inserts in (1, 2, 10, 100):
+      tree = selectors.SampleTree(branching)
+      for k in range(inserts):
+        tree.insert(k, 1)
+      depths, _ = tree.shape()
+      target = max(1, int(np.ceil(np.log(inserts) / np.log(branching))))
+      assert len(depths) == inserts and (depths == target).all()
+    tree = selectors.SampleTree(branching)
+    assert tree.shape()[1] == 1
+    gen = np.random.default_rng(0)
+    for k in gen.permutation(100):
+      tree.insert(int(k), 1)
+    nodes = tree.shape()[1]
+    for k in gen.permutation(100):
+      tree.remove(int(k))
+    assert tree.shape()[1] == 1 and len(tree) == 0
+    for k in gen.permutation(100):
+      tree.insert(int(k), 1)
+    assert tree.shape()[1] == nodes
+    total = selectors.SampleTree(branching)
+    for k in range(50):
+      assert total.total == sum(range(k))
+      total.insert(k, k)
