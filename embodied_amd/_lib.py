@@ -101,7 +101,7 @@ SIGNATURES = {
     'emb_replay_destroy': [p],
     'emb_replay_set_keys': [p, i32, p, p, p],
     'emb_replay_grow': [p, i64, p],
-    'emb_replay_add_index': [p, i64, p, p, p],
+    'emb_replay_add_index': [p, i64, p, p, p, p],
     'emb_replay_sample_index': [p, i64, i32, p, p],
     'emb_replay_resolve': [p, i64, p, i64, p, p],
     'emb_replay_prioritize': [p, p, p, i64],

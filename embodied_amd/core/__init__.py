@@ -1,3 +1,7 @@
 from .base import Agent, Env, Stream
+from .driver import Driver
+from .random import RandomAgent
+from .replay import Replay
 from . import limiters
 from . import selectors
+from . import streams

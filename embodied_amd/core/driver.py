@@ -1,0 +1,270 @@
+"""Vectorised env loop with the reference's interface
+(embodied/core/driver.py:9-137).
+
+Three ways to run the same loop:
+
+* `Driver(fns, device=None)` — host plumbing exactly like the reference: numpy
+  stack, numpy mask, per-env callbacks (BASELINE config "numpy Driver on CPU").
+* `Driver(fns, device='cuda')` — per-env observations are written into a pinned
+  (N, S) slab, uploaded with one copy per key and handed to the policy as
+  device tensors; the action mask (`emb_mask_actions`) runs on the GPU; the
+  build's own `Replay.add` callback is served by ONE batched scatter per step
+  instead of N Python calls.
+* `Driver(batch_env=env, device='cuda')` — a device-resident vector env
+  (`step(acts) -> dict of (N, ...) tensors`): nothing leaves HBM.
+
+Callbacks registered with `on_step(fn)` keep the reference contract
+`fn(tran, worker, **kwargs)` per env in order; `on_batch(fn)` receives the
+stacked transition once per step.
+"""
+import multiprocessing as mp
+import time
+
+import cloudpickle
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import api
+from . import replay as replaylib
+
+_DTYPE_CODE = {
+    torch.uint8: _lib.U8, torch.int8: _lib.I8, torch.int16: _lib.I16,
+    torch.int32: _lib.I32, torch.int64: _lib.I64, torch.float16: _lib.F16,
+    torch.bfloat16: _lib.BF16, torch.float32: _lib.F32,
+    torch.float64: _lib.F64, torch.bool: _lib.BOOL,
+}
+
+
+def mask_actions(value, is_last):
+  """value * ~is_last in value's dtype (driver.py:72-74, 84-87)."""
+  if torch.is_tensor(value) and value.is_cuda:
+    value = value.contiguous().clone()
+    flags = is_last.contiguous()
+    flags = flags.view(torch.uint8) if flags.dtype == torch.bool else flags
+    n = value.shape[0]
+    api.emb_mask_actions(
+        value.data_ptr(), n, value.numel() // max(n, 1),
+        _DTYPE_CODE[value.dtype], flags.data_ptr(),
+        torch.cuda.current_stream(value.device).cuda_stream)
+    return value
+  if torch.is_tensor(value):
+    value = value.numpy()
+  keep = ~np.asarray(is_last)
+  keep = keep.reshape(keep.shape + (1,) * (value.ndim - keep.ndim))
+  return value * keep.astype(value.dtype)
+
+
+class Driver:
+
+  def __init__(self, make_env_fns=None, parallel=True, device=None,
+               batch_env=None, **kwargs):
+    self.kwargs = kwargs
+    self.device = torch.device(device) if device is not None else None
+    self.batch_env = batch_env
+    self.parallel = parallel and batch_env is None
+    if batch_env is not None:
+      assert self.device is not None and self.device.type == 'cuda'
+      self.length = len(batch_env)
+      self.act_space = batch_env.act_space
+    else:
+      assert len(make_env_fns) >= 1
+      self.length = len(make_env_fns)
+      if self.parallel:
+        context = mp.get_context()
+        self.pipes, pipes = zip(*[context.Pipe() for _ in range(self.length)])
+        fns = [cloudpickle.dumps(fn) for fn in make_env_fns]
+        self.procs = [
+            context.Process(target=_env_server, args=(i, pipe, fn), daemon=True)
+            for i, (fn, pipe) in enumerate(zip(fns, pipes))]
+        [proc.start() for proc in self.procs]
+        self.pipes[0].send(('act_space',))
+        self.act_space = self._receive(self.pipes[0])
+      else:
+        self.envs = [fn() for fn in make_env_fns]
+        self.act_space = self.envs[0].act_space
+    self.callbacks = []
+    self.batch_callbacks = []
+    self.acts = None
+    self.carry = None
+    self._slab = {}
+    self._workers = np.arange(self.length, dtype=np.int64)
+    self.reset()
+
+  # driver.py:34-39
+  def reset(self, init_policy=None):
+    if self.batch_env is not None:
+      self.acts = {
+          k: torch.zeros((self.length, *v.shape), dtype=replaylib._TORCH_OF[np.dtype(v.dtype)],
+                         device=self.device)
+          for k, v in self.act_space.items()}
+      self.acts['reset'] = torch.ones(self.length, dtype=torch.bool, device=self.device)
+    else:
+      self.acts = {
+          k: np.zeros((self.length,) + tuple(v.shape), v.dtype)
+          for k, v in self.act_space.items()}
+      self.acts['reset'] = np.ones(self.length, bool)
+    self.carry = init_policy and init_policy(self.length)
+
+  def close(self):
+    if self.batch_env is not None:
+      getattr(self.batch_env, 'close', lambda: None)()
+    elif self.parallel:
+      [proc.kill() for proc in self.procs]
+    else:
+      [env.close() for env in self.envs]
+
+  def on_step(self, callback):
+    """fn(tran, worker, **kwargs) per env (driver.py:47-48).  A bound
+    `embodied_amd.Replay.add` is recognised and served in batched form."""
+    owner = getattr(callback, '__self__', None)
+    if (self.device is not None and isinstance(owner, replaylib.Replay)
+        and getattr(callback, '__func__', None) is replaylib.Replay.add):
+      self.batch_callbacks.append(
+          lambda trans, workers, **kw: owner.add_batch(trans, workers))
+    else:
+      self.callbacks.append(callback)
+
+  def on_batch(self, callback):
+    """fn(trans, workers, **kwargs) once per step with (N, ...) values."""
+    self.batch_callbacks.append(callback)
+
+  def __call__(self, policy, steps=0, episodes=0):
+    step, episode = 0, 0
+    while step < steps or episode < episodes:
+      step, episode = self._step(policy, step, episode)
+
+  # driver.py:55-82
+  def _step(self, policy, step, episode):
+    acts = self.acts
+    assert all(len(x) == self.length for x in acts.values())
+    if self.batch_env is not None:
+      obs = self.batch_env.step(acts)
+    else:
+      host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
+      assert all(isinstance(v, np.ndarray) for v in host.values())
+      per_env = [{k: v[i] for k, v in host.items()} for i in range(self.length)]
+      if self.parallel:
+        [pipe.send(('step', act)) for pipe, act in zip(self.pipes, per_env)]
+        results = [self._receive(pipe) for pipe in self.pipes]
+      else:
+        results = [env.step(act) for env, act in zip(self.envs, per_env)]
+      obs = self._stack(results)
+    logs = {k: v for k, v in obs.items() if k.startswith('log/')}
+    obs = {k: v for k, v in obs.items() if not k.startswith('log/')}
+    assert all(len(x) == self.length for x in obs.values()), obs
+    self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
+    assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
+    is_last = obs['is_last']
+    if self.device is not None:
+      acts = {k: self._to_device(v) for k, v in acts.items()}
+      outs = {k: self._to_device(v) for k, v in outs.items()}
+      if self.batch_env is not None:
+        # No host sync: mask unconditionally (a no-op when nothing ended).
+        acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
+        ended = None
+      else:
+        ended = self._host_flags['is_last']
+        if ended.any():
+          acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
+      self.acts = {**acts, 'reset': is_last.clone()}
+    else:
+      ended = is_last
+      if ended.any():
+        acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
+      self.acts = {**acts, 'reset': is_last.copy()}
+    trans = {**obs, **acts, **outs, **logs}
+    for fn in self.batch_callbacks:
+      fn(trans, self._workers, **self.kwargs)
+    if self.callbacks:
+      for i in range(self.length):
+        tran = {k: v[i] for k, v in trans.items()}
+        [fn(tran, i, **self.kwargs) for fn in self.callbacks]
+    step += self.length
+    if ended is None:
+      # Device env: count episodes lazily (one scalar readback per step only
+      # if the caller asked to stop on episodes).
+      episode = episode
+      self._pending_last = is_last
+    else:
+      episode += int(ended.sum())
+    return step, episode
+
+  def _to_device(self, value):
+    if torch.is_tensor(value):
+      return value.to(self.device, non_blocking=True)
+    return torch.from_numpy(np.ascontiguousarray(value)).to(self.device, non_blocking=True)
+
+  def _stack(self, results):
+    """np.stack of the per-env dicts (driver.py:65).  In device mode rows are
+    written straight into a pinned (N, ...) slab per key and uploaded with one
+    async copy each."""
+    keys = results[0].keys()
+    if self.device is None:
+      return {k: np.stack([r[k] for r in results]) for k in keys}
+    out, self._host_flags = {}, {}
+    for k in keys:
+      first = np.asarray(results[0][k])
+      slab = self._slab.get(k)
+      if slab is None or slab[1].shape[1:] != first.shape or slab[1].dtype != first.dtype:
+        pinned = torch.empty(
+            (self.length, *first.shape), dtype=replaylib._TORCH_OF[first.dtype]).pin_memory()
+        slab = self._slab[k] = (pinned, pinned.numpy())
+      pinned, view = slab
+      for i, r in enumerate(results):
+        view[i] = r[k]
+      if k in ('is_first', 'is_last', 'is_terminal'):
+        self._host_flags[k] = view.copy()
+      out[k] = pinned.to(self.device, non_blocking=True)
+    # The slab is overwritten by the next step's env results: uploads must be
+    # done by then.  One event wait per step, not per key.
+    torch.cuda.current_stream(self.device).synchronize()
+    return out
+
+  def _receive(self, pipe):
+    try:
+      msg, arg = pipe.recv()
+      if msg == 'error':
+        raise RuntimeError(arg)
+      assert msg == 'result'
+      return arg
+    except Exception:
+      print('Terminating workers due to an exception.')
+      [proc.kill() for proc in self.procs]
+      raise
+
+
+def _env_server(envid, pipe, ctor):
+  """Worker process: ('step', act) -> ('result', obs) (driver.py:101-137)."""
+  env = None
+  try:
+    env = cloudpickle.loads(ctor)()
+    while True:
+      if not pipe.poll(0.1):
+        continue
+      try:
+        msg, *args = pipe.recv()
+      except EOFError:
+        return
+      if msg == 'step':
+        pipe.send(('result', env.step(args[0])))
+      elif msg == 'obs_space':
+        pipe.send(('result', env.obs_space))
+      elif msg == 'act_space':
+        pipe.send(('result', env.act_space))
+      else:
+        raise ValueError(f'Invalid message {msg}')
+  except (ConnectionResetError, BrokenPipeError):
+    print('Connection to driver lost')
+  except Exception as e:
+    try:
+      pipe.send(('error', e))
+    except Exception:
+      pass
+    raise
+  finally:
+    try:
+      env and env.close()
+    except Exception:
+      pass
+    pipe.close()

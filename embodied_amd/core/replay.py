@@ -1,0 +1,398 @@
+"""Replay buffer with the reference's interface (embodied/core/replay.py:14-127)
+on an HBM-resident chunk pool.
+
+Layout: for every key one device buffer of `n_slots * chunksize` rows of
+`rowbytes` bytes — the reference's `Chunk` dict of numpy arrays
+(embodied/core/chunk.py:43-47) flattened into one pool per key.  A step lives at
+row `slot * chunksize + index`.  All integer state (items, FIFO, refcounts,
+online queue, selector, PRNG) is in the host index core of libembodied_hip.so;
+payload moves with three kernels: scatter (add), gather (sample, with the
+is_first / is_last annotation fused) and scatter (update).
+
+`sample()` returns torch tensors on the replay's device (set `numpy=True` for
+host arrays like the reference's).  There is no CPU implementation.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import api
+from . import limiters
+from . import selectors as selectorlib
+
+_TORCH_OF = {
+    np.dtype(np.uint8): torch.uint8, np.dtype(np.int8): torch.int8,
+    np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32,
+    np.dtype(np.int64): torch.int64, np.dtype(np.float16): torch.float16,
+    np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+    np.dtype(np.bool_): torch.bool, np.dtype(np.uint16): torch.uint16,
+    np.dtype(np.uint32): torch.uint32, np.dtype(np.uint64): torch.uint64,
+}
+_ITEMSIZE = {torch.bfloat16: 2}
+
+
+def _itemsize(dtype):
+  return _ITEMSIZE.get(dtype) or torch.empty((), dtype=dtype).element_size()
+
+
+class _Key:
+  __slots__ = ('name', 'dtype', 'shape', 'rowbytes', 'pool', 'stage', 'stage_np')
+
+  def __init__(self, name, dtype, shape):
+    self.name = name
+    self.dtype = dtype              # torch dtype
+    self.shape = tuple(shape)
+    self.rowbytes = _itemsize(dtype) * int(np.prod(shape, dtype=np.int64))
+    self.pool = None                # uint8 (rows * rowbytes,) on device
+    self.stage = None               # pinned uint8 (stage_rows, rowbytes)
+
+
+class Replay:
+
+  def __init__(
+      self, length, capacity=None, directory=None, chunksize=1024,
+      online=False, selector=None, save_wait=False, name='unnamed', seed=0,
+      device='cuda', numpy=False, slots=None, stage_rows=256, replica=0):
+    self.length = int(length)
+    self.capacity = capacity and int(capacity)
+    self.chunksize = int(chunksize)
+    self.name = name
+    self.online = online
+    self.device = torch.device(device)
+    if self.device.type != 'cuda':
+      raise RuntimeError(
+          'embodied_amd.Replay keeps its chunk pool in HBM and moves it with '
+          f'HIP kernels; device={device!r} is not a GPU (no CPU fallback).')
+    self.numpy = numpy
+    self.save_wait = save_wait
+    self.directory = directory
+    # `selector or Uniform(seed)` in the reference (replay.py:26) silently drops
+    # an empty selector that defines __len__; test for None instead.
+    if selector is None:
+      selector = selectorlib.Uniform(seed)
+    self.sampler = selector
+    self._native = selectorlib._as_native(selector)
+    if slots is None:
+      slots = 64
+      if self.capacity:
+        slots = -(-(self.capacity + self.length) // self.chunksize) + 130
+    self._slots = int(slots)
+    cfg = _lib.ReplayConfig(
+        self.length, self.capacity or 0, self.chunksize, self._slots,
+        int(bool(online)), 0, int(replica))
+    self._handle = C.c_void_p()
+    api.emb_replay_create(
+        C.byref(cfg), self._native._handle, int(seed), C.byref(self._handle))
+    self._keys = None
+    self._keyid = {}
+    self._lock = threading.RLock()
+    self._stage_rows = int(stage_rows)
+    self._staged = 0
+    self._stage_dst = np.zeros(self._stage_rows, np.int32)
+    self._one_worker = np.zeros(1, np.int64)
+    self._one_row = np.zeros(1, np.int32)
+    self._one_sid = np.zeros((1, _lib.STEPID_BYTES), np.uint8)
+    self._new_chunks = C.c_int32()
+    self._saved = set()
+    self._updates = 0
+
+  def __del__(self):
+    handle, self._handle = getattr(self, '_handle', None), None
+    if handle is not None and api is not None:
+      api.raw.emb_replay_destroy(handle)
+
+  # ------------------------------------------------------------------ state --
+
+  def __len__(self):
+    n = C.c_int64()
+    api.emb_replay_len(self._handle, C.byref(n))
+    return n.value
+
+  def _stream(self):
+    return torch.cuda.current_stream(self.device).cuda_stream
+
+  def stats(self):
+    """replay.py:58-74 (counters reset on read)."""
+    out = np.zeros(6, np.int64)
+    api.emb_replay_stats(self._handle, _lib.ptr(out), 1)
+    items, chunks, streams, inserts, samples, _ = out.tolist()
+    updates, self._updates = self._updates, 0
+    rowbytes = sum(k.rowbytes for k in self._keys) if self._keys else 0
+    return {
+        'items': items,
+        'chunks': chunks,
+        'streams': streams,
+        'ram_gb': chunks * self.chunksize * rowbytes / 1024 ** 3,
+        'inserts': inserts,
+        'samples': samples,
+        'updates': updates,
+        'replay_ratio': self.length * samples / inserts if inserts else np.nan,
+    }
+
+  # ----------------------------------------------------------------- schema --
+
+  def _init_keys(self, example):
+    """Keys, dtypes and shapes are fixed by the first step (chunk.py:43-47)."""
+    keys = []
+    for name, value in example.items():
+      if torch.is_tensor(value):
+        keys.append(_Key(name, value.dtype, value.shape))
+      else:
+        value = np.asarray(value)
+        if value.dtype not in _TORCH_OF:
+          raise TypeError(f'replay key {name!r}: unsupported dtype {value.dtype}')
+        keys.append(_Key(name, _TORCH_OF[value.dtype], value.shape))
+    keys.append(_Key('stepid', torch.uint8, (_lib.STEPID_BYTES,)))
+    rows = self._slots * self.chunksize
+    for key in keys:
+      key.pool = torch.empty(rows * key.rowbytes, dtype=torch.uint8, device=self.device)
+      key.stage = torch.empty(
+          (self._stage_rows, key.rowbytes), dtype=torch.uint8).pin_memory()
+      key.stage_np = key.stage.numpy()
+    self._keys = keys
+    self._keyid = {k.name: i for i, k in enumerate(keys)}
+    self._push_keys()
+
+  def _push_keys(self):
+    n = len(self._keys)
+    names = (C.c_char_p * n)(*[k.name.encode() for k in self._keys])
+    rowbytes = (C.c_int64 * n)(*[k.rowbytes for k in self._keys])
+    pools = (C.c_void_p * n)(*[k.pool.data_ptr() for k in self._keys])
+    api.emb_replay_set_keys(self._handle, n, names, rowbytes, pools)
+
+  def _grow(self, at_least=0):
+    """Pool exhausted: double it, copying the live rows device-to-device."""
+    new_slots = max(2 * self._slots, self._slots + at_least + 2)
+    if self._keys is not None:
+      rows = new_slots * self.chunksize
+      for key in self._keys:
+        bigger = torch.empty(rows * key.rowbytes, dtype=torch.uint8, device=self.device)
+        bigger[:key.pool.numel()].copy_(key.pool)
+        key.pool = bigger
+      pools = (C.c_void_p * len(self._keys))(*[k.pool.data_ptr() for k in self._keys])
+      api.emb_replay_grow(self._handle, new_slots, pools)
+    else:
+      api.emb_replay_grow(self._handle, new_slots, None)
+    self._slots = new_slots
+
+  # -------------------------------------------------------------------- add --
+
+  def add(self, step, worker=0):
+    """One step of one worker stream (replay.py:77-118).  Host values are
+    staged in pinned memory and written to HBM by one scatter launch per
+    `stage_rows` steps (or at the next sample/update); device tensors go through
+    `add_batch`."""
+    step = {k: v for k, v in step.items() if not k.startswith('log/')}
+    if any(torch.is_tensor(v) and v.is_cuda for v in step.values()):
+      batch = {k: (v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v)))[None]
+               for k, v in step.items()}
+      return self.add_batch(batch, [worker])
+    with self._lock:
+      if self._keys is None:
+        self._init_keys(step)
+      self._one_worker[0] = worker
+      while True:
+        try:
+          api.emb_replay_add_index(
+              self._handle, 1, _lib.ptr(self._one_worker), _lib.ptr(self._one_row),
+              _lib.ptr(self._one_sid), C.byref(self._new_chunks))
+          break
+        except _lib.PoolFull:
+          self._flush()
+          self._grow()
+      self._reraise()
+      slot = self._staged
+      if len(step) + 1 != len(self._keys):
+        raise KeyError(f'replay step keys {sorted(step)} differ from the first step')
+      for name, value in step.items():
+        key = self._keys[self._keyid[name]]
+        value = np.asarray(value)
+        if value.shape != key.shape:
+          raise ValueError((name, value.shape, key.shape))
+        key.stage_np[slot] = np.ascontiguousarray(value).astype(
+            _numpy_of(key.dtype), copy=False).reshape(-1).view(np.uint8)
+      self._keys[-1].stage_np[slot] = self._one_sid[0]
+      self._stage_dst[slot] = self._one_row[0]
+      self._staged += 1
+      if self._staged == self._stage_rows or self._new_chunks.value:
+        self._flush()
+
+  def _flush(self):
+    """Pinned staging -> HBM: one H2D copy per key, one scatter launch."""
+    n = self._staged
+    if not n:
+      return
+    srcs = []
+    for key in self._keys:
+      srcs.append(key.stage[:n].to(self.device, non_blocking=True))
+    ids = (C.c_int32 * len(self._keys))(*range(len(self._keys)))
+    ptrs = (C.c_void_p * len(self._keys))(*[s.data_ptr() for s in srcs])
+    rows = self._stage_dst[:n].copy()
+    api.emb_replay_scatter_rows(
+        self._handle, _lib.ptr(rows), n, len(self._keys), ids, ptrs, self._stream())
+    # The pinned rows are reused by the next add: wait for the H2D copies.
+    torch.cuda.current_stream(self.device).synchronize()
+    self._staged = 0
+
+  def add_batch(self, steps, workers):
+    """N steps, one per listed worker, from (N, ...) arrays or device tensors:
+    one host call, one scatter launch.  Equivalent to N `add` calls in order."""
+    steps = {k: v for k, v in steps.items() if not k.startswith('log/')}
+    workers = np.ascontiguousarray(workers, np.int64)
+    n = len(workers)
+    with self._lock:
+      if self._keys is None:
+        self._init_keys({
+            k: (v[0] if torch.is_tensor(v) else np.asarray(v)[0])
+            for k, v in steps.items()})
+      self._flush()
+      if len(steps) + 1 != len(self._keys):
+        raise KeyError(f'replay step keys {sorted(steps)} differ from the first step')
+      ptrs = (C.c_void_p * len(self._keys))()
+      keep = []
+      for name, value in steps.items():
+        i = self._keyid[name]
+        key = self._keys[i]
+        if not torch.is_tensor(value):
+          value = torch.from_numpy(np.ascontiguousarray(value))
+        if tuple(value.shape) != (n, *key.shape):
+          raise ValueError((name, tuple(value.shape), (n, *key.shape)))
+        value = value.to(self.device, key.dtype, non_blocking=True).contiguous()
+        keep.append(value)
+        ptrs[i] = value.data_ptr()
+      while True:
+        try:
+          api.emb_replay_add(self._handle, n, _lib.ptr(workers), ptrs, self._stream())
+          break
+        except _lib.PoolFull:
+          self._grow(2 * n)
+      self._reraise()
+
+  # ----------------------------------------------------------------- sample --
+
+  def sample(self, batch, mode='train'):
+    """`batch` sequences of `length` steps -> dict of (batch, length, ...)
+    (replay.py:121-127): index draws on the host, one gather launch."""
+    assert mode in _lib.MODES, mode
+    limiters.wait(
+        lambda: len(self._native), f'Replay buffer {self.name} is empty')
+    with self._lock:
+      self._flush()
+      out, ptrs = self._alloc_batch(batch, self.length)
+      api.emb_replay_sample(
+          self._handle, batch, _lib.MODES[mode], ptrs, None, self._stream())
+      self._reraise()
+    return self._finish(out)
+
+  def _alloc_batch(self, batch, length):
+    out, ptrs = {}, (C.c_void_p * len(self._keys))()
+    for i, key in enumerate(self._keys):
+      out[key.name] = torch.empty(
+          (batch, length, *key.shape), dtype=key.dtype, device=self.device)
+      ptrs[i] = out[key.name].data_ptr()
+    return out, ptrs
+
+  def _finish(self, out):
+    if self.numpy:
+      return {k: v.cpu().numpy() for k, v in out.items()}
+    return out
+
+  def sample_index(self, batch, mode='train'):
+    """Index-only draw: (batch, length) pool rows and the came-from-online-queue
+    flags.  Advances the PRNG exactly like `sample`."""
+    rows = np.zeros((batch, self.length), np.int32)
+    online = np.zeros(batch, np.uint8)
+    with self._lock:
+      api.emb_replay_sample_index(
+          self._handle, batch, _lib.MODES[mode], _lib.ptr(rows), _lib.ptr(online))
+      self._reraise()
+    return rows, online.astype(bool)
+
+  def gather(self, rows):
+    """Materialise an explicit (batch, length) row table (owner-side gather in
+    the sharded layout; also used when loading)."""
+    rows = np.ascontiguousarray(rows, np.int32)
+    batch, length = rows.shape
+    with self._lock:
+      self._flush()
+      out, ptrs = self._alloc_batch(batch, length)
+      api.emb_replay_gather_rows(
+          self._handle, _lib.ptr(rows), rows.size, length, ptrs, self._stream())
+    return self._finish(out)
+
+  # ----------------------------------------------------------------- update --
+
+  def update(self, data):
+    """Write agent outputs back over sampled steps and/or re-prioritise
+    (replay.py:129-149).  Rows whose first chunk was evicted are skipped."""
+    data = dict(data)
+    stepid = data.pop('stepid')
+    priority = data.pop('priority', None)
+    if torch.is_tensor(stepid):
+      stepid = stepid.detach().cpu().numpy()
+    stepid = np.ascontiguousarray(stepid, np.uint8)
+    assert stepid.ndim == 3, stepid.shape
+    B = stepid.shape[0]
+    with self._lock:
+      self._flush()
+      if priority is not None:
+        if torch.is_tensor(priority):
+          priority = priority.detach().cpu().numpy()
+        assert np.ndim(priority) == 2, np.shape(priority)
+        prios = np.ascontiguousarray(priority, np.float64).reshape(-1)
+        flat = stepid.reshape(-1, stepid.shape[-1])
+        if not hasattr(self.sampler, 'prioritize'):
+          raise AttributeError(       # what replay.py:137 raises
+              f'{type(self.sampler).__name__!r} object has no attribute '
+              "'prioritize'")
+        api.emb_replay_prioritize(
+            self._handle, _lib.ptr(flat), _lib.ptr(prios), len(prios))
+        self._reraise()
+      if data:
+        T = None
+        ids = (C.c_int32 * len(data))()
+        ptrs = (C.c_void_p * len(data))()
+        keep = []
+        for j, (name, value) in enumerate(data.items()):
+          key = self._keys[self._keyid[name]]
+          if not torch.is_tensor(value):
+            value = torch.from_numpy(np.ascontiguousarray(value))
+          value = value.to(self.device, key.dtype, non_blocking=True).contiguous()
+          T = value.shape[1] if T is None else T
+          if tuple(value.shape) != (B, T, *key.shape):
+            raise ValueError((name, tuple(value.shape), (B, T, *key.shape)))
+          keep.append(value)
+          ids[j] = self._keyid[name]
+          ptrs[j] = value.data_ptr()
+        first = np.ascontiguousarray(stepid[:, 0])
+        api.emb_replay_update(
+            self._handle, B, T, _lib.ptr(first), len(data), ids, ptrs,
+            self._stream())
+      # replay.py:134: every call counts B*T steps, written or not.
+      self._updates += int(np.prod(stepid.shape[:-1]))
+
+  def _reraise(self):
+    if isinstance(self._native, selectorlib.Foreign):
+      self._native.reraise()
+
+  # ------------------------------------------------------------- profiling --
+
+  def profile(self, enable=True):
+    """HIP-event timing of this replay's gather launches (bench roofline)."""
+    api.emb_replay_profile(self._handle, int(enable))
+
+  def profile_read(self, reset=True):
+    launches, ms = C.c_int64(), C.c_double()
+    api.emb_replay_profile_read(
+        self._handle, C.byref(launches), C.byref(ms), int(reset))
+    return launches.value, ms.value
+
+
+def _numpy_of(dtype):
+  for np_dtype, t in _TORCH_OF.items():
+    if t == dtype:
+      return np_dtype
+  raise TypeError(dtype)

@@ -1,0 +1,168 @@
+"""Batch streams (reference: embodied/core/streams.py): `Stateless` wraps a
+sampling function, `Consec` serves one long sampled batch as consecutive
+overlapping windows, `Prefetch` runs a source one batch ahead in a thread.
+
+Batches may be dicts of numpy arrays or of torch device tensors; for device
+tensors the window copy is the `emb_window` kernel (one launch per key).
+"""
+import functools
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import api
+from . import base
+
+
+class Stateless(base.Stream):
+  """streams.py:12-29."""
+
+  def __init__(self, nextfn, *args, **kwargs):
+    if not callable(nextfn) and hasattr(nextfn, '__next__'):
+      nextfn = nextfn.__next__
+    self.nextfn = functools.partial(nextfn, *args, **kwargs)
+
+  def __iter__(self):
+    return self
+
+  def __next__(self):
+    return self.nextfn()
+
+  def save(self):
+    return None
+
+  def load(self, data):
+    pass
+
+
+def window(value, start, count):
+  """value[:, start:start+count] as a contiguous array (streams.py:133-138)."""
+  if not torch.is_tensor(value):
+    return np.ascontiguousarray(value[:, start: start + count])
+  if start == 0 and count == value.shape[1]:
+    return value if value.is_contiguous() else value.contiguous()
+  if not value.is_cuda:
+    return value[:, start: start + count].contiguous()
+  value = value.contiguous()
+  out = torch.empty(
+      (value.shape[0], count, *value.shape[2:]), dtype=value.dtype,
+      device=value.device)
+  rowbytes = value.element_size() * int(np.prod(value.shape[2:], dtype=np.int64))
+  api.emb_window(
+      value.data_ptr(), out.data_ptr(), value.shape[0], value.shape[1], start,
+      count, rowbytes, torch.cuda.current_stream(value.device).cuda_stream)
+  return out
+
+
+class Consec(base.Stream):
+  """Sequence windowing (streams.py:89-150): a source batch of
+  `consec * length + prefix` steps is served as `consec` windows
+  `[:, i*length : i*length + length + prefix]`, each with an int32 `consec` key
+  holding the window number; the prefix columns of successive windows overlap."""
+
+  def __init__(
+      self, source, length, consec, prefix=0, strict=True, contiguous=False):
+    self.source = source
+    self.length = length
+    self.consec = consec
+    self.prefix = prefix
+    self.strict = strict
+    self.contiguous = contiguous
+    self.index = 0
+    self.current = None
+    self.it = None
+
+  def __iter__(self):
+    self.it = iter(self.source)
+    return self
+
+  def __next__(self):
+    if self.index >= self.consec:
+      self.index = 0
+    if self.index == 0:
+      self.current = next(self.it)
+      have = self.current['is_first'].shape[1]
+      need = self.length * self.consec + self.prefix
+      assert need <= have, (self.length, self.consec, self.prefix, have)
+      if self.strict:
+        assert need == have, (self.consec, self.length, self.prefix, have)
+    start = self.index * self.length
+    count = self.length + self.prefix
+    first = self.current['is_first']
+    if torch.is_tensor(first):
+      # Device batches are always materialised contiguously (one kernel per
+      # key); `contiguous` only matters for numpy views.
+      chunk = {k: window(v, start, count) for k, v in self.current.items()}
+      chunk['consec'] = torch.full(
+          chunk['is_first'].shape, self.index, dtype=torch.int32,
+          device=first.device)
+    else:
+      chunk = {k: v[:, start: start + count] for k, v in self.current.items()}
+      chunk['consec'] = np.full(chunk['is_first'].shape, self.index, np.int32)
+      if self.contiguous:
+        chunk = {k: np.ascontiguousarray(v) for k, v in chunk.items()}
+    self.index += 1
+    return chunk
+
+  def save(self):
+    return {'source': self.source.save(), 'index': self.index}
+
+  def load(self, data):
+    self.source.load(data['source'])
+    self.index = data['index']
+
+
+class Prefetch(base.Stream):
+  """`amount`-deep pipeline: a daemon thread pulls from the source and applies
+  `transform` ahead of the consumer (streams.py:32-86)."""
+
+  def __init__(self, source, transform=None, amount=1):
+    self.source = iter(source) if hasattr(source, '__iter__') else source()
+    self.transform = transform or (lambda x: x)
+    self.state = self._getstate()
+    self.requests = threading.Semaphore(amount)
+    self.amount = amount
+    self.queue = queue.Queue()
+    self.worker = threading.Thread(target=self._worker, daemon=True)
+    self.started = False
+
+  def __iter__(self):
+    assert not self.started
+    self.worker.start()
+    self.started = True
+    return self
+
+  def __next__(self):
+    assert self.started
+    result = self.queue.get()
+    self.requests.release()
+    if isinstance(result, BaseException):
+      raise RuntimeError(str(result)) from result
+    data, self.state = result
+    return data
+
+  def save(self):
+    return self.state
+
+  def load(self, state):
+    if self.started:
+      for _ in range(self.amount):
+        self.queue.get()
+    self.source.load(state)
+    if self.started:
+      self.requests.release(self.amount)
+
+  def _worker(self):
+    try:
+      while True:
+        self.requests.acquire()
+        data = self.transform(next(self.source))
+        self.queue.put((data, self._getstate()))
+    except BaseException as e:
+      self.queue.put(e)
+
+  def _getstate(self):
+    return self.source.save() if hasattr(self.source, 'save') else None

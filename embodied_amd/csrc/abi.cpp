@@ -491,12 +491,14 @@ static void sample_index_locked(emb_replay* rep, int64_t batch, int32_t mode, in
 }
 
 int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* workers,
-                             int32_t* rows_out, uint8_t* stepids_out) {
+                             int32_t* rows_out, uint8_t* stepids_out, int32_t* new_chunks_out) {
   REP_OP({
     need(n >= 0 && workers && rows_out, "add_index: bad arguments");
     rep->ids.resize(n);
+    const int64_t before = rep->index->chunks_opened();
     add_index_locked(rep, n, workers, rows_out, rep->ids.data());
     if (stepids_out) std::memcpy(stepids_out, rep->ids.data(), n * EMB_STEPID_BYTES);
+    if (new_chunks_out) *new_chunks_out = static_cast<int32_t>(rep->index->chunks_opened() - before);
   });
 }
 

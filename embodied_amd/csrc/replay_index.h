@@ -51,7 +51,7 @@ class ReplayIndex {
       throw std::invalid_argument("replay: bad length/chunksize/n_slots/capacity");
     if (cfg_.n_slots * cfg_.chunksize > INT32_MAX)
       throw std::invalid_argument("replay: more than 2^31 rows in the pool");
-    for (int64_t s = cfg_.n_slots - 1; s >= 0; --s) free_.push_back(s);
+    for (int64_t s = 0; s < cfg_.n_slots; ++s) free_.push_back(s);
   }
 
   const ReplayConfig& config() const { return cfg_; }
@@ -59,12 +59,15 @@ class ReplayIndex {
   int64_t size() const { return static_cast<int64_t>(items_.size()); }
   int64_t free_slots() const { return static_cast<int64_t>(free_.size()); }
   int64_t next_item() const { return next_item_; }
+  // Chunks opened so far: a caller that batches payload writes flushes them
+  // whenever this moves, so a recycled slot never sees two writers in one launch.
+  int64_t chunks_opened() const { return static_cast<int64_t>(next_uid_) - 1 + loaded_; }
 
   void grow(int64_t n_slots) {
     if (n_slots < cfg_.n_slots) throw std::invalid_argument("replay: pool cannot shrink");
     if (n_slots * cfg_.chunksize > INT32_MAX)
       throw std::invalid_argument("replay: more than 2^31 rows in the pool");
-    for (int64_t s = n_slots - 1; s >= cfg_.n_slots; --s) free_.insert(free_.begin(), s);
+    for (int64_t s = cfg_.n_slots; s < n_slots; ++s) free_.push_back(s);
     cfg_.n_slots = n_slots;
   }
 
@@ -231,9 +234,10 @@ class ReplayIndex {
     c.succ = succ;
     c.fill = fill;
     c.refs = 0;
-    c.slot = free_.back();
-    free_.pop_back();
+    c.slot = free_.front();
+    free_.pop_front();
     chunks_[uid] = c;
+    ++loaded_;
     if (uid >= next_uid_) next_uid_ = uid + 1;
     return c.slot;
   }
@@ -254,8 +258,8 @@ class ReplayIndex {
     Chunk c;
     c.uid = next_uid_++;
     c.refs = refs;
-    c.slot = free_.back();
-    free_.pop_back();
+    c.slot = free_.front();
+    free_.pop_front();
     return chunks_[c.uid] = c;
   }
 
@@ -305,11 +309,12 @@ class ReplayIndex {
   ReplayConfig cfg_;
   std::shared_ptr<Selector> selector_;
   std::unordered_map<uint64_t, Chunk> chunks_;
-  std::vector<int64_t> free_;
+  std::deque<int64_t> free_;   // FIFO: a freed slot is recycled as late as possible
   std::unordered_map<int64_t, Pos> items_;
   std::deque<int64_t> fifo_;
   int64_t next_item_ = 0;
   uint64_t next_uid_ = 1;
+  int64_t loaded_ = 0;
   std::unordered_map<int64_t, Pos> cursor_;
   std::unordered_map<int64_t, std::deque<Pos>> pending_;
   std::unordered_map<int64_t, int64_t> steps_seen_;

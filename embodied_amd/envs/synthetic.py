@@ -1,0 +1,105 @@
+"""Device-resident synthetic vector env: N simulators' worth of 84x84x4 uint8
+frames generated straight into HBM by one kernel (`emb_synth_env_step`), with
+the episode logic of the reference's Dummy env (embodied/envs/dummy.py:38-48).
+This is the benchmark/test input of SURVEY.md 8d: real simulators are CPU code
+outside the hot path.  `host_step` restates the same generator in numpy so the
+frames can be verified and a CPU baseline can run on identical data.
+"""
+import numpy as np
+import torch
+
+from ..space import Space
+from .._lib import api
+
+
+class SyntheticBatchEnv:
+
+  def __init__(self, n, shape=(84, 84, 4), episode_len=1000, env0=0,
+               actions=6, device='cuda'):
+    self.n = n
+    self.shape = tuple(shape)
+    self.frame_bytes = int(np.prod(shape))
+    assert self.frame_bytes % 16 == 0
+    self.episode_len = episode_len
+    self.env0 = env0
+    self.actions = actions
+    self.device = torch.device(device)
+    self.counters = torch.zeros(2 * n, dtype=torch.int32, device=self.device)
+
+  def __len__(self):
+    return self.n
+
+  @property
+  def obs_space(self):
+    return {
+        'image': Space(np.uint8, self.shape),
+        'reward': Space(np.float32),
+        'is_first': Space(bool),
+        'is_last': Space(bool),
+        'is_terminal': Space(bool),
+    }
+
+  @property
+  def act_space(self):
+    return {
+        'reset': Space(bool),
+        'action': Space(np.int32, (), 0, self.actions),
+    }
+
+  def step(self, acts):
+    n, dev = self.n, self.device
+    obs = {
+        'image': torch.empty((n, *self.shape), dtype=torch.uint8, device=dev),
+        'reward': torch.empty(n, dtype=torch.float32, device=dev),
+        'is_first': torch.empty(n, dtype=torch.bool, device=dev),
+        'is_last': torch.empty(n, dtype=torch.bool, device=dev),
+        'is_terminal': torch.empty(n, dtype=torch.bool, device=dev),
+    }
+    reset = acts['reset']
+    api.emb_synth_env_step(
+        obs['image'].data_ptr(), obs['reward'].data_ptr(),
+        obs['is_first'].data_ptr(), obs['is_last'].data_ptr(),
+        obs['is_terminal'].data_ptr(), n, self.frame_bytes, self.env0,
+        self.episode_len, reset.data_ptr(), self.counters.data_ptr(),
+        torch.cuda.current_stream(dev).cuda_stream)
+    return obs
+
+
+def host_frame(env, count, frame_bytes):
+  """Byte i of env `env`'s frame at episode step `count`."""
+  salt = (env * 131 + count * 7) & 0xFFFFFFFF
+  return ((salt + np.arange(frame_bytes, dtype=np.int64)) & 0xFF).astype(np.uint8)
+
+
+class HostSyntheticEnv:
+  """One env of the same generator on the host (numpy), `Env` protocol."""
+
+  def __init__(self, env, shape=(84, 84, 4), episode_len=1000, actions=6):
+    self.env = env
+    self.shape = tuple(shape)
+    self.frame_bytes = int(np.prod(shape))
+    self.length = episode_len + (env % 8) * 13
+    self.actions = actions
+    self.count = 0
+    self.done = False
+
+  obs_space = property(lambda self: SyntheticBatchEnv.obs_space.fget(self))
+  act_space = property(lambda self: SyntheticBatchEnv.act_space.fget(self))
+
+  def step(self, action):
+    restart = bool(action['reset']) or self.done
+    if restart:
+      self.count, self.done = 0, False
+    else:
+      self.count += 1
+      self.done = self.count >= self.length
+    return {
+        'image': host_frame(self.env, self.count, self.frame_bytes).reshape(self.shape),
+        'reward': np.float32(0 if restart else self.count % 7),
+        'is_first': restart,
+        'is_last': self.done,
+        'is_terminal': self.done,
+    }
+
+  def close(self):
+    pass

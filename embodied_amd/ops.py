@@ -1,0 +1,58 @@
+"""Driver-side device ops: observation stack/transpose into the policy batch
+and per-env carry rows by env id (embodied/core/driver.py:65,
+embodied/jax/agent.py:173-181,230)."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import api
+
+_OUT = {torch.uint8: _lib.U8, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16,
+        torch.float32: _lib.F32}
+
+
+def _stream(t):
+  return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
+              scale=1.0, offset=0.0):
+  """frames: uint8 (N_total, H, W, C) slab on the GPU.  Returns the policy batch
+  (n, C, H, W) [channels_first] or (n, H, W, C) [same] as `dtype`, values
+  `x * scale + offset` for float outputs; batch row j is env `env_ids[j]`."""
+  if not (torch.is_tensor(frames) and frames.is_cuda and frames.dtype == torch.uint8):
+    raise RuntimeError('obs_stack needs a uint8 CUDA tensor (no CPU fallback)')
+  frames = frames.contiguous()
+  total, h, w, c = frames.shape
+  ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int32)
+  n = total if ids is None else len(ids)
+  first = layout == 'channels_first'
+  shape = (n, c, h, w) if first else (n, h, w, c)
+  out = torch.empty(shape, dtype=dtype, device=frames.device)
+  api.emb_obs_stack(
+      frames.data_ptr(), _lib.ptr(ids), n, h * w, c,
+      _lib.LAYOUT_CHANNELS_FIRST if first else _lib.LAYOUT_SAME, _OUT[dtype],
+      float(scale), float(offset), out.data_ptr(), _stream(frames))
+  return out
+
+
+def rows_gather(table, ids):
+  """out[j] = table[ids[j]] (rows are whatever follows the first axis)."""
+  table = table.contiguous()
+  ids = np.ascontiguousarray(ids, np.int32)
+  out = torch.empty((len(ids), *table.shape[1:]), dtype=table.dtype, device=table.device)
+  rowbytes = table.element_size() * int(np.prod(table.shape[1:], dtype=np.int64))
+  api.emb_rows_gather(table.data_ptr(), rowbytes, _lib.ptr(ids), len(ids),
+                      out.data_ptr(), _stream(table))
+  return out
+
+
+def rows_scatter(table, ids, rows):
+  """table[ids[j]] = rows[j], in place."""
+  assert table.is_contiguous()
+  ids = np.ascontiguousarray(ids, np.int32)
+  rows = rows.to(table.device, table.dtype).contiguous()
+  rowbytes = table.element_size() * int(np.prod(table.shape[1:], dtype=np.int64))
+  api.emb_rows_scatter(table.data_ptr(), rowbytes, _lib.ptr(ids), len(ids),
+                       rows.data_ptr(), _stream(table))
+  return table

@@ -1,0 +1,108 @@
+"""Return scans on device (float32): GAE (ppo/agent.py:188-201), lambda-return
+(dreamerv3/agent.py:482-490) and the Director critic target
+(director/agent.py:430-445), each one kernel launch.
+
+Inputs are torch CUDA tensors; bool flags may be torch.bool or uint8.
+"""
+import numpy as np
+import torch
+
+from ._lib import api
+
+
+def _stream(t):
+  return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _f32(x, device):
+  if not torch.is_tensor(x):
+    x = torch.as_tensor(np.asarray(x))
+  return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _flag(x, device):
+  if not torch.is_tensor(x):
+    x = torch.as_tensor(np.asarray(x))
+  if x.dtype != torch.bool and x.dtype != torch.uint8:
+    x = x != 0
+  x = x.to(device).contiguous()
+  return x.view(torch.uint8) if x.dtype == torch.bool else x
+
+
+def _device(*xs):
+  for x in xs:
+    if torch.is_tensor(x) and x.is_cuda:
+      return x.device
+  raise RuntimeError(
+      'embodied_amd.scans run as HIP kernels: pass CUDA tensors (no CPU fallback)')
+
+
+def gae(rew, val, last, term, hor=200, lam=0.8):
+  """adv_t = delta_t + live_t*cont_t*adv_{t+1}; tar = adv + val[:, :-1].
+  rew, val (B,T) f32; last, term (B,T) bool -> adv, tar (B,T-1)."""
+  dev = _device(rew, val, last, term)
+  rew, val = _f32(rew, dev), _f32(val, dev)
+  last, term = _flag(last, dev), _flag(term, dev)
+  B, T = rew.shape
+  assert val.shape == last.shape == term.shape == (B, T)
+  adv = torch.empty((B, T - 1), dtype=torch.float32, device=dev)
+  tar = torch.empty_like(adv)
+  api.emb_scan_gae(
+      rew.data_ptr(), val.data_ptr(), last.data_ptr(), term.data_ptr(), B, T,
+      float(np.float32(1 - 1 / hor)), float(np.float32(lam)), adv.data_ptr(),
+      tar.data_ptr(), _stream(rew))
+  return adv, tar
+
+
+def lambda_return(last, term, rew, val, boot, disc, lam):
+  """ret_t = interm_t + live_t*cont_t*ret_{t+1}, seeded with boot[:, -1].
+  All (B,T) -> (B,T-1).  `val` is only shape-checked, as in the reference."""
+  dev = _device(rew, boot, last, term)
+  rew, boot = _f32(rew, dev), _f32(boot, dev)
+  last, term = _flag(last, dev), _flag(term, dev)
+  B, T = rew.shape
+  assert boot.shape == last.shape == term.shape == (B, T)
+  assert val is None or tuple(val.shape) == (B, T)
+  ret = torch.empty((B, T - 1), dtype=torch.float32, device=dev)
+  api.emb_scan_lambda(
+      last.data_ptr(), term.data_ptr(), rew.data_ptr(), boot.data_ptr(), B, T,
+      float(np.float32(disc)), float(np.float32(lam)), ret.data_ptr(),
+      _stream(rew))
+  return ret
+
+
+def director_score(rew, cont, value, horizon=333, lam=0.95):
+  """Time-major: rew (T-1,B), cont, value (T,B) -> ret (T-1,B)."""
+  dev = _device(rew, cont, value)
+  rew, cont, value = _f32(rew, dev), _f32(cont, dev), _f32(value, dev)
+  T, B = value.shape
+  assert cont.shape == (T, B) and rew.shape == (T - 1, B)
+  ret = torch.empty((T - 1, B), dtype=torch.float32, device=dev)
+  api.emb_scan_director(
+      rew.data_ptr(), cont.data_ptr(), value.data_ptr(), T, B,
+      float(np.float32(1 - 1 / horizon)), float(np.float32(lam)),
+      ret.data_ptr(), _stream(rew))
+  return ret
+
+
+def split_traj(x, k, is_reward=False):
+  """Director worker windows (director/hierarchy.py:224-238): time-major
+  (T,B,...) -> (k, (T/k)*B, ...) views/reshapes; reward keys shift by one."""
+  if is_reward:
+    x = torch.cat([0 * x[:1], x], 0)
+  x = x.reshape((x.shape[0] // k, k) + tuple(x.shape[1:]))
+  x = x.transpose(0, 1)
+  x = x.reshape((x.shape[0], -1) + tuple(x.shape[3:]))
+  return x[1:] if is_reward else x
+
+
+def abstract_traj(x, cont, k, kind='first'):
+  """Director manager steps (director/hierarchy.py:240-256)."""
+  fold = lambda a: a.reshape((a.shape[0] // k, k) + tuple(a.shape[1:]))
+  if kind == 'reward':
+    w = torch.cumprod(fold(cont), 1)
+    x = torch.cat([0 * x[:1], x], 0)
+    return (fold(x) * w).mean(1)[1:]
+  if kind == 'cont':
+    return fold(x).prod(1)
+  return fold(x)[:, 0]

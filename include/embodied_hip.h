@@ -152,13 +152,16 @@ int32_t emb_replay_grow(emb_replay_t* rep, int64_t n_slots, void* const* pools);
 /* Host-only index steps (no GPU needed; bit-exact with the reference):
  * add_index    = bookkeeping of Replay.add for n steps, one per workers[i], in
  *                order (replay.py:77-118); rows_out[i] = pool row to write,
- *                stepids_out = n x 20 bytes.
+ *                stepids_out = n x 20 bytes; new_chunks_out = chunks opened by
+ *                this call (a caller that batches the payload writes must
+ *                flush them whenever it is non-zero: the new chunk may sit in
+ *                a recycled slot).
  * sample_index = `batch` sequence draws (replay.py:121-127,151-169,193-214):
  *                rows_out[batch*length] pool rows, online_out[batch] flags.
  * resolve      = Replay.update's decode of stepid[i,0] -> `count` pool rows
  *                (replay.py:139-149,216-235); evicted -> rows -1, found 0.   */
 int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* workers,
-                             int32_t* rows_out, uint8_t* stepids_out);
+                             int32_t* rows_out, uint8_t* stepids_out, int32_t* new_chunks_out);
 int32_t emb_replay_sample_index(emb_replay_t* rep, int64_t batch, int32_t mode,
                                 int32_t* rows_out, uint8_t* online_out);
 int32_t emb_replay_resolve(emb_replay_t* rep, int64_t n, const uint8_t* stepids, int64_t count,

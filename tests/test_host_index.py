@@ -43,7 +43,7 @@ class HostReplay:
     workers = np.array([worker], np.int64)
     rows = np.zeros(1, np.int32)
     sid = np.zeros((1, 20), np.uint8)
-    api.emb_replay_add_index(self.h, 1, _lib.ptr(workers), _lib.ptr(rows), _lib.ptr(sid))
+    api.emb_replay_add_index(self.h, 1, _lib.ptr(workers), _lib.ptr(rows), _lib.ptr(sid), None)
     step['stepid'] = sid[0]
     if self.pool is None:
       self.pool = {k: np.zeros((self.n_slots * self.chunksize, *v.shape), v.dtype)
