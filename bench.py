@@ -1,0 +1,256 @@
+"""Headline benchmark: env steps/s (+ learner train-steps/s) of the Driver ->
+Replay -> return-scan hot path, 64 envs x 84x84x4 uint8 obs per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+
+One "step" = one vectorised Driver step of 64 synthetic device envs (env frame
+generation, obs stack/transpose into the policy batch, stub policy, action
+mask, Replay insert) plus the train steps the reference's `Ratio(train_ratio /
+(B*T))` schedules for those 64 env steps (run/train.py:25-26,69-79); a train
+step = Replay.sample(B=16, L=65) + Consec window + GAE scan.  The model
+forward/backward is outside the path and is not run.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the Replay-sample gather
+kernel, timed with HIP events on its own stream inside the timed region;
+`cpu_baseline` is the numpy oracle of the same workload on this box's host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+  p = argparse.ArgumentParser()
+  p.add_argument('--gpus', type=int, default=1)
+  p.add_argument('--steps', type=int, default=2000)
+  p.add_argument('--warmup', type=int, default=200)
+  p.add_argument('--envs', type=int, default=64)
+  p.add_argument('--batch', type=int, default=16)
+  p.add_argument('--length', type=int, default=64)
+  p.add_argument('--context', type=int, default=1)
+  p.add_argument('--capacity', type=int, default=100_000)   # ppo/configs.yaml:39
+  p.add_argument('--train-ratio', type=float, default=3.0)  # ppo/configs.yaml:51
+  p.add_argument('--grad-numel', type=int, default=16_000_000)
+  p.add_argument('--cpu-seconds', type=float, default=15.0)
+  p.add_argument('--no-cpu-baseline', action='store_true')
+  p.add_argument('--prefetch', type=int, default=1, help='train batches gathered per launch')
+  return p.parse_args()
+
+
+class Ratio:
+  """elements.when.Ratio as run/train.py:25-26 uses it [SURVEY App. A]."""
+
+  def __init__(self, ratio):
+    self.ratio = ratio
+    self.prev = None
+
+  def __call__(self, step):
+    if self.ratio <= 0:
+      return 0
+    if self.prev is None:
+      self.prev = step
+      return 1
+    repeats = int((step - self.prev) * self.ratio)
+    self.prev += repeats / self.ratio
+    return repeats
+
+
+def build_path(args, rank, device):
+  import embodied_amd as emb
+  from embodied_amd.envs import synthetic
+  L = args.length + args.context
+  env = synthetic.SyntheticBatchEnv(
+      args.envs, shape=(84, 84, 4), episode_len=1000, env0=rank * args.envs,
+      device=device)
+  replay = emb.Replay(
+      length=L, capacity=args.capacity, chunksize=1024, online=True, seed=0,
+      device=device, replica=rank)
+  driver = emb.Driver(batch_env=env, device=device)
+  driver.on_step(replay.add)
+  n = args.envs
+  actions = torch.randint(0, 6, (4096, n), dtype=torch.int32, device=device)
+  logp = torch.zeros(n, dtype=torch.float32, device=device)
+  state = {'tick': 0}
+
+  def policy(carry, obs, **kw):
+    # obs stack/transpose into the policy batch (N, C, H, W) bf16 in [0, 1]:
+    # what the agent does first with the frames (jax/agent.py:230).
+    batch = emb.ops.obs_stack(
+        obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+    state['tick'] += 1
+    state['policy_batch'] = batch
+    return carry, {'action': actions[state['tick'] % 4096]}, {}
+
+  return emb, env, replay, driver, policy
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local))
+  assert world == args.gpus or world == 1, (world, args.gpus)
+  torch.cuda.set_device(local)
+  device = torch.device('cuda', local)
+
+  emb, env, replay, driver, policy = build_path(args, rank, device)
+  B, T, L = args.batch, args.length, args.length + args.context
+  stream = iter(emb.streams.Consec(
+      emb.streams.Stateless(replay.sample, B * args.prefetch, 'train'),
+      length=T, consec=1, prefix=args.context, strict=True, contiguous=True))
+  should_train = Ratio(args.train_ratio / (B * T))
+  value = torch.randn(B * args.prefetch, L, device=device)
+  grads = torch.zeros(args.grad_numel, device=device) if world > 1 else None
+  counters = {'env_steps': 0, 'train_steps': 0}
+
+  def train_step():
+    batch = next(stream)
+    adv, tar = emb.scans.gae(
+        batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
+    if world > 1:
+      # trajectory exchange + gradient all-reduce over xGMI (RCCL)
+      gathered = torch.empty((world, *batch['image'].shape), dtype=torch.uint8, device=device)
+      dist.all_gather_into_tensor(gathered, batch['image'])
+      dist.all_reduce(grads)
+    counters['train_steps'] += args.prefetch
+    return adv
+
+  def one_step():
+    driver(policy, steps=args.envs)            # exactly one vectorised step
+    counters['env_steps'] += args.envs
+    if len(replay) >= B * T:
+      for _ in range(should_train(counters['env_steps'])):
+        train_step()
+
+  # Fill the buffer so sampled windows come from all over HBM, not from cache.
+  driver.reset()
+  fill = -(-(args.capacity + L) // args.envs) + L
+  for _ in range(fill):
+    driver(policy, steps=args.envs)
+  counters['env_steps'] = fill * args.envs
+  for _ in range(args.warmup):
+    one_step()
+  replay.profile(True)
+  replay.profile_read(reset=True)
+  base = dict(counters)
+
+  def fence():
+    torch.cuda.synchronize(device)
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize(device)
+
+  fence()
+  start = time.perf_counter()
+  for _ in range(args.steps):
+    one_step()
+  fence()
+  elapsed = time.perf_counter() - start
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  launches, gather_ms = replay.profile_read(reset=True)
+  env_steps = (counters['env_steps'] - base['env_steps']) * world
+  train_steps = (counters['train_steps'] - base['train_steps']) * world
+  S = sum(k.rowbytes for k in replay._keys)
+  algo_bytes = 2 * B * args.prefetch * L * S      # read B*L*S + write B*L*S
+  roofline = None
+  if launches:
+    avg_s = gather_ms / launches / 1e3
+    achieved = algo_bytes / avg_s / 1e9
+    roofline = {
+        'bound': 'hbm', 'kernel': 'gather_kernel (Replay.sample)',
+        'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'read_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
+        'bytes_per_launch': algo_bytes, 'avg_launch_us': round(avg_s * 1e6, 2),
+        'launches': launches,
+    }
+
+  cpu = None
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    cpu = cpu_baseline(args)
+
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'env steps/sec (+ learner train-steps/sec), 64 envs 84x84x4 obs',
+        'value': round(env_steps / elapsed, 1),
+        'unit': 'env_steps/s',
+        'train_steps_per_s': round(train_steps / elapsed, 2),
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 5),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'u8', 'data': 'synthetic',
+        'config': {
+            'workload': 'ppo_atari_pong_64env: 64 device envs/GPU, 84x84x4 u8, '
+                        f'Replay(length={L}, capacity={args.capacity}, online, '
+                        f'Uniform), B={B}, T={T}, train_ratio={args.train_ratio}, GAE',
+            'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
+            'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch,
+            'parallelism': f'env-sharded x{world}' if world > 1 else 'single',
+        },
+        'roofline': roofline, 'cpu_baseline': cpu,
+    }))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def cpu_baseline(args):
+  """The numpy oracle of the same step on this host, single thread: serial
+  Driver over 64 host synthetic envs + oracle Replay.add/sample + numpy GAE.
+  Bounded: ~args.cpu_seconds of work on a smaller buffer (capacity 20k)."""
+  from oracle import np_oracle
+  from embodied_amd.envs import synthetic
+  L, B, T = args.length + args.context, args.batch, args.length
+  envs = [synthetic.HostSyntheticEnv(e) for e in range(args.envs)]
+  drv = np_oracle.Driver(envs)
+  rep = np_oracle.Replay(L, 20_000, 1024, online=True, seed=0)
+  drv.on_step(rep.add)
+  gen = np.random.default_rng(0)
+  val = gen.standard_normal((B, L)).astype(np.float32)
+
+  def policy(carry, obs):
+    n = len(obs['is_first'])
+    _ = np.ascontiguousarray(obs['image'].transpose(0, 3, 1, 2)).astype(np.float32) * (1 / 255)
+    return carry, {'action': gen.integers(0, 6, n).astype(np.int32)}, {}
+
+  should_train = Ratio(args.train_ratio / (B * T))
+  env_steps = train_steps = 0
+  for _ in range(L + 4):
+    drv.step(policy)
+  begin = time.perf_counter()
+  while time.perf_counter() - begin < args.cpu_seconds:
+    drv.step(policy)
+    env_steps += args.envs
+    for _ in range(should_train(env_steps)):
+      batch = rep.sample(B)
+      np_oracle.gae(batch['reward'], val, batch['is_last'], batch['is_terminal'])
+      train_steps += 1
+  took = time.perf_counter() - begin
+  return {
+      'value': round(env_steps / took, 1), 'unit': 'env_steps/s', 'cores': 1,
+      'kind': 'port',
+      'train_steps_per_s': round(train_steps / took, 3),
+      'sample': f'{env_steps} env steps / {train_steps} train steps in {took:.1f}s, '
+                'numpy oracle, capacity 20000, same envs/shapes/ratio',
+      'host_cpus': os.cpu_count(),
+  }
+
+
+if __name__ == '__main__':
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  main()

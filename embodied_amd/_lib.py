@@ -6,6 +6,11 @@ this module raises.  Build it with `python -m embodied_amd.build`.
 import ctypes as C
 import pathlib
 
+# torch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Import it
+# first so this library binds to the copy torch uses: two HIP runtimes in one
+# process do not share devices, streams or allocations.
+import torch  # noqa: F401
+
 HERE = pathlib.Path(__file__).resolve().parent
 PATH = HERE / 'libembodied_hip.so'
 

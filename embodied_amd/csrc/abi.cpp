@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "kernels.h"
@@ -147,7 +148,9 @@ class LaunchTimer {
     }
   }
   bool enabled = false;
-  void begin(hipStream_t s) {
+  // Next (start, stop) pair for hipExtLaunchKernelGGL, or nulls when disabled.
+  void next(hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
     if (!enabled) return;
     if (used_ == pairs_.size()) {
       if (pairs_.size() >= 8192) collect();
@@ -158,11 +161,8 @@ class LaunchTimer {
         pairs_.emplace_back(a, b);
       }
     }
-    HIP_OK(hipEventRecord(pairs_[used_].first, s));
-  }
-  void end(hipStream_t s) {
-    if (!enabled) return;
-    HIP_OK(hipEventRecord(pairs_[used_].second, s));
+    *start = pairs_[used_].first;
+    *stop = pairs_[used_].second;
     ++used_;
   }
   void collect() {
@@ -553,9 +553,13 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   rep->ring.upload(lease, total, stream);
   plan.rows = reinterpret_cast<const int32_t*>(lease.device);
   plan.n_rows = static_cast<int32_t>(n_rows);
-  if (gather) rep->timer.begin(stream);
-  HIP_OK(gather ? emb::launch_gather(plan, stream) : emb::launch_scatter(plan, stream));
-  if (gather) rep->timer.end(stream);
+  if (gather) {
+    hipEvent_t start, stop;
+    rep->timer.next(&start, &stop);
+    HIP_OK(emb::launch_gather(plan, stream, start, stop));
+  } else {
+    HIP_OK(emb::launch_scatter(plan, stream));
+  }
   rep->ring.retire(lease, stream);
 }
 
@@ -637,6 +641,12 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
       else
         for (int64_t j = 0; j < T; ++j) rep->rows[i * T + j] = -1;
     }
+    // The reference applies batch rows one after another (replay.py:139-149),
+    // so when sampled windows overlap the LAST writer of a step wins.  One
+    // launch has no order: drop all but the last occurrence of every pool row.
+    std::unordered_set<int32_t> seen;
+    for (int64_t i = B * T - 1; i >= 0; --i)
+      if (rep->rows[i] >= 0 && !seen.insert(rep->rows[i]).second) rep->rows[i] = -1;
     run_move(rep, plan, rep->rows.data(), B * T, nullptr, -1, false, static_cast<hipStream_t>(stream));
   });
 }

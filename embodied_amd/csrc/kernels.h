@@ -26,7 +26,10 @@ struct MovePlan {
 };
 
 // pool[rows[r]] -> batch[r]   (Replay.sample: replay.py:255-292 on device)
-hipError_t launch_gather(const MovePlan& plan, hipStream_t stream);
+// start/stop (optional): events stamped with the dispatch's own begin/end
+// (hipExtLaunchKernelGGL), i.e. the kernel duration rocprofv3 reports.
+hipError_t launch_gather(const MovePlan& plan, hipStream_t stream,
+                         hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // batch[r] -> pool[rows[r]]   (Replay.add / Replay.update: chunk.py:41-58)
 hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream);
 

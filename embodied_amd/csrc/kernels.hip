@@ -8,6 +8,10 @@
 
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
+
+#include <cstdio>
+#include <cstdlib>
 
 namespace emb {
 namespace {
@@ -15,8 +19,6 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one dwordx4
 
 constexpr int kThreads = 256;
-constexpr int kUnroll = 8;                       // 16-byte loads in flight per lane
-constexpr int kTileVec = kThreads * kUnroll;     // 2048 x 16 B = 32 KiB per workgroup
 
 // Per-launch plan in kernel-argument memory (< 4 KiB).
 struct MoveArgs {
@@ -25,6 +27,7 @@ struct MoveArgs {
   int32_t unit[kMaxKeys];           // 0: tiled 16-byte path; else bytes per lane
   int32_t tiles_per_row[kMaxKeys];
   int32_t n_keys, n_rows, seq_len, key_is_first, key_is_last;
+  int32_t xcd_remap;
   const int32_t* rows;
 };
 
@@ -49,41 +52,66 @@ __device__ __forceinline__ void copy_bytes(const uint8_t* s, uint8_t* d, int uni
   }
 }
 
-// One workgroup moves one 32 KiB tile of one row: every lane issues up to
-// kUnroll independent 16-byte loads before the first store.
-template <bool kGather>
-__device__ __forceinline__ void move_tile(const KeyDesc& key, int64_t pool_row,
-                                          int64_t batch_row, int tile) {
-  const int64_t nvec = key.rowbytes >> 4;
-  const int64_t v0 = static_cast<int64_t>(tile) * kTileVec;
-  const u32x4* pool = reinterpret_cast<const u32x4*>(key.pool + pool_row * key.rowbytes);
-  const u32x4* batch = reinterpret_cast<const u32x4*>(key.batch + batch_row * key.rowbytes);
-  const u32x4* src = kGather ? pool : batch;
-  u32x4* dst = const_cast<u32x4*>(kGather ? batch : pool);
-  u32x4 buf[kUnroll];
+// A key's rows are moved as a flat sequence of 16-byte units: unit u belongs to
+// batch row u / upr.  Lane j of the key's workgroup range owns units
+// j, j + stride, ... (U of them): consecutive lanes touch consecutive 16 bytes
+// on both sides, every lane has U independent row lookups and then U
+// independent loads in flight before its first store, and no lane waits on a
+// per-workgroup scalar dependency chain.
+template <bool kGather, int U, int NT>
+__device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key, int local,
+                                          int nblocks) {
+  const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
+  const uint32_t total = upr * static_cast<uint32_t>(a.n_rows);
+  // Workgroup b runs on XCD b % 8 (observed; speed only): give every XCD one
+  // contiguous eighth of the batch so its L2 / TLB sees few distinct source
+  // sequences.  EMB_MOVE_VARIANT's third field = 0 turns the remap off.
+  int vlocal = local;
+  const int per_xcd = nblocks >> 3;
+  if (a.xcd_remap && local < (per_xcd << 3)) vlocal = (local & 7) * per_xcd + (local >> 3);
+  const uint32_t first = static_cast<uint32_t>(vlocal) * (kThreads * U) + threadIdx.x;
+  const uint32_t stride = kThreads;
+  uint32_t r[U], off[U];
+  int32_t row[U];
 #pragma unroll
-  for (int u = 0; u < kUnroll; ++u) {
-    const int64_t i = v0 + threadIdx.x + u * kThreads;
-    if (i < nvec) buf[u] = __builtin_nontemporal_load(src + i);
+  for (int j = 0; j < U; ++j) {
+    const uint32_t u = first + j * stride;
+    r[j] = u / upr;
+    off[j] = u - r[j] * upr;
+    row[j] = (u < total) ? a.rows[r[j]] : -1;
+  }
+  u32x4 buf[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    if (row[j] < 0) continue;
+    const uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
+    const uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
+    const u32x4* src = reinterpret_cast<const u32x4*>(kGather ? pool : batch) + off[j];
+    if (NT & 8) buf[j] = u32x4{off[j], r[j], 0u, 0u};   // diagnostic: no loads
+    else buf[j] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
   }
 #pragma unroll
-  for (int u = 0; u < kUnroll; ++u) {
-    const int64_t i = v0 + threadIdx.x + u * kThreads;
-    if (i < nvec) dst[i] = buf[u];
+  for (int j = 0; j < U; ++j) {
+    if (row[j] < 0) continue;
+    uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
+    uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
+    u32x4* dst = reinterpret_cast<u32x4*>(kGather ? batch : pool) + off[j];
+    if (NT & 4) { if (buf[j].x == 0x9E3779B9u && buf[j].w == 0x7F4A7C15u) *dst = buf[j]; }  // diagnostic: no stores
+    else if (NT & 2) __builtin_nontemporal_store(buf[j], dst);
+    else *dst = buf[j];
   }
 }
 
 // pool[rows[r]] -> batch[r] for every key of the replay in ONE launch, with
 // the is_first / is_last annotation of replay.py:277-292 applied in flight.
+template <int U, int NT>
 __global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
   const int k = find_key(a, blockIdx.x);
   const KeyDesc key = a.key[k];
   const int local = blockIdx.x - a.first_block[k];
   const int unit = a.unit[k];
   if (unit == 0) {
-    const int tpr = a.tiles_per_row[k];
-    const int r = local / tpr;
-    move_tile<true>(key, a.rows[r], r, local - r * tpr);
+    move_wide<true, U, NT>(a, key, local, a.first_block[k + 1] - a.first_block[k]);
     return;
   }
   const int64_t upr = key.rowbytes / unit;
@@ -109,17 +137,14 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
 }
 
 // batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
+template <int U, int NT>
 __global__ __launch_bounds__(kThreads) void scatter_kernel(const MoveArgs a) {
   const int k = find_key(a, blockIdx.x);
   const KeyDesc key = a.key[k];
   const int local = blockIdx.x - a.first_block[k];
   const int unit = a.unit[k];
   if (unit == 0) {
-    const int tpr = a.tiles_per_row[k];
-    const int r = local / tpr;
-    const int row = a.rows[r];
-    if (row < 0) return;
-    move_tile<false>(key, row, r, local - r * tpr);
+    move_wide<false, U, NT>(a, key, local, a.first_block[k + 1] - a.first_block[k]);
     return;
   }
   const int64_t upr = key.rowbytes / unit;
@@ -130,6 +155,18 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const MoveArgs a) {
   const int64_t row = a.rows[r];
   if (row < 0) return;
   copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
+}
+
+// Tuning knobs (EMB_MOVE_VARIANT="U,NT"): loads in flight per lane and
+// non-temporal hints (bit0 loads, bit1 stores).  Defaults chosen on MI355X.
+struct MoveVariant { int unroll; int nt; int remap; };
+MoveVariant move_variant(int64_t n_rows) {
+  MoveVariant v{0, -1, 1};
+  if (const char* s = std::getenv("EMB_MOVE_VARIANT")) std::sscanf(s, "%d,%d,%d", &v.unroll, &v.nt, &v.remap);
+  (void)n_rows;
+  if (v.unroll == 0) v.unroll = 2;
+  if (v.nt < 0) v.nt = 1;
+  return v;
 }
 
 int pick_unit(const KeyDesc& key) {
@@ -143,10 +180,13 @@ int pick_unit(const KeyDesc& key) {
   return 1;
 }
 
-hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream) {
+hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream,
+                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
   if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || !plan.rows)
     return hipErrorInvalidValue;
   if (plan.n_rows == 0) return hipSuccess;
+  const MoveVariant variant = move_variant(plan.n_rows);
+  const int unroll = (variant.unroll == 1 || variant.unroll == 2 || variant.unroll == 4) ? variant.unroll : 8;
   MoveArgs a;
   a.n_keys = plan.n_keys;
   a.n_rows = plan.n_rows;
@@ -154,15 +194,17 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
   a.key_is_first = plan.key_is_first;
   a.key_is_last = plan.key_is_last;
   a.rows = plan.rows;
+  a.xcd_remap = variant.remap;
   int64_t blocks = 0;
   for (int k = 0; k < plan.n_keys; ++k) {
     a.key[k] = plan.key[k];
     a.unit[k] = pick_unit(plan.key[k]);
     a.first_block[k] = static_cast<int32_t>(blocks);
     if (a.unit[k] == 0) {
-      const int64_t nvec = plan.key[k].rowbytes >> 4;
-      a.tiles_per_row[k] = static_cast<int32_t>((nvec + kTileVec - 1) / kTileVec);
-      blocks += static_cast<int64_t>(plan.n_rows) * a.tiles_per_row[k];
+      const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes >> 4);
+      if (units > UINT32_MAX / 2) return hipErrorInvalidValue;
+      a.tiles_per_row[k] = 0;
+      blocks += (units + kThreads * unroll - 1) / (kThreads * unroll);
     } else {
       a.tiles_per_row[k] = 0;
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes / a.unit[k]);
@@ -171,10 +213,29 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
     if (blocks > INT32_MAX) return hipErrorInvalidValue;
   }
   a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
-  if (gather)
-    hipLaunchKernelGGL(gather_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(kThreads), 0, stream, a);
-  else
-    hipLaunchKernelGGL(scatter_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(kThreads), 0, stream, a);
+  const dim3 grid(static_cast<uint32_t>(blocks)), block(kThreads);
+#define EMB_MOVE(U_, NT_)                                                        \
+  do {                                                                           \
+    if (gather) hipExtLaunchKernelGGL((gather_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);  \
+    else hipExtLaunchKernelGGL((scatter_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);        \
+  } while (0)
+#define EMB_MOVE_NT(U_)                                                          \
+  switch (variant.nt) {                                                          \
+    case 0: EMB_MOVE(U_, 0); break;                                              \
+    case 2: EMB_MOVE(U_, 2); break;                                              \
+    case 3: EMB_MOVE(U_, 3); break;                                              \
+    case 4: EMB_MOVE(U_, 4); break;                                              \
+    case 8: EMB_MOVE(U_, 8); break;                                              \
+    default: EMB_MOVE(U_, 1); break;                                             \
+  }
+  switch (variant.unroll) {
+    case 1: EMB_MOVE_NT(1) break;
+    case 2: EMB_MOVE_NT(2) break;
+    case 4: EMB_MOVE_NT(4) break;
+    default: EMB_MOVE_NT(8) break;
+  }
+#undef EMB_MOVE_NT
+#undef EMB_MOVE
   return hipGetLastError();
 }
 
@@ -315,22 +376,19 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel(
   }
 }
 
-template <>
-__global__ __launch_bounds__(kThreads) void mask_rows_kernel<__half>(
-    __half* act, int64_t n, int64_t row_elems, const uint8_t* is_last) {
-  const int64_t total = n * row_elems;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads)
-    act[i] = __float2half(__half2float(act[i]) * (is_last[i / row_elems] ? 0.f : 1.f));
-}
-
+// bf16 has no native multiply: widen to f32 (exact), multiply, narrow (the
+// product is x, +-0 or NaN, all exactly representable).
 template <>
 __global__ __launch_bounds__(kThreads) void mask_rows_kernel<__hip_bfloat16>(
     __hip_bfloat16* act, int64_t n, int64_t row_elems, const uint8_t* is_last) {
   const int64_t total = n * row_elems;
+  uint16_t* bits = reinterpret_cast<uint16_t*>(act);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads)
-    act[i] = __float2bfloat16(__bfloat162float(act[i]) * (is_last[i / row_elems] ? 0.f : 1.f));
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const float x = __uint_as_float(static_cast<uint32_t>(bits[i]) << 16);
+    const float y = x * (is_last[i / row_elems] ? 0.f : 1.f);
+    bits[i] = static_cast<uint16_t>(__float_as_uint(y) >> 16);
+  }
 }
 
 // ------------------------------------------------------------ return scans --
@@ -474,8 +532,9 @@ __global__ __launch_bounds__(kThreads) void synth_env_kernel(
 
 }  // namespace
 
-hipError_t launch_gather(const MovePlan& plan, hipStream_t stream) {
-  return plan_and_launch(plan, true, stream);
+hipError_t launch_gather(const MovePlan& plan, hipStream_t stream, hipEvent_t start,
+                         hipEvent_t stop) {
+  return plan_and_launch(plan, true, stream, start, stop);
 }
 
 hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream) {
@@ -521,7 +580,7 @@ hipError_t launch_mask_rows(void* act, int64_t n, int64_t row_elems, int dtype,
     case kI16: EMB_MASK(int16_t); break;
     case kI32: EMB_MASK(int32_t); break;
     case kI64: EMB_MASK(int64_t); break;
-    case kF16: EMB_MASK(__half); break;
+    case kF16: EMB_MASK(_Float16); break;
     case kBF16: EMB_MASK(__hip_bfloat16); break;
     case kF32: EMB_MASK(float); break;
     case kF64: EMB_MASK(double); break;

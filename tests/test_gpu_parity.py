@@ -124,19 +124,19 @@ def test_update_roundtrip_full_rows(emb):
   batch = rep.sample(4)
   new = torch.randn(4, 8, 2048, device='cuda')
   rep.update({'stepid': batch['stepid'], 'deter': new})
-  rows = {tuple(s[-4:].tolist()): (b, t) for b, seq in enumerate(batch['stepid'].cpu().numpy())
+  rows = {tuple(s.tolist()): (b, t) for b, seq in enumerate(batch['stepid'].cpu().numpy())
           for t, s in enumerate(seq)}
   again = rep.sample(32)
   sid = again['stepid'].cpu().numpy()
   hits = 0
   for b in range(32):
     for t in range(8):
-      key = tuple(sid[b, t, -4:].tolist())
+      key = tuple(sid[b, t].tolist())
       if key in rows:
         # Overlapping windows: the last writer of a step wins; accept any of the
         # values written for that step.
         cands = [new[bb, tt] for (bb, seq) in enumerate(batch['stepid'].cpu().numpy())
-                 for tt, s in enumerate(seq) if tuple(s[-4:].tolist()) == key]
+                 for tt, s in enumerate(seq) if tuple(s.tolist()) == key]
         assert any(torch.equal(again['deter'][b, t], c) for c in cands)
         hits += 1
   assert hits > 0
@@ -285,3 +285,12 @@ def test_device_driver_with_batch_env_feeds_replay(emb):
   sid = batch['stepid'].cpu().numpy()
   assert (np.diff(sid[..., -1].astype(int), axis=1) % 16 == 1).all() or True
   assert batch['image'].shape == (5, 4, 8, 8, 4)
+
+
+def test_mask_actions_bfloat16(emb):
+  from embodied_amd.core.driver import mask_actions
+  value = torch.tensor([[-1.5, 2.0], [3.0, -0.25], [0.0, -7.0]], dtype=torch.bfloat16).cuda()
+  last = torch.tensor([True, False, True]).cuda()
+  got = mask_actions(value, last).view(torch.int16).cpu().numpy().view(np.uint16)
+  want = np.array([[0x8000, 0x0000], [0x4040, 0xBE80], [0x0000, 0x8000]], np.uint16)
+  assert (got == want).all()
