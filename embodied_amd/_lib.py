@@ -126,7 +126,7 @@ SIGNATURES = {
     'emb_replay_load_chunk': [p, u64, u64, i64, p],
     'emb_replay_load_items': [p, u64, i64],
     'emb_obs_stack': [p, p, i64, i64, i64, i32, i32, f32, f32, p, p],
-    'emb_mask_actions': [p, i64, i64, i32, p, p],
+    'emb_mask_actions': [p, p, i64, i64, i32, p, p],
     'emb_rows_gather': [p, i64, p, i64, p, p],
     'emb_rows_scatter': [p, i64, p, i64, p, p],
     'emb_window': [p, p, i64, i64, i64, i64, i64, p],
@@ -179,6 +179,11 @@ class _Api:
 
 
 api = _Api()
+
+
+def raw_stream(device):
+  """hipStream_t of torch's current stream on `device` (cheap C getter)."""
+  return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
 
 
 def ptr(array):

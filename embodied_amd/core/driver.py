@@ -39,15 +39,15 @@ _DTYPE_CODE = {
 def mask_actions(value, is_last):
   """value * ~is_last in value's dtype (driver.py:72-74, 84-87)."""
   if torch.is_tensor(value) and value.is_cuda:
-    value = value.contiguous().clone()
-    flags = is_last.contiguous()
-    flags = flags.view(torch.uint8) if flags.dtype == torch.bool else flags
+    if not value.is_contiguous():
+      value = value.contiguous()
+    out = torch.empty_like(value)
     n = value.shape[0]
     api.emb_mask_actions(
-        value.data_ptr(), n, value.numel() // max(n, 1),
-        _DTYPE_CODE[value.dtype], flags.data_ptr(),
-        torch.cuda.current_stream(value.device).cuda_stream)
-    return value
+        value.data_ptr(), out.data_ptr(), n, value.numel() // max(n, 1),
+        _DTYPE_CODE[value.dtype], is_last.data_ptr(),
+        _lib.raw_stream(value.device))
+    return out
   if torch.is_tensor(value):
     value = value.numpy()
   keep = ~np.asarray(is_last)
@@ -131,25 +131,25 @@ class Driver:
 
   def __call__(self, policy, steps=0, episodes=0):
     step, episode = 0, 0
+    self._count_episodes = episodes > 0
     while step < steps or episode < episodes:
       step, episode = self._step(policy, step, episode)
 
   # driver.py:55-82
   def _step(self, policy, step, episode):
+    if self.batch_env is not None:
+      return self._step_device_env(policy, step, episode)
     acts = self.acts
     assert all(len(x) == self.length for x in acts.values())
-    if self.batch_env is not None:
-      obs = self.batch_env.step(acts)
+    host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
+    assert all(isinstance(v, np.ndarray) for v in host.values())
+    per_env = [{k: v[i] for k, v in host.items()} for i in range(self.length)]
+    if self.parallel:
+      [pipe.send(('step', act)) for pipe, act in zip(self.pipes, per_env)]
+      results = [self._receive(pipe) for pipe in self.pipes]
     else:
-      host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
-      assert all(isinstance(v, np.ndarray) for v in host.values())
-      per_env = [{k: v[i] for k, v in host.items()} for i in range(self.length)]
-      if self.parallel:
-        [pipe.send(('step', act)) for pipe, act in zip(self.pipes, per_env)]
-        results = [self._receive(pipe) for pipe in self.pipes]
-      else:
-        results = [env.step(act) for env, act in zip(self.envs, per_env)]
-      obs = self._stack(results)
+      results = [env.step(act) for env, act in zip(self.envs, per_env)]
+    obs = self._stack(results)
     logs = {k: v for k, v in obs.items() if k.startswith('log/')}
     obs = {k: v for k, v in obs.items() if not k.startswith('log/')}
     assert all(len(x) == self.length for x in obs.values()), obs
@@ -159,14 +159,9 @@ class Driver:
     if self.device is not None:
       acts = {k: self._to_device(v) for k, v in acts.items()}
       outs = {k: self._to_device(v) for k, v in outs.items()}
-      if self.batch_env is not None:
-        # No host sync: mask unconditionally (a no-op when nothing ended).
+      ended = self._host_flags['is_last']
+      if ended.any():
         acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
-        ended = None
-      else:
-        ended = self._host_flags['is_last']
-        if ended.any():
-          acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
       self.acts = {**acts, 'reset': is_last.clone()}
     else:
       ended = is_last
@@ -174,24 +169,41 @@ class Driver:
         acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
       self.acts = {**acts, 'reset': is_last.copy()}
     trans = {**obs, **acts, **outs, **logs}
+    self._dispatch(trans)
+    return step + self.length, episode + int(ended.sum())
+
+  def _step_device_env(self, policy, step, episode):
+    """Same step with a device-resident vector env: nothing is read back, so
+    the mask runs unconditionally (a no-op where nothing ended) and episodes
+    are counted only when the caller stops on them."""
+    obs = self.batch_env.step(self.acts)
+    logs = {k: v for k, v in obs.items() if k.startswith('log/')}
+    if logs:
+      obs = {k: v for k, v in obs.items() if not k.startswith('log/')}
+    self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
+    assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
+    is_last = obs['is_last']
+    acts = {k: mask_actions(self._to_device(v), is_last) for k, v in acts.items()}
+    # Device flags are never mutated in place: `reset` may alias is_last.
+    self.acts = {**acts, 'reset': is_last}
+    self._dispatch({**obs, **acts, **outs, **logs})
+    step += self.length
+    if self._count_episodes:
+      episode += int(is_last.sum().item())
+    return step, episode
+
+  def _dispatch(self, trans):
     for fn in self.batch_callbacks:
       fn(trans, self._workers, **self.kwargs)
     if self.callbacks:
       for i in range(self.length):
         tran = {k: v[i] for k, v in trans.items()}
         [fn(tran, i, **self.kwargs) for fn in self.callbacks]
-    step += self.length
-    if ended is None:
-      # Device env: count episodes lazily (one scalar readback per step only
-      # if the caller asked to stop on episodes).
-      episode = episode
-      self._pending_last = is_last
-    else:
-      episode += int(ended.sum())
-    return step, episode
 
   def _to_device(self, value):
     if torch.is_tensor(value):
+      if value.device == self.device:
+        return value
       return value.to(self.device, non_blocking=True)
     return torch.from_numpy(np.ascontiguousarray(value)).to(self.device, non_blocking=True)
 

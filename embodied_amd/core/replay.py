@@ -62,6 +62,8 @@ class Replay:
     self.name = name
     self.online = online
     self.device = torch.device(device)
+    if self.device.type == 'cuda' and self.device.index is None:
+      self.device = torch.device('cuda', torch.cuda.current_device())
     if self.device.type != 'cuda':
       raise RuntimeError(
           'embodied_amd.Replay keeps its chunk pool in HBM and moves it with '
@@ -112,7 +114,7 @@ class Replay:
     return n.value
 
   def _stream(self):
-    return torch.cuda.current_stream(self.device).cuda_stream
+    return _lib.raw_stream(self.device)
 
   def stats(self):
     """replay.py:58-74 (counters reset on read)."""
@@ -258,9 +260,11 @@ class Replay:
         key = self._keys[i]
         if not torch.is_tensor(value):
           value = torch.from_numpy(np.ascontiguousarray(value))
-        if tuple(value.shape) != (n, *key.shape):
+        if value.shape[1:] != key.shape or value.shape[0] != n:
           raise ValueError((name, tuple(value.shape), (n, *key.shape)))
-        value = value.to(self.device, key.dtype, non_blocking=True).contiguous()
+        if (value.dtype != key.dtype or value.device != self.device
+            or not value.is_contiguous()):
+          value = value.to(self.device, key.dtype, non_blocking=True).contiguous()
         keep.append(value)
         ptrs[i] = value.data_ptr()
       while True:

@@ -53,7 +53,7 @@ def window(value, start, count):
   rowbytes = value.element_size() * int(np.prod(value.shape[2:], dtype=np.int64))
   api.emb_window(
       value.data_ptr(), out.data_ptr(), value.shape[0], value.shape[1], start,
-      count, rowbytes, torch.cuda.current_stream(value.device).cuda_stream)
+      count, rowbytes, _lib.raw_stream(value.device))
   return out
 
 

@@ -225,7 +225,7 @@ struct emb_replay {
   int key_stepid = -1, key_is_first = -1, key_is_last = -1;
   TableRing ring;
   LaunchTimer timer;
-  std::vector<int32_t> rows;
+  std::vector<int32_t> rows, spans;
   std::vector<emb::StepId> ids;
 };
 
@@ -478,16 +478,20 @@ static void add_index_locked(emb_replay* rep, int64_t n, const int64_t* workers,
 }
 
 static void sample_index_locked(emb_replay* rep, int64_t batch, int32_t mode, int32_t* rows,
-                                uint8_t* online) {
+                                uint8_t* online, std::vector<int32_t>* spans = nullptr) {
   need(mode >= EMB_MODE_TRAIN && mode <= EMB_MODE_EVAL, "sample: bad mode");
   const int64_t L = rep->index->config().length;
+  bool spans_ok = spans != nullptr;
+  if (spans) spans->resize(3 * batch);
   for (int64_t b = 0; b < batch; ++b) {
     bool from_online = false;
     const auto pos = rep->index->draw(mode == EMB_MODE_TRAIN, &from_online);
     if (!rep->index->rows(pos, L, rows + b * L))
       throw std::logic_error("replay: sampled window vanished");
+    if (spans_ok) spans_ok = rep->index->two_spans(pos, L, spans->data() + 3 * b);
     if (online) online[b] = from_online ? 1 : 0;
   }
+  if (spans && !spans_ok) spans->clear();
 }
 
 int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* workers,
@@ -538,21 +542,45 @@ int32_t emb_replay_sampler_len(emb_replay_t* rep, int64_t* n) { REP_OP(*n = rep-
 int32_t emb_replay_free_slots(emb_replay_t* rep, int64_t* n) { REP_OP(*n = rep->index->free_slots()); }
 int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset) { REP_OP(rep->index->stats(out, reset != 0)); }
 
+// Launch one gather/scatter.  Small tables travel inside the kernel arguments;
+// larger ones through the pinned ring (one async upload).
 static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, int64_t n_rows,
-                     const emb::StepId* ids, int stepid_plan_slot, bool gather, hipStream_t stream) {
-  // Table layout in the ring slot: int32 rows[n_rows] | (16-aligned) stepids.
-  const size_t rows_bytes = static_cast<size_t>(n_rows) * sizeof(int32_t);
-  const size_t ids_off = (rows_bytes + 15) & ~size_t(15);
-  const size_t total = ids ? ids_off + static_cast<size_t>(n_rows) * EMB_STEPID_BYTES : rows_bytes;
-  auto lease = rep->ring.acquire(total, stream);
-  std::memcpy(lease.host, rows, rows_bytes);
-  if (ids) {
-    std::memcpy(lease.host + ids_off, ids, static_cast<size_t>(n_rows) * EMB_STEPID_BYTES);
-    plan.key[stepid_plan_slot].batch = lease.device + ids_off;
-  }
-  rep->ring.upload(lease, total, stream);
-  plan.rows = reinterpret_cast<const int32_t*>(lease.device);
+                     const emb::StepId* ids, int stepid_plan_slot, bool gather, hipStream_t stream,
+                     const std::vector<int32_t>* spans = nullptr) {
   plan.n_rows = static_cast<int32_t>(n_rows);
+  plan.rows_host = rows;
+  if (spans && !spans->empty()) {
+    plan.spans_host = spans->data();
+    plan.n_seq = static_cast<int32_t>(spans->size() / 3);
+  }
+  if (ids) {
+    plan.inline_key = stepid_plan_slot;
+    plan.inline_bytes = reinterpret_cast<const uint8_t*>(ids);
+  }
+  TableRing::Lease lease{-1, nullptr, nullptr};
+  bool fits = emb::plan_fits_inline(plan);          // spans (+ step ids)
+  if (!fits && plan.spans_host) {
+    plan.spans_host = nullptr;
+    plan.n_seq = 0;
+    fits = emb::plan_fits_inline(plan);             // plain rows (+ step ids)
+  }
+  if (!fits) {
+    // Ring slot layout: int32 rows[n_rows] | (16-aligned) step ids.
+    plan.rows_host = nullptr;
+    plan.inline_key = -1;
+    plan.inline_bytes = nullptr;
+    const size_t rows_bytes = static_cast<size_t>(n_rows) * sizeof(int32_t);
+    const size_t ids_off = (rows_bytes + 15) & ~size_t(15);
+    const size_t total = ids ? ids_off + static_cast<size_t>(n_rows) * EMB_STEPID_BYTES : rows_bytes;
+    lease = rep->ring.acquire(total, stream);
+    std::memcpy(lease.host, rows, rows_bytes);
+    if (ids) {
+      std::memcpy(lease.host + ids_off, ids, static_cast<size_t>(n_rows) * EMB_STEPID_BYTES);
+      plan.key[stepid_plan_slot].batch = lease.device + ids_off;
+    }
+    rep->ring.upload(lease, total, stream);
+    plan.rows = reinterpret_cast<const int32_t*>(lease.device);
+  }
   if (gather) {
     hipEvent_t start, stop;
     rep->timer.next(&start, &stop);
@@ -560,7 +588,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   } else {
     HIP_OK(emb::launch_scatter(plan, stream));
   }
-  rep->ring.retire(lease, stream);
+  if (lease.slot >= 0) rep->ring.retire(lease, stream);
 }
 
 int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers, const void* const* src,
@@ -607,8 +635,9 @@ int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* 
     }
     plan.seq_len = static_cast<int32_t>(L);
     rep->rows.resize(batch * L);
-    sample_index_locked(rep, batch, mode, rep->rows.data(), online_out);
-    run_move(rep, plan, rep->rows.data(), batch * L, nullptr, -1, true, static_cast<hipStream_t>(stream));
+    sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans);
+    run_move(rep, plan, rep->rows.data(), batch * L, nullptr, -1, true,
+             static_cast<hipStream_t>(stream), &rep->spans);
   });
 }
 
@@ -744,11 +773,11 @@ int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_
   });
 }
 
-int32_t emb_mask_actions(void* act, int64_t n, int64_t row_elems, int32_t dtype,
+int32_t emb_mask_actions(const void* act, void* out, int64_t n, int64_t row_elems, int32_t dtype,
                          const void* is_last, void* stream) {
   return guarded([&] {
-    need(act && is_last && n >= 0 && row_elems >= 0, "mask_actions: bad arguments");
-    HIP_OK(emb::launch_mask_rows(act, n, row_elems, dtype, static_cast<const uint8_t*>(is_last),
+    need(act && out && is_last && n >= 0 && row_elems >= 0, "mask_actions: bad arguments");
+    HIP_OK(emb::launch_mask_rows(act, out, n, row_elems, dtype, static_cast<const uint8_t*>(is_last),
                                  static_cast<hipStream_t>(stream)));
   });
 }

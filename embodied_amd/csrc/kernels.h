@@ -6,7 +6,8 @@
 
 namespace emb {
 
-constexpr int kMaxKeys = 32;
+constexpr int kMaxKeys = 16;
+constexpr int kInlineWords = 704;  // row table / spans / step ids carried in kernel arguments
 
 // One replay column: its chunk pool in HBM and the batch-side buffer.
 struct KeyDesc {
@@ -22,8 +23,25 @@ struct MovePlan {
   int32_t seq_len = 1;       // rows per sequence (annotate uses t = r % seq_len)
   int32_t key_is_first = -1; // gather only: fuse replay.py:277-292
   int32_t key_is_last = -1;
-  const int32_t* rows = nullptr;  // device-visible table of pool rows (-1 = skip)
+  // Pool rows, one of:
+  //   rows        device-visible int32[n_rows] (-1 = skip)               [any size]
+  //   rows_host   the same table on the host: if it fits it travels in the
+  //               kernel arguments (no upload, no dependent global load)
+  //   spans_host  per sequence {row0, count0, row1}: windows that cross at most
+  //               one chunk boundary, n_rows = n_seq * seq_len            [gather]
+  const int32_t* rows = nullptr;
+  const int32_t* rows_host = nullptr;
+  const int32_t* spans_host = nullptr;
+  int32_t n_seq = 0;
+  // Scatter only: the batch bytes of this key (4-byte multiple rows, e.g. the
+  // 20-byte step ids) come from host memory through the kernel arguments.
+  int32_t inline_key = -1;
+  const uint8_t* inline_bytes = nullptr;
 };
+
+// True if this plan's tables fit the kernel-argument block (else the caller
+// must provide `rows` in device-visible memory).
+bool plan_fits_inline(const MovePlan& plan);
 
 // pool[rows[r]] -> batch[r]   (Replay.sample: replay.py:255-292 on device)
 // start/stop (optional): events stamped with the dispatch's own begin/end
@@ -53,9 +71,9 @@ hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* ds
                             int layout, int out_dtype, float scale, float offset,
                             hipStream_t stream);
 
-// act[n, :] *= !is_last[n] in the action's own dtype (driver.py:72-74,84-87).
-hipError_t launch_mask_rows(void* act, int64_t n, int64_t row_elems, int dtype,
-                            const uint8_t* is_last, hipStream_t stream);
+// out[n, :] = act[n, :] * !is_last[n] in the action's own dtype (out may be act) (driver.py:72-74,84-87).
+hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems,
+                            int dtype, const uint8_t* is_last, hipStream_t stream);
 
 // Return scans (float32).  Batch-major (B, T) unless stated.
 hipError_t launch_gae(const float* rew, const float* val, const uint8_t* last,

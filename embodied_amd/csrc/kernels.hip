@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace emb {
 namespace {
@@ -24,17 +25,32 @@ constexpr int kThreads = 256;
 struct MoveArgs {
   KeyDesc key[kMaxKeys];
   int32_t first_block[kMaxKeys + 1];
-  int32_t unit[kMaxKeys];           // 0: tiled 16-byte path; else bytes per lane
-  int32_t tiles_per_row[kMaxKeys];
+  int32_t unit[kMaxKeys];           // 0: 16-byte flat path; else bytes per lane
   int32_t n_keys, n_rows, seq_len, key_is_first, key_is_last;
   int32_t xcd_remap;
+  int32_t rows_mode;                // 0 device table, 1 inline rows, 2 inline spans
+  int32_t inline_key, inline_key_word0;
   const int32_t* rows;
+  uint32_t inline_words[kInlineWords];
 };
+static_assert(sizeof(MoveArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 __device__ __forceinline__ int find_key(const MoveArgs& a, int block) {
   int k = 0;
   while (k + 1 < a.n_keys && block >= a.first_block[k + 1]) ++k;
   return k;
+}
+
+// Pool row of batch row r.
+__device__ __forceinline__ int32_t row_of(const MoveArgs& a, uint32_t r) {
+  if (a.rows_mode == 2) {
+    const uint32_t seq = r / static_cast<uint32_t>(a.seq_len);
+    const uint32_t t = r - seq * static_cast<uint32_t>(a.seq_len);
+    const uint32_t row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
+    return static_cast<int32_t>(t < n0 ? row0 + t : a.inline_words[3 * seq + 2] + (t - n0));
+  }
+  if (a.rows_mode == 1) return static_cast<int32_t>(a.inline_words[r]);
+  return a.rows[r];
 }
 
 template <typename T>
@@ -78,7 +94,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
     const uint32_t u = first + j * stride;
     r[j] = u / upr;
     off[j] = u - r[j] * upr;
-    row[j] = (u < total) ? a.rows[r[j]] : -1;
+    row[j] = (u < total) ? row_of(a, r[j]) : -1;
   }
   u32x4 buf[U];
 #pragma unroll
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
   if (u >= upr * a.n_rows) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
-  const int64_t row = a.rows[r];
+  const int64_t row = row_of(a, static_cast<uint32_t>(r));
   const uint8_t* src = key.pool + row * key.rowbytes + off;
   uint8_t* dst = key.batch + r * key.rowbytes + off;
   if (key.rowbytes == 1 && (k == a.key_is_first || k == a.key_is_last)) {
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
     if (k == a.key_is_first) {
       if (t == 0) v = 1;
     } else if (a.key_is_first >= 0 && t + 1 < a.seq_len) {
-      v |= a.key[a.key_is_first].pool[a.rows[r + 1]];
+      v |= a.key[a.key_is_first].pool[row_of(a, static_cast<uint32_t>(r + 1))];
     }
     *dst = v;
     return;
@@ -152,8 +168,13 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const MoveArgs a) {
   if (u >= upr * a.n_rows) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
-  const int64_t row = a.rows[r];
+  const int64_t row = row_of(a, static_cast<uint32_t>(r));
   if (row < 0) return;
+  if (k == a.inline_key) {   // batch bytes of this key ride in the kernel arguments
+    const uint32_t w = a.inline_words[a.inline_key_word0 + r * (key.rowbytes >> 2) + (off >> 2)];
+    *reinterpret_cast<uint32_t*>(key.pool + row * key.rowbytes + off) = w;
+    return;
+  }
   copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
 }
 
@@ -180,9 +201,22 @@ int pick_unit(const KeyDesc& key) {
   return 1;
 }
 
+// Words of kernel-argument space the plan's tables need, or -1 if they cannot
+// go inline.
+int inline_words_needed(const MovePlan& plan) {
+  int64_t words = 0;
+  if (plan.spans_host) words = 3ll * plan.n_seq;
+  else if (plan.rows_host) words = plan.n_rows;
+  else return plan.inline_key >= 0 ? -1 : 0;
+  if (plan.inline_key >= 0) words += static_cast<int64_t>(plan.n_rows) * (plan.key[plan.inline_key].rowbytes >> 2);
+  return words <= kInlineWords ? static_cast<int>(words) : -1;
+}
+
 hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream,
                            hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
-  if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || !plan.rows)
+  const int inline_need = inline_words_needed(plan);
+  const bool use_inline = inline_need > 0 && (plan.spans_host || plan.rows_host);
+  if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || (!plan.rows && !use_inline))
     return hipErrorInvalidValue;
   if (plan.n_rows == 0) return hipSuccess;
   const MoveVariant variant = move_variant(plan.n_rows);
@@ -194,19 +228,40 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
   a.key_is_first = plan.key_is_first;
   a.key_is_last = plan.key_is_last;
   a.rows = plan.rows;
+  a.rows_mode = 0;
+  a.inline_key = -1;
+  a.inline_key_word0 = 0;
+  if (use_inline) {
+    int words;
+    if (plan.spans_host) {
+      a.rows_mode = 2;
+      words = 3 * plan.n_seq;
+      std::memcpy(a.inline_words, plan.spans_host, sizeof(uint32_t) * words);
+    } else {
+      a.rows_mode = 1;
+      words = plan.n_rows;
+      std::memcpy(a.inline_words, plan.rows_host, sizeof(uint32_t) * words);
+    }
+    if (plan.inline_key >= 0) {
+      a.inline_key = plan.inline_key;
+      a.inline_key_word0 = words;
+      std::memcpy(a.inline_words + words, plan.inline_bytes,
+                  static_cast<size_t>(plan.n_rows) * plan.key[plan.inline_key].rowbytes);
+    }
+  } else if (plan.inline_key >= 0) {
+    return hipErrorInvalidValue;
+  }
   a.xcd_remap = variant.remap;
   int64_t blocks = 0;
   for (int k = 0; k < plan.n_keys; ++k) {
     a.key[k] = plan.key[k];
-    a.unit[k] = pick_unit(plan.key[k]);
+    a.unit[k] = (k == a.inline_key) ? 4 : pick_unit(plan.key[k]);
     a.first_block[k] = static_cast<int32_t>(blocks);
     if (a.unit[k] == 0) {
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes >> 4);
       if (units > UINT32_MAX / 2) return hipErrorInvalidValue;
-      a.tiles_per_row[k] = 0;
       blocks += (units + kThreads * unroll - 1) / (kThreads * unroll);
     } else {
-      a.tiles_per_row[k] = 0;
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes / a.unit[k]);
       blocks += (units + kThreads - 1) / kThreads;
     }
@@ -365,14 +420,14 @@ hipError_t obs_stack_typed(const uint8_t* src, const int32_t* env_ids, void* dst
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mask_rows_kernel(
-    T* act, int64_t n, int64_t row_elems, const uint8_t* is_last) {
+    const T* act, T* out, int64_t n, int64_t row_elems, const uint8_t* is_last) {
   const int64_t total = n * row_elems;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
        i += static_cast<int64_t>(gridDim.x) * kThreads) {
     const int64_t r = i / row_elems;
     // value * mask.astype(value.dtype): a real multiply, so -x -> -0.0 and
     // NaN stays NaN exactly as numpy does (driver.py:84-87).
-    act[i] = act[i] * static_cast<T>(is_last[r] ? 0 : 1);
+    out[i] = act[i] * static_cast<T>(is_last[r] ? 0 : 1);
   }
 }
 
@@ -380,14 +435,16 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel(
 // product is x, +-0 or NaN, all exactly representable).
 template <>
 __global__ __launch_bounds__(kThreads) void mask_rows_kernel<__hip_bfloat16>(
-    __hip_bfloat16* act, int64_t n, int64_t row_elems, const uint8_t* is_last) {
+    const __hip_bfloat16* act, __hip_bfloat16* out, int64_t n, int64_t row_elems,
+    const uint8_t* is_last) {
   const int64_t total = n * row_elems;
-  uint16_t* bits = reinterpret_cast<uint16_t*>(act);
+  const uint16_t* bits = reinterpret_cast<const uint16_t*>(act);
+  uint16_t* obits = reinterpret_cast<uint16_t*>(out);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
        i += static_cast<int64_t>(gridDim.x) * kThreads) {
     const float x = __uint_as_float(static_cast<uint32_t>(bits[i]) << 16);
     const float y = x * (is_last[i / row_elems] ? 0.f : 1.f);
-    bits[i] = static_cast<uint16_t>(__float_as_uint(y) >> 16);
+    obits[i] = static_cast<uint16_t>(__float_as_uint(y) >> 16);
   }
 }
 
@@ -537,6 +594,8 @@ hipError_t launch_gather(const MovePlan& plan, hipStream_t stream, hipEvent_t st
   return plan_and_launch(plan, true, stream, start, stop);
 }
 
+bool plan_fits_inline(const MovePlan& plan) { return inline_words_needed(plan) > 0; }
+
 hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream) {
   return plan_and_launch(plan, false, stream);
 }
@@ -568,12 +627,12 @@ hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* ds
   }
 }
 
-hipError_t launch_mask_rows(void* act, int64_t n, int64_t row_elems, int dtype,
+hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems, int dtype,
                             const uint8_t* is_last, hipStream_t stream) {
   const int64_t total = n * row_elems;
   if (total <= 0) return hipSuccess;
   const dim3 grid(static_cast<uint32_t>(std::min<int64_t>((total + kThreads - 1) / kThreads, 2048)));
-#define EMB_MASK(T) hipLaunchKernelGGL(mask_rows_kernel<T>, grid, dim3(kThreads), 0, stream, static_cast<T*>(act), n, row_elems, is_last)
+#define EMB_MASK(T) hipLaunchKernelGGL(mask_rows_kernel<T>, grid, dim3(kThreads), 0, stream, static_cast<const T*>(act), static_cast<T*>(out), n, row_elems, is_last)
   switch (dtype) {
     case kU8: case kBool: EMB_MASK(uint8_t); break;
     case kI8: EMB_MASK(int8_t); break;

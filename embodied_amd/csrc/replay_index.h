@@ -182,6 +182,15 @@ class ReplayIndex {
     return true;
   }
 
+  // {row0, count0, row1} if the window crosses at most one chunk boundary.
+  bool two_spans(const Pos& pos, int64_t count, int32_t out[3]) const {
+    if (!spans(pos, count, &scratch_) || scratch_.size() > 2) return false;
+    out[0] = static_cast<int32_t>(scratch_[0].slot * cfg_.chunksize + scratch_[0].index);
+    out[1] = static_cast<int32_t>(scratch_[0].count);
+    out[2] = scratch_.size() > 1 ? static_cast<int32_t>(scratch_[1].slot * cfg_.chunksize) : 0;
+    return true;
+  }
+
   StepId make_stepid(uint64_t uid, int64_t index) const {
     StepId s;
     for (int i = 0; i < 8; ++i) s.b[i] = static_cast<uint8_t>(cfg_.uid_hi >> (56 - 8 * i));
@@ -278,12 +287,16 @@ class ReplayIndex {
     while (cfg_.capacity && size() >= cfg_.capacity) evict();
     const int64_t key = next_item_++;
     items_[key] = start;
-    if (!spans(start, cfg_.length, &scratch_))
-      throw std::logic_error("replay: inserted window is incomplete");
-    ids_.clear();
-    for (const Span& s : scratch_)
-      for (int64_t i = 0; i < s.count; ++i) ids_.push_back(make_stepid(s.uid, s.index + i));
-    selector_->insert(key, ids_.data(), static_cast<int>(ids_.size()));
+    if (selector_->needs_stepids()) {
+      if (!spans(start, cfg_.length, &scratch_))
+        throw std::logic_error("replay: inserted window is incomplete");
+      ids_.clear();
+      for (const Span& s : scratch_)
+        for (int64_t i = 0; i < s.count; ++i) ids_.push_back(make_stepid(s.uid, s.index + i));
+      selector_->insert(key, ids_.data(), static_cast<int>(ids_.size()));
+    } else {
+      selector_->insert(key, nullptr, 0);
+    }
     fifo_.push_back(key);
   }
 

@@ -47,6 +47,8 @@ class Selector {
   virtual int64_t size() const = 0;
   virtual void insert(int64_t key, const StepId* steps, int n) = 0;
   virtual void remove(int64_t key) = 0;
+  // False if insert() ignores the step ids (lets the replay skip building them).
+  virtual bool needs_stepids() const { return true; }
   virtual bool can_prioritize() const { return false; }
   virtual void prioritize(const StepId*, const double*, int64_t) {}
 };
@@ -58,6 +60,7 @@ class Fifo : public Selector {
     return q_.front();
   }
   int64_t size() const override { return static_cast<int64_t>(q_.size()); }
+  bool needs_stepids() const override { return false; }
   void insert(int64_t key, const StepId*, int) override { q_.push_back(key); }
   void remove(int64_t key) override {
     if (!q_.empty() && q_.front() == key) {
@@ -81,6 +84,7 @@ class Uniform : public Selector {
     return keys_[rng_.integers(static_cast<int64_t>(keys_.size()))];
   }
   int64_t size() const override { return static_cast<int64_t>(keys_.size()); }
+  bool needs_stepids() const override { return false; }
   void insert(int64_t key, const StepId*, int) override {
     pos_[key] = static_cast<int64_t>(keys_.size());
     keys_.push_back(key);
@@ -368,6 +372,10 @@ class Mixture : public Selector {
   }
   bool can_prioritize() const override {
     for (auto& m : members_) if (m->can_prioritize()) return true;
+    return false;
+  }
+  bool needs_stepids() const override {
+    for (auto& m : members_) if (m->needs_stepids()) return true;
     return false;
   }
   void prioritize(const StepId* s, const double* p, int64_t n) override {

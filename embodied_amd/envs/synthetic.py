@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from ..space import Space
+from .. import _lib
 from .._lib import api
 
 
@@ -24,6 +25,8 @@ class SyntheticBatchEnv:
     self.env0 = env0
     self.actions = actions
     self.device = torch.device(device)
+    if self.device.index is None:
+      self.device = torch.device('cuda', torch.cuda.current_device())
     self.counters = torch.zeros(2 * n, dtype=torch.int32, device=self.device)
 
   def __len__(self):
@@ -61,7 +64,7 @@ class SyntheticBatchEnv:
         obs['is_first'].data_ptr(), obs['is_last'].data_ptr(),
         obs['is_terminal'].data_ptr(), n, self.frame_bytes, self.env0,
         self.episode_len, reset.data_ptr(), self.counters.data_ptr(),
-        torch.cuda.current_stream(dev).cuda_stream)
+        _lib.raw_stream(dev))
     return obs
 
 

@@ -12,7 +12,7 @@ _OUT = {torch.uint8: _lib.U8, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16
 
 
 def _stream(t):
-  return torch.cuda.current_stream(t.device).cuda_stream
+  return _lib.raw_stream(t.device)
 
 
 def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,

@@ -7,11 +7,12 @@ Inputs are torch CUDA tensors; bool flags may be torch.bool or uint8.
 import numpy as np
 import torch
 
+from . import _lib
 from ._lib import api
 
 
 def _stream(t):
-  return torch.cuda.current_stream(t.device).cuda_stream
+  return _lib.raw_stream(t.device)
 
 
 def _f32(x, device):

@@ -218,9 +218,10 @@ int32_t emb_replay_load_items(emb_replay_t* rep, uint64_t uid, int64_t amount);
 int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_t pixels,
                       int64_t channels, int32_t layout, int32_t out_dtype, float scale,
                       float offset, void* dst, void* stream);
-/* acts zeroed where is_last (driver.py:72-74,84-87): act (n, row_elems).     */
-int32_t emb_mask_actions(void* act, int64_t n, int64_t row_elems, int32_t dtype,
-                         const void* is_last, void* stream);
+/* acts zeroed where is_last (driver.py:72-74,84-87): out = act * ~is_last as a
+ * real multiply in `dtype`; act, out (n, row_elems), out may alias act.      */
+int32_t emb_mask_actions(const void* act, void* out, int64_t n, int64_t row_elems,
+                         int32_t dtype, const void* is_last, void* stream);
 /* Per-env policy carry rows by env id (embodied/jax/agent.py:173-181,
  * run/parallel.py:94-104): dst[j] = table[ids[j]] / table[ids[j]] = src[j].  */
 int32_t emb_rows_gather(const void* table, int64_t rowbytes, const int32_t* ids, int64_t n,
