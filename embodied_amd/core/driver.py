@@ -61,6 +61,8 @@ class Driver:
                batch_env=None, **kwargs):
     self.kwargs = kwargs
     self.device = torch.device(device) if device is not None else None
+    if self.device is not None and self.device.type == 'cuda' and self.device.index is None:
+      self.device = torch.device('cuda', torch.cuda.current_device())
     self.batch_env = batch_env
     self.parallel = parallel and batch_env is None
     if batch_env is not None:
