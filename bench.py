@@ -37,7 +37,8 @@ def parse():
   p.add_argument('--context', type=int, default=1)
   p.add_argument('--capacity', type=int, default=100_000)   # ppo/configs.yaml:39
   p.add_argument('--train-ratio', type=float, default=3.0)  # ppo/configs.yaml:51
-  p.add_argument('--grad-numel', type=int, default=16_000_000)
+  p.add_argument('--grad-numel', type=int, default=10_000_000)   # PPO-sized f32 gradient
+  p.add_argument('--exchange', default='trajectories', choices=['trajectories', 'returns', 'none'])
   p.add_argument('--cpu-seconds', type=float, default=15.0)
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--prefetch', type=int, default=1, help='train batches gathered per launch')
@@ -96,14 +97,16 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
-  if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local))
-  assert world == args.gpus or world == 1, (world, args.gpus)
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
+  # EMB_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank.
+  use_dist = world > 1 or os.environ.get('EMB_BENCH_FORCE_DIST') == '1'
+  if use_dist:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29517')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+  assert world == args.gpus or world == 1, (world, args.gpus)
 
   emb, env, replay, driver, policy = build_path(args, rank, device)
   B, T, L = args.batch, args.length, args.length + args.context
@@ -112,20 +115,42 @@ def main():
       length=T, consec=1, prefix=args.context, strict=True, contiguous=True))
   should_train = Ratio(args.train_ratio / (B * T))
   value = torch.randn(B * args.prefetch, L, device=device)
-  grads = torch.zeros(args.grad_numel, device=device) if world > 1 else None
+  grads = torch.zeros(args.grad_numel, device=device) if use_dist else None
   counters = {'env_steps': 0, 'train_steps': 0}
+  pending = []
 
   def train_step():
-    batch = next(stream)
-    adv, tar = emb.scans.gae(
-        batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
-    if world > 1:
-      # trajectory exchange + gradient all-reduce over xGMI (RCCL)
-      gathered = torch.empty((world, *batch['image'].shape), dtype=torch.uint8, device=device)
-      dist.all_gather_into_tensor(gathered, batch['image'])
-      dist.all_reduce(grads)
+    if not use_dist:
+      batch = next(stream)
+      adv, tar = emb.scans.gae(
+          batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
+    else:
+      from embodied_amd import distributed as D
+      # Sample straight into one packed buffer so the trajectory exchange is a
+      # single RCCL all-gather; both collectives run async on RCCL's stream and
+      # are waited for one train step later (the reference returns train outs
+      # one step late too: embodied/jax/agent.py:286-294).
+      flat, batch, layout = D.sample_packed(replay, B * args.prefetch)
+      adv, tar = emb.scans.gae(
+          batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
+      for work in pending:
+        work.wait()
+      pending.clear()
+      if args.exchange == 'trajectories':
+        send = flat
+      elif args.exchange == 'returns':
+        send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
+      else:
+        send = None
+      if send is not None:
+        gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
+        pending.append(dist.all_gather_into_tensor(gathered, send, async_op=True))
+        state_keep[:] = [gathered, send]
+      pending.append(dist.all_reduce(grads, async_op=True))
     counters['train_steps'] += args.prefetch
     return adv
+
+  state_keep = []
 
   def one_step():
     driver(policy, steps=args.envs)            # exactly one vectorised step
@@ -147,8 +172,11 @@ def main():
   base = dict(counters)
 
   def fence():
+    for work in pending:
+      work.wait()
+    pending.clear()
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
       dist.barrier()
     torch.cuda.synchronize(device)
 
@@ -158,7 +186,7 @@ def main():
     one_step()
   fence()
   elapsed = time.perf_counter() - start
-  if world > 1:
+  if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -201,11 +229,13 @@ def main():
                         f'Uniform), B={B}, T={T}, train_ratio={args.train_ratio}, GAE',
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch,
-            'parallelism': f'env-sharded x{world}' if world > 1 else 'single',
+            'parallelism': (f'env-sharded x{world}, {args.exchange} all-gather + '
+                            f'{args.grad_numel * 4 >> 20} MiB grad all-reduce (RCCL)')
+                           if use_dist else 'single',
         },
         'roofline': roofline, 'cpu_baseline': cpu,
     }))
-  if world > 1:
+  if use_dist:
     dist.destroy_process_group()
 
 

@@ -1,0 +1,159 @@
+"""Multi-GPU plumbing: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+Sharding follows the reference's own multi-replica layout (ppo/main.py:190-192,
+embodied/jax/internal.py:145-152): rank r owns the env block
+[r*N, (r+1)*N) and the Replay those envs feed; payload never moves on insert.
+The exchange steps are the two north_star names:
+
+  * `all_gather_batch`  — RCCL all-gather of the sampled trajectories.  The
+    local batch is sampled straight into ONE packed byte buffer (all keys, 256-B
+    aligned), so the exchange is a single collective of B*L*S bytes per rank
+    instead of one per key.
+  * `all_reduce_mean`   — all-reduce of one flat gradient buffer
+    (embodied/jax/opt.py:52-54's pmean).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ALIGN = 256
+
+
+def init(backend=None, device=None):
+  """Join the job described by RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  if world > 1 and not dist.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+    kwargs = {}
+    if backend == 'nccl' and device is not None:
+      kwargs['device_id'] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+  return rank, world
+
+
+def world():
+  return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+  return dist.get_rank() if dist.is_initialized() else 0
+
+
+def env_block(n_global, r=None, w=None):
+  """Global env ids owned by rank r: one contiguous block per rank."""
+  r = rank() if r is None else r
+  w = world() if w is None else w
+  assert n_global % w == 0, (n_global, w)
+  per = n_global // w
+  return np.arange(r * per, (r + 1) * per, dtype=np.int64)
+
+
+class PackedLayout:
+  """Byte offsets of every key of a (B, L, ...) batch inside one flat buffer."""
+
+  def __init__(self, specs, batch, length):
+    # specs: [(name, torch dtype, per-step shape)]
+    self.batch, self.length = batch, length
+    self.entries = []
+    offset = 0
+    for name, dtype, shape in specs:
+      itemsize = torch.empty((), dtype=dtype).element_size()
+      nbytes = batch * length * itemsize * int(np.prod(shape, dtype=np.int64))
+      self.entries.append((name, dtype, tuple(shape), offset, nbytes))
+      offset += -(-nbytes // ALIGN) * ALIGN
+    self.nbytes = offset
+
+  def views(self, flat, lead=None):
+    """Typed views into `flat` ((nbytes,) or (world, nbytes) uint8)."""
+    lead = (self.batch,) if lead is None else lead
+    out = {}
+    for name, dtype, shape, offset, nbytes in self.entries:
+      if flat.dim() == 1:
+        out[name] = flat[offset: offset + nbytes].view(dtype).view(
+            *lead, self.length, *shape)
+      else:
+        part = flat[:, offset: offset + nbytes]
+        out[name] = part.view(dtype).view(
+            flat.shape[0], *lead, self.length, *shape)
+    return out
+
+
+def sample_packed(replay, batch, mode='train'):
+  """`replay.sample` into one packed buffer: returns (flat uint8, dict of
+  views).  The gather kernel writes each key at its offset directly."""
+  import ctypes as C
+  from . import _lib
+  from ._lib import api
+  from .core import limiters
+  limiters.wait(lambda: len(replay._native), f'Replay buffer {replay.name} is empty')
+  with replay._lock:
+    replay._flush()
+    layout = PackedLayout(
+        [(k.name, k.dtype, k.shape) for k in replay._keys], batch, replay.length)
+    flat = torch.empty(layout.nbytes, dtype=torch.uint8, device=replay.device)
+    views = layout.views(flat)
+    ptrs = (C.c_void_p * len(replay._keys))(
+        *[views[k.name].data_ptr() for k in replay._keys])
+    api.emb_replay_sample(
+        replay._handle, batch, _lib.MODES[mode], ptrs, None, replay._stream())
+  return flat, views, layout
+
+
+def all_gather_packed(flat, layout):
+  """One all-gather of the packed local batch; returns per-key views shaped
+  (world, B, L, ...) over the gathered buffer (no regroup copy)."""
+  w = world()
+  if w == 1:
+    return layout.views(flat[None])
+  out = torch.empty(w * flat.numel(), dtype=torch.uint8, device=flat.device)
+  dist.all_gather_into_tensor(out, flat)
+  return layout.views(out.view(w, flat.numel()))
+
+
+def all_gather_batch(batch):
+  """Generic form for any dict of same-leading-dim tensors: packs, gathers
+  once, returns dict of (world*B, ...) tensors."""
+  w = world()
+  if w == 1:
+    return dict(batch)
+  names = list(batch)
+  device = batch[names[0]].device
+  sizes, offset = [], 0
+  for k in names:
+    nbytes = batch[k].numel() * batch[k].element_size()
+    sizes.append((offset, nbytes))
+    offset += -(-nbytes // ALIGN) * ALIGN
+  flat = torch.empty(offset, dtype=torch.uint8, device=device)
+  for k, (off, nbytes) in zip(names, sizes):
+    flat[off: off + nbytes].copy_(batch[k].contiguous().view(torch.uint8).reshape(-1))
+  out = torch.empty(w * offset, dtype=torch.uint8, device=device)
+  dist.all_gather_into_tensor(out, flat)
+  out = out.view(w, offset)
+  result = {}
+  for k, (off, nbytes) in zip(names, sizes):
+    v = batch[k]
+    part = out[:, off: off + nbytes].contiguous().view(v.dtype)
+    result[k] = part.view(w * v.shape[0], *v.shape[1:])
+  return result
+
+
+def all_reduce_mean(flat):
+  """In-place mean over ranks of one flat buffer (the gradient pmean)."""
+  w = world()
+  if w > 1:
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(w)
+  return flat
+
+
+def max_over_ranks(value, device):
+  if world() == 1:
+    return float(value)
+  t = torch.tensor([value], dtype=torch.float64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item())

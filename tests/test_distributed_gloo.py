@@ -1,0 +1,106 @@
+"""N>1 path on CPU: world_size-2 gloo process groups (127.0.0.1)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn, out):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from embodied_amd import distributed as D
+  D.init('gloo')
+  try:
+    out[rank] = fn(rank, world, D)
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def run2(fn):
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_worker, args=(2, _free_port(), fn, out), nprocs=2, join=True)
+  return dict(out)
+
+
+def _gather_job(rank, world, D):
+  gen = np.random.default_rng(rank)
+  batch = {
+      'image': torch.as_tensor(gen.integers(0, 255, (3, 5, 4, 4, 2), dtype=np.uint8)),
+      'reward': torch.as_tensor(gen.standard_normal((3, 5)).astype(np.float32)),
+      'is_first': torch.as_tensor(gen.random((3, 5)) < 0.3),
+      'stepid': torch.as_tensor(gen.integers(0, 255, (3, 5, 20), dtype=np.uint8)),
+  }
+  got = D.all_gather_batch(batch)
+  layout = D.PackedLayout(
+      [(k, v.dtype, v.shape[2:]) for k, v in batch.items()], 3, 5)
+  flat = torch.zeros(layout.nbytes, dtype=torch.uint8)
+  for k, v in layout.views(flat).items():
+    v.copy_(batch[k])
+  packed = D.all_gather_packed(flat, layout)
+  grads = torch.full((1000,), float(rank + 1))
+  D.all_reduce_mean(grads)
+  return ({k: v.numpy() for k, v in got.items()},
+          {k: v.numpy().copy() for k, v in packed.items()}, grads.numpy(),
+          D.env_block(64).tolist(), D.max_over_ranks(rank + 0.5, 'cpu'))
+
+
+def test_all_gather_and_all_reduce_world2():
+  out = run2(_gather_job)
+  for rank in (0, 1):
+    got, packed, grads, block, mx = out[rank]
+    for k in got:
+      want = np.concatenate([
+          _expected(r)[k] for r in (0, 1)], 0)
+      assert np.array_equal(got[k], want), k
+      assert np.array_equal(packed[k].reshape(want.shape), want), k
+    assert np.allclose(grads, 1.5)
+    assert block == list(range(rank * 32, rank * 32 + 32))
+    assert mx == 1.5
+
+
+def _expected(rank):
+  gen = np.random.default_rng(rank)
+  return {
+      'image': gen.integers(0, 255, (3, 5, 4, 4, 2), dtype=np.uint8),
+      'reward': gen.standard_normal((3, 5)).astype(np.float32),
+      'is_first': gen.random((3, 5)) < 0.3,
+      'stepid': gen.integers(0, 255, (3, 5, 20), dtype=np.uint8),
+  }
+
+
+def _index_job(rank, world, D):
+  """Ranks that advance the host index identically draw identical row tables
+  (what a replicated-index sharding relies on; host code only, no GPU)."""
+  import ctypes as C
+  from embodied_amd import _lib
+  from embodied_amd._lib import api
+  cfg = _lib.ReplayConfig(5, 40, 8, 64, 0, 0, 0)
+  h = C.c_void_p()
+  api.emb_replay_create(C.byref(cfg), None, 7, C.byref(h))
+  workers = np.arange(6, dtype=np.int64)
+  rows = np.zeros(6, np.int32)
+  for _ in range(30):
+    api.emb_replay_add_index(h, 6, _lib.ptr(workers), _lib.ptr(rows), None, None)
+  table = np.zeros((4, 5), np.int32)
+  api.emb_replay_sample_index(h, 4, 0, _lib.ptr(table), None)
+  mine = torch.as_tensor(table)
+  both = [torch.zeros_like(mine) for _ in range(world)]
+  torch.distributed.all_gather(both, mine)
+  api.raw.emb_replay_destroy(h)
+  return bool((both[0] == both[1]).all()), table.tolist()
+
+
+def test_replicated_index_draws_agree_world2():
+  out = run2(_index_job)
+  assert out[0][0] and out[1][0]
+  assert out[0][1] == out[1][1]
