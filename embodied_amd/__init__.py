@@ -16,3 +16,7 @@ from .core import replay
 from . import scans
 from . import ops
 from . import envs
+from . import utils
+from . import run
+from . import distributed
+from .utils import Counter, LocalClock

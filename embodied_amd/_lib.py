@@ -122,8 +122,8 @@ SIGNATURES = {
     'emb_replay_profile': [p, i32],
     'emb_replay_profile_read': [p, p, p, i32],
     'emb_replay_complete_all': [p],
-    'emb_replay_chunks': [p, i64, p, p, p, p, p],
-    'emb_replay_load_chunk': [p, u64, u64, i64, p],
+    'emb_replay_chunks': [p, i64, p, p, p, p, p, p],
+    'emb_replay_load_chunk': [p, u64, u64, i64, i64, p],
     'emb_replay_load_items': [p, u64, i64],
     'emb_obs_stack': [p, p, i64, i64, i64, i32, i32, f32, f32, p, p],
     'emb_mask_actions': [p, p, i64, i64, i32, p, p],

@@ -12,8 +12,12 @@ is_first / is_last annotation fused) and scatter (update).
 `sample()` returns torch tensors on the replay's device (set `numpy=True` for
 host arrays like the reference's).  There is no CPU implementation.
 """
+import concurrent.futures
 import ctypes as C
+import io
+import pathlib
 import threading
+import time
 
 import numpy as np
 import torch
@@ -100,6 +104,8 @@ class Replay:
     self._new_chunks = C.c_int32()
     self._saved = set()
     self._updates = 0
+    self._replica = int(replica)
+    self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
 
   def __del__(self):
     handle, self._handle = getattr(self, '_handle', None), None
@@ -382,6 +388,122 @@ class Replay:
     if isinstance(self._native, selectorlib.Foreign):
       self._native.reraise()
 
+  # ------------------------------------------------------------ save / load --
+
+  def _chunk_table(self):
+    n = C.c_int64()
+    api.emb_replay_chunks(self._handle, 0, None, None, None, None, None, C.byref(n))
+    cap = n.value
+    uid, succ = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+    fill, slot, tms = (np.zeros(cap, np.int64) for _ in range(3))
+    api.emb_replay_chunks(
+        self._handle, cap, _lib.ptr(uid), _lib.ptr(succ), _lib.ptr(fill),
+        _lib.ptr(slot), _lib.ptr(tms), C.byref(n))
+    return [
+        dict(uid=int(uid[i]), succ=int(succ[i]), fill=int(fill[i]),
+             slot=int(slot[i]), time_ms=int(tms[i])) for i in range(min(cap, n.value))]
+
+  def _full_uid(self, serial):
+    return (self._replica << 64) | serial if serial else 0
+
+  def save(self):
+    """Write every unsaved, non-empty chunk as `{time}-{uid}-{succ}-{length}.npz`
+    (chunk.py:31-33,64-75; replay.py:294-309): open chunks are closed first, the
+    rows come back from HBM with one copy per key.  Returns None: the directory
+    is the state."""
+    if not self.directory:
+      return None
+    directory = pathlib.Path(self.directory)
+    directory.mkdir(parents=True, exist_ok=True)
+    with self._lock:
+      self._flush()
+      api.emb_replay_complete_all(self._handle)
+      jobs = []
+      for chunk in self._chunk_table():
+        if chunk['fill'] <= 0 or chunk['uid'] in self._saved:
+          continue
+        self._saved.add(chunk['uid'])
+        lo = chunk['slot'] * self.chunksize
+        data = {}
+        for key in self._keys:
+          rows = key.pool[lo * key.rowbytes: (lo + chunk['fill']) * key.rowbytes]
+          host = rows.cpu().numpy()
+          if key.dtype == torch.bfloat16:
+            host = host.view(np.uint16)
+          else:
+            host = host.view(_numpy_of(key.dtype))
+          data[key.name] = host.reshape(chunk['fill'], *key.shape)
+        name = chunk_filename(
+            chunk['time_ms'], self._full_uid(chunk['uid']),
+            self._full_uid(chunk['succ']), chunk['fill'])
+        jobs.append(self._savers.submit(_write_npz, directory / name, data))
+      if self.save_wait:
+        [job.result() for job in jobs]
+    return None
+
+  def load(self, data=None, directory=None, amount=None):
+    """Restore the newest chunks from disk until `amount` items are back
+    (replay.py:311-359): file order, per-chunk item counts and reference
+    counting as the reference; payload goes up with one copy per key per chunk."""
+    directory = directory or self.directory
+    amount = amount or self.capacity or np.inf
+    if not directory:
+      return
+    directory = pathlib.Path(directory)
+    with self._lock:
+      self._flush()
+      table = self._chunk_table()
+      loaded = sorted((chunk_filename(
+          c['time_ms'], self._full_uid(c['uid']), self._full_uid(c['succ']), c['fill'])
+          for c in table), reverse=True)
+      loaded_uids = {self._full_uid(c['uid']) for c in table}
+      ondisk = sorted((p.name for p in directory.glob('*.npz')), reverse=True)
+      ondisk = [x for x in ondisk if parse_filename(x)[1] not in loaded_uids]
+      if not ondisk:
+        return
+      counts = count_items(loaded + ondisk, self.length)
+      total, take = 0, 0
+      for name in ondisk:
+        take += 1
+        total += counts[parse_filename(name)[1]]
+        if total >= amount:
+          break
+      chunks = []
+      for name in ondisk[:take]:
+        try:
+          with np.load(directory / name) as f:
+            arrays = {k: f[k] for k in f.files}
+        except Exception as e:            # corrupted file: skip (chunk.py:81-91)
+          print(f'Error loading chunk {name}: {e}')
+          continue
+        chunks.append((name, arrays))
+      if not chunks:
+        return
+      counts = count_items([name for name, _ in chunks], self.length)
+      if self._keys is None:
+        first = {k: v[0] for k, v in chunks[0][1].items() if k != 'stepid'}
+        self._init_keys(first)
+      free = C.c_int64()
+      api.emb_replay_free_slots(self._handle, C.byref(free))
+      if free.value < len(chunks) + 2:
+        self._grow(len(chunks))
+      for name, arrays in chunks:
+        time_ms, uid, succ, length = parse_filename(name)
+        slot = C.c_int64()
+        api.emb_replay_load_chunk(
+            self._handle, uid & _MASK64, succ & _MASK64, length, time_ms,
+            C.byref(slot))
+        lo = slot.value * self.chunksize
+        for key in self._keys:
+          host = np.ascontiguousarray(arrays[key.name][:length])
+          flat = torch.from_numpy(host.reshape(-1).view(np.uint8))
+          key.pool[lo * key.rowbytes: (lo + length) * key.rowbytes].copy_(flat)
+        self._saved.add(uid & _MASK64)
+      for name, _ in reversed(chunks):
+        _, uid, _, _ = parse_filename(name)
+        api.emb_replay_load_items(self._handle, uid & _MASK64, int(counts[uid]))
+      self._reraise()
+
   # ------------------------------------------------------------- profiling --
 
   def profile(self, enable=True):
@@ -400,3 +522,62 @@ def _numpy_of(dtype):
     if t == dtype:
       return np_dtype
   raise TypeError(dtype)
+
+
+_MASK64 = (1 << 64) - 1
+_B62 = '0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ'
+
+
+def _b62(value):
+  chars = []
+  while value:
+    value, rem = divmod(value, 62)
+    chars.append(_B62[rem])
+  return ''.join(reversed(chars)).rjust(22, '0')
+
+
+def _unb62(text):
+  value = 0
+  for char in text:
+    value = value * 62 + _B62.index(char)
+  return value
+
+
+def chunk_filename(time_ms, uid, succ, length):
+  """`{time}-{uid}-{succ}-{length}.npz` (chunk.py:31-33): sortable timestamp
+  with milliseconds, 128-bit ids in base 62."""
+  stamp = time.strftime('%Y%m%dT%H%M%S', time.gmtime(time_ms / 1000))
+  return f'{stamp}F{time_ms % 1000:03d}-{_b62(uid)}-{_b62(succ)}-{length}.npz'
+
+
+def parse_filename(name):
+  stem = name[:-4] if name.endswith('.npz') else name
+  stamp, uid, succ, length = stem.split('-')
+  try:
+    import calendar
+    secs = calendar.timegm(time.strptime(stamp[:15], '%Y%m%dT%H%M%S'))
+    time_ms = secs * 1000 + int(stamp[16:19] or 0)
+  except Exception:
+    time_ms = 0
+  return time_ms, _unb62(uid), _unb62(succ), int(length)
+
+
+def count_items(names, length):
+  """Items each chunk file contributes once its successors are present
+  (replay.py:372-388)."""
+  stems = sorted((n[:-4] if n.endswith('.npz') else n for n in names), reverse=True)
+  parsed = [parse_filename(s) for s in stems]
+  lengths = {uid: n for _, uid, _, n in parsed}
+  future = {}
+  for _, uid, succ, n in parsed:
+    future[uid] = n + future.get(succ, 0)
+  counts = {}
+  for _, uid, succ, n in parsed:
+    counts[uid] = int(np.clip(n + 1 - length + future.get(succ, 0), 0, lengths[uid]))
+  return counts
+
+
+def _write_npz(path, data):
+  with io.BytesIO() as stream:
+    np.savez_compressed(stream, **data)
+    path.write_bytes(stream.getvalue())

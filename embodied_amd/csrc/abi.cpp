@@ -720,7 +720,7 @@ int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* to
 int32_t emb_replay_complete_all(emb_replay_t* rep) { REP_OP(rep->index->complete_all()); }
 
 int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_t* succ,
-                          int64_t* fill, int64_t* slot, int64_t* n) {
+                          int64_t* fill, int64_t* slot, int64_t* time_ms, int64_t* n) {
   REP_OP({
     need(n, "chunks: n is null");
     int64_t i = 0;
@@ -730,6 +730,7 @@ int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_
         if (succ) succ[i] = kv.second.succ;
         if (fill) fill[i] = kv.second.fill;
         if (slot) slot[i] = kv.second.slot;
+        if (time_ms) time_ms[i] = kv.second.time_ms;
       }
       ++i;
     }
@@ -737,10 +738,11 @@ int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_
   });
 }
 
-int32_t emb_replay_load_chunk(emb_replay_t* rep, uint64_t uid, uint64_t succ, int64_t fill, int64_t* slot) {
+int32_t emb_replay_load_chunk(emb_replay_t* rep, uint64_t uid, uint64_t succ, int64_t fill,
+                              int64_t time_ms, int64_t* slot) {
   REP_OP({
     need(slot, "load_chunk: slot is null");
-    *slot = rep->index->load_chunk(uid, succ, fill);
+    *slot = rep->index->load_chunk(uid, succ, fill, time_ms);
   });
 }
 

@@ -8,6 +8,7 @@
 // step is addressed by the global row  slot * chunksize + index.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
 #include <deque>
 #include <memory>
@@ -41,6 +42,7 @@ class ReplayIndex {
     int64_t fill = 0;
     int64_t refs = 0;
     int64_t slot = -1;
+    int64_t time_ms = 0;   // creation time (file naming / load order)
   };
   struct Span { uint64_t uid; int64_t slot; int64_t index; int64_t count; };
   using Pos = std::pair<uint64_t, int64_t>;  // (chunk uid, row in chunk)
@@ -235,7 +237,7 @@ class ReplayIndex {
   }
 
   // Re-create a saved chunk (replay.py:347-359): returns its slot.
-  int64_t load_chunk(uint64_t uid, uint64_t succ, int64_t fill) {
+  int64_t load_chunk(uint64_t uid, uint64_t succ, int64_t fill, int64_t time_ms = 0) {
     if (chunks_.count(uid)) throw std::runtime_error("replay: chunk already loaded");
     if (free_.empty()) throw PoolFull();
     Chunk c;
@@ -243,6 +245,7 @@ class ReplayIndex {
     c.succ = succ;
     c.fill = fill;
     c.refs = 0;
+    c.time_ms = time_ms;
     c.slot = free_.front();
     free_.pop_front();
     chunks_[uid] = c;
@@ -267,6 +270,8 @@ class ReplayIndex {
     Chunk c;
     c.uid = next_uid_++;
     c.refs = refs;
+    c.time_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
+        std::chrono::system_clock::now().time_since_epoch()).count();
     c.slot = free_.front();
     free_.pop_front();
     return chunks_[c.uid] = c;

@@ -1,0 +1,3 @@
+from .train import train
+from .eval_only import eval_only
+from .train_eval import train_eval

@@ -205,9 +205,9 @@ int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* to
 /* Checkpoint support (replay.py:294-388): chunk table in/out.                */
 int32_t emb_replay_complete_all(emb_replay_t* rep);
 int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_t* succ,
-                          int64_t* fill, int64_t* slot, int64_t* n);
+                          int64_t* fill, int64_t* slot, int64_t* time_ms, int64_t* n);
 int32_t emb_replay_load_chunk(emb_replay_t* rep, uint64_t uid, uint64_t succ, int64_t fill,
-                              int64_t* slot);
+                              int64_t time_ms, int64_t* slot);
 int32_t emb_replay_load_items(emb_replay_t* rep, uint64_t uid, int64_t amount);
 
 /* ---- Driver-side kernels (embodied/core/driver.py:55-87) ------------------ */

@@ -1,0 +1,162 @@
+"""Driver episode bookkeeping, re-expressing what the reference pins in
+embodied/tests/test_driver.py:9-112 (host mode: numpy, no GPU).  Where the
+reference test is stale — it reads tran['reset'], which the current Driver no
+longer puts in the transition (driver.py:74-76) — the check is made on the
+action the env receives instead."""
+from functools import partial as bind
+
+import numpy as np
+import pytest
+
+import embodied_amd as emb
+from embodied_amd.envs import dummy
+
+
+def make_env(length=10):
+  return dummy.Dummy('disc', length=length)
+
+
+def make_agent():
+  env = make_env()
+  agent = emb.RandomAgent(env.obs_space, env.act_space)
+  env.close()
+  return agent
+
+
+@pytest.mark.parametrize('parallel', [False, True])
+def test_episode_length(parallel):
+  agent = make_agent()
+  driver = emb.Driver([make_env], parallel=parallel)
+  driver.reset(agent.init_policy)
+  seq = []
+  driver.on_step(lambda tran, _: seq.append(tran))
+  driver(agent.policy, episodes=1)
+  driver.close()
+  assert len(seq) == 11
+
+
+def test_first_and_last_step_flags():
+  agent = make_agent()
+  driver = emb.Driver([make_env], parallel=False)
+  driver.reset(agent.init_policy)
+  seq = []
+  driver.on_step(lambda tran, _: seq.append(tran))
+  driver(agent.policy, episodes=2)
+  assert len(seq) == 22
+  for index in [0, 11]:
+    assert seq[index]['is_first'].item() is True
+    assert seq[index]['is_last'].item() is False
+  for index in [1, 10, 12]:
+    assert seq[index]['is_first'].item() is False
+  for index in [10, 21]:
+    assert seq[index]['is_last'].item() is True
+    assert seq[index]['is_first'].item() is False
+  for index in [0, 1, 9, 11, 20]:
+    assert seq[index]['is_last'].item() is False
+
+
+def test_env_reset_zeroes_action_and_requests_reset():
+  received = []
+
+  class Spy(dummy.Dummy):
+    def step(self, action):
+      received.append({k: np.array(v) for k, v in action.items()})
+      return super().step(action)
+
+  driver = emb.Driver([lambda: Spy('disc', length=5)], parallel=False)
+  driver.reset(lambda n: ())
+  seq = []
+  driver.on_step(lambda tran, _: seq.append(tran))
+  action = {'act_disc': np.ones(1, np.int32), 'act_cont': np.zeros((1, 6), np.float32)}
+  driver(lambda carry, obs: (carry, action, {}), episodes=2)
+  assert len(seq) == 12
+  cols = {k: np.array([s[k] for s in seq]) for k in seq[0]}
+  assert (cols['is_first'] == [1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0]).all()
+  assert (cols['is_last'] == [0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1]).all()
+  assert (cols['act_disc'] == [1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0]).all()
+  assert 'reset' not in cols
+  resets = [bool(a['reset']) for a in received]
+  assert resets == [True, False, False, False, False, False, True] + [False] * 5
+
+
+def test_agent_inputs_and_carry_threading():
+  agent = make_agent()
+  driver = emb.Driver([make_env], parallel=False)
+  driver.reset(agent.init_policy)
+  inputs, states = [], []
+
+  def policy(carry, obs, mode='train'):
+    inputs.append(obs)
+    states.append(carry)
+    _, act, _ = agent.policy(carry, obs, mode)
+    return 'carry', act, {}
+
+  seq = []
+  driver.on_step(lambda tran, _: seq.append(tran))
+  driver(policy, episodes=2)
+  assert len(seq) == 22
+  assert states == ([()] + ['carry'] * 21)
+  for index in [0, 11]:
+    assert inputs[index]['is_first'].item() is True
+  for index in [1, 10, 12, 21]:
+    assert inputs[index]['is_first'].item() is False
+  for index in [10, 21]:
+    assert inputs[index]['is_last'].item() is True
+
+
+def test_unexpected_reset_mid_episode():
+  class UnexpectedReset:
+    """is_first without a preceding is_last."""
+    def __init__(self, env, when):
+      self.env, self.when, self.count = env, when, 0
+    act_space = property(lambda self: self.env.act_space)
+    obs_space = property(lambda self: self.env.obs_space)
+    def step(self, action):
+      if self.count == self.when:
+        action = {**action, 'reset': np.ones_like(action['reset'])}
+      self.count += 1
+      return self.env.step(action)
+    def close(self):
+      pass
+
+  env = UnexpectedReset(make_env(length=4), when=3)
+  agent = make_agent()
+  driver = emb.Driver([lambda: env], parallel=False)
+  driver.reset(agent.init_policy)
+  steps = []
+  driver.on_step(lambda tran, _: steps.append(tran))
+  driver(agent.policy, episodes=1)
+  assert len(steps) == 8
+  cols = {k: np.array([x[k] for x in steps]) for k in steps[0]}
+  assert (cols['is_first'] == [1, 0, 0, 1, 0, 0, 0, 0]).all()
+  assert (cols['is_last'] == [0, 0, 0, 0, 0, 0, 0, 1]).all()
+
+
+def test_out_keys_must_not_shadow_actions():
+  agent = make_agent()
+  driver = emb.Driver([make_env], parallel=False)
+  driver.reset(agent.init_policy)
+  def policy(carry, obs):
+    _, act, _ = agent.policy(carry, obs)
+    return carry, act, {'act_disc': np.zeros(1)}
+  with pytest.raises(AssertionError):
+    driver(policy, steps=1)
+
+
+def test_log_keys_reach_callbacks_but_not_policy():
+  class Logging(dummy.Dummy):
+    def step(self, action):
+      obs = super().step(action)
+      obs['log/extra'] = np.float32(7)
+      return obs
+  seen, trans = [], []
+  driver = emb.Driver([lambda: Logging('disc')], parallel=False)
+  agent = make_agent()
+  driver.reset(agent.init_policy)
+  def policy(carry, obs):
+    seen.append(set(obs))
+    return agent.policy(carry, obs)
+  driver.on_step(lambda tran, _: trans.append(set(tran)))
+  driver(policy, steps=3)
+  assert all('log/extra' not in s for s in seen)
+  assert all('log/extra' in t for t in trans)

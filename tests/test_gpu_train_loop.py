@@ -1,0 +1,112 @@
+"""run.train end to end with a self-checking agent, the integration the
+reference pins in embodied/tests/test_train.py:12-33 + tests/utils.py:8-104
+(count continuity Driver -> Replay -> batch; train/report/save/load counts)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class CheckingAgent:
+  """Asserts `obs['count']` continuity in policy (per env) and along T in every
+  training batch; counts calls."""
+
+  def __init__(self, obs_space, act_space):
+    self.obs_space, self.act_space = obs_space, act_space
+    self.policies = self.trains = self.reports = self.saves = self.loads = 0
+    self.prev = None
+
+  def init_policy(self, n):
+    return ()
+
+  init_train = init_report = init_policy
+
+  def stream(self, st):
+    return st
+
+  def policy(self, carry, obs, mode='train'):
+    count = np.asarray(obs['count'].cpu() if torch.is_tensor(obs['count']) else obs['count'])
+    first = np.asarray(obs['is_first'].cpu() if torch.is_tensor(obs['is_first']) else obs['is_first'])
+    if self.prev is not None:
+      ok = np.where(first, count == 0, count == self.prev + 1)
+      assert ok.all(), (self.prev, count, first)
+    self.prev = count
+    self.policies += 1
+    n = len(first)
+    act = {k: np.stack([v.sample() for _ in range(n)])
+           for k, v in self.act_space.items() if k != 'reset'}
+    return carry, act, {}
+
+  def train(self, carry, data):
+    count = data['count'].cpu().numpy() if torch.is_tensor(data['count']) else data['count']
+    first = data['is_first'].cpu().numpy() if torch.is_tensor(data['is_first']) else data['is_first']
+    for b in range(count.shape[0]):
+      for t in range(1, count.shape[1]):
+        assert first[b, t] or count[b, t] == count[b, t - 1] + 1
+    assert 'consec' in data and 'stepid' in data
+    self.trains += 1
+    return carry, {}, {'loss': np.float32(self.trains)}
+
+  def report(self, carry, data):
+    self.reports += 1
+    return carry, {'metric': np.float32(1)}
+
+  def save(self):
+    self.saves += 1
+    return {'trains': self.trains}
+
+  def load(self, data):
+    self.loads += 1
+
+
+def make_args(tmp_path, **kw):
+  args = dict(
+      logdir=str(tmp_path), batch_size=4, batch_length=8, train_ratio=32.0,
+      log_every=0.05, report_every=0.05, save_every=0.05, envs=3, debug=True,
+      from_checkpoint='', steps=600, consec_report=1, report_batches=1, device='cuda')
+  args.update(kw)
+  return types.SimpleNamespace(**args)
+
+
+def run(tmp_path, agent_box, **kw):
+  import embodied_amd as emb
+  from embodied_amd.envs import dummy
+  args = make_args(tmp_path, **kw)
+  env0 = dummy.Dummy('disc', size=(8, 8), length=17)
+
+  def make_agent():
+    agent_box.append(CheckingAgent(env0.obs_space, env0.act_space))
+    return agent_box[-1]
+
+  make_replay = lambda: emb.Replay(
+      length=args.batch_length + 1, capacity=500, chunksize=64,
+      directory=tmp_path / 'replay', save_wait=True)
+  make_env = lambda i: dummy.Dummy('disc', size=(8, 8), length=17 + i)
+  make_stream = lambda replay, mode: emb.streams.Consec(
+      emb.streams.Stateless(replay.sample, args.batch_size, mode),
+      length=args.batch_length, consec=1, prefix=1, strict=True, contiguous=True)
+  logger = emb.utils.Logger()
+  emb.run.train(make_agent, make_replay, make_env, make_stream, lambda: logger, args)
+  return logger, agent_box[-1]
+
+
+def test_train_loop_counts_and_resume(tmp_path):
+  box = []
+  logger, agent = run(tmp_path, box)
+  assert int(logger.step) >= 600
+  # one policy call per vectorised step
+  assert abs(agent.policies - int(logger.step) / 3) <= 4
+  expected_trains = (int(logger.step) - 4 * 8) * 32.0 / (4 * 8)
+  assert 0.7 * expected_trains <= agent.trains <= 1.1 * expected_trains + 2
+  assert agent.reports >= 1
+  assert agent.saves >= 2
+  assert agent.loads == 0
+  stats_seen = [r for r in logger.history if 'replay/items' in r]
+  assert stats_seen and stats_seen[-1]['replay/items'] > 0
+  # resume: checkpoint exists -> agent.load called once, replay restored
+  logger2, agent2 = run(tmp_path, box, steps=700)
+  assert agent2.loads == 1
+  assert int(logger2.step) >= 700
