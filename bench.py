@@ -38,10 +38,20 @@ def parse():
   p.add_argument('--capacity', type=int, default=100_000)   # ppo/configs.yaml:39
   p.add_argument('--train-ratio', type=float, default=3.0)  # ppo/configs.yaml:51
   p.add_argument('--grad-numel', type=int, default=10_000_000)   # PPO-sized f32 gradient
-  p.add_argument('--exchange', default='trajectories', choices=['trajectories', 'returns', 'none'])
+  p.add_argument('--exchange', default='online',
+                 choices=['online', 'trajectories', 'returns', 'none'],
+                 help='N>1: what each train step all-gathers. online (default) = the packed '
+                      'batch whenever it holds fresh on-policy windows (every trajectory crosses '
+                      'xGMI once; re-sampled windows are not re-sent); trajectories = every batch')
   p.add_argument('--cpu-seconds', type=float, default=15.0)
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--prefetch', type=int, default=1, help='train batches gathered per launch')
+  p.add_argument('--workload', default='ppo', choices=['ppo', 'dreamer'],
+                 help='ppo = BASELINE configs[1] (default); dreamer = configs[2]: 1M-step '
+                      'uniform replay, train_ratio 32, 40 KB/step latents written back')
+  p.add_argument('--host-envs', action='store_true',
+                 help='step 64 numpy envs on the host and upload through the pinned slab '
+                      '(PCIe-inclusive rate; never the headline value)')
   return p.parse_args()
 
 
@@ -67,18 +77,25 @@ def build_path(args, rank, device):
   import embodied_amd as emb
   from embodied_amd.envs import synthetic
   L = args.length + args.context
-  env = synthetic.SyntheticBatchEnv(
-      args.envs, shape=(84, 84, 4), episode_len=1000, env0=rank * args.envs,
-      device=device)
+  dreamer = args.workload == 'dreamer'
   replay = emb.Replay(
-      length=L, capacity=args.capacity, chunksize=1024, online=True, seed=0,
+      length=L, capacity=args.capacity, chunksize=1024, online=not dreamer, seed=0,
       device=device, replica=rank)
-  driver = emb.Driver(batch_env=env, device=device)
-  driver.on_step(replay.add)
   n = args.envs
+  if args.host_envs:
+    fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]
+    driver = emb.Driver(fns, parallel=False, device=device)
+    env = None
+  else:
+    env = synthetic.SyntheticBatchEnv(
+        n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device)
+    driver = emb.Driver(batch_env=env, device=device)
+  driver.on_step(replay.add)
   actions = torch.randint(0, 6, (4096, n), dtype=torch.int32, device=device)
-  logp = torch.zeros(n, dtype=torch.float32, device=device)
   state = {'tick': 0}
+  if dreamer:   # replay-context latents every policy step (dreamerv3/rssm.py:40-43)
+    deter = torch.zeros((n, 8192), dtype=torch.float32, device=device)
+    stoch = torch.zeros((n, 32, 64), dtype=torch.float32, device=device)
 
   def policy(carry, obs, **kw):
     # obs stack/transpose into the policy batch (N, C, H, W) bf16 in [0, 1]:
@@ -87,13 +104,19 @@ def build_path(args, rank, device):
         obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
     state['tick'] += 1
     state['policy_batch'] = batch
-    return carry, {'action': actions[state['tick'] % 4096]}, {}
+    outs = {'dyn/deter': deter, 'dyn/stoch': stoch} if dreamer else {}
+    return carry, {'action': actions[state['tick'] % 4096]}, outs
 
   return emb, env, replay, driver, policy
 
 
 def main():
   args = parse()
+  if args.workload == 'dreamer':      # dreamerv3/configs.yaml:11,15,40-42 (size overridden to 1e6)
+    if args.capacity == 100_000:
+      args.capacity = 1_000_000
+    if args.train_ratio == 3.0:
+      args.train_ratio = 32.0
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -115,12 +138,23 @@ def main():
       length=T, consec=1, prefix=args.context, strict=True, contiguous=True))
   should_train = Ratio(args.train_ratio / (B * T))
   value = torch.randn(B * args.prefetch, L, device=device)
+  imag_rew = torch.randn(B * T, 16, device=device)
+  imag_flags = torch.zeros(B * T, 16, dtype=torch.bool, device=device)
   grads = torch.zeros(args.grad_numel, device=device) if use_dist else None
   counters = {'env_steps': 0, 'train_steps': 0}
   pending = []
 
   def train_step():
-    if not use_dist:
+    if not use_dist and args.workload == 'dreamer':
+      # sample -> lambda-returns (replay (B,T) and imagination (B*K,H+1)) ->
+      # write the new latents back over the sampled steps (agent.py:144-150).
+      batch = next(stream)
+      adv = emb.scans.lambda_return(
+          batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95)
+      emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
+      replay.update({'stepid': batch['stepid'], 'dyn/deter': batch['dyn/deter'],
+                     'dyn/stoch': batch['dyn/stoch']})
+    elif not use_dist:
       batch = next(stream)
       adv, tar = emb.scans.gae(
           batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
@@ -136,7 +170,7 @@ def main():
       for work in pending:
         work.wait()
       pending.clear()
-      if args.exchange == 'trajectories':
+      if args.exchange == 'trajectories' or (args.exchange == 'online' and layout.online.any()):
         send = flat
       elif args.exchange == 'returns':
         send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
@@ -210,7 +244,7 @@ def main():
     }
 
   cpu = None
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ppo' and not args.host_envs:
     cpu = cpu_baseline(args)
 
   if rank == 0:
@@ -224,9 +258,13 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'u8', 'data': 'synthetic',
         'config': {
-            'workload': 'ppo_atari_pong_64env: 64 device envs/GPU, 84x84x4 u8, '
-                        f'Replay(length={L}, capacity={args.capacity}, online, '
-                        f'Uniform), B={B}, T={T}, train_ratio={args.train_ratio}, GAE',
+            'workload': (
+                f'{"dreamerv3_1M_uniform" if args.workload == "dreamer" else "ppo_atari_pong"}_64env: '
+                f'64 {"host (numpy, PCIe upload)" if args.host_envs else "device"} envs/GPU, 84x84x4 u8, '
+                f'Replay(length={L}, capacity={args.capacity}, '
+                f'{"uniform, latents written back" if args.workload == "dreamer" else "online"}), '
+                f'B={B}, T={T}, train_ratio={args.train_ratio}, '
+                f'{"lambda-return" if args.workload == "dreamer" else "GAE"}'),
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch,
             'parallelism': (f'env-sharded x{world}, {args.exchange} all-gather + '

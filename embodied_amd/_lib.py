@@ -115,7 +115,7 @@ SIGNATURES = {
     'emb_replay_free_slots': [p, p],
     'emb_replay_stats': [p, p, i32],
     'emb_replay_add': [p, i64, p, p, p],
-    'emb_replay_sample': [p, i64, i32, p, p, p],
+    'emb_replay_sample': [p, i64, i32, p, p, p, p],
     'emb_replay_update': [p, i64, i64, p, i32, p, p, p],
     'emb_replay_gather_rows': [p, p, i64, i64, p, p],
     'emb_replay_scatter_rows': [p, p, i64, i32, p, p, p],
@@ -182,8 +182,15 @@ api = _Api()
 
 
 def raw_stream(device):
-  """hipStream_t of torch's current stream on `device` (cheap C getter)."""
-  return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+  """hipStream_t of torch's current stream on `device`.  Also makes `device`
+  the calling thread's current HIP device: the library launches on whatever
+  device is current, and helper threads (Prefetch, savers) start on device 0."""
+  index = device.index
+  if index is None:
+    index = torch._C._cuda_getDevice()
+  elif torch._C._cuda_getDevice() != index:
+    torch.cuda.set_device(index)
+  return torch._C._cuda_getCurrentRawStream(index)
 
 
 def ptr(array):

@@ -292,9 +292,14 @@ class Replay:
     with self._lock:
       self._flush()
       out, ptrs = self._alloc_batch(batch, self.length)
+      first = np.empty((batch, _lib.STEPID_BYTES), np.uint8)
       api.emb_replay_sample(
-          self._handle, batch, _lib.MODES[mode], ptrs, None, self._stream())
+          self._handle, batch, _lib.MODES[mode], ptrs, None, _lib.ptr(first),
+          self._stream())
       self._reraise()
+      # Host copy of stepid[:, 0] rides on the tensor object so `update` with
+      # the same tensor needs no device read-back (a sync).
+      out['stepid']._emb_first = first
     return self._finish(out)
 
   def _alloc_batch(self, batch, length):
@@ -341,11 +346,15 @@ class Replay:
     data = dict(data)
     stepid = data.pop('stepid')
     priority = data.pop('priority', None)
-    if torch.is_tensor(stepid):
-      stepid = stepid.detach().cpu().numpy()
-    stepid = np.ascontiguousarray(stepid, np.uint8)
     assert stepid.ndim == 3, stepid.shape
-    B = stepid.shape[0]
+    first = getattr(stepid, '_emb_first', None)
+    steps = int(np.prod(stepid.shape[:-1]))
+    if first is None or priority is not None:
+      if torch.is_tensor(stepid):
+        stepid = stepid.detach().cpu().numpy()
+      stepid = np.ascontiguousarray(stepid, np.uint8)
+      first = np.ascontiguousarray(stepid[:, 0])
+    B = len(first)
     with self._lock:
       self._flush()
       if priority is not None:
@@ -377,12 +386,11 @@ class Replay:
           keep.append(value)
           ids[j] = self._keyid[name]
           ptrs[j] = value.data_ptr()
-        first = np.ascontiguousarray(stepid[:, 0])
         api.emb_replay_update(
             self._handle, B, T, _lib.ptr(first), len(data), ids, ptrs,
             self._stream())
       # replay.py:134: every call counts B*T steps, written or not.
-      self._updates += int(np.prod(stepid.shape[:-1]))
+      self._updates += steps
 
   def _reraise(self):
     if isinstance(self._native, selectorlib.Foreign):

@@ -478,7 +478,8 @@ static void add_index_locked(emb_replay* rep, int64_t n, const int64_t* workers,
 }
 
 static void sample_index_locked(emb_replay* rep, int64_t batch, int32_t mode, int32_t* rows,
-                                uint8_t* online, std::vector<int32_t>* spans = nullptr) {
+                                uint8_t* online, std::vector<int32_t>* spans = nullptr,
+                                uint8_t* first_ids = nullptr) {
   need(mode >= EMB_MODE_TRAIN && mode <= EMB_MODE_EVAL, "sample: bad mode");
   const int64_t L = rep->index->config().length;
   bool spans_ok = spans != nullptr;
@@ -490,6 +491,10 @@ static void sample_index_locked(emb_replay* rep, int64_t batch, int32_t mode, in
       throw std::logic_error("replay: sampled window vanished");
     if (spans_ok) spans_ok = rep->index->two_spans(pos, L, spans->data() + 3 * b);
     if (online) online[b] = from_online ? 1 : 0;
+    if (first_ids) {
+      const emb::StepId sid = rep->index->make_stepid(pos.first, pos.second);
+      std::memcpy(first_ids + b * EMB_STEPID_BYTES, sid.b, EMB_STEPID_BYTES);
+    }
   }
   if (spans && !spans_ok) spans->clear();
 }
@@ -620,7 +625,7 @@ int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers, con
 }
 
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
-                          uint8_t* online_out, void* stream) {
+                          uint8_t* online_out, uint8_t* first_stepids_out, void* stream) {
   REP_OP({
     need(batch >= 0 && dst, "sample: bad arguments");
     need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
@@ -635,7 +640,7 @@ int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* 
     }
     plan.seq_len = static_cast<int32_t>(L);
     rep->rows.resize(batch * L);
-    sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans);
+    sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
     run_move(rep, plan, rep->rows.data(), batch * L, nullptr, -1, true,
              static_cast<hipStream_t>(stream), &rep->spans);
   });

@@ -99,8 +99,11 @@ def sample_packed(replay, batch, mode='train'):
     views = layout.views(flat)
     ptrs = (C.c_void_p * len(replay._keys))(
         *[views[k.name].data_ptr() for k in replay._keys])
+    online = np.zeros(batch, np.uint8)
     api.emb_replay_sample(
-        replay._handle, batch, _lib.MODES[mode], ptrs, None, replay._stream())
+        replay._handle, batch, _lib.MODES[mode], ptrs, _lib.ptr(online), None,
+        replay._stream())
+  layout.online = online.astype(bool)
   return flat, views, layout
 
 

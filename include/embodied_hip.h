@@ -178,13 +178,15 @@ int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset);
  * add:    src[k] = device (n, rowbytes[k]) for every key except "stepid",
  *         which the library synthesises (entry ignored).   Replay.add
  * sample: dst[k] = device (batch, length, rowbytes[k]); is_first / is_last are
- *         annotated in flight (replay.py:277-292).         Replay.sample
+ *         annotated in flight (replay.py:277-292); online_out[batch] and
+ *         first_stepids_out[batch*20] (host, optional) receive the online-queue
+ *         flags and stepid[:,0] without a device read-back.   Replay.sample
  * update: stepids = host (B, 20) first step of each row; key_ids/src select the
  *         columns to overwrite, src[j] = device (B, T, rowbytes).  Replay.update */
 int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers,
                        const void* const* src, void* stream);
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
-                          uint8_t* online_out, void* stream);
+                          uint8_t* online_out, uint8_t* first_stepids_out, void* stream);
 int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t* stepids,
                           int32_t n_keys, const int32_t* key_ids, const void* const* src,
                           void* stream);
