@@ -294,3 +294,40 @@ def test_mask_actions_bfloat16(emb):
   got = mask_actions(value, last).view(torch.int16).cpu().numpy().view(np.uint16)
   want = np.array([[0x8000, 0x0000], [0x4040, 0xBE80], [0x0000, 0x8000]], np.uint16)
   assert (got == want).all()
+
+
+def test_large_tables_take_the_ring_path(emb):
+  """> 117 inserted rows, > 234 sequences and windows crossing several chunks:
+  row tables no longer fit the kernel arguments and go through the pinned ring."""
+  n, L = 300, 7
+  ours = emb.Replay(length=L, capacity=5000, chunksize=4, seed=2)
+  ref = np_oracle.Replay(L, 5000, 4, seed=2)
+  for t in range(12):
+    steps = {'t': np.full(n, t, np.int32), 'w': np.arange(n, dtype=np.int32),
+             'vec': np.random.default_rng(t).standard_normal((n, 600)).astype(np.float32),
+             'is_first': np.full(n, t == 0), 'is_last': np.zeros(n, bool)}
+    ours.add_batch({k: torch.as_tensor(v).cuda() for k, v in steps.items()}, list(range(n)))
+    for w in range(n):
+      ref.add({k: v[w] for k, v in steps.items()}, w)
+  assert len(ours) == len(ref)
+  got = {k: v.cpu().numpy() for k, v in ours.sample(400).items()}
+  assert_same(got, ref.sample(400), 'ring-path')
+
+
+def test_prefetch_stream_and_python_selector(emb):
+  """Prefetch thread over Consec over Replay.sample, with the replay driven by
+  a plain Python selector object through the callback ABI."""
+  sel = np_oracle.Uniform(9)
+  ours = emb.Replay(length=5, capacity=60, chunksize=8, selector=sel)
+  ref = np_oracle.Replay(5, 60, 8, selector=np_oracle.Uniform(9))
+  for t in range(40):
+    for w in range(2):
+      ours.add(scenarios.synth_step(t, w), w)
+      ref.add(scenarios.synth_step(t, w), w)
+  stream = emb.streams.Prefetch(emb.streams.Consec(
+      emb.streams.Stateless(ours.sample, 3, 'train'), length=2, consec=2, prefix=1))
+  it = iter(stream)
+  want_src = np_oracle.Consec(lambda: ref.sample(3), 2, 2, 1)
+  for _ in range(6):
+    got = {k: v.cpu().numpy() for k, v in next(it).items()}
+    assert_same(got, next(want_src), 'prefetch')

@@ -1,0 +1,90 @@
+"""Host-side pieces: limiters and numpy streams (no GPU)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from embodied_amd import limiters, streams
+from oracle import np_oracle, refload
+
+
+def drive(lim):
+  log = []
+  log.append((lim.want_insert(), lim.want_sample()))
+  for _ in range(3):
+    lim.insert()
+  while lim.want_sample():
+    lim.sample()
+    log.append(('s', lim.avail))
+  while lim.want_insert():
+    lim.insert()
+    log.append(('i', lim.avail))
+  log.append(lim.save())
+  return log
+
+
+def test_samples_per_insert_limiter():
+  lim = limiters.SamplesPerInsert(samples_per_insert=2, tolerance=4, minsize=3)
+  log = drive(lim)
+  assert log[0] == (True, False)
+  assert [x for x in log if isinstance(x, tuple) and x[0] == 's'] == [('s', -2), ('s', -3), ('s', -4)]
+  assert lim.avail >= lim.max_avail
+  other = limiters.SamplesPerInsert(2, 4, 3)
+  other.load(lim.save())
+  assert (other.avail, other.size) == (lim.avail, lim.size)
+
+
+@pytest.mark.reference
+def test_limiter_matches_reference():
+  if not refload.available():
+    pytest.skip('no /root/reference here')
+  ref = refload.load().limiters.SamplesPerInsert(2, 4, 3)
+  assert drive(ref) == drive(limiters.SamplesPerInsert(2, 4, 3))
+
+
+def test_wait_returns_when_predicate_turns_true():
+  flag = []
+  threading.Timer(0.05, lambda: flag.append(1)).start()
+  waited = limiters.wait(lambda: bool(flag), 'waiting', sleep=0.005)
+  assert 0.03 < waited < 1.0
+  assert limiters.wait(lambda: True, 'no wait') == 0
+
+
+def test_consec_numpy_matches_oracle():
+  gen = np.random.default_rng(0)
+  def source():
+    return {'x': gen.integers(0, 9, (2, 7, 3)), 'is_first': gen.random((2, 7)) < 0.2}
+  batches = [source() for _ in range(3)]
+  ours = iter(streams.Consec(iter(batches), length=3, consec=2, prefix=1, contiguous=True))
+  it = iter(batches)
+  want = np_oracle.Consec(lambda: next(it), 3, 2, 1)
+  for _ in range(6):
+    a, b = next(ours), next(want)
+    assert set(a) == set(b)
+    for k in a:
+      assert np.array_equal(a[k], b[k]) and a[k].flags['C_CONTIGUOUS']
+  with pytest.raises(AssertionError):
+    next(iter(streams.Consec(iter([source()]), length=3, consec=1, prefix=1, strict=True)))
+
+
+def test_prefetch_propagates_errors_and_state():
+  class Source:
+    def __init__(self):
+      self.n = 0
+    def __iter__(self):
+      return self
+    def __next__(self):
+      self.n += 1
+      if self.n == 4:
+        raise ValueError('boom')
+      return {'n': self.n}
+    def save(self):
+      return self.n
+    def load(self, n):
+      self.n = n
+  pre = iter(streams.Prefetch(Source(), lambda d: {**d, 'seen': True}))
+  assert [next(pre)['n'] for _ in range(3)] == [1, 2, 3]
+  assert pre.save() == 3
+  with pytest.raises(RuntimeError, match='boom'):
+    next(pre)
