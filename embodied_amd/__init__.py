@@ -7,7 +7,7 @@ from . import _lib  # raises if libembodied_hip.so is missing: no CPU fallback
 from .space import Space
 from .core.base import Agent, Env, Stream
 from .core.driver import Driver
-from .core.random import RandomAgent
+from .core.agents import RandomAgent
 from .core.replay import Replay
 from .core import limiters
 from .core import selectors

@@ -1,6 +1,6 @@
 from .base import Agent, Env, Stream
 from .driver import Driver
-from .random import RandomAgent
+from .agents import RandomAgent
 from .replay import Replay
 from . import limiters
 from . import selectors

@@ -1,73 +1,74 @@
 """The drop-in boundary: the duck-typed protocols every agent, env and stream
-is written against (reference: embodied/core/base.py:1-73).  Signatures and
-error behaviour (NotImplementedError naming the expected signature) are kept so
-code written for the reference runs unchanged."""
+is written against (reference: embodied/core/base.py:1-73).  Method names,
+argument order and the NotImplementedError texts (which spell the expected
+signature) are what callers rely on, so they are kept; the classes are
+generated from the signature tables below.
+"""
+
+AGENT_METHODS = {
+    'init_train': ('batch_size', 'carry'),
+    'init_report': ('batch_size', 'carry'),
+    'init_policy': ('batch_size', 'carry'),
+    'train': ('carry, data', 'carry, out, metrics'),
+    'report': ('carry, data', 'carry, metrics'),
+    'policy': ('carry, obs, mode', 'carry, act, out'),
+    'stream': ('st', 'st'),
+    'save': ('', 'data'),
+    'load': ('data', 'None'),
+}
 
 
-def _missing(signature):
-  return NotImplementedError(signature)
+def _unimplemented(name, params, returns):
+  message = f'{name}({params}) -> {returns}'
+
+  def method(self, *args, **kwargs):
+    raise NotImplementedError(message)
+
+  method.__name__ = name
+  method.__doc__ = f'Expected signature: {message}'
+  return method
 
 
 class Agent:
-  """policy/train/report/stream/init_*/save/load (base.py:1-31)."""
+  """policy / train / report / stream / init_* / save / load.  `policy`'s `out`
+  keys must be disjoint from its `act` keys (driver.py:70-71); an
+  `out['replay']` from `train` is fed to `Replay.update` (run/train.py:77-78)."""
 
   def __init__(self, obs_space, act_space, config):
     pass
 
-  def init_train(self, batch_size):
-    raise _missing('init_train(batch_size) -> carry')
 
-  def init_report(self, batch_size):
-    raise _missing('init_report(batch_size) -> carry')
-
-  def init_policy(self, batch_size):
-    raise _missing('init_policy(batch_size) -> carry')
-
-  def train(self, carry, data):
-    raise _missing('train(carry, data) -> carry, out, metrics')
-
-  def report(self, carry, data):
-    raise _missing('report(carry, data) -> carry, metrics')
-
-  def policy(self, carry, obs, mode):
-    raise _missing('policy(carry, obs, mode) -> carry, act, out')
-
-  def stream(self, st):
-    raise _missing('stream(st) -> st')
-
-  def save(self):
-    raise _missing('save() -> data')
-
-  def load(self, data):
-    raise _missing('load(data) -> None')
+for _name, (_params, _returns) in AGENT_METHODS.items():
+  setattr(Agent, _name, _unimplemented(_name, _params, _returns))
 
 
 class Env:
-  """step/obs_space/act_space/close (base.py:34-58).  Observations carry
-  is_first, is_last, is_terminal (and usually reward); keys starting with
-  'log/' bypass agent and replay; the action space contains 'reset'."""
-
-  def __repr__(self):
-    return (f'{type(self).__name__}(obs_space={self.obs_space}, '
-            f'act_space={self.act_space})')
+  """One environment instance.  `obs_space` must contain is_first, is_last and
+  is_terminal (usually also reward and image); keys starting with 'log/' are
+  shown to callbacks but neither to the agent nor to the replay; `act_space`
+  must contain `reset`."""
 
   @property
   def obs_space(self):
-    raise _missing('Returns: dict of spaces')
+    raise NotImplementedError('Returns: dict of spaces')
 
   @property
   def act_space(self):
-    raise _missing('Returns: dict of spaces')
+    raise NotImplementedError('Returns: dict of spaces')
 
   def step(self, action):
-    raise _missing('Returns: dict')
+    raise NotImplementedError('Returns: dict')
 
   def close(self):
-    pass
+    return None
+
+  def __repr__(self):
+    name = type(self).__name__
+    return f'{name}(obs_space={self.obs_space}, act_space={self.act_space})'
 
 
 class Stream:
-  """Iterator with save()/load(state) (base.py:61-73)."""
+  """An iterator whose position can be checkpointed."""
 
   def __iter__(self):
     return self

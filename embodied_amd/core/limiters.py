@@ -1,62 +1,72 @@
-"""Blocking predicate wait and the samples-per-insert rate limiter
+"""Blocking wait and the samples-per-insert rate limiter
 (reference: embodied/core/limiters.py:5-80)."""
 import threading
 import time
 
 
 def wait(predicate, message, info=None, sleep=0.01, notify=60):
-  """Spin until `predicate()`; returns the seconds waited (limiters.py:5-16)."""
-  if predicate():
-    return 0
-  began = reported = time.time()
+  """Poll `predicate` every `sleep` seconds until it holds; print `message`
+  every `notify` seconds meanwhile.  Returns the seconds spent waiting (0 if it
+  held at once).  Replay.sample uses it to block on an empty buffer."""
+  began = time.time()
+  reminded = began
+  waited = False
   while not predicate():
+    waited = True
     now = time.time()
-    if now - reported > notify:
+    if now - reminded > notify:
       print(f'{message} {now - began:.1f}s: {info}')
-      reported = now
+      reminded = now
     time.sleep(sleep)
-  return time.time() - began
+  return time.time() - began if waited else 0
 
 
 class SamplesPerInsert:
-  """Keeps sampling within `tolerance` of `samples_per_insert` x inserts once
-  `minsize` inserts happened (limiters.py:19-80)."""
+  """Token bucket coupling the learner's sampling rate to the actors' insert
+  rate: each insert (once `minsize` items exist) adds `samples_per_insert`
+  tokens, each sample takes one; inserting pauses when the surplus exceeds
+  `tolerance * samples_per_insert`, sampling when the deficit exceeds
+  `tolerance`.  State = (size, avail), checkpointable."""
 
   def __init__(self, samples_per_insert, tolerance, minsize):
-    assert 1 <= minsize
+    if minsize < 1:
+      raise AssertionError(minsize)
     self.samples_per_insert = samples_per_insert
     self.minsize = minsize
+    self.size = 0
     self.avail = -minsize
     self.min_avail = -tolerance
     self.max_avail = tolerance * samples_per_insert
-    self.size = 0
     self.lock = threading.Lock()
 
-  def save(self):
-    return {'size': self.size, 'avail': self.avail}
+  @property
+  def _warm(self):
+    return self.size >= self.minsize
 
-  def load(self, data):
-    self.size = data['size']
-    self.avail = data['avail']
+  @property
+  def _limited(self):
+    return self.samples_per_insert > 0
 
   def want_insert(self):
-    if self.size < self.minsize or self.samples_per_insert <= 0:
-      return True
-    return self.avail < self.max_avail
+    return (not self._warm) or (not self._limited) or self.avail < self.max_avail
 
   def want_sample(self):
-    if self.size < self.minsize:
+    if not self._warm:
       return False
-    if self.samples_per_insert <= 0:
-      return True
-    return self.min_avail < self.avail
+    return (not self._limited) or self.avail > self.min_avail
 
   def insert(self):
     with self.lock:
       self.size += 1
-      if self.size >= self.minsize:
+      if self._warm:
         self.avail += self.samples_per_insert
 
   def sample(self):
     with self.lock:
       self.avail -= 1
+
+  def save(self):
+    return dict(size=self.size, avail=self.avail)
+
+  def load(self, data):
+    self.size, self.avail = data['size'], data['avail']

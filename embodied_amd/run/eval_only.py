@@ -1,45 +1,33 @@
-"""Policy-only loop (reference: embodied/run/eval_only.py:9-74)."""
-import collections
+"""Policy-only loop (reference: embodied/run/eval_only.py:9-74, same
+signature): steps the envs with `mode='eval'`, logs episode statistics."""
 from functools import partial as bind
-
-import numpy as np
 
 from .. import utils
 from ..core.driver import Driver
-from .train import _scalar
+from .stats import EpisodeStats
 
 
 def eval_only(make_agent, make_env, make_logger, args):
-  agent = make_agent()
-  logger = make_logger()
+  agent, logger = make_agent(), make_logger()
   step = logger.step
-  episodes = collections.defaultdict(utils.Agg)
   epstats = utils.Agg()
   policy_fps = utils.FPS()
   should_log = utils.LocalClock(args.log_every)
+  driver = Driver(
+      [bind(make_env, index) for index in range(args.envs)],
+      parallel=not args.debug, device=getattr(args, 'device', None))
+  episodes = EpisodeStats(logger, epstats)
 
-  def logfn(tran, worker):
-    episode = episodes[worker]
-    if bool(_scalar(tran['is_first'])):
-      episode.reset()
-    episode.add('score', _scalar(tran['reward']), agg='sum')
-    episode.add('length', 1, agg='sum')
-    if bool(_scalar(tran['is_last'])):
-      result = episode.result()
-      logger.add({'score': result.pop('score'), 'length': result.pop('length')},
-                 prefix='episode')
-      epstats.add(result)
+  def count(trans, workers, **kw):
+    step.increment(args.envs)
+    policy_fps.step(args.envs)
 
-  fns = [bind(make_env, i) for i in range(args.envs)]
-  driver = Driver(fns, parallel=not args.debug, device=getattr(args, 'device', None))
-  driver.on_step(lambda tran, _: step.increment())
-  driver.on_step(lambda tran, _: policy_fps.step())
-  driver.on_step(logfn)
-
+  driver.on_batch(count)
+  driver.on_batch(episodes.on_batch)
   if getattr(args, 'from_checkpoint', ''):
-    cp = utils.Checkpoint()
-    cp.agent = agent
-    cp.load(args.from_checkpoint, keys=['agent'])
+    checkpoint = utils.Checkpoint()
+    checkpoint.agent = agent
+    checkpoint.load(args.from_checkpoint, keys=['agent'])
 
   print('Start evaluation')
   policy = lambda *a, **kw: agent.policy(*a, mode='eval', **kw)
@@ -50,5 +38,6 @@ def eval_only(make_agent, make_env, make_logger, args):
       logger.add(epstats.result(), prefix='epstats')
       logger.add({'fps/policy': policy_fps.result()})
       logger.write()
+  episodes.flush()
   logger.close()
   driver.close()

@@ -5,6 +5,7 @@ from functools import partial as bind
 
 from .. import utils
 from ..core.driver import Driver
+from .train import _Learner
 
 
 def train_eval(
@@ -16,11 +17,7 @@ def train_eval(
   logger = make_logger()
   step = logger.step
   logdir = pathlib.Path(args.logdir)
-  train_agg = utils.Agg()
-  train_fps = utils.FPS()
   policy_fps = utils.FPS()
-  batch_steps = args.batch_size * args.batch_length
-  should_train = utils.Ratio(args.train_ratio / batch_steps)
   should_log = utils.LocalClock(args.log_every)
   should_eval = utils.LocalClock(getattr(args, 'eval_every', args.report_every), first=True)
   should_save = utils.LocalClock(args.save_every)
@@ -28,8 +25,7 @@ def train_eval(
 
   fns = [bind(make_env_train, i) for i in range(args.envs)]
   driver_train = Driver(fns, parallel=not args.debug, device=device)
-  driver_train.on_step(lambda tran, _: step.increment())
-  driver_train.on_step(lambda tran, _: policy_fps.step())
+  driver_train.on_batch(lambda trans, workers, **kw: (step.increment(args.envs), policy_fps.step(args.envs)))
   driver_train.on_step(replay_train.add)
 
   fns = [bind(make_env_eval, i) for i in range(getattr(args, 'eval_envs', 1))]
@@ -39,21 +35,11 @@ def train_eval(
   stream_train = iter(agent.stream(make_stream(replay_train, 'train')))
   stream_report = iter(agent.stream(make_stream(replay_train, 'report')))
   stream_eval = iter(agent.stream(make_stream(replay_eval, 'eval')))
-  carry_train = [agent.init_train(args.batch_size)]
   carry_report = agent.init_report(args.batch_size)
   carry_eval = agent.init_report(args.batch_size)
 
-  def trainfn(tran, worker):
-    if len(replay_train) < args.batch_size * args.batch_length:
-      return
-    for _ in range(should_train(step)):
-      batch = next(stream_train)
-      carry_train[0], outs, mets = agent.train(carry_train[0], batch)
-      train_fps.step(batch_steps)
-      if 'replay' in outs:
-        replay_train.update(outs['replay'])
-      train_agg.add(mets, prefix='train')
-  driver_train.on_step(trainfn)
+  learner = _Learner(agent, replay_train, stream_train, step, args)
+  driver_train.on_batch(learner)
 
   cp = utils.Checkpoint(logdir / 'checkpoint.pkl')
   cp.step = step
@@ -77,9 +63,9 @@ def train_eval(
         logger.add(mets, prefix='report')
     driver_train(train_policy, steps=10)
     if should_log(step):
-      logger.add(train_agg.result())
+      logger.add(learner.metrics.result())
       logger.add(replay_train.stats(), prefix='replay')
-      logger.add({'fps/policy': policy_fps.result(), 'fps/train': train_fps.result()})
+      logger.add({'fps/policy': policy_fps.result(), 'fps/train': learner.fps.result()})
       logger.write()
     if should_save(step):
       cp.save()
