@@ -85,8 +85,8 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   int vlocal = local;
   const int per_xcd = nblocks >> 3;
   if (a.xcd_remap && local < (per_xcd << 3)) vlocal = (local & 7) * per_xcd + (local >> 3);
-  const uint32_t first = static_cast<uint32_t>(vlocal) * (kThreads * U) + threadIdx.x;
-  const uint32_t stride = kThreads;
+  const uint32_t first = static_cast<uint32_t>(vlocal) * (blockDim.x * U) + threadIdx.x;
+  const uint32_t stride = blockDim.x;
   uint32_t r[U], off[U];
   int32_t row[U];
 #pragma unroll
@@ -103,8 +103,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
     const uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
     const uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
     const u32x4* src = reinterpret_cast<const u32x4*>(kGather ? pool : batch) + off[j];
-    if (NT & 8) buf[j] = u32x4{off[j], r[j], 0u, 0u};   // diagnostic: no loads
-    else buf[j] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+    buf[j] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
   }
 #pragma unroll
   for (int j = 0; j < U; ++j) {
@@ -112,8 +111,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
     uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
     uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
     u32x4* dst = reinterpret_cast<u32x4*>(kGather ? batch : pool) + off[j];
-    if (NT & 4) { if (buf[j].x == 0x9E3779B9u && buf[j].w == 0x7F4A7C15u) *dst = buf[j]; }  // diagnostic: no stores
-    else if (NT & 2) __builtin_nontemporal_store(buf[j], dst);
+    if (NT & 2) __builtin_nontemporal_store(buf[j], dst);
     else *dst = buf[j];
   }
 }
@@ -121,7 +119,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
 // pool[rows[r]] -> batch[r] for every key of the replay in ONE launch, with
 // the is_first / is_last annotation of replay.py:277-292 applied in flight.
 template <int U, int NT>
-__global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
+__global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) {
   const int k = find_key(a, blockIdx.x);
   const KeyDesc key = a.key[k];
   const int local = blockIdx.x - a.first_block[k];
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
     return;
   }
   const int64_t upr = key.rowbytes / unit;
-  const int64_t u = static_cast<int64_t>(local) * kThreads + threadIdx.x;
+  const int64_t u = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
   if (u >= upr * a.n_rows) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
@@ -154,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(const MoveArgs a) {
 
 // batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
 template <int U, int NT>
-__global__ __launch_bounds__(kThreads) void scatter_kernel(const MoveArgs a) {
+__global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) {
   const int k = find_key(a, blockIdx.x);
   const KeyDesc key = a.key[k];
   const int local = blockIdx.x - a.first_block[k];
@@ -164,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const MoveArgs a) {
     return;
   }
   const int64_t upr = key.rowbytes / unit;
-  const int64_t u = static_cast<int64_t>(local) * kThreads + threadIdx.x;
+  const int64_t u = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
   if (u >= upr * a.n_rows) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
@@ -178,16 +176,23 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const MoveArgs a) {
   copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
 }
 
-// Tuning knobs (EMB_MOVE_VARIANT="U,NT"): loads in flight per lane and
-// non-temporal hints (bit0 loads, bit1 stores).  Defaults chosen on MI355X.
-struct MoveVariant { int unroll; int nt; int remap; };
-MoveVariant move_variant(int64_t n_rows) {
-  MoveVariant v{0, -1, 1};
-  if (const char* s = std::getenv("EMB_MOVE_VARIANT")) std::sscanf(s, "%d,%d,%d", &v.unroll, &v.nt, &v.remap);
-  (void)n_rows;
-  if (v.unroll == 0) v.unroll = 2;
-  if (v.nt < 0) v.nt = 1;
-  return v;
+// Tuning knobs, read once: EMB_MOVE_VARIANT="U,NT,remap,threads" = 16-byte units
+// per lane, non-temporal hints (bit0 loads, bit1 stores), XCD remap on/off and
+// workgroup size.  Defaults from the MI355X sweep (tools/bench_gather.py):
+// U=2 beats 4/8 by 10-15 %, workgroup size 64..512 and the hints are within
+// noise, 1024 is slower.
+struct MoveVariant { int unroll; int nt; int remap; int threads; };
+const MoveVariant& move_variant() {
+  static const MoveVariant variant = [] {
+    MoveVariant v{2, 1, 1, 256};
+    if (const char* s = std::getenv("EMB_MOVE_VARIANT"))
+      std::sscanf(s, "%d,%d,%d,%d", &v.unroll, &v.nt, &v.remap, &v.threads);
+    if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 2;
+    if (v.nt < 0 || v.nt > 3) v.nt = 1;
+    if (v.threads != 64 && v.threads != 128 && v.threads != 512 && v.threads != 1024) v.threads = 256;
+    return v;
+  }();
+  return variant;
 }
 
 int pick_unit(const KeyDesc& key) {
@@ -219,8 +224,9 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
   if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || (!plan.rows && !use_inline))
     return hipErrorInvalidValue;
   if (plan.n_rows == 0) return hipSuccess;
-  const MoveVariant variant = move_variant(plan.n_rows);
-  const int unroll = (variant.unroll == 1 || variant.unroll == 2 || variant.unroll == 4) ? variant.unroll : 8;
+  const MoveVariant& variant = move_variant();
+  const int unroll = variant.unroll;
+  const int threads = variant.threads;
   MoveArgs a;
   a.n_keys = plan.n_keys;
   a.n_rows = plan.n_rows;
@@ -260,15 +266,15 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
     if (a.unit[k] == 0) {
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes >> 4);
       if (units > UINT32_MAX / 2) return hipErrorInvalidValue;
-      blocks += (units + kThreads * unroll - 1) / (kThreads * unroll);
+      blocks += (units + threads * unroll - 1) / (threads * unroll);
     } else {
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes / a.unit[k]);
-      blocks += (units + kThreads - 1) / kThreads;
+      blocks += (units + threads - 1) / threads;
     }
     if (blocks > INT32_MAX) return hipErrorInvalidValue;
   }
   a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
-  const dim3 grid(static_cast<uint32_t>(blocks)), block(kThreads);
+  const dim3 grid(static_cast<uint32_t>(blocks)), block(threads);
 #define EMB_MOVE(U_, NT_)                                                        \
   do {                                                                           \
     if (gather) hipExtLaunchKernelGGL((gather_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);  \
@@ -279,8 +285,6 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
     case 0: EMB_MOVE(U_, 0); break;                                              \
     case 2: EMB_MOVE(U_, 2); break;                                              \
     case 3: EMB_MOVE(U_, 3); break;                                              \
-    case 4: EMB_MOVE(U_, 4); break;                                              \
-    case 8: EMB_MOVE(U_, 8); break;                                              \
     default: EMB_MOVE(U_, 1); break;                                             \
   }
   switch (variant.unroll) {

@@ -1,2 +1,3 @@
+from . import cartpole
 from . import dummy
 from . import synthetic

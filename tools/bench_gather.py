@@ -15,7 +15,7 @@ from embodied_amd.envs import synthetic
 p = argparse.ArgumentParser()
 p.add_argument('--capacity', type=int, default=100_000)
 p.add_argument('--iters', type=int, default=50)
-p.add_argument('--variants', default='8,1;8,0;8,3;8,2;4,1;4,0;2,1;2,0;1,1')
+p.add_argument('--variants', default='', help='unused: set EMB_MOVE_VARIANT=U,NT,remap,threads per process')
 p.add_argument('--batches', default='16,64,256')
 args = p.parse_args()
 
@@ -50,8 +50,9 @@ for B in map(int, args.batches.split(',')):
   print(f'torch copy_  B={B:4d} {us:8.2f} us  {2 * nbytes / us / 1e3:8.1f} GB/s (r+w)', flush=True)
 
 rep.profile(True)
-for variant in args.variants.split(';'):
-  os.environ['EMB_MOVE_VARIANT'] = variant
+# The library reads EMB_MOVE_VARIANT once per process: to sweep, run this script
+# once per variant (see --variants help); a single run measures the active one.
+for variant in [os.environ.get('EMB_MOVE_VARIANT', 'default')]:
   for B in map(int, args.batches.split(',')):
     for _ in range(5):
       rep.sample(B)
