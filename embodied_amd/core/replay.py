@@ -104,6 +104,8 @@ class Replay:
     self._new_chunks = C.c_int32()
     self._saved = set()
     self._updates = 0
+    self._workers_seen = None
+    self._workers_np = None
     self._replica = int(replica)
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
 
@@ -162,6 +164,7 @@ class Replay:
       key.stage_np = key.stage.numpy()
     self._keys = keys
     self._keyid = {k.name: i for i, k in enumerate(keys)}
+    self._batch_ptrs = (C.c_void_p * len(keys))()
     self._push_keys()
 
   def _push_keys(self):
@@ -248,31 +251,40 @@ class Replay:
   def add_batch(self, steps, workers):
     """N steps, one per listed worker, from (N, ...) arrays or device tensors:
     one host call, one scatter launch.  Equivalent to N `add` calls in order."""
-    steps = {k: v for k, v in steps.items() if not k.startswith('log/')}
-    workers = np.ascontiguousarray(workers, np.int64)
+    if workers is not self._workers_seen:
+      self._workers_np = np.ascontiguousarray(workers, np.int64)
+      self._workers_seen = workers
+    workers = self._workers_np
     n = len(workers)
     with self._lock:
       if self._keys is None:
         self._init_keys({
             k: (v[0] if torch.is_tensor(v) else np.asarray(v)[0])
-            for k, v in steps.items()})
-      self._flush()
-      if len(steps) + 1 != len(self._keys):
-        raise KeyError(f'replay step keys {sorted(steps)} differ from the first step')
-      ptrs = (C.c_void_p * len(self._keys))()
-      keep = []
+            for k, v in steps.items() if not k.startswith('log/')})
+      if self._staged:
+        self._flush()
+      keyid, keys, device = self._keyid, self._keys, self.device
+      ptrs = self._batch_ptrs
+      keep, seen = [], 0
       for name, value in steps.items():
-        i = self._keyid[name]
-        key = self._keys[i]
+        i = keyid.get(name)
+        if i is None:
+          if name.startswith('log/'):
+            continue
+          raise KeyError(f'replay step key {name!r} was not in the first step')
+        key = keys[i]
         if not torch.is_tensor(value):
           value = torch.from_numpy(np.ascontiguousarray(value))
         if value.shape[1:] != key.shape or value.shape[0] != n:
           raise ValueError((name, tuple(value.shape), (n, *key.shape)))
-        if (value.dtype != key.dtype or value.device != self.device
+        if (value.dtype != key.dtype or value.device != device
             or not value.is_contiguous()):
-          value = value.to(self.device, key.dtype, non_blocking=True).contiguous()
+          value = value.to(device, key.dtype, non_blocking=True).contiguous()
         keep.append(value)
         ptrs[i] = value.data_ptr()
+        seen += 1
+      if seen + 1 != len(keys):
+        raise KeyError(f'replay step keys {sorted(steps)} differ from the first step')
       while True:
         try:
           api.emb_replay_add(self._handle, n, _lib.ptr(workers), ptrs, self._stream())

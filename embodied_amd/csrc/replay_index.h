@@ -76,6 +76,8 @@ class ReplayIndex {
   // Upper bound on the chunk slots `add` may take for these workers; lets the
   // caller fail (PoolFull) before any state changes.
   int64_t slots_needed(const int64_t* workers, int64_t n) const {
+    // Cheap bound first: every row can open at most two chunks.
+    if (2 * n <= free_slots()) return 0;
     int64_t need = 0;
     std::unordered_map<int64_t, int64_t> seen;  // worker -> simulated index
     for (int64_t i = 0; i < n; ++i) {
@@ -84,9 +86,9 @@ class ReplayIndex {
       if (s != seen.end()) {
         index = s->second;
       } else {
-        auto c = cursor_.find(workers[i]);
-        if (c == cursor_.end()) { ++need; index = 0; }
-        else index = c->second.second;
+        const Worker* w = find_worker(workers[i]);
+        if (!w) { ++need; index = 0; }
+        else index = w->cursor.second;
       }
       ++index;
       if (index >= cfg_.chunksize) { ++need; index = 0; }
@@ -97,32 +99,32 @@ class ReplayIndex {
 
   // replay.py:77-118.  Returns the device row the step's payload goes to.
   int64_t add(int64_t worker, StepId* stepid) {
-    auto cur = cursor_.find(worker);
-    if (cur == cursor_.end()) {
+    Worker* w = find_worker(worker);
+    if (!w) {
       Chunk& c = new_chunk(1);
-      cur = cursor_.emplace(worker, Pos(c.uid, 0)).first;
+      w = &make_worker(worker);
+      w->cursor = Pos(c.uid, 0);
     }
-    const uint64_t uid = cur->second.first;
-    int64_t index = cur->second.second;
+    const uint64_t uid = w->cursor.first;
+    int64_t index = w->cursor.second;
     Chunk& chunk = chunks_.at(uid);
     if (chunk.fill != index) throw std::logic_error("replay: chunk cursor out of sync");
     *stepid = make_stepid(uid, index);
     const int64_t row = chunk.slot * cfg_.chunksize + index;
     chunk.fill += 1;
-    auto& stream = pending_[worker];
-    stream.emplace_back(uid, index);
+    w->pending.emplace_back(uid, index);
     chunk.refs += 1;
     index += 1;
-    if (index < cfg_.chunksize) cur->second.second = index;
-    else rotate(chunk, worker);
-    if (static_cast<int64_t>(stream.size()) >= cfg_.length) {
+    if (index < cfg_.chunksize) w->cursor.second = index;
+    else rotate(chunk, *w);
+    if (static_cast<int64_t>(w->pending.size()) >= cfg_.length) {
       metrics_[kInserts] += 1;
-      const Pos start = stream.front();
-      stream.pop_front();
+      const Pos start = w->pending.front();
+      w->pending.pop_front();
       insert_item(start);
-      if (cfg_.online && steps_seen_[worker] % cfg_.length == 0) fresh_.push_back(start);
+      if (cfg_.online && w->steps_seen % cfg_.length == 0) fresh_.push_back(start);
     }
-    if (cfg_.online) steps_seen_[worker] += 1;
+    if (cfg_.online) w->steps_seen += 1;
     return row;
   }
 
@@ -137,7 +139,7 @@ class ReplayIndex {
         fresh_.pop_front();
         *from_online = true;
       } else {
-        pos = items_.at(selector_->sample());
+        pos = item_at(selector_->sample());
         *from_online = false;
       }
       if (chunks_.count(pos.first)) return pos;
@@ -218,7 +220,7 @@ class ReplayIndex {
   void stats(int64_t out[6], bool reset) {
     out[0] = size();
     out[1] = static_cast<int64_t>(chunks_.size());
-    out[2] = static_cast<int64_t>(pending_.size());
+    out[2] = static_cast<int64_t>(workers_.size());
     out[3] = metrics_[kInserts];
     out[4] = metrics_[kSamples];
     out[5] = metrics_[kUpdates];
@@ -226,14 +228,14 @@ class ReplayIndex {
   }
 
   const std::unordered_map<uint64_t, Chunk>& chunks() const { return chunks_; }
-  const std::unordered_map<int64_t, Pos>& cursors() const { return cursor_; }
 
   // Checkpoint support (replay.py:295-359): close every worker's open chunk.
   void complete_all() {
-    std::vector<int64_t> workers;
-    for (auto& kv : cursor_)
-      if (chunks_.at(kv.second.first).fill > 0) workers.push_back(kv.first);
-    for (int64_t w : workers) rotate(chunks_.at(cursor_.at(w).first), w);
+    for (auto& kv : workers_) {
+      Worker& w = *kv.second;
+      Chunk& chunk = chunks_.at(w.cursor.first);
+      if (chunk.fill > 0) rotate(chunk, w);
+    }
   }
 
   // Re-create a saved chunk (replay.py:347-359): returns its slot.
@@ -277,21 +279,50 @@ class ReplayIndex {
     return chunks_[c.uid] = c;
   }
 
+  struct Worker {
+    Pos cursor;                 // (open chunk uid, next row)
+    std::deque<Pos> pending;    // steps not yet the start of an item
+    int64_t steps_seen = 0;     // online mode
+  };
+
+  // Worker ids are usually 0..N-1: a flat table in front of the general map.
+  Worker* find_worker(int64_t id) const {
+    if (id >= 0 && id < static_cast<int64_t>(dense_.size())) return dense_[id];
+    auto it = workers_.find(id);
+    return it == workers_.end() ? nullptr : it->second.get();
+  }
+  Worker& make_worker(int64_t id) {
+    auto& slot = workers_[id];
+    slot = std::make_unique<Worker>();
+    if (id >= 0 && id < 65536) {
+      if (id >= static_cast<int64_t>(dense_.size())) dense_.resize(id + 1, nullptr);
+      dense_[id] = slot.get();
+    }
+    return *slot;
+  }
+
+  // itemids are handed out consecutively and evicted oldest-first, so the live
+  // ones are always the contiguous range [first_item_, next_item_).
+  const Pos& item_at(int64_t key) const {
+    if (key < first_item_ || key >= next_item_) throw std::out_of_range("replay: unknown item");
+    return items_[static_cast<size_t>(key - first_item_)];
+  }
+
   // replay.py:362-370
-  void rotate(Chunk& chunk, int64_t worker) {
+  void rotate(Chunk& chunk, Worker& worker) {
     const uint64_t old = chunk.uid;
-    Chunk& succ = new_chunk(2);      // may rehash: re-find `chunk` below
+    Chunk& succ = new_chunk(2);
     Chunk& prev = chunks_.at(old);
     prev.refs -= 1;
     prev.succ = succ.uid;
-    cursor_[worker] = Pos(succ.uid, 0);
+    worker.cursor = Pos(succ.uid, 0);
   }
 
   // replay.py:171-179
   void insert_item(const Pos& start) {
     while (cfg_.capacity && size() >= cfg_.capacity) evict();
     const int64_t key = next_item_++;
-    items_[key] = start;
+    items_.push_back(start);
     if (selector_->needs_stepids()) {
       if (!spans(start, cfg_.length, &scratch_))
         throw std::logic_error("replay: inserted window is incomplete");
@@ -302,17 +333,15 @@ class ReplayIndex {
     } else {
       selector_->insert(key, nullptr, 0);
     }
-    fifo_.push_back(key);
   }
 
   // replay.py:181-191
   void evict() {
-    const int64_t key = fifo_.front();
-    fifo_.pop_front();
+    const int64_t key = first_item_;
     selector_->remove(key);
-    auto it = items_.find(key);
-    const uint64_t uid = it->second.first;
-    items_.erase(it);
+    const uint64_t uid = items_.front().first;
+    items_.pop_front();
+    ++first_item_;
     Chunk& chunk = chunks_.at(uid);
     chunk.refs -= 1;
     if (chunk.refs < 1) {
@@ -328,14 +357,13 @@ class ReplayIndex {
   std::shared_ptr<Selector> selector_;
   std::unordered_map<uint64_t, Chunk> chunks_;
   std::deque<int64_t> free_;   // FIFO: a freed slot is recycled as late as possible
-  std::unordered_map<int64_t, Pos> items_;
-  std::deque<int64_t> fifo_;
+  std::deque<Pos> items_;
+  int64_t first_item_ = 0;
   int64_t next_item_ = 0;
   uint64_t next_uid_ = 1;
   int64_t loaded_ = 0;
-  std::unordered_map<int64_t, Pos> cursor_;
-  std::unordered_map<int64_t, std::deque<Pos>> pending_;
-  std::unordered_map<int64_t, int64_t> steps_seen_;
+  std::unordered_map<int64_t, std::unique_ptr<Worker>> workers_;
+  std::vector<Worker*> dense_;
   std::deque<Pos> fresh_;
   int64_t metrics_[3] = {0, 0, 0};
   mutable std::vector<Span> scratch_;
