@@ -128,7 +128,10 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29517')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    import datetime
+    dist.init_process_group(
+        'nccl', rank=rank, world_size=world, device_id=device,
+        timeout=datetime.timedelta(seconds=300))
   assert world == args.gpus or world == 1, (world, args.gpus)
 
   emb, env, replay, driver, policy = build_path(args, rank, device)

@@ -1,7 +1,7 @@
 """ctypes binding of libembodied_hip.so (include/embodied_hip.h).
 
 There is no CPU fallback: if the library is missing or fails to load, importing
-this module raises.  Build it with `python -m embodied_amd.build`.
+this module raises.  Build it with `python embodied_amd/build.py`.
 """
 import ctypes as C
 import pathlib
@@ -58,9 +58,20 @@ class SelectorCallbacks(C.Structure):
 
 def _load():
   if not PATH.exists():
-    raise ImportError(
-        f'{PATH} is missing. embodied_amd has no CPU fallback: build the HIP '
-        'library with `python -m embodied_amd.build` (needs hipcc, gfx950).')
+    # Git-ignored artefact: compile it in-tree on first use (hipcc cross-compiles
+    # gfx950 without a GPU).  No hipcc -> no library -> ImportError, never a
+    # CPU fallback.
+    try:
+      import importlib.util
+      spec = importlib.util.spec_from_file_location('_emb_build', HERE / 'build.py')
+      builder = importlib.util.module_from_spec(spec)
+      spec.loader.exec_module(builder)
+      builder.build(verbose=False)
+    except Exception as e:
+      raise ImportError(
+          f'{PATH} is missing and could not be built ({e}). embodied_amd has no '
+          'CPU fallback: build the HIP library with `python embodied_amd/build.py` '
+          '(needs hipcc, gfx950).') from e
   try:
     return C.CDLL(str(PATH))
   except OSError as e:

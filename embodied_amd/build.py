@@ -1,11 +1,12 @@
 """Build libembodied_hip.so in-tree with hipcc for gfx950.
 
-    python -m embodied_amd.build [--force]
+    python embodied_amd/build.py [--force]
 
 One hipcc invocation per translation unit (parallel), then a link.  The .so is
 git-ignored but travels to the GPU box with the repo snapshot.
 """
 import concurrent.futures
+import fcntl
 import os
 import pathlib
 import shutil
@@ -40,6 +41,11 @@ def build(force=False, verbose=True):
     return OUT
   cc = hipcc()
   OBJ.mkdir(exist_ok=True)
+  # One builder at a time (pytest-xdist workers, torchrun ranks).
+  lock = open(OBJ / '.lock', 'w')
+  fcntl.flock(lock, fcntl.LOCK_EX)
+  if not force and not stale():
+    return OUT
   flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall',
            '-Wno-unused-function', '-x', 'hip']
 

@@ -10,6 +10,15 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = ROOT / 'tests' / 'golden'
 
+# The HIP library is git-ignored: (re)build it in-tree if it is missing or older
+# than its sources.  hipcc cross-compiles gfx950 without a GPU.
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location(
+    '_emb_build', ROOT / 'embodied_amd' / 'build.py')   # not via the package:
+_build = importlib.util.module_from_spec(_spec)         # its __init__ needs the .so
+_spec.loader.exec_module(_build)
+_build.build(verbose=False)
+
 
 def pytest_configure(config):
   config.addinivalue_line(
