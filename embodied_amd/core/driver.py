@@ -18,6 +18,7 @@ Callbacks registered with `on_step(fn)` keep the reference contract
 stacked transition once per step.
 """
 import multiprocessing as mp
+from multiprocessing import shared_memory
 import time
 
 import cloudpickle
@@ -58,7 +59,7 @@ def mask_actions(value, is_last):
 class Driver:
 
   def __init__(self, make_env_fns=None, parallel=True, device=None,
-               batch_env=None, **kwargs):
+               batch_env=None, shared_obs=True, **kwargs):
     self.kwargs = kwargs
     self.device = torch.device(device) if device is not None else None
     if self.device is not None and self.device.type == 'cuda' and self.device.index is None:
@@ -82,6 +83,9 @@ class Driver:
         [proc.start() for proc in self.procs]
         self.pipes[0].send(('act_space',))
         self.act_space = self._receive(self.pipes[0])
+        self._shared = {}
+        if shared_obs:
+          self._attach_shared_slab()
       else:
         self.envs = [fn() for fn in make_env_fns]
         self.act_space = self.envs[0].act_space
@@ -108,11 +112,45 @@ class Driver:
       self.acts['reset'] = np.ones(self.length, bool)
     self.carry = init_policy and init_policy(self.length)
 
+  def _attach_shared_slab(self):
+    """Env workers write their observations straight into one shared (N, ...)
+    slab per key instead of pickling ~S bytes per env per step through a pipe
+    (driver.py:17-25,61-62).  In device mode the slab is registered with the
+    HIP runtime, so it is also the pinned source of the upload."""
+    self.pipes[0].send(('obs_space',))
+    try:
+      space = self._receive(self.pipes[0])
+      spec = {
+          k: (tuple(v.shape), np.dtype(v.dtype).str) for k, v in space.items()
+          if not k.startswith('log/')}
+    except Exception:
+      return
+    layout = {}
+    for key, (shape, dtype) in spec.items():
+      nbytes = max(1, self.length * int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize)
+      block = shared_memory.SharedMemory(create=True, size=nbytes)
+      view = np.ndarray((self.length, *shape), dtype, buffer=block.buf)
+      self._shared[key] = (block, view)
+      layout[key] = (block.name, shape, dtype)
+      if self.device is not None:
+        tensor = torch.from_numpy(view)
+        if torch.cuda.cudart().cudaHostRegister(tensor.data_ptr(), nbytes, 0) == 0:
+          self._registered = getattr(self, '_registered', []) + [tensor.data_ptr()]
+    [pipe.send(('attach', layout, self.length)) for pipe in self.pipes]
+    [self._receive(pipe) for pipe in self.pipes]
+
   def close(self):
     if self.batch_env is not None:
       getattr(self.batch_env, 'close', lambda: None)()
     elif self.parallel:
       [proc.kill() for proc in self.procs]
+      for ptr in getattr(self, '_registered', []):
+        torch.cuda.cudart().cudaHostUnregister(ptr)
+      self._registered = []
+      for block, _ in getattr(self, '_shared', {}).values():
+        block.close()
+        block.unlink()
+      self._shared = {}
     else:
       [env.close() for env in self.envs]
 
@@ -213,10 +251,19 @@ class Driver:
     """np.stack of the per-env dicts (driver.py:65).  In device mode rows are
     written straight into a pinned (N, ...) slab per key and uploaded with one
     async copy each."""
-    keys = results[0].keys()
+    shared = getattr(self, '_shared', None) if self.parallel else None
+    keys = list(results[0].keys())
     if self.device is None:
-      return {k: np.stack([r[k] for r in results]) for k in keys}
+      # With a shared slab the rows are already stacked: one copy per key.
+      out = {k: view.copy() for k, (_, view) in shared.items()} if shared else {}
+      out.update({k: np.stack([r[k] for r in results]) for k in keys})
+      return out
     out, self._host_flags = {}, {}
+    if shared:
+      for k, (_, view) in shared.items():
+        if k in ('is_first', 'is_last', 'is_terminal'):
+          self._host_flags[k] = view.copy()
+        out[k] = torch.from_numpy(view).to(self.device, non_blocking=True)
     for k in keys:
       first = np.asarray(results[0][k])
       slab = self._slab.get(k)
@@ -249,8 +296,11 @@ class Driver:
 
 
 def _env_server(envid, pipe, ctor):
-  """Worker process: ('step', act) -> ('result', obs) (driver.py:101-137)."""
+  """Worker process: ('step', act) -> ('result', obs) (driver.py:101-137).
+  After ('attach', layout, n) the observation keys named in `layout` are written
+  into row `envid` of the shared slabs and only the rest travels back."""
   env = None
+  blocks, slabs = [], {}
   try:
     env = cloudpickle.loads(ctor)()
     while True:
@@ -261,7 +311,24 @@ def _env_server(envid, pipe, ctor):
       except EOFError:
         return
       if msg == 'step':
-        pipe.send(('result', env.step(args[0])))
+        obs = env.step(args[0])
+        if slabs:
+          rest = {}
+          for key, value in obs.items():
+            slab = slabs.get(key)
+            if slab is None:
+              rest[key] = value
+            else:
+              slab[envid] = value
+          obs = rest
+        pipe.send(('result', obs))
+      elif msg == 'attach':
+        layout, n = args
+        for key, (name, shape, dtype) in layout.items():
+          block = shared_memory.SharedMemory(name=name)
+          blocks.append(block)
+          slabs[key] = np.ndarray((n, *shape), dtype, buffer=block.buf)
+        pipe.send(('result', True))
       elif msg == 'obs_space':
         pipe.send(('result', env.obs_space))
       elif msg == 'act_space':
@@ -281,4 +348,10 @@ def _env_server(envid, pipe, ctor):
       env and env.close()
     except Exception:
       pass
+    slabs.clear()
+    for block in blocks:
+      try:
+        block.close()
+      except Exception:
+        pass
     pipe.close()

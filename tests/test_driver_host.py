@@ -160,3 +160,33 @@ def test_log_keys_reach_callbacks_but_not_policy():
   driver(policy, steps=3)
   assert all('log/extra' not in s for s in seen)
   assert all('log/extra' in t for t in trans)
+
+
+@pytest.mark.parametrize('shared_obs', [True, False])
+def test_parallel_workers_match_serial(shared_obs):
+  """Env processes (shared-memory obs slab or pickled pipes) produce exactly
+  the transitions of the in-process loop."""
+  from tests import scenarios
+
+  def run(**kw):
+    fns = [bind(scenarios.ScriptEnv, i, 3 + i) for i in range(3)]
+    driver = emb.Driver(fns, **kw)
+    log = []
+    driver.on_step(lambda tran, w: log.append((w, {k: np.array(v) for k, v in tran.items()})))
+    driver.reset(lambda n: 0)
+    def policy(carry, obs):
+      n = len(obs['is_first'])
+      act = {'act_disc': (np.arange(n) + carry).astype(np.int32),
+             'act_cont': np.full((n, 3), carry, np.float32)}
+      return carry + 1, act, {}
+    driver(policy, steps=36)
+    driver.close()
+    return log
+
+  serial = run(parallel=False)
+  par = run(parallel=True, shared_obs=shared_obs)
+  assert len(serial) == len(par) == 36
+  for (w0, t0), (w1, t1) in zip(serial, par):
+    assert w0 == w1 and set(t0) == set(t1)
+    for k in t0:
+      assert np.array_equal(t0[k], t1[k]) and t0[k].dtype == t1[k].dtype, k

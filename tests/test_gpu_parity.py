@@ -331,3 +331,33 @@ def test_prefetch_stream_and_python_selector(emb):
   for _ in range(6):
     got = {k: v.cpu().numpy() for k, v in next(it).items()}
     assert_same(got, next(want_src), 'prefetch')
+
+
+def test_parallel_env_workers_upload_from_shared_slab(emb):
+  """Env processes write into the shared, HIP-registered slab; the device
+  Driver uploads from it.  Transitions must equal the serial host loop's."""
+  from functools import partial
+
+  def run(**kw):
+    fns = [partial(scenarios.ScriptEnv, i, 3 + i) for i in range(4)]
+    driver = emb.Driver(fns, **kw)
+    log = []
+    driver.on_batch(lambda trans, workers, **k: log.append(
+        {key: (v.cpu().numpy() if torch.is_tensor(v) else np.array(v)) for key, v in trans.items()}))
+    driver.reset(lambda n: 0)
+
+    def policy(carry, obs):
+      n = len(obs['is_first'])
+      act = {'act_disc': (np.arange(n) + carry).astype(np.int32),
+             'act_cont': np.full((n, 3), carry, np.float32)}
+      return carry + 1, act, {}
+
+    driver(policy, steps=40)
+    driver.close()
+    return log
+
+  want = run(parallel=False)
+  got = run(parallel=True, device='cuda')
+  assert len(want) == len(got) == 10
+  for a, b in zip(want, got):
+    assert_same(b, a, 'parallel-device')
