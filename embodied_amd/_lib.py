@@ -131,6 +131,7 @@ SIGNATURES = {
     'emb_replay_gather_rows': [p, p, i64, i64, p, p],
     'emb_replay_scatter_rows': [p, p, i64, i32, p, p, p],
     'emb_replay_profile': [p, i32],
+    'emb_replay_multistream': [p, i32],
     'emb_replay_profile_read': [p, p, p, i32],
     'emb_replay_complete_all': [p],
     'emb_replay_chunks': [p, i64, p, p, p, p, p, p],

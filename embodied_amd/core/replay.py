@@ -105,6 +105,8 @@ class Replay:
     self._saved = set()
     self._updates = 0
     self._workers_seen = None
+    self._last_stream = None
+    self._multistream = False
     self._workers_np = None
     self._replica = int(replica)
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
@@ -122,7 +124,15 @@ class Replay:
     return n.value
 
   def _stream(self):
-    return _lib.raw_stream(self.device)
+    stream = _lib.raw_stream(self.device)
+    if stream != self._last_stream:
+      # A second stream appeared (actor / learner split): from now on order
+      # pool writes and reads across streams.
+      if self._last_stream is not None and not self._multistream:
+        api.emb_replay_multistream(self._handle, 1)
+        self._multistream = True
+      self._last_stream = stream
+    return stream
 
   def stats(self):
     """replay.py:58-74 (counters reset on read)."""

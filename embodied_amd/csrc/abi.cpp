@@ -227,6 +227,42 @@ struct emb_replay {
   LaunchTimer timer;
   std::vector<int32_t> rows, spans;
   std::vector<emb::StepId> ids;
+  // Actor and learner on different HIP streams: pool writes (add/update) and
+  // pool reads (sample) are ordered across streams with one event each way.
+  bool multistream = false;
+  hipEvent_t wrote = nullptr, read = nullptr;
+  hipStream_t wrote_on = nullptr, read_on = nullptr;
+  bool has_wrote = false, has_read = false;
+
+  ~emb_replay() {
+    if (wrote) (void)hipEventDestroy(wrote);
+    if (read) (void)hipEventDestroy(read);
+  }
+
+  void order_before(bool gather, hipStream_t stream) {
+    if (!multistream) return;
+    if (!wrote) {
+      HIP_OK(hipEventCreateWithFlags(&wrote, hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&read, hipEventDisableTiming));
+    }
+    // A read must see every earlier write; a write must not overtake a read
+    // of rows it may recycle, nor an earlier write on another stream.
+    if (has_wrote && wrote_on != stream) HIP_OK(hipStreamWaitEvent(stream, wrote, 0));
+    if (!gather && has_read && read_on != stream) HIP_OK(hipStreamWaitEvent(stream, read, 0));
+  }
+
+  void order_after(bool gather, hipStream_t stream) {
+    if (!multistream) return;
+    if (gather) {
+      HIP_OK(hipEventRecord(read, stream));
+      read_on = stream;
+      has_read = true;
+    } else {
+      HIP_OK(hipEventRecord(wrote, stream));
+      wrote_on = stream;
+      has_wrote = true;
+    }
+  }
 };
 
 extern "C" {
@@ -586,6 +622,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     rep->ring.upload(lease, total, stream);
     plan.rows = reinterpret_cast<const int32_t*>(lease.device);
   }
+  rep->order_before(gather, stream);
   if (gather) {
     hipEvent_t start, stop;
     rep->timer.next(&start, &stop);
@@ -593,6 +630,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   } else {
     HIP_OK(emb::launch_scatter(plan, stream));
   }
+  rep->order_after(gather, stream);
   if (lease.slot >= 0) rep->ring.retire(lease, stream);
 }
 
@@ -714,6 +752,8 @@ int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t 
 }
 
 int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) { REP_OP(rep->timer.enabled = enable != 0); }
+
+int32_t emb_replay_multistream(emb_replay_t* rep, int32_t enable) { REP_OP(rep->multistream = enable != 0); }
 
 int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* total_ms, int32_t reset) {
   REP_OP({

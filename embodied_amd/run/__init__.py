@@ -1,3 +1,4 @@
 from .train import train
 from .eval_only import eval_only
 from .train_eval import train_eval
+from .actor_learner import actor_learner

@@ -198,6 +198,11 @@ int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t 
                                 int32_t n_keys, const int32_t* key_ids, const void* const* src,
                                 void* stream);
 
+/* Callers that add/update and sample from DIFFERENT streams (actor stream +
+ * learner stream, run/parallel.py's split in one process) enable this: pool
+ * writes and reads are then ordered across streams with events.             */
+int32_t emb_replay_multistream(emb_replay_t* rep, int32_t enable);
+
 /* HIP-event timing of the gather launches issued through this handle (on their
  * own stream): total milliseconds and launch count since the last reset.     */
 int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable);

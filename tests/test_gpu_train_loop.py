@@ -110,3 +110,40 @@ def test_train_loop_counts_and_resume(tmp_path):
   logger2, agent2 = run(tmp_path, box, steps=700)
   assert agent2.loads == 1
   assert int(logger2.step) >= 700
+
+
+def test_actor_learner_split_respects_samples_per_insert(tmp_path):
+  """Actor and learner threads on separate HIP streams, coupled by the
+  SamplesPerInsert limiter: the realised sample/insert ratio stays near
+  train_ratio / batch_length and batches stay consistent (the agent asserts
+  count continuity on every batch, so a cross-stream race would trip it)."""
+  import embodied_amd as emb
+  from embodied_amd.envs import dummy
+  args = make_args(tmp_path, steps=3000, train_ratio=16.0, log_every=0.2)
+  env0 = dummy.Dummy('disc', size=(8, 8), length=17)
+  box = []
+
+  def make_agent():
+    box.append(CheckingAgent(env0.obs_space, env0.act_space))
+    return box[-1]
+
+  replay_box = []
+  def make_replay():
+    replay_box.append(emb.Replay(length=args.batch_length + 1, capacity=400, chunksize=32))
+    return replay_box[-1]
+
+  make_stream = lambda replay, mode: emb.streams.Consec(
+      emb.streams.Stateless(replay.sample, args.batch_size, mode),
+      length=args.batch_length, consec=1, prefix=1, strict=True, contiguous=True)
+  logger = emb.utils.Logger()
+  counters = emb.run.actor_learner(
+      make_agent, make_replay, lambda i: dummy.Dummy('disc', size=(8, 8), length=17 + i),
+      make_stream, lambda: logger, args)
+  agent = box[-1]
+  assert int(logger.step) >= 3000
+  assert agent.trains == counters['trains'] > 10
+  # samples taken / steps inserted ~= train_ratio / batch_length (after warm-up)
+  want = args.train_ratio / args.batch_length
+  got = counters['trains'] * args.batch_size / int(logger.step)
+  assert 0.6 * want <= got <= 1.2 * want, (got, want)
+  assert replay_box[-1]._multistream
