@@ -233,3 +233,71 @@ class SampleTree:
         self._handle, len(depths), _lib.ptr(depths), C.byref(leaves),
         C.byref(nodes))
     return depths[:leaves.value], nodes.value
+
+
+class Recency:
+  """Age-biased sampling: the item inserted `age` inserts ago is drawn with
+  probability proportional to `uprobs[age]` (reference: selectors.py:60-125).
+
+  The reference implementation cannot draw (`_sample` reads an unbound
+  `segment`, selectors.py:98-105), so nothing pins its stream; this class
+  implements the evident intent — a b-ary table of normalised block masses, one
+  `choice` per level — on the host in numpy.  It plugs into `Replay` / `Mixture`
+  through the callback ABI like any other Python selector.
+  """
+
+  def __init__(self, uprobs, seed=0, bfactor=16):
+    uprobs = np.asarray(uprobs, np.float64)
+    assert uprobs[0] >= uprobs[-1], uprobs
+    assert np.isfinite(uprobs).all() and (uprobs >= 0).all(), uprobs
+    self.uprobs = uprobs
+    self.bfactor = bfactor
+    self.levels = self._build(uprobs, bfactor)
+    self.rng = np.random.default_rng(seed)
+    self.step = 0
+    self.steps = {}
+    self.items = {}
+
+  def __len__(self):
+    return len(self.items)
+
+  def __call__(self):
+    for _ in range(1000):
+      age = self._draw_age()
+      if len(self.items) < len(self.uprobs):
+        age = int(age / len(self.uprobs) * len(self.items))
+      key = self.items.get(self.step - 1 - age)
+      if key is not None:       # deleted slots (evicted items) are redrawn
+        return key
+    raise KeyError('Recency: no live item found')
+
+  def __setitem__(self, key, stepids):
+    self.steps[key] = self.step
+    self.items[self.step] = key
+    self.step += 1
+
+  def __delitem__(self, key):
+    del self.items[self.steps.pop(key)]
+
+  def _draw_age(self):
+    index = 0
+    for level in self.levels:
+      probs = level[index]
+      index = index * self.bfactor + int(self.rng.choice(len(probs), p=probs))
+    return index
+
+  @staticmethod
+  def _build(uprobs, bfactor):
+    depth = max(1, int(np.ceil(np.log(len(uprobs)) / np.log(bfactor))))
+    padded = np.zeros(bfactor ** depth)
+    padded[:len(uprobs)] = uprobs
+    levels = []
+    masses = padded
+    for _ in range(depth):
+      groups = masses.reshape(-1, bfactor)
+      totals = groups.sum(-1, keepdims=True)
+      with np.errstate(divide='ignore', invalid='ignore'):
+        probs = np.where(totals > 0, groups / totals, 1.0 / bfactor)
+      levels.insert(0, probs)
+      masses = totals[:, 0]
+    return levels

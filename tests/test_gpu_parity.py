@@ -361,3 +361,31 @@ def test_parallel_env_workers_upload_from_shared_slab(emb):
   assert len(want) == len(got) == 10
   for a, b in zip(want, got):
     assert_same(b, a, 'parallel-device')
+
+
+def test_replay_with_mixture_of_all_selectors(emb):
+  """ppo/main.py:196-205 builds Mixture(uniform, priority, recency) when
+  fracs.uniform < 1; with the reference's own Mixture this cannot sample
+  (no __len__).  Product vs oracle (Recency has no oracle twin: fraction 0 as
+  in the shipped configs, it is constructed and dropped)."""
+  def build(ns_sel, Replay, **kw):
+    sel = ns_sel.Mixture(
+        dict(uniform=ns_sel.Uniform(1),
+             priority=ns_sel.Prioritized(exponent=0.8, initial=np.inf, maxfrac=0.5,
+                                         zero_on_sample=True, seed=2),
+             recency=emb.selectors.Recency(1.0 / np.arange(1, 41))),
+        dict(uniform=0.5, priority=0.5, recency=0.0), seed=3)
+    return Replay(length=4, capacity=40, chunksize=6, selector=sel, **kw)
+
+  ours = build(emb.selectors, emb.Replay)
+  ref = build(np_oracle, np_oracle.Replay)
+  for t in range(30):
+    for w in range(2):
+      ours.add(scenarios.synth_step(t, w), w)
+      ref.add(scenarios.synth_step(t, w), w)
+  for r in range(5):
+    got, want = ours.sample(6), ref.sample(6)
+    assert_same({k: v.cpu().numpy() for k, v in got.items()}, want, f'mixture r{r}')
+    prio = (want['step'] % 4 + 0.25 * r).astype(np.float32)
+    ours.update({'stepid': got['stepid'], 'priority': torch.as_tensor(prio).cuda()})
+    ref.update({'stepid': want['stepid'], 'priority': prio})

@@ -88,3 +88,26 @@ def test_prefetch_propagates_errors_and_state():
   assert pre.save() == 3
   with pytest.raises(RuntimeError, match='boom'):
     next(pre)
+
+
+def test_recency_selector_prefers_recent_items():
+  """Not pinned by the reference (its Recency cannot draw); checks the intent:
+  draw frequency follows uprobs over age, deleted items are never returned."""
+  from embodied_amd import selectors
+  n = 300
+  uprobs = 1.0 / np.arange(1, n + 1) ** 1.0
+  sel = selectors.Recency(uprobs, seed=0)
+  for key in range(n):
+    sel[key] = None
+  del sel[n - 1]                      # newest item evicted
+  draws = np.array([sel() for _ in range(4000)])
+  assert (draws != n - 1).all() and len(sel) == n - 1
+  ages = (n - 1) - draws
+  assert (ages == 1).mean() > (ages == 10).mean() > (ages >= 200).mean() / 100
+  expected = uprobs[1] / (uprobs.sum() - uprobs[0])
+  assert abs((ages == 1).mean() - expected) < 0.03
+  # partially filled: ages are rescaled onto the live range
+  small = selectors.Recency(uprobs, seed=1)
+  for key in range(5):
+    small[key] = None
+  assert set(small() for _ in range(200)) <= set(range(5))
