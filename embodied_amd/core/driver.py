@@ -19,7 +19,6 @@ stacked transition once per step.
 """
 import multiprocessing as mp
 from multiprocessing import shared_memory
-import time
 
 import cloudpickle
 import numpy as np

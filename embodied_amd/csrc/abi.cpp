@@ -905,7 +905,7 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
          "synth_env_step: bad arguments");
     HIP_OK(emb::launch_synth_env(static_cast<uint8_t*>(image), static_cast<float*>(reward),
                                  static_cast<uint8_t*>(is_first), static_cast<uint8_t*>(is_last),
-                                 static_cast<uint8_t*>(is_terminal), n, frame_bytes, env0, 0, episode_len,
+                                 static_cast<uint8_t*>(is_terminal), n, frame_bytes, env0, episode_len,
                                  static_cast<const uint8_t*>(reset), static_cast<int32_t*>(counters),
                                  static_cast<hipStream_t>(stream)));
   });

@@ -93,8 +93,8 @@ hipError_t launch_director_score(const float* rew, const float* cont,
 // into HBM, SURVEY.md 8d.
 hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first,
                             uint8_t* is_last, uint8_t* is_terminal, int64_t n,
-                            int64_t frame_bytes, int64_t env0, int64_t tick,
-                            int64_t episode_len, const uint8_t* reset,
-                            int32_t* counters, hipStream_t stream);
+                            int64_t frame_bytes, int64_t env0, int64_t episode_len,
+                            const uint8_t* reset, int32_t* counters,
+                            hipStream_t stream);
 
 }  // namespace emb

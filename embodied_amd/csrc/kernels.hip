@@ -69,9 +69,9 @@ __device__ __forceinline__ void copy_bytes(const uint8_t* s, uint8_t* d, int uni
 }
 
 // A key's rows are moved as a flat sequence of 16-byte units: unit u belongs to
-// batch row u / upr.  Lane j of the key's workgroup range owns units
-// j, j + stride, ... (U of them): consecutive lanes touch consecutive 16 bytes
-// on both sides, every lane has U independent row lookups and then U
+// batch row u / upr.  A workgroup owns blockDim.x * U consecutive units; lane j
+// takes units j, j + blockDim.x, ...: consecutive lanes touch consecutive
+// 16 bytes on both sides, every lane has U independent row lookups and then U
 // independent loads in flight before its first store, and no lane waits on a
 // per-workgroup scalar dependency chain.
 template <bool kGather, int U, int NT>
@@ -694,9 +694,8 @@ hipError_t launch_director_score(const float* rew, const float* cont, const floa
 
 hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, uint8_t* is_last,
                             uint8_t* is_terminal, int64_t n, int64_t frame_bytes, int64_t env0,
-                            int64_t tick, int64_t episode_len, const uint8_t* reset,
-                            int32_t* counters, hipStream_t stream) {
-  (void)tick;
+                            int64_t episode_len, const uint8_t* reset, int32_t* counters,
+                            hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   if (frame_bytes % 16 != 0 || reinterpret_cast<uint64_t>(image) % 16 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(synth_env_kernel, dim3(1, static_cast<uint32_t>(n)), dim3(kThreads), 0, stream,
