@@ -234,13 +234,15 @@ def main():
   S = sum(k.rowbytes for k in replay._keys)
   algo_bytes = 2 * B * args.prefetch * L * S      # read B*L*S + write B*L*S
   roofline = None
+  traffic, traffic_source = pmc_traffic(algo_bytes)
   if launches:
     avg_s = gather_ms / launches / 1e3
     achieved = algo_bytes / avg_s / 1e9
     roofline = {
         'bound': 'hbm', 'kernel': 'gather_kernel (Replay.sample)',
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+        'traffic_source': traffic_source,
         'read_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
         'bytes_per_launch': algo_bytes, 'avg_launch_us': round(avg_s * 1e6, 2),
         'launches': launches,
@@ -278,6 +280,23 @@ def main():
     }))
   if use_dist:
     dist.destroy_process_group()
+
+
+def pmc_traffic(algo_bytes):
+  """HBM bytes per gather launch from the committed PMC passes (counters cannot
+  be read from inside the process): the newest profiles/r*_pmc_gather.json whose
+  workload matches this run, else None."""
+  import glob
+  here = os.path.dirname(os.path.abspath(__file__))
+  for path in sorted(glob.glob(os.path.join(here, 'profiles', 'r*_pmc_gather.json')), reverse=True):
+    try:
+      with open(path) as f:
+        rec = json.load(f)
+      if rec['algorithmic_bytes_per_launch'] == algo_bytes:
+        return rec['traffic_bytes_per_launch'], os.path.relpath(path, here)
+    except Exception:
+      continue
+  return None, None
 
 
 def cpu_baseline(args):
