@@ -214,6 +214,21 @@ class Replay:
     with self._lock:
       if self._keys is None:
         self._init_keys(step)
+      # Validate and convert BEFORE touching the index: a rejected step must
+      # leave no trace (no row without payload).
+      if len(step) + 1 != len(self._keys):
+        raise KeyError(f'replay step keys {sorted(step)} differ from the first step')
+      rows = []
+      for name, value in step.items():
+        i = self._keyid.get(name)
+        if i is None:
+          raise KeyError(f'replay step key {name!r} was not in the first step')
+        key = self._keys[i]
+        value = np.asarray(value)
+        if value.shape != key.shape:
+          raise ValueError((name, value.shape, key.shape))
+        rows.append((key, np.ascontiguousarray(value).astype(
+            _numpy_of(key.dtype), copy=False).reshape(-1).view(np.uint8)))
       self._one_worker[0] = worker
       while True:
         try:
@@ -226,15 +241,8 @@ class Replay:
           self._grow()
       self._reraise()
       slot = self._staged
-      if len(step) + 1 != len(self._keys):
-        raise KeyError(f'replay step keys {sorted(step)} differ from the first step')
-      for name, value in step.items():
-        key = self._keys[self._keyid[name]]
-        value = np.asarray(value)
-        if value.shape != key.shape:
-          raise ValueError((name, value.shape, key.shape))
-        key.stage_np[slot] = np.ascontiguousarray(value).astype(
-            _numpy_of(key.dtype), copy=False).reshape(-1).view(np.uint8)
+      for key, data in rows:
+        key.stage_np[slot] = data
       self._keys[-1].stage_np[slot] = self._one_sid[0]
       self._stage_dst[slot] = self._one_row[0]
       self._staged += 1

@@ -253,3 +253,35 @@ def test_threading(Replay, tmp_path, length=5, capacity=128, chunksize=32, adder
     [w.join() for w in workers]
   assert not errors, errors
   assert len(replay) == capacity
+
+
+def test_sample_blocks_until_the_buffer_has_an_item(Replay):
+  """replay.py:123: sampling from an empty buffer waits (limiters.wait) instead
+  of failing; it returns as soon as the first full window exists."""
+  replay = Replay(length=3, capacity=10)
+  got = []
+  thread = threading.Thread(target=lambda: got.append(replay.sample(2)))
+  thread.start()
+  time.sleep(0.1)
+  assert thread.is_alive() and not got
+  replay.add({'step': 0})
+  replay.add({'step': 1})
+  time.sleep(0.05)
+  assert thread.is_alive()                 # two steps are not a window yet
+  replay.add({'step': 2})
+  thread.join(timeout=5)
+  assert not thread.is_alive()
+  assert (got[0]['step'] == [[0, 1, 2], [0, 1, 2]]).all()
+
+
+def test_schema_is_fixed_by_the_first_step(Replay):
+  replay = Replay(length=2, capacity=10)
+  replay.add({'a': np.float32(1), 'b': np.zeros(3, np.int32)})
+  with pytest.raises((KeyError, ValueError)):
+    replay.add({'a': np.float32(1)})
+  with pytest.raises(ValueError):
+    replay.add({'a': np.float32(1), 'b': np.zeros(4, np.int32)})
+  replay.add({'a': 2.0, 'b': [1, 2, 3], 'log/ignored': 5})   # casts like numpy, drops log/*
+  seq = one(replay)
+  assert seq['a'].dtype == np.float32 and seq['b'].dtype == np.int32
+  assert seq['a'].tolist() == [1.0, 2.0] and seq['b'][1].tolist() == [1, 2, 3]
