@@ -38,7 +38,8 @@ class ReplayConfig(C.Structure):
   _fields_ = [
       ('length', C.c_int64), ('capacity', C.c_int64), ('chunksize', C.c_int64),
       ('n_slots', C.c_int64), ('online', C.c_int32), ('reserved', C.c_int32),
-      ('uid_hi', C.c_uint64)]
+      ('uid_hi', C.c_uint64), ('owners', C.c_int64),
+      ('workers_per_owner', C.c_int64)]
 
 
 SAMPLE_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p)
@@ -118,7 +119,7 @@ SIGNATURES = {
     'emb_replay_set_keys': [p, i32, p, p, p],
     'emb_replay_grow': [p, i64, p],
     'emb_replay_add_index': [p, i64, p, p, p, p],
-    'emb_replay_sample_index': [p, i64, i32, p, p],
+    'emb_replay_sample_index': [p, i64, i32, p, p, p],
     'emb_replay_resolve': [p, i64, p, i64, p, p],
     'emb_replay_prioritize': [p, p, p, i64],
     'emb_replay_len': [p, p],

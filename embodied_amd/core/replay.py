@@ -59,7 +59,8 @@ class Replay:
   def __init__(
       self, length, capacity=None, directory=None, chunksize=1024,
       online=False, selector=None, save_wait=False, name='unnamed', seed=0,
-      device='cuda', numpy=False, slots=None, stage_rows=256, replica=0):
+      device='cuda', numpy=False, slots=None, stage_rows=256, replica=0,
+      owners=1, owner=0, workers_per_owner=0):
     self.length = int(length)
     self.capacity = capacity and int(capacity)
     self.chunksize = int(chunksize)
@@ -85,10 +86,15 @@ class Replay:
       slots = 64
       if self.capacity:
         slots = -(-(self.capacity + self.length) // self.chunksize) + 130
+    # Sharded pools (distributed.ShardedReplay): the index covers every owner's
+    # workers, this process holds only owner `owner`'s slot range in HBM.
+    self._owners, self._owner = int(owners), int(owner)
+    if self._owners > 1:
+      slots = -(-int(slots) // self._owners) * self._owners
     self._slots = int(slots)
     cfg = _lib.ReplayConfig(
         self.length, self.capacity or 0, self.chunksize, self._slots,
-        int(bool(online)), 0, int(replica))
+        int(bool(online)), 0, int(replica), self._owners, int(workers_per_owner))
     self._handle = C.c_void_p()
     api.emb_replay_create(
         C.byref(cfg), self._native._handle, int(seed), C.byref(self._handle))
@@ -166,7 +172,7 @@ class Replay:
           raise TypeError(f'replay key {name!r}: unsupported dtype {value.dtype}')
         keys.append(_Key(name, _TORCH_OF[value.dtype], value.shape))
     keys.append(_Key('stepid', torch.uint8, (_lib.STEPID_BYTES,)))
-    rows = self._slots * self.chunksize
+    rows = self._slots // self._owners * self.chunksize
     for key in keys:
       key.pool = torch.empty(rows * key.rowbytes, dtype=torch.uint8, device=self.device)
       key.stage = torch.empty(
@@ -181,11 +187,17 @@ class Replay:
     n = len(self._keys)
     names = (C.c_char_p * n)(*[k.name.encode() for k in self._keys])
     rowbytes = (C.c_int64 * n)(*[k.rowbytes for k in self._keys])
-    pools = (C.c_void_p * n)(*[k.pool.data_ptr() for k in self._keys])
+    # With sharded pools the library sees a virtual base: only this owner's row
+    # range [first, first + rows) is ever dereferenced.
+    first = self._owner * (self._slots // self._owners) * self.chunksize
+    pools = (C.c_void_p * n)(*[
+        k.pool.data_ptr() - first * k.rowbytes for k in self._keys])
     api.emb_replay_set_keys(self._handle, n, names, rowbytes, pools)
 
   def _grow(self, at_least=0):
     """Pool exhausted: double it, copying the live rows device-to-device."""
+    if self._owners > 1:
+      raise _lib.PoolFull(_lib.ERR_POOL_FULL, 'a sharded replay pool cannot grow: raise `slots`')
     new_slots = max(2 * self._slots, self._slots + at_least + 2)
     if self._keys is not None:
       rows = new_slots * self.chunksize
@@ -352,7 +364,7 @@ class Replay:
     online = np.zeros(batch, np.uint8)
     with self._lock:
       api.emb_replay_sample_index(
-          self._handle, batch, _lib.MODES[mode], _lib.ptr(rows), _lib.ptr(online))
+          self._handle, batch, _lib.MODES[mode], _lib.ptr(rows), _lib.ptr(online), None)
       self._reraise()
     return rows, online.astype(bool)
 

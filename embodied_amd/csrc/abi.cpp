@@ -457,6 +457,8 @@ int32_t emb_replay_create(const emb_replay_config_t* cfg, emb_selector_t* select
     c.n_slots = cfg->n_slots;
     c.online = cfg->online != 0;
     c.uid_hi = cfg->uid_hi;
+    c.owners = cfg->owners > 0 ? cfg->owners : 1;
+    c.workers_per_owner = cfg->workers_per_owner;
     auto rep = std::make_unique<emb_replay>();
     rep->selector = selector ? selector->impl : std::make_shared<emb::Uniform>(seed);
     rep->index = std::make_unique<emb::ReplayIndex>(c, rep->selector);
@@ -508,14 +510,14 @@ int32_t emb_replay_grow(emb_replay_t* rep, int64_t n_slots, void* const* pools) 
 
 static void add_index_locked(emb_replay* rep, int64_t n, const int64_t* workers, int32_t* rows,
                              emb::StepId* ids) {
-  if (rep->index->slots_needed(workers, n) > rep->index->free_slots()) throw emb::PoolFull();
+  if (!rep->index->fits(workers, n)) throw emb::PoolFull();
   for (int64_t i = 0; i < n; ++i)
     rows[i] = static_cast<int32_t>(rep->index->add(workers[i], &ids[i]));
 }
 
 static void sample_index_locked(emb_replay* rep, int64_t batch, int32_t mode, int32_t* rows,
                                 uint8_t* online, std::vector<int32_t>* spans = nullptr,
-                                uint8_t* first_ids = nullptr) {
+                                uint8_t* first_ids = nullptr, int64_t* workers = nullptr) {
   need(mode >= EMB_MODE_TRAIN && mode <= EMB_MODE_EVAL, "sample: bad mode");
   const int64_t L = rep->index->config().length;
   bool spans_ok = spans != nullptr;
@@ -527,6 +529,7 @@ static void sample_index_locked(emb_replay* rep, int64_t batch, int32_t mode, in
       throw std::logic_error("replay: sampled window vanished");
     if (spans_ok) spans_ok = rep->index->two_spans(pos, L, spans->data() + 3 * b);
     if (online) online[b] = from_online ? 1 : 0;
+    if (workers) workers[b] = rep->index->worker_of(pos);
     if (first_ids) {
       const emb::StepId sid = rep->index->make_stepid(pos.first, pos.second);
       std::memcpy(first_ids + b * EMB_STEPID_BYTES, sid.b, EMB_STEPID_BYTES);
@@ -548,10 +551,10 @@ int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* worker
 }
 
 int32_t emb_replay_sample_index(emb_replay_t* rep, int64_t batch, int32_t mode, int32_t* rows_out,
-                                uint8_t* online_out) {
+                                uint8_t* online_out, int64_t* workers_out) {
   REP_OP({
     need(batch >= 0 && rows_out, "sample_index: bad arguments");
-    sample_index_locked(rep, batch, mode, rows_out, online_out);
+    sample_index_locked(rep, batch, mode, rows_out, online_out, nullptr, nullptr, workers_out);
   });
 }
 

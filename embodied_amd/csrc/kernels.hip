@@ -134,6 +134,7 @@ __global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) {
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
   const int64_t row = row_of(a, static_cast<uint32_t>(r));
+  if (row < 0) return;   // not this rank's sequence (sharded pools): leave as is
   const uint8_t* src = key.pool + row * key.rowbytes + off;
   uint8_t* dst = key.batch + r * key.rowbytes + off;
   if (key.rowbytes == 1 && (k == a.key_is_first || k == a.key_is_last)) {

@@ -32,6 +32,11 @@ struct ReplayConfig {
   int64_t n_slots = 0;    // chunk slots in the device pool
   bool online = false;
   uint64_t uid_hi = 0;    // high 64 bits of every chunk uid (replica id)
+  // Sharded pools: worker w belongs to owner w / workers_per_owner and its chunks
+  // only ever use that owner's contiguous range of n_slots / owners slots, so a
+  // rank that holds one owner's range can address its rows without the others'.
+  int64_t owners = 1;
+  int64_t workers_per_owner = 0;
 };
 
 class ReplayIndex {
@@ -43,6 +48,7 @@ class ReplayIndex {
     int64_t refs = 0;
     int64_t slot = -1;
     int64_t time_ms = 0;   // creation time (file naming / load order)
+    int64_t worker = 0;    // the stream this chunk belongs to
   };
   struct Span { uint64_t uid; int64_t slot; int64_t index; int64_t count; };
   using Pos = std::pair<uint64_t, int64_t>;  // (chunk uid, row in chunk)
@@ -53,13 +59,29 @@ class ReplayIndex {
       throw std::invalid_argument("replay: bad length/chunksize/n_slots/capacity");
     if (cfg_.n_slots * cfg_.chunksize > INT32_MAX)
       throw std::invalid_argument("replay: more than 2^31 rows in the pool");
-    for (int64_t s = 0; s < cfg_.n_slots; ++s) free_.push_back(s);
+    if (cfg_.owners < 1 || cfg_.n_slots % cfg_.owners != 0 ||
+        (cfg_.owners > 1 && cfg_.workers_per_owner < 1))
+      throw std::invalid_argument("replay: bad owners / workers_per_owner / n_slots");
+    free_.resize(cfg_.owners);
+    const int64_t per = cfg_.n_slots / cfg_.owners;
+    for (int64_t s = 0; s < cfg_.n_slots; ++s) free_[s / per].push_back(s);
   }
 
   const ReplayConfig& config() const { return cfg_; }
   Selector& selector() { return *selector_; }
   int64_t size() const { return static_cast<int64_t>(items_.size()); }
-  int64_t free_slots() const { return static_cast<int64_t>(free_.size()); }
+  // Free slots of the tightest owner (what bounds the next insert).
+  int64_t free_slots() const {
+    size_t least = free_[0].size();
+    for (const auto& f : free_) least = f.size() < least ? f.size() : least;
+    return static_cast<int64_t>(least);
+  }
+  int64_t owner_of(int64_t worker) const {
+    if (cfg_.owners == 1 || worker < 0) return 0;
+    const int64_t o = worker / cfg_.workers_per_owner;
+    return o < cfg_.owners ? o : cfg_.owners - 1;
+  }
+  int64_t worker_of(const Pos& pos) const { return chunks_.at(pos.first).worker; }
   int64_t next_item() const { return next_item_; }
   // Chunks opened so far: a caller that batches payload writes flushes them
   // whenever this moves, so a recycled slot never sees two writers in one launch.
@@ -67,41 +89,44 @@ class ReplayIndex {
 
   void grow(int64_t n_slots) {
     if (n_slots < cfg_.n_slots) throw std::invalid_argument("replay: pool cannot shrink");
+    if (cfg_.owners != 1) throw std::invalid_argument("replay: a sharded pool cannot grow");
     if (n_slots * cfg_.chunksize > INT32_MAX)
       throw std::invalid_argument("replay: more than 2^31 rows in the pool");
-    for (int64_t s = cfg_.n_slots; s < n_slots; ++s) free_.push_back(s);
+    for (int64_t s = cfg_.n_slots; s < n_slots; ++s) free_[0].push_back(s);
     cfg_.n_slots = n_slots;
   }
 
-  // Upper bound on the chunk slots `add` may take for these workers; lets the
-  // caller fail (PoolFull) before any state changes.
-  int64_t slots_needed(const int64_t* workers, int64_t n) const {
-    // Cheap bound first: every row can open at most two chunks.
-    if (2 * n <= free_slots()) return 0;
-    int64_t need = 0;
+  // Would `add` for these workers run out of slots?  Checked before any state
+  // changes so the caller can grow the pool and retry.
+  bool fits(const int64_t* workers, int64_t n) const {
+    if (2 * n <= free_slots()) return true;   // a row opens at most two chunks
+    std::vector<int64_t> need(cfg_.owners, 0);
     std::unordered_map<int64_t, int64_t> seen;  // worker -> simulated index
     for (int64_t i = 0; i < n; ++i) {
+      const int64_t o = owner_of(workers[i]);
       auto s = seen.find(workers[i]);
       int64_t index;
       if (s != seen.end()) {
         index = s->second;
       } else {
         const Worker* w = find_worker(workers[i]);
-        if (!w) { ++need; index = 0; }
+        if (!w) { ++need[o]; index = 0; }
         else index = w->cursor.second;
       }
       ++index;
-      if (index >= cfg_.chunksize) { ++need; index = 0; }
+      if (index >= cfg_.chunksize) { ++need[o]; index = 0; }
       seen[workers[i]] = index;
     }
-    return need;
+    for (int64_t o = 0; o < cfg_.owners; ++o)
+      if (need[o] > static_cast<int64_t>(free_[o].size())) return false;
+    return true;
   }
 
   // replay.py:77-118.  Returns the device row the step's payload goes to.
   int64_t add(int64_t worker, StepId* stepid) {
     Worker* w = find_worker(worker);
     if (!w) {
-      Chunk& c = new_chunk(1);
+      Chunk& c = new_chunk(1, worker);
       w = &make_worker(worker);
       w->cursor = Pos(c.uid, 0);
     }
@@ -241,15 +266,15 @@ class ReplayIndex {
   // Re-create a saved chunk (replay.py:347-359): returns its slot.
   int64_t load_chunk(uint64_t uid, uint64_t succ, int64_t fill, int64_t time_ms = 0) {
     if (chunks_.count(uid)) throw std::runtime_error("replay: chunk already loaded");
-    if (free_.empty()) throw PoolFull();
+    if (free_[0].empty()) throw PoolFull();
     Chunk c;
     c.uid = uid;
     c.succ = succ;
     c.fill = fill;
     c.refs = 0;
     c.time_ms = time_ms;
-    c.slot = free_.front();
-    free_.pop_front();
+    c.slot = free_[0].front();
+    free_[0].pop_front();
     chunks_[uid] = c;
     ++loaded_;
     if (uid >= next_uid_) next_uid_ = uid + 1;
@@ -267,15 +292,17 @@ class ReplayIndex {
  private:
   enum { kInserts = 0, kSamples = 1, kUpdates = 2 };
 
-  Chunk& new_chunk(int64_t refs) {
-    if (free_.empty()) throw PoolFull();
+  Chunk& new_chunk(int64_t refs, int64_t worker) {
+    auto& free = free_[owner_of(worker)];
+    if (free.empty()) throw PoolFull();
     Chunk c;
     c.uid = next_uid_++;
     c.refs = refs;
     c.time_ms = std::chrono::duration_cast<std::chrono::milliseconds>(
         std::chrono::system_clock::now().time_since_epoch()).count();
-    c.slot = free_.front();
-    free_.pop_front();
+    c.slot = free.front();
+    free.pop_front();
+    c.worker = worker;
     return chunks_[c.uid] = c;
   }
 
@@ -311,7 +338,7 @@ class ReplayIndex {
   // replay.py:362-370
   void rotate(Chunk& chunk, Worker& worker) {
     const uint64_t old = chunk.uid;
-    Chunk& succ = new_chunk(2);
+    Chunk& succ = new_chunk(2, chunk.worker);
     Chunk& prev = chunks_.at(old);
     prev.refs -= 1;
     prev.succ = succ.uid;
@@ -346,7 +373,7 @@ class ReplayIndex {
     chunk.refs -= 1;
     if (chunk.refs < 1) {
       const uint64_t succ = chunk.succ;
-      free_.push_back(chunk.slot);
+      free_[chunk.slot / (cfg_.n_slots / cfg_.owners)].push_back(chunk.slot);
       chunks_.erase(uid);
       auto nx = chunks_.find(succ);
       if (nx != chunks_.end()) nx->second.refs -= 1;
@@ -356,7 +383,7 @@ class ReplayIndex {
   ReplayConfig cfg_;
   std::shared_ptr<Selector> selector_;
   std::unordered_map<uint64_t, Chunk> chunks_;
-  std::deque<int64_t> free_;   // FIFO: a freed slot is recycled as late as possible
+  std::vector<std::deque<int64_t>> free_;   // per owner, FIFO: a freed slot is recycled as late as possible
   std::deque<Pos> items_;
   int64_t first_item_ = 0;
   int64_t next_item_ = 0;

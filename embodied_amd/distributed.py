@@ -160,3 +160,103 @@ def max_over_ranks(value, device):
   t = torch.tensor([value], dtype=torch.float64, device=device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   return float(t.item())
+
+
+class ShardedReplay:
+  """One logical replay over the envs of ALL ranks.
+
+  Every rank advances the same host index for every global worker (same seed,
+  same insert order by global env id), so item ids, eviction and sampled indices
+  are identical on all ranks and identical to a single-process replay over all
+  envs.  Payload stays where it was produced: rank r holds only the chunk slots
+  of its own env block.  `sample` gathers the sequences this rank owns into
+  their final positions of a zero-filled packed (B, L, S) buffer and one RCCL
+  all-reduce(sum) — supports are disjoint, so the sum is a merge — leaves the
+  full batch on every rank.
+  """
+
+  def __init__(self, length, capacity, envs_per_rank, rank=None, world=None,
+               reduce=None, **kwargs):
+    from .core.replay import Replay
+    self.rank = globals()['rank']() if rank is None else rank
+    self.world = globals()['world']() if world is None else world
+    self.envs_per_rank = envs_per_rank
+    self.n_global = envs_per_rank * self.world
+    self.workers = np.arange(self.n_global, dtype=np.int64)
+    self.local = slice(self.rank * envs_per_rank, (self.rank + 1) * envs_per_rank)
+    self._reduce = reduce or self._all_reduce
+    slots = kwargs.pop('slots', None)
+    if slots is None:
+      chunksize = kwargs.get('chunksize', 1024)
+      per_owner = -(-(capacity + length) // (chunksize * self.world)) + 2 * envs_per_rank + 4
+      slots = per_owner * self.world
+    self.replay = Replay(
+        length, capacity, owners=self.world, owner=self.rank,
+        workers_per_owner=envs_per_rank, slots=slots, **kwargs)
+    self.length = self.replay.length
+
+  def __len__(self):
+    return len(self.replay)
+
+  @staticmethod
+  def _all_reduce(flat):
+    if world() > 1:
+      dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+  def add_batch(self, steps):
+    """One vectorised step of THIS rank's env block ((envs_per_rank, ...) device
+    tensors).  All ranks call it in lockstep."""
+    import ctypes as C
+    from . import _lib
+    from ._lib import api
+    rep = self.replay
+    steps = {k: v for k, v in steps.items() if not k.startswith('log/')}
+    with rep._lock:
+      if rep._keys is None:
+        rep._init_keys({k: v[0] for k, v in steps.items()})
+      n = self.n_global
+      rows = np.zeros(n, np.int32)
+      sids = np.zeros((n, _lib.STEPID_BYTES), np.uint8)
+      api.emb_replay_add_index(
+          rep._handle, n, _lib.ptr(self.workers), _lib.ptr(rows), _lib.ptr(sids), None)
+      mine = np.ascontiguousarray(rows[self.local])
+      sid_dev = torch.from_numpy(np.ascontiguousarray(sids[self.local])).to(
+          rep.device, non_blocking=True)
+      ids = (C.c_int32 * len(rep._keys))(*range(len(rep._keys)))
+      ptrs = (C.c_void_p * len(rep._keys))()
+      keep = [sid_dev]
+      for i, key in enumerate(rep._keys):
+        if key.name == 'stepid':
+          ptrs[i] = sid_dev.data_ptr()
+          continue
+        value = steps[key.name].to(rep.device, key.dtype).contiguous()
+        assert value.shape == (self.envs_per_rank, *key.shape), (key.name, value.shape)
+        keep.append(value)
+        ptrs[i] = value.data_ptr()
+      api.emb_replay_scatter_rows(
+          rep._handle, _lib.ptr(mine), len(mine), len(rep._keys), ids, ptrs, rep._stream())
+
+  def sample(self, batch, mode='train'):
+    """The same (batch, length, ...) dict on every rank."""
+    import ctypes as C
+    from . import _lib
+    from ._lib import api
+    from .core import limiters
+    rep = self.replay
+    limiters.wait(lambda: len(rep._native), f'Replay buffer {rep.name} is empty')
+    with rep._lock:
+      rows = np.zeros((batch, rep.length), np.int32)
+      owners = np.zeros(batch, np.int64)
+      api.emb_replay_sample_index(
+          rep._handle, batch, _lib.MODES[mode], _lib.ptr(rows), None, _lib.ptr(owners))
+      rows[owners // self.envs_per_rank != self.rank] = -1
+      layout = PackedLayout(
+          [(k.name, k.dtype, k.shape) for k in rep._keys], batch, rep.length)
+      flat = torch.zeros(layout.nbytes, dtype=torch.uint8, device=rep.device)
+      views = layout.views(flat)
+      ptrs = (C.c_void_p * len(rep._keys))(*[views[k.name].data_ptr() for k in rep._keys])
+      api.emb_replay_gather_rows(
+          rep._handle, _lib.ptr(rows), rows.size, rep.length, ptrs, rep._stream())
+    self._reduce(flat)
+    return views

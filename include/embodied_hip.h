@@ -136,6 +136,10 @@ typedef struct {
   int32_t online;     /*                                    replay.py:39-42    */
   int32_t reserved;
   uint64_t uid_hi;    /* high 64 bits of chunk uids (replica id)              */
+  /* Sharded pools (0/1 = off): worker w belongs to owner w / workers_per_owner,
+   * whose chunks only use slots [o, o+1) * n_slots / owners.                 */
+  int64_t owners;
+  int64_t workers_per_owner;
 } emb_replay_config_t;
 
 /* selector may be NULL: Uniform(seed), as replay.py:26.                      */
@@ -157,13 +161,14 @@ int32_t emb_replay_grow(emb_replay_t* rep, int64_t n_slots, void* const* pools);
  *                flush them whenever it is non-zero: the new chunk may sit in
  *                a recycled slot).
  * sample_index = `batch` sequence draws (replay.py:121-127,151-169,193-214):
- *                rows_out[batch*length] pool rows, online_out[batch] flags.
+ *                rows_out[batch*length] pool rows, online_out[batch] flags,
+ *                workers_out[batch] the worker stream of each sequence.
  * resolve      = Replay.update's decode of stepid[i,0] -> `count` pool rows
  *                (replay.py:139-149,216-235); evicted -> rows -1, found 0.   */
 int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* workers,
                              int32_t* rows_out, uint8_t* stepids_out, int32_t* new_chunks_out);
 int32_t emb_replay_sample_index(emb_replay_t* rep, int64_t batch, int32_t mode,
-                                int32_t* rows_out, uint8_t* online_out);
+                                int32_t* rows_out, uint8_t* online_out, int64_t* workers_out);
 int32_t emb_replay_resolve(emb_replay_t* rep, int64_t n, const uint8_t* stepids, int64_t count,
                            int32_t* rows_out, uint8_t* found_out);
 int32_t emb_replay_prioritize(emb_replay_t* rep, const uint8_t* stepids, const double* prios,

@@ -84,7 +84,7 @@ def _index_job(rank, world, D):
   import ctypes as C
   from embodied_amd import _lib
   from embodied_amd._lib import api
-  cfg = _lib.ReplayConfig(5, 40, 8, 64, 0, 0, 0)
+  cfg = _lib.ReplayConfig(5, 40, 8, 64, 0, 0, 0, 1, 0)
   h = C.c_void_p()
   api.emb_replay_create(C.byref(cfg), None, 7, C.byref(h))
   workers = np.arange(6, dtype=np.int64)
@@ -92,7 +92,7 @@ def _index_job(rank, world, D):
   for _ in range(30):
     api.emb_replay_add_index(h, 6, _lib.ptr(workers), _lib.ptr(rows), None, None)
   table = np.zeros((4, 5), np.int32)
-  api.emb_replay_sample_index(h, 4, 0, _lib.ptr(table), None)
+  api.emb_replay_sample_index(h, 4, 0, _lib.ptr(table), None, None)
   mine = torch.as_tensor(table)
   both = [torch.zeros_like(mine) for _ in range(world)]
   torch.distributed.all_gather(both, mine)

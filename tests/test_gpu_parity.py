@@ -389,3 +389,42 @@ def test_replay_with_mixture_of_all_selectors(emb):
     prio = (want['step'] % 4 + 0.25 * r).astype(np.float32)
     ours.update({'stepid': got['stepid'], 'priority': torch.as_tensor(prio).cuda()})
     ref.update({'stepid': want['stepid'], 'priority': prio})
+
+
+def test_sharded_replay_equals_single_process_replay(emb):
+  """replicated index + owner-local payload.  Two 'ranks' are run in
+  one process on one GPU; the all-reduce is emulated by summing their packed
+  buffers.  The merged batch must equal, bit for bit, what ONE replay over all
+  envs returns (same seed), and what the oracle returns."""
+  from embodied_amd import distributed as D
+  n, L, world = 3, 5, 2
+  kw = dict(chunksize=8, seed=4)
+  flats = {}
+  shards = [
+      D.ShardedReplay(L, 40, n, rank=r, world=world,
+                      reduce=lambda flat, r=r: flats.__setitem__(r, flat.clone()), **kw)
+      for r in range(world)]
+  single = emb.Replay(L, 40, **kw)
+  ref = np_oracle.Replay(L, 40, 8, seed=4)
+  for t in range(37):
+    steps = [scenarios.synth_step(t, w) for w in range(n * world)]
+    stacked = {k: torch.as_tensor(np.stack([s[k] for s in steps])).cuda() for k in steps[0]}
+    single.add_batch(stacked, list(range(n * world)))
+    for w, step in enumerate(steps):
+      ref.add(step, w)
+    for r, shard in enumerate(shards):
+      shard.add_batch({k: v[r * n:(r + 1) * n] for k, v in stacked.items()})
+    assert len(shards[0]) == len(shards[1]) == len(single) == len(ref)
+  for _ in range(4):
+    want = {k: v.cpu().numpy() for k, v in single.sample(7).items()}
+    views = [shard.sample(7) for shard in shards]
+    merged = flats[0] + flats[1]
+    layout = D.PackedLayout(
+        [(k.name, k.dtype, k.shape) for k in shards[0].replay._keys], 7, L)
+    got = {k: v.cpu().numpy() for k, v in layout.views(merged).items()}
+    assert_same(got, want, 'sharded-vs-single')
+    assert_same(got, ref.sample(7), 'sharded-vs-oracle')
+    # supports are disjoint and every sequence has exactly one owner
+    owned0 = flats[0].view(torch.uint8) != 0
+    owned1 = flats[1].view(torch.uint8) != 0
+    assert not bool((owned0 & owned1).any())

@@ -22,7 +22,7 @@ class HostReplay:
   def __init__(self, length, capacity=None, chunksize=1024, online=False,
                selector=None, seed=0, n_slots=64):
     self.length, self.chunksize, self.n_slots = length, chunksize, n_slots
-    cfg = _lib.ReplayConfig(length, capacity or 0, chunksize, n_slots, int(online), 0, 0)
+    cfg = _lib.ReplayConfig(length, capacity or 0, chunksize, n_slots, int(online), 0, 0, 1, 0)
     self.selector = selector
     self.h = C.c_void_p()
     api.emb_replay_create(
@@ -55,7 +55,7 @@ class HostReplay:
     rows = np.zeros((batch, self.length), np.int32)
     online = np.zeros(batch, np.uint8)
     api.emb_replay_sample_index(
-        self.h, batch, _lib.MODES[mode], _lib.ptr(rows), _lib.ptr(online))
+        self.h, batch, _lib.MODES[mode], _lib.ptr(rows), _lib.ptr(online), None)
     return rows, online
 
   def sample(self, batch, mode='train'):
