@@ -428,3 +428,43 @@ def test_sharded_replay_equals_single_process_replay(emb):
     owned0 = flats[0].view(torch.uint8) != 0
     owned1 = flats[1].view(torch.uint8) != 0
     assert not bool((owned0 & owned1).any())
+
+
+def test_replay_dtype_and_shape_coverage(emb):
+  """Every dtype the wrappers can emit (wrappers.py:228-241 unify to
+  uint8/int32/float32; agents add f16/bf16/f64/i64), odd row sizes that exercise
+  the 1/2/4/8/16-byte unit paths, and rank-0 .. rank-3 shapes."""
+  gen = np.random.default_rng(0)
+  def step(t):
+    return {
+        'u8_odd': gen.integers(0, 255, (7,), dtype=np.uint8),        # 7 B rows  -> 1-byte units
+        'i16': gen.integers(-9, 9, (3,), dtype=np.int16),            # 6 B       -> 2-byte units
+        'f32_3': gen.standard_normal(3).astype(np.float32),          # 12 B      -> 4-byte units
+        'f64': gen.standard_normal(()).astype(np.float64),           # 8 B       -> 8-byte units
+        'f16': gen.standard_normal((2, 4)).astype(np.float16),       # 16 B      -> 16-byte units
+        'i64': np.int64(t * 2 ** 40),
+        'flag3': gen.random((3,)) < 0.5,
+        'wide': gen.standard_normal((3, 200, 2)).astype(np.float32),  # 4800 B  -> flat 16-byte path
+        'is_first': t % 6 == 0, 'is_last': t % 6 == 5,
+    }
+  ours = emb.Replay(length=4, capacity=30, chunksize=5, seed=3, stage_rows=7)
+  ref = np_oracle.Replay(4, 30, 5, seed=3)
+  for t in range(40):
+    s = step(t)
+    ours.add(s, 0)
+    ref.add(s, 0)
+  for _ in range(3):
+    got = {k: v.cpu().numpy() for k, v in ours.sample(5).items()}
+    assert_same(got, ref.sample(5), 'dtypes')
+  # bfloat16 has no numpy twin: device tensors in, same bits out
+  rep = emb.Replay(length=2, capacity=8, chunksize=4)
+  rows = torch.randn(6, 3, 5, device='cuda').to(torch.bfloat16)
+  for t in range(6):
+    rep.add_batch({'x': rows[t:t + 1], 'is_first': torch.zeros(1, dtype=torch.bool, device='cuda')}, [0])
+  out = rep.sample(4)
+  assert out['x'].dtype == torch.bfloat16
+  sid = out['stepid'][..., -1].cpu().numpy()      # row in chunk; chunk serial is byte 15
+  idx = (out['stepid'][..., 8:16].cpu().numpy().astype(np.int64)[..., -1] - 1) * 4 + sid
+  for b in range(4):
+    for t in range(2):
+      assert torch.equal(out['x'][b, t], rows[int(idx[b, t])])
