@@ -85,16 +85,31 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   int vlocal = local;
   const int per_xcd = nblocks >> 3;
   if (a.xcd_remap && local < (per_xcd << 3)) vlocal = (local & 7) * per_xcd + (local >> 3);
-  const uint32_t first = static_cast<uint32_t>(vlocal) * (blockDim.x * U) + threadIdx.x;
-  const uint32_t stride = blockDim.x;
+  // One division per wave for the workgroup's first unit; lanes step from it
+  // with adds and compares (a 32-bit divide costs ~40 VALU instructions).
+  const uint32_t base = static_cast<uint32_t>(vlocal) * (blockDim.x * U);
+  const uint32_t r0 = base / upr;
+  const uint32_t off0 = base - r0 * upr;
+  const uint32_t L = static_cast<uint32_t>(a.seq_len);
+  const uint32_t seq0 = r0 / L, t0 = r0 - seq0 * L;
   uint32_t r[U], off[U];
   int32_t row[U];
 #pragma unroll
   for (int j = 0; j < U; ++j) {
-    const uint32_t u = first + j * stride;
-    r[j] = u / upr;
-    off[j] = u - r[j] * upr;
-    row[j] = (u < total) ? row_of(a, r[j]) : -1;
+    uint32_t x = off0 + j * blockDim.x + threadIdx.x, dr = 0;
+    while (x >= upr) { x -= upr; ++dr; }
+    r[j] = r0 + dr;
+    off[j] = x;
+    if (base + j * blockDim.x + threadIdx.x >= total) {
+      row[j] = -1;
+    } else if (a.rows_mode == 2) {
+      uint32_t seq = seq0, t = t0 + dr;
+      while (t >= L) { t -= L; ++seq; }
+      const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
+      row[j] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
+    } else {
+      row[j] = row_of(a, r[j]);
+    }
   }
   u32x4 buf[U];
 #pragma unroll
@@ -461,8 +476,10 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel<__hip_bfloat16>(
 // rows longer than W are walked right-to-left in W-wide pieces with the
 // running y carried in a register.  Episode boundaries need no flags: b_t = 0.
 
+// Composite map of lanes [sl, W) of a segment: returns (A, B) with
+// y_sl = A + B * y_{segment end + 1}.
 template <int W>
-__device__ __forceinline__ float affine_suffix_scan(float a, float b, int sl, float carry) {
+__device__ __forceinline__ void affine_suffix(float& a, float& b, int sl) {
 #pragma unroll
   for (int off = 1; off < W; off <<= 1) {
     const float ap = __shfl_down(a, off, W);
@@ -472,68 +489,112 @@ __device__ __forceinline__ float affine_suffix_scan(float a, float b, int sl, fl
       b = b * bp;
     }
   }
-  return fmaf(b, carry, a);
 }
 
-template <int W>
-__global__ __launch_bounds__(kThreads) void gae_kernel(
-    const float* __restrict__ rew, const float* __restrict__ val,
-    const uint8_t* __restrict__ last, const uint8_t* __restrict__ term, int64_t B,
-    int64_t T, float live_scale, float lam, float* __restrict__ adv,
-    float* __restrict__ tar) {
+// What differs between the scans: how (a_t, b_t) are formed from the inputs,
+// the seed y_n, and what is stored.
+struct GaeOp {   // ppo/agent.py:188-201
+  const float* rew; const float* val; const uint8_t* last; const uint8_t* term;
+  int64_t T; float live_scale, lam; float* adv; float* tar;
+  __device__ float seed(int64_t) const { return 0.f; }
+  __device__ void coef(int64_t b, int64_t t, float& a, float& bc, float& keep) const {
+    const int64_t i = b * T + t;
+    const bool tm = term[i + 1] != 0;
+    const float live = tm ? 0.f : live_scale;
+    const float cont = (tm || last[i + 1] != 0) ? 0.f : lam;
+    keep = val[i];
+    a = rew[i + 1] + live * val[i + 1] - keep;
+    bc = live * cont;
+  }
+  __device__ void store(int64_t b, int64_t t, float y, float keep) const {
+    adv[b * (T - 1) + t] = y;
+    tar[b * (T - 1) + t] = y + keep;
+  }
+};
+
+struct LambdaOp {   // dreamerv3/agent.py:482-490
+  const uint8_t* last; const uint8_t* term; const float* rew; const float* boot;
+  int64_t T; float disc, lam; float* ret;
+  __device__ float seed(int64_t b) const { return boot[b * T + T - 1]; }
+  __device__ void coef(int64_t b, int64_t t, float& a, float& bc, float& keep) const {
+    const int64_t i = b * T + t;
+    const float live = (1.f - static_cast<float>(term[i + 1] != 0)) * disc;
+    const float cont = (1.f - static_cast<float>(last[i + 1] != 0)) * lam;
+    keep = 0.f;
+    a = rew[i + 1] + (1.f - cont) * live * boot[i + 1];
+    bc = live * cont;
+  }
+  __device__ void store(int64_t b, int64_t t, float y, float) const { ret[b * (T - 1) + t] = y; }
+};
+
+// Short rows: a W-lane segment per row, rows longer than W walked right to
+// left with the running value in a register.
+template <int W, typename Op>
+__global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op, int64_t B, int64_t n) {
   const int sl = threadIdx.x % W;
   const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
   const bool row_ok = b < B;
-  const int64_t n = T - 1;
-  const int64_t in = b * T, on = b * n;
-  float carry = 0.f;
+  float carry = row_ok ? op.seed(b) : 0.f;
   for (int64_t base = ((n - 1) / W) * W; base >= 0; base -= W) {
     const int64_t t = base + sl;
     const bool ok = row_ok && t < n;
-    float a = 0.f, bc = 1.f, v0 = 0.f;
-    if (ok) {
-      const bool tm = term[in + t + 1] != 0;
-      const bool ls = last[in + t + 1] != 0;
-      const float live = tm ? 0.f : live_scale;
-      const float cont = (ls || tm) ? 0.f : lam;
-      v0 = val[in + t];
-      a = rew[in + t + 1] + live * val[in + t + 1] - v0;
-      bc = live * cont;
-    }
-    const float y = affine_suffix_scan<W>(a, bc, sl, carry);
-    if (ok) {
-      adv[on + t] = y;
-      tar[on + t] = y + v0;
-    }
+    float a = 0.f, bc = 1.f, keep = 0.f;     // (0, 1) = identity map
+    if (ok) op.coef(b, t, a, bc, keep);
+    affine_suffix<W>(a, bc, sl);
+    const float y = fmaf(bc, carry, a);
+    if (ok) op.store(b, t, y, keep);
     carry = __shfl(y, 0, W);
   }
 }
 
-template <int W>
-__global__ __launch_bounds__(kThreads) void lambda_return_kernel(
-    const uint8_t* __restrict__ last, const uint8_t* __restrict__ term,
-    const float* __restrict__ rew, const float* __restrict__ boot, int64_t B, int64_t T,
-    float disc, float lam, float* __restrict__ ret) {
-  const int sl = threadIdx.x % W;
-  const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
-  const bool row_ok = b < B;
-  const int64_t n = T - 1;
-  const int64_t in = b * T, on = b * n;
-  float carry = row_ok ? boot[in + T - 1] : 0.f;
-  for (int64_t base = ((n - 1) / W) * W; base >= 0; base -= W) {
-    const int64_t t = base + sl;
-    const bool ok = row_ok && t < n;
-    float a = 0.f, bc = 1.f;
-    if (ok) {
-      const float live = (1.f - static_cast<float>(term[in + t + 1] != 0)) * disc;
-      const float cont = (1.f - static_cast<float>(last[in + t + 1] != 0)) * lam;
-      a = rew[in + t + 1] + (1.f - cont) * live * boot[in + t + 1];
-      bc = live * cont;
+// Long rows: one workgroup of `waves` wavefronts per row.  Each wave reduces its
+// 64 steps to one affine map, the per-wave maps are staged in LDS, every wave
+// folds the maps to its right into its carry, and the workgroup walks the row
+// right to left in pieces of 64 * waves steps with the carry handed on through
+// LDS.
+template <typename Op>
+__global__ __launch_bounds__(1024) void scan_long_rows_kernel(const Op op, int64_t n) {
+  __shared__ float s_a[16], s_b[16], s_carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int64_t b = blockIdx.x;
+  const int64_t span = 64 * waves;
+  if (threadIdx.x == 0) s_carry = op.seed(b);
+  for (int64_t base = ((n - 1) / span) * span; base >= 0; base -= span) {
+    const int64_t t = base + threadIdx.x;
+    const bool ok = t < n;
+    float a = 0.f, bc = 1.f, keep = 0.f;
+    if (ok) op.coef(b, t, a, bc, keep);
+    affine_suffix<64>(a, bc, lane);
+    if (lane == 0) {
+      s_a[wave] = a;
+      s_b[wave] = bc;
     }
-    const float y = affine_suffix_scan<W>(a, bc, sl, carry);
-    if (ok) ret[on + t] = y;
-    carry = __shfl(y, 0, W);
+    __syncthreads();
+    float carry = s_carry;
+    for (int w = waves - 1; w > wave; --w) carry = fmaf(s_b[w], carry, s_a[w]);
+    const float y = fmaf(bc, carry, a);
+    if (ok) op.store(b, t, y, keep);
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = y;
+    // the next iteration's first __syncthreads orders this write before its reads
   }
+}
+
+template <typename Op>
+hipError_t launch_scan(const Op& op, int64_t B, int64_t n, hipStream_t stream) {
+  if (n > 256) {
+    const int waves = static_cast<int>(std::min<int64_t>(16, (n + 63) / 64));
+    hipLaunchKernelGGL(scan_long_rows_kernel<Op>, dim3(static_cast<uint32_t>(B)), dim3(64 * waves),
+                       0, stream, op, n);
+    return hipGetLastError();
+  }
+  const int W = n <= 16 ? 16 : n <= 32 ? 32 : 64;
+  const int64_t rows_per_block = kThreads / W;
+  const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
+  if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+  else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+  else hipLaunchKernelGGL((scan_rows_kernel<64, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+  return hipGetLastError();
 }
 
 // Time-major: lane = batch column (coalesced), the T-step recurrence runs
@@ -654,34 +715,18 @@ hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_e
   return hipGetLastError();
 }
 
-namespace {
-inline int scan_width(int64_t n) { return n <= 16 ? 16 : n <= 32 ? 32 : 64; }
-inline dim3 scan_grid(int64_t B, int W) {
-  const int64_t rows_per_block = kThreads / W;
-  return dim3(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
-}
-}  // namespace
-
 hipError_t launch_gae(const float* rew, const float* val, const uint8_t* last,
                       const uint8_t* term, int64_t B, int64_t T, float live_scale, float lam,
                       float* adv, float* tar, hipStream_t stream) {
   if (B <= 0 || T < 2) return hipSuccess;
-  const int W = scan_width(T - 1);
-#define EMB_GAE(W_) hipLaunchKernelGGL(gae_kernel<W_>, scan_grid(B, W_), dim3(kThreads), 0, stream, rew, val, last, term, B, T, live_scale, lam, adv, tar)
-  if (W == 16) EMB_GAE(16); else if (W == 32) EMB_GAE(32); else EMB_GAE(64);
-#undef EMB_GAE
-  return hipGetLastError();
+  return launch_scan(GaeOp{rew, val, last, term, T, live_scale, lam, adv, tar}, B, T - 1, stream);
 }
 
 hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term, const float* rew,
                                 const float* boot, int64_t B, int64_t T, float disc, float lam,
                                 float* ret, hipStream_t stream) {
   if (B <= 0 || T < 2) return hipSuccess;
-  const int W = scan_width(T - 1);
-#define EMB_LAM(W_) hipLaunchKernelGGL(lambda_return_kernel<W_>, scan_grid(B, W_), dim3(kThreads), 0, stream, last, term, rew, boot, B, T, disc, lam, ret)
-  if (W == 16) EMB_LAM(16); else if (W == 32) EMB_LAM(32); else EMB_LAM(64);
-#undef EMB_LAM
-  return hipGetLastError();
+  return launch_scan(LambdaOp{last, term, rew, boot, T, disc, lam, ret}, B, T - 1, stream);
 }
 
 hipError_t launch_director_score(const float* rew, const float* cont, const float* value,

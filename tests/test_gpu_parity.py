@@ -142,7 +142,8 @@ def test_update_roundtrip_full_rows(emb):
   assert hits > 0
 
 
-@pytest.mark.parametrize('shape', [(16, 64), (1024, 16), (16, 1024), (3, 2), (5, 65), (7, 200)])
+@pytest.mark.parametrize('shape', [(16, 64), (1024, 16), (16, 1024), (3, 2), (5, 65), (7, 200),
+                                   (4, 258), (3, 300), (2, 2500), (3, 1025)])
 @pytest.mark.parametrize('seed', [0, 1])
 def test_scans_match_oracle(emb, shape, seed):
   """Tolerance (north_star): 1e-5 on float returns.  atol+rtol 1e-5 on values
