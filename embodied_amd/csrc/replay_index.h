@@ -132,7 +132,8 @@ class ReplayIndex {
     }
     const uint64_t uid = w->cursor.first;
     int64_t index = w->cursor.second;
-    Chunk& chunk = chunks_.at(uid);
+    if (!w->open || w->open->uid != uid) w->open = &chunks_.at(uid);   // node addresses are stable
+    Chunk& chunk = *w->open;
     if (chunk.fill != index) throw std::logic_error("replay: chunk cursor out of sync");
     *stepid = make_stepid(uid, index);
     const int64_t row = chunk.slot * cfg_.chunksize + index;
@@ -308,6 +309,7 @@ class ReplayIndex {
 
   struct Worker {
     Pos cursor;                 // (open chunk uid, next row)
+    Chunk* open = nullptr;      // cached node of the open chunk
     std::deque<Pos> pending;    // steps not yet the start of an item
     int64_t steps_seen = 0;     // online mode
   };
@@ -343,6 +345,7 @@ class ReplayIndex {
     prev.refs -= 1;
     prev.succ = succ.uid;
     worker.cursor = Pos(succ.uid, 0);
+    worker.open = &succ;
   }
 
   // replay.py:171-179
@@ -369,11 +372,14 @@ class ReplayIndex {
     const uint64_t uid = items_.front().first;
     items_.pop_front();
     ++first_item_;
-    Chunk& chunk = chunks_.at(uid);
+    // Consecutive evictions usually hit the same chunk: remember the node.
+    if (!evict_hint_ || evict_hint_->uid != uid) evict_hint_ = &chunks_.at(uid);
+    Chunk& chunk = *evict_hint_;
     chunk.refs -= 1;
     if (chunk.refs < 1) {
       const uint64_t succ = chunk.succ;
       free_[chunk.slot / (cfg_.n_slots / cfg_.owners)].push_back(chunk.slot);
+      evict_hint_ = nullptr;
       chunks_.erase(uid);
       auto nx = chunks_.find(succ);
       if (nx != chunks_.end()) nx->second.refs -= 1;
@@ -392,6 +398,7 @@ class ReplayIndex {
   std::unordered_map<int64_t, std::unique_ptr<Worker>> workers_;
   std::vector<Worker*> dense_;
   std::deque<Pos> fresh_;
+  Chunk* evict_hint_ = nullptr;
   int64_t metrics_[3] = {0, 0, 0};
   mutable std::vector<Span> scratch_;
   std::vector<StepId> ids_;

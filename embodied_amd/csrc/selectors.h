@@ -86,30 +86,68 @@ class Uniform : public Selector {
   int64_t size() const override { return static_cast<int64_t>(keys_.size()); }
   bool needs_stepids() const override { return false; }
   void insert(int64_t key, const StepId*, int) override {
-    pos_[key] = static_cast<int64_t>(keys_.size());
+    set_pos(key, static_cast<int64_t>(keys_.size()));
     keys_.push_back(key);
   }
   // Swap-with-last.  The reference asserts len >= 2 here (selectors.py:52),
   // which makes a capacity-1 replay raise on its second insert although its own
   // test expects it to work (tests/test_replay.py:49); we allow it.
   void remove(int64_t key) override {
-    auto it = pos_.find(key);
-    if (it == pos_.end()) throw std::runtime_error("Uniform: unknown key");
-    const int64_t at = it->second;
-    pos_.erase(it);
+    const int64_t at = take_pos(key);
     const int64_t tail = keys_.back();
     keys_.pop_back();
     if (at != static_cast<int64_t>(keys_.size())) {
       keys_[at] = tail;
-      pos_[tail] = at;
+      set_pos(tail, at);
     }
   }
   const std::vector<int64_t>& keys() const { return keys_; }
 
  private:
+  // key -> position in keys_.  Replay hands out consecutive item ids and evicts
+  // the oldest, so the live keys form a sliding window: a deque indexed by
+  // key - base_ serves them without hashing; any other key pattern falls back
+  // to the hash map for good.
+  static constexpr int64_t kGone = -1;
+  void set_pos(int64_t key, int64_t at) {
+    if (dense_) {
+      if (window_.empty()) base_ = key;
+      const int64_t i = key - base_;
+      if (i >= 0 && i < static_cast<int64_t>(window_.size())) { window_[i] = at; return; }
+      if (i == static_cast<int64_t>(window_.size())) { window_.push_back(at); return; }
+      for (size_t j = 0; j < window_.size(); ++j)      // pattern broken: migrate
+        if (window_[j] != kGone) sparse_[base_ + static_cast<int64_t>(j)] = window_[j];
+      window_.clear();
+      dense_ = false;
+    }
+    sparse_[key] = at;
+  }
+  int64_t take_pos(int64_t key) {
+    if (dense_) {
+      const int64_t i = key - base_;
+      if (i < 0 || i >= static_cast<int64_t>(window_.size()) || window_[i] == kGone)
+        throw std::runtime_error("Uniform: unknown key");
+      const int64_t at = window_[i];
+      window_[i] = kGone;
+      while (!window_.empty() && window_.front() == kGone) {
+        window_.pop_front();
+        ++base_;
+      }
+      return at;
+    }
+    auto it = sparse_.find(key);
+    if (it == sparse_.end()) throw std::runtime_error("Uniform: unknown key");
+    const int64_t at = it->second;
+    sparse_.erase(it);
+    return at;
+  }
+
   NpRandom rng_;
   std::vector<int64_t> keys_;
-  std::unordered_map<int64_t, int64_t> pos_;
+  bool dense_ = true;
+  int64_t base_ = 0;
+  std::deque<int64_t> window_;
+  std::unordered_map<int64_t, int64_t> sparse_;
 };
 
 // b-ary sum tree (selectors.py:231-354).  Children keep list order because the

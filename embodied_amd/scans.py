@@ -16,18 +16,24 @@ def _stream(t):
 
 
 def _f32(x, device):
+  if torch.is_tensor(x) and x.dtype == torch.float32 and x.device == device and x.is_contiguous():
+    return x
   if not torch.is_tensor(x):
     x = torch.as_tensor(np.asarray(x))
   return x.to(device=device, dtype=torch.float32).contiguous()
 
 
 def _flag(x, device):
+  """bool / uint8 flags as a contiguous 1-byte tensor on `device` (the kernels
+  read the bytes; torch.bool is one byte per element)."""
+  if (torch.is_tensor(x) and x.device == device and x.is_contiguous()
+      and (x.dtype == torch.bool or x.dtype == torch.uint8)):
+    return x
   if not torch.is_tensor(x):
     x = torch.as_tensor(np.asarray(x))
   if x.dtype != torch.bool and x.dtype != torch.uint8:
     x = x != 0
-  x = x.to(device).contiguous()
-  return x.view(torch.uint8) if x.dtype == torch.bool else x
+  return x.to(device).contiguous()
 
 
 def _device(*xs):
