@@ -254,7 +254,7 @@ def main():
 
   if rank == 0:
     print(json.dumps({
-        'metric': 'env steps/sec (+ learner train-steps/sec), 64 envs 84x84x4 obs',
+        'metric': 'env steps/sec + learner train-steps/sec, 64 envs 84x84x4 obs, 1/2/4/8 GPU',
         'value': round(env_steps / elapsed, 1),
         'unit': 'env_steps/s',
         'train_steps_per_s': round(train_steps / elapsed, 2),
