@@ -87,8 +87,10 @@ def build_path(args, rank, device):
     driver = emb.Driver(fns, parallel=False, device=device)
     env = None
   else:
+    # The env owns a 4-deep ring of output buffers (transitions are copied into
+    # the replay pool within the step, `reset` aliases the previous is_last).
     env = synthetic.SyntheticBatchEnv(
-        n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device)
+        n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device, ring=4)
     driver = emb.Driver(batch_env=env, device=device)
   driver.on_step(replay.add)
   actions = torch.randint(0, 6, (4096, n), dtype=torch.int32, device=device)

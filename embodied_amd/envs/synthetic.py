@@ -16,7 +16,7 @@ from .._lib import api
 class SyntheticBatchEnv:
 
   def __init__(self, n, shape=(84, 84, 4), episode_len=1000, env0=0,
-               actions=6, device='cuda'):
+               actions=6, device='cuda', ring=0):
     self.n = n
     self.shape = tuple(shape)
     self.frame_bytes = int(np.prod(shape))
@@ -28,6 +28,11 @@ class SyntheticBatchEnv:
     if self.device.index is None:
       self.device = torch.device('cuda', torch.cuda.current_device())
     self.counters = torch.zeros(2 * n, dtype=torch.int32, device=self.device)
+    # ring > 0: observations are written into `ring` rotating sets of output
+    # buffers instead of fresh tensors (like vector envs that own their output
+    # arrays): a returned dict is overwritten `ring` steps later.
+    self.ring = [self._alloc() for _ in range(ring)]
+    self.turn = 0
 
   def __len__(self):
     return self.n
@@ -49,15 +54,23 @@ class SyntheticBatchEnv:
         'action': Space(np.int32, (), 0, self.actions),
     }
 
-  def step(self, acts):
+  def _alloc(self):
     n, dev = self.n, self.device
-    obs = {
+    return {
         'image': torch.empty((n, *self.shape), dtype=torch.uint8, device=dev),
         'reward': torch.empty(n, dtype=torch.float32, device=dev),
         'is_first': torch.empty(n, dtype=torch.bool, device=dev),
         'is_last': torch.empty(n, dtype=torch.bool, device=dev),
         'is_terminal': torch.empty(n, dtype=torch.bool, device=dev),
     }
+
+  def step(self, acts):
+    n, dev = self.n, self.device
+    if self.ring:
+      obs = dict(self.ring[self.turn])
+      self.turn = (self.turn + 1) % len(self.ring)
+    else:
+      obs = self._alloc()
     reset = acts['reset']
     api.emb_synth_env_step(
         obs['image'].data_ptr(), obs['reward'].data_ptr(),

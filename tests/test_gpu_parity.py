@@ -469,3 +469,21 @@ def test_replay_dtype_and_shape_coverage(emb):
   for b in range(4):
     for t in range(2):
       assert torch.equal(out['x'][b, t], rows[int(idx[b, t])])
+
+
+def test_env_output_ring_does_not_change_what_the_replay_stores(emb):
+  """SyntheticBatchEnv(ring=K) reuses its output buffers; transitions are
+  copied into the pool within the step, so the stored data must be identical."""
+  from embodied_amd.envs import synthetic
+
+  def run(ring):
+    env = synthetic.SyntheticBatchEnv(6, shape=(8, 8, 4), episode_len=4, ring=ring)
+    rep = emb.Replay(length=5, capacity=200, chunksize=16, seed=1)
+    driver = emb.Driver(batch_env=env, device='cuda')
+    driver.on_step(rep.add)
+    act = torch.arange(6, dtype=torch.int32, device='cuda')
+    driver.reset()
+    driver(lambda carry, obs: (carry, {'action': act + 1}, {}), steps=6 * 40)
+    return {k: v.cpu().numpy() for k, v in rep.sample(12).items()}
+
+  assert_same(run(3), run(0), 'ring')
