@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -481,7 +482,7 @@ int32_t emb_replay_destroy(emb_replay_t* rep) {
 int32_t emb_replay_set_keys(emb_replay_t* rep, int32_t n_keys, const char* const* names,
                             const int64_t* rowbytes, void* const* pools) {
   REP_OP({
-    need(n_keys >= 1 && n_keys <= emb::kMaxKeys && names && rowbytes, "set_keys: bad arguments");
+    need(n_keys >= 1 && n_keys <= 1024 && names && rowbytes, "set_keys: bad arguments");
     rep->keys.clear();
     rep->key_stepid = rep->key_is_first = rep->key_is_last = -1;
     for (int k = 0; k < n_keys; ++k) {
@@ -637,31 +638,57 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   if (lease.slot >= 0) rep->ring.retire(lease, stream);
 }
 
+// Any number of keys: launches of at most kMaxKeys keys each (the kernel
+// argument block is 4 KiB).
+struct KeyList {
+  std::vector<emb::KeyDesc> key;
+  int key_is_first = -1, key_is_last = -1, key_stepid = -1;
+  int32_t seq_len = 1;
+  void push(uint8_t* pool, const void* batch, int64_t rowbytes) {
+    key.push_back({pool, const_cast<uint8_t*>(static_cast<const uint8_t*>(batch)), rowbytes});
+  }
+};
+
+static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, int64_t n_rows,
+                         const emb::StepId* ids, bool gather, hipStream_t stream,
+                         const std::vector<int32_t>* spans = nullptr) {
+  const uint8_t* first_pool = list.key_is_first >= 0 ? list.key[list.key_is_first].pool : nullptr;
+  const int total = static_cast<int>(list.key.size());
+  for (int lo = 0; lo < total; lo += emb::kMaxKeys) {
+    const int hi = std::min(total, lo + emb::kMaxKeys);
+    emb::MovePlan plan;
+    plan.seq_len = list.seq_len;
+    plan.is_first_pool = first_pool;
+    for (int k = lo; k < hi; ++k) plan.key[plan.n_keys++] = list.key[k];
+    if (list.key_is_first >= lo && list.key_is_first < hi) plan.key_is_first = list.key_is_first - lo;
+    if (list.key_is_last >= lo && list.key_is_last < hi) plan.key_is_last = list.key_is_last - lo;
+    const int sid = (ids && list.key_stepid >= lo && list.key_stepid < hi) ? list.key_stepid - lo : -1;
+    run_move(rep, plan, rows, n_rows, sid >= 0 ? ids : nullptr, sid, gather, stream, spans);
+  }
+}
+
 int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers, const void* const* src,
                        void* stream) {
   REP_OP({
     need(n >= 0 && workers && src, "add: bad arguments");
     need(!rep->keys.empty(), "add: call emb_replay_set_keys first");
     if (n == 0) return;
-    emb::MovePlan plan;
-    int sid_slot = -1;
+    KeyList list;
     for (size_t k = 0; k < rep->keys.size(); ++k) {
       need(rep->keys[k].pool, "add: key has no pool");
       if (static_cast<int>(k) == rep->key_stepid) {
-        sid_slot = plan.n_keys;
-        plan.key[plan.n_keys++] = {rep->keys[k].pool, nullptr, rep->keys[k].rowbytes};
+        list.key_stepid = static_cast<int>(list.key.size());
+        list.push(rep->keys[k].pool, nullptr, rep->keys[k].rowbytes);
         continue;
       }
       need(src[k], "add: null source buffer");
-      plan.key[plan.n_keys++] = {rep->keys[k].pool,
-                                 const_cast<uint8_t*>(static_cast<const uint8_t*>(src[k])),
-                                 rep->keys[k].rowbytes};
+      list.push(rep->keys[k].pool, src[k], rep->keys[k].rowbytes);
     }
     rep->rows.resize(n);
     rep->ids.resize(n);
     add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());
-    run_move(rep, plan, rep->rows.data(), n, sid_slot >= 0 ? rep->ids.data() : nullptr, sid_slot,
-             false, static_cast<hipStream_t>(stream));
+    run_move_all(rep, list, rep->rows.data(), n, list.key_stepid >= 0 ? rep->ids.data() : nullptr,
+                 false, static_cast<hipStream_t>(stream));
   });
 }
 
@@ -672,33 +699,32 @@ int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* 
     need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
     if (batch == 0) return;
     const int64_t L = rep->index->config().length;
-    emb::MovePlan plan;
+    KeyList list;
     for (size_t k = 0; k < rep->keys.size(); ++k) {
       need(dst[k] && rep->keys[k].pool, "sample: null buffer");
-      if (static_cast<int>(k) == rep->key_is_first) plan.key_is_first = plan.n_keys;
-      if (static_cast<int>(k) == rep->key_is_last) plan.key_is_last = plan.n_keys;
-      plan.key[plan.n_keys++] = {rep->keys[k].pool, static_cast<uint8_t*>(dst[k]), rep->keys[k].rowbytes};
+      if (static_cast<int>(k) == rep->key_is_first) list.key_is_first = static_cast<int>(list.key.size());
+      if (static_cast<int>(k) == rep->key_is_last) list.key_is_last = static_cast<int>(list.key.size());
+      list.push(rep->keys[k].pool, dst[k], rep->keys[k].rowbytes);
     }
-    plan.seq_len = static_cast<int32_t>(L);
+    list.seq_len = static_cast<int32_t>(L);
     rep->rows.resize(batch * L);
     sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
-    run_move(rep, plan, rep->rows.data(), batch * L, nullptr, -1, true,
-             static_cast<hipStream_t>(stream), &rep->spans);
+    run_move_all(rep, list, rep->rows.data(), batch * L, nullptr, true,
+                 static_cast<hipStream_t>(stream), &rep->spans);
   });
 }
 
-static emb::MovePlan plan_subset(emb_replay* rep, int32_t n_keys, const int32_t* key_ids,
-                                 const void* const* bufs) {
-  emb::MovePlan plan;
+static KeyList list_subset(emb_replay* rep, int32_t n_keys, const int32_t* key_ids,
+                           const void* const* bufs) {
+  KeyList list;
   need(n_keys >= 1 && key_ids && bufs, "bad key subset");
   for (int j = 0; j < n_keys; ++j) {
     need(key_ids[j] >= 0 && key_ids[j] < static_cast<int>(rep->keys.size()), "key id out of range");
     const KeyInfo& info = rep->keys[key_ids[j]];
     need(bufs[j] && info.pool, "null buffer");
-    plan.key[plan.n_keys++] = {info.pool, const_cast<uint8_t*>(static_cast<const uint8_t*>(bufs[j])),
-                               info.rowbytes};
+    list.push(info.pool, bufs[j], info.rowbytes);
   }
-  return plan;
+  return list;
 }
 
 int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t* stepids,
@@ -707,7 +733,7 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
   REP_OP({
     need(B >= 0 && T >= 1 && stepids, "update: bad arguments");
     if (B == 0) return;
-    emb::MovePlan plan = plan_subset(rep, n_keys, key_ids, src);
+    KeyList list = list_subset(rep, n_keys, key_ids, src);
     rep->rows.resize(B * T);
     for (int64_t i = 0; i < B; ++i) {
       emb::ReplayIndex::Pos pos;
@@ -722,7 +748,7 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
     std::unordered_set<int32_t> seen;
     for (int64_t i = B * T - 1; i >= 0; --i)
       if (rep->rows[i] >= 0 && !seen.insert(rep->rows[i]).second) rep->rows[i] = -1;
-    run_move(rep, plan, rep->rows.data(), B * T, nullptr, -1, false, static_cast<hipStream_t>(stream));
+    run_move_all(rep, list, rep->rows.data(), B * T, nullptr, false, static_cast<hipStream_t>(stream));
   });
 }
 
@@ -731,15 +757,15 @@ int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n
   REP_OP({
     need(rows && n_rows >= 0 && dst && seq_len >= 1, "gather_rows: bad arguments");
     if (n_rows == 0) return;
-    emb::MovePlan plan;
+    KeyList list;
     for (size_t k = 0; k < rep->keys.size(); ++k) {
       need(dst[k] && rep->keys[k].pool, "gather_rows: null buffer");
-      if (static_cast<int>(k) == rep->key_is_first) plan.key_is_first = plan.n_keys;
-      if (static_cast<int>(k) == rep->key_is_last) plan.key_is_last = plan.n_keys;
-      plan.key[plan.n_keys++] = {rep->keys[k].pool, static_cast<uint8_t*>(dst[k]), rep->keys[k].rowbytes};
+      if (static_cast<int>(k) == rep->key_is_first) list.key_is_first = static_cast<int>(list.key.size());
+      if (static_cast<int>(k) == rep->key_is_last) list.key_is_last = static_cast<int>(list.key.size());
+      list.push(rep->keys[k].pool, dst[k], rep->keys[k].rowbytes);
     }
-    plan.seq_len = static_cast<int32_t>(seq_len);
-    run_move(rep, plan, rows, n_rows, nullptr, -1, true, static_cast<hipStream_t>(stream));
+    list.seq_len = static_cast<int32_t>(seq_len);
+    run_move_all(rep, list, rows, n_rows, nullptr, true, static_cast<hipStream_t>(stream));
   });
 }
 
@@ -749,8 +775,8 @@ int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t 
   REP_OP({
     need(rows && n_rows >= 0, "scatter_rows: bad arguments");
     if (n_rows == 0) return;
-    emb::MovePlan plan = plan_subset(rep, n_keys, key_ids, src);
-    run_move(rep, plan, rows, n_rows, nullptr, -1, false, static_cast<hipStream_t>(stream));
+    KeyList list = list_subset(rep, n_keys, key_ids, src);
+    run_move_all(rep, list, rows, n_rows, nullptr, false, static_cast<hipStream_t>(stream));
   });
 }
 

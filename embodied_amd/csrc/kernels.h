@@ -23,6 +23,7 @@ struct MovePlan {
   int32_t seq_len = 1;       // rows per sequence (annotate uses t = r % seq_len)
   int32_t key_is_first = -1; // gather only: fuse replay.py:277-292
   int32_t key_is_last = -1;
+  const uint8_t* is_first_pool = nullptr;  // pool of the is_first key (may be in another launch)
   // Pool rows, one of:
   //   rows        device-visible int32[n_rows] (-1 = skip)               [any size]
   //   rows_host   the same table on the host: if it fits it travels in the

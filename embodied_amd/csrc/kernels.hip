@@ -30,6 +30,7 @@ struct MoveArgs {
   int32_t xcd_remap;
   int32_t rows_mode;                // 0 device table, 1 inline rows, 2 inline spans
   int32_t inline_key, inline_key_word0;
+  const uint8_t* is_first_pool;
   const int32_t* rows;
   uint32_t inline_words[kInlineWords];
 };
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) {
     uint8_t v = *src;
     if (k == a.key_is_first) {
       if (t == 0) v = 1;
-    } else if (a.key_is_first >= 0 && t + 1 < a.seq_len) {
-      v |= a.key[a.key_is_first].pool[row_of(a, static_cast<uint32_t>(r + 1))];
+    } else if (a.is_first_pool && t + 1 < a.seq_len) {
+      v |= a.is_first_pool[row_of(a, static_cast<uint32_t>(r + 1))];
     }
     *dst = v;
     return;
@@ -249,6 +250,8 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
   a.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;
   a.key_is_first = plan.key_is_first;
   a.key_is_last = plan.key_is_last;
+  a.is_first_pool = plan.is_first_pool;
+  if (!a.is_first_pool && plan.key_is_first >= 0) a.is_first_pool = plan.key[plan.key_is_first].pool;
   a.rows = plan.rows;
   a.rows_mode = 0;
   a.inline_key = -1;

@@ -487,3 +487,31 @@ def test_env_output_ring_does_not_change_what_the_replay_stores(emb):
     return {k: v.cpu().numpy() for k, v in rep.sample(12).items()}
 
   assert_same(run(3), run(0), 'ring')
+
+
+def test_more_keys_than_one_launch_holds(emb):
+  """40 replay keys (> 16 per launch): launches are grouped; the is_last
+  annotation still sees is_first although they land in different groups."""
+  gen = np.random.default_rng(0)
+  names = [f'k{i:02d}' for i in range(36)]
+  def step(t):
+    s = {'is_last': t % 5 == 4}
+    for i, name in enumerate(names):
+      s[name] = gen.integers(0, 100, (i % 4 + 1,)).astype([np.int32, np.float32, np.uint8][i % 3])
+    s['is_first'] = t % 5 == 0
+    s['tail'] = np.float32(t)
+    return s
+  ours = emb.Replay(length=4, capacity=50, chunksize=6, seed=5, stage_rows=9)
+  ref = np_oracle.Replay(4, 50, 6, seed=5)
+  for t in range(60):
+    s = step(t)
+    ours.add(s, 0)
+    ref.add(s, 0)
+  batch = ours.sample(8)
+  assert len(batch) == 40
+  assert_same({k: v.cpu().numpy() for k, v in batch.items()}, ref.sample(8), 'many-keys')
+  upd = {'stepid': batch['stepid'], 'k35': torch.full_like(batch['k35'], 7),
+         'tail': -batch['tail']}
+  ours.update(upd)
+  ref.update({k: v.cpu().numpy() for k, v in upd.items()})
+  assert_same({k: v.cpu().numpy() for k, v in ours.sample(8).items()}, ref.sample(8), 'many-keys-upd')
