@@ -343,6 +343,32 @@ def replay_prioritized(ns):
   return out
 
 
+def replay_baseline_shape(ns):
+  """BASELINE chunking and fan-in with a tiny payload: 64 workers in lockstep,
+  length 65, chunksize 1024, online queue, capacity churn; windows cross the
+  1024-row chunk boundary.  Pins the index streams at the benchmark's shape."""
+  out = {}
+  rep = ns.Replay(length=65, capacity=5000, chunksize=1024, online=True, seed=0)
+  checkpoints = {400: 'a', 1100: 'b'}
+  for t in range(1101):
+    for w in range(64):
+      rep.add({'t': np.int32(t), 'w': np.int32(w),
+               'is_first': np.bool_((t + 13 * w) % 250 == 0),
+               'is_last': np.bool_((t + 13 * w) % 250 == 249)}, worker=w)
+    if t in checkpoints:
+      tag = checkpoints[t]
+      out[f'{tag}/len'] = np.array(len(rep))
+      for i in range(3):
+        batch = rep.sample(16, 'train')
+        for k in ('t', 'w', 'is_first', 'is_last'):
+          out[f'{tag}/train{i}/{k}'] = ns.tonp(batch[k])
+        out[f'{tag}/train{i}/row'] = ns.tonp(batch['stepid'])[..., 16:]
+      batch = rep.sample(16, 'report')
+      out[f'{tag}/report/t'] = ns.tonp(batch['t'])
+      out[f'{tag}/report/w'] = ns.tonp(batch['w'])
+  return out
+
+
 def stream_consec(ns):
   out = {}
   rep = ns.Replay(length=7, capacity=40, chunksize=8, seed=3)
@@ -404,6 +430,7 @@ SCENARIOS = {
     'replay_online': replay_online,
     'replay_update': replay_update,
     'replay_prioritized': replay_prioritized,
+    'replay_baseline_shape': replay_baseline_shape,
     'stream_consec': stream_consec,
     'driver_script': driver_script,
 }

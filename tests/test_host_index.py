@@ -20,7 +20,7 @@ class HostReplay:
   the device pool; the product's Replay moves rows with HIP kernels)."""
 
   def __init__(self, length, capacity=None, chunksize=1024, online=False,
-               selector=None, seed=0, n_slots=64):
+               selector=None, seed=0, n_slots=256):
     self.length, self.chunksize, self.n_slots = length, chunksize, n_slots
     cfg = _lib.ReplayConfig(length, capacity or 0, chunksize, n_slots, int(online), 0, 0, 1, 0)
     self.selector = selector
