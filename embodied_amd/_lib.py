@@ -4,6 +4,7 @@ There is no CPU fallback: if the library is missing or fails to load, importing
 this module raises.  Build it with `python embodied_amd/build.py`.
 """
 import ctypes as C
+import os
 import pathlib
 
 # torch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Import it
@@ -12,7 +13,7 @@ import pathlib
 import torch  # noqa: F401
 
 HERE = pathlib.Path(__file__).resolve().parent
-PATH = HERE / 'libembodied_hip.so'
+PATH = pathlib.Path(os.environ.get('EMB_LIB_PATH') or HERE / 'libembodied_hip.so')
 
 OK, ERR_INVALID, ERR_HIP, ERR_EMPTY, ERR_POOL_FULL, ERR_NOT_FOUND, ERR_INTERNAL = (
     0, -1, -2, -3, -4, -5, -6)
