@@ -122,6 +122,9 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
+  # (LOCAL_RANK wraps so that the multi-rank control flow can be exercised on a
+  # box with fewer GPUs: EMB_BENCH_BACKEND=gloo, several ranks on one device.)
+  local %= max(torch.cuda.device_count(), 1)
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
   # EMB_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank.
@@ -131,9 +134,10 @@ def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29517')
     import datetime
+    backend = os.environ.get('EMB_BENCH_BACKEND', 'nccl')
     dist.init_process_group(
-        'nccl', rank=rank, world_size=world, device_id=device,
-        timeout=datetime.timedelta(seconds=300))
+        backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
+        **({'device_id': device} if backend == 'nccl' else {}))
   assert world == args.gpus or world == 1, (world, args.gpus)
 
   emb, env, replay, driver, policy = build_path(args, rank, device)
