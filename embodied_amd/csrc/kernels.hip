@@ -196,16 +196,17 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) {
 // Tuning knobs, read once: EMB_MOVE_VARIANT="U,NT,remap,threads" = 16-byte units
 // per lane, non-temporal hints (bit0 loads, bit1 stores), XCD remap on/off and
 // workgroup size.  Defaults from the MI355X sweep (tools/bench_gather.py):
-// U=2 beats 4/8 by 10-15 %, workgroup size 64..512 and the hints are within
-// noise, 1024 is slower.
+// U=2 beats 4/8 by 10-15 %, workgroup size 64..512 is within noise, 1024 is
+// slower; non-temporal loads+stores are ~3 % faster than plain ones inside the
+// benchmark (cold output lines) and equal in a tight loop.
 struct MoveVariant { int unroll; int nt; int remap; int threads; };
 const MoveVariant& move_variant() {
   static const MoveVariant variant = [] {
-    MoveVariant v{2, 1, 1, 256};
+    MoveVariant v{2, 3, 1, 256};
     if (const char* s = std::getenv("EMB_MOVE_VARIANT"))
       std::sscanf(s, "%d,%d,%d,%d", &v.unroll, &v.nt, &v.remap, &v.threads);
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 2;
-    if (v.nt < 0 || v.nt > 3) v.nt = 1;
+    if (v.nt < 0 || v.nt > 3) v.nt = 3;
     if (v.threads != 64 && v.threads != 128 && v.threads != 512 && v.threads != 1024) v.threads = 256;
     return v;
   }();
@@ -303,8 +304,8 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
   switch (variant.nt) {                                                          \
     case 0: EMB_MOVE(U_, 0); break;                                              \
     case 2: EMB_MOVE(U_, 2); break;                                              \
-    case 3: EMB_MOVE(U_, 3); break;                                              \
-    default: EMB_MOVE(U_, 1); break;                                             \
+    case 1: EMB_MOVE(U_, 1); break;                                              \
+    default: EMB_MOVE(U_, 3); break;                                             \
   }
   switch (variant.unroll) {
     case 1: EMB_MOVE_NT(1) break;

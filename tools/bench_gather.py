@@ -17,6 +17,7 @@ p.add_argument('--capacity', type=int, default=100_000)
 p.add_argument('--iters', type=int, default=50)
 p.add_argument('--variants', default='', help='unused: set EMB_MOVE_VARIANT=U,NT,remap,threads per process')
 p.add_argument('--batches', default='16,64,256')
+p.add_argument('--sleep-us', type=float, default=0, help='host idle time between samples')
 args = p.parse_args()
 
 n, L = 64, 65
@@ -60,6 +61,10 @@ for variant in [os.environ.get('EMB_MOVE_VARIANT', 'default')]:
     t0 = time.perf_counter()
     for _ in range(args.iters):
       rep.sample(B)
+      if args.sleep_us:
+        t1 = time.perf_counter()
+        while (time.perf_counter() - t1) * 1e6 < args.sleep_us:
+          pass
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / args.iters * 1e6
     launches, ms = rep.profile_read(reset=True)
