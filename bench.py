@@ -52,6 +52,8 @@ def parse():
   p.add_argument('--host-envs', action='store_true',
                  help='step 64 numpy envs on the host and upload through the pinned slab '
                       '(PCIe-inclusive rate; never the headline value)')
+  p.add_argument('--parallel-envs', action='store_true',
+                 help='with --host-envs: one process per env writing into the shared slab')
   return p.parse_args()
 
 
@@ -84,7 +86,7 @@ def build_path(args, rank, device):
   n = args.envs
   if args.host_envs:
     fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]
-    driver = emb.Driver(fns, parallel=False, device=device)
+    driver = emb.Driver(fns, parallel=args.parallel_envs, device=device)
     env = None
   else:
     # The env owns a 4-deep ring of output buffers (transitions are copied into

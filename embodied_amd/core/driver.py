@@ -19,6 +19,7 @@ stacked transition once per step.
 """
 import multiprocessing as mp
 from multiprocessing import shared_memory
+import time
 
 import cloudpickle
 import numpy as np
@@ -76,13 +77,14 @@ class Driver:
         context = mp.get_context()
         self.pipes, pipes = zip(*[context.Pipe() for _ in range(self.length)])
         fns = [cloudpickle.dumps(fn) for fn in make_env_fns]
+        self._wake = [context.Semaphore(0) for _ in range(self.length)]
         self.procs = [
-            context.Process(target=_env_server, args=(i, pipe, fn), daemon=True)
-            for i, (fn, pipe) in enumerate(zip(fns, pipes))]
+            context.Process(target=_env_server, args=(i, pipe, fn, wake), daemon=True)
+            for i, (fn, pipe, wake) in enumerate(zip(fns, pipes, self._wake))]
         [proc.start() for proc in self.procs]
         self.pipes[0].send(('act_space',))
         self.act_space = self._receive(self.pipes[0])
-        self._shared = {}
+        self._shared, self._act_slab, self._fast = {}, {}, False
         if shared_obs:
           self._attach_shared_slab()
       else:
@@ -135,8 +137,28 @@ class Driver:
         tensor = torch.from_numpy(view)
         if torch.cuda.cudart().cudaHostRegister(tensor.data_ptr(), nbytes, 0) == 0:
           self._registered = getattr(self, '_registered', []) + [tensor.data_ptr()]
-    [pipe.send(('attach', layout, self.length)) for pipe in self.pipes]
+    # Actions go down and completion flags come up through shared memory too:
+    # per step the parent copies (N, ...) actions into the action slabs, bumps a
+    # sequence number, wakes the workers (one semaphore each) and polls the
+    # per-env `done` words — no pickling, no pipe round trip per env.
+    acts = {k: (tuple(v.shape), np.dtype(v.dtype).str) for k, v in self.act_space.items()}
+    acts['reset'] = ((), np.dtype(bool).str)
+    act_layout = {}
+    for key, (shape, dtype) in acts.items():
+      nbytes = max(1, self.length * int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize)
+      block = shared_memory.SharedMemory(create=True, size=nbytes)
+      self._act_slab[key] = (block, np.ndarray((self.length, *shape), dtype, buffer=block.buf))
+      act_layout[key] = (block.name, shape, dtype)
+    self._ctrl_block = shared_memory.SharedMemory(create=True, size=8 * (2 + 2 * self.length))
+    self._ctrl = np.ndarray(2 + 2 * self.length, np.int64, buffer=self._ctrl_block.buf)
+    self._ctrl[:] = 0
+    self._done = self._ctrl[2: 2 + self.length]
+    self._extra = self._ctrl[2 + self.length:]
+    self._seq = 0
+    [pipe.send(('attach', layout, self.length, act_layout, self._ctrl_block.name))
+     for pipe in self.pipes]
     [self._receive(pipe) for pipe in self.pipes]
+    self._fast = True
 
   def close(self):
     if self.batch_env is not None:
@@ -146,10 +168,19 @@ class Driver:
       for ptr in getattr(self, '_registered', []):
         torch.cuda.cudart().cudaHostUnregister(ptr)
       self._registered = []
-      for block, _ in getattr(self, '_shared', {}).values():
-        block.close()
-        block.unlink()
-      self._shared = {}
+      blocks = [b for b, _ in getattr(self, '_shared', {}).values()]
+      blocks += [b for b, _ in getattr(self, '_act_slab', {}).values()]
+      if getattr(self, '_ctrl_block', None) is not None:
+        self._ctrl = self._done = self._extra = None
+        blocks.append(self._ctrl_block)
+        self._ctrl_block = None
+      self._shared, self._act_slab = {}, {}
+      for block in blocks:
+        try:
+          block.close()
+          block.unlink()
+        except Exception:
+          pass
     else:
       [env.close() for env in self.envs]
 
@@ -182,12 +213,15 @@ class Driver:
     assert all(len(x) == self.length for x in acts.values())
     host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
     assert all(isinstance(v, np.ndarray) for v in host.values())
-    per_env = [{k: v[i] for k, v in host.items()} for i in range(self.length)]
-    if self.parallel:
-      [pipe.send(('step', act)) for pipe, act in zip(self.pipes, per_env)]
-      results = [self._receive(pipe) for pipe in self.pipes]
+    if self.parallel and self._fast:
+      results = self._step_workers(host)
     else:
-      results = [env.step(act) for env, act in zip(self.envs, per_env)]
+      per_env = [{k: v[i] for k, v in host.items()} for i in range(self.length)]
+      if self.parallel:
+        [pipe.send(('step', act)) for pipe, act in zip(self.pipes, per_env)]
+        results = [self._receive(pipe) for pipe in self.pipes]
+      else:
+        results = [env.step(act) for env, act in zip(self.envs, per_env)]
     obs = self._stack(results)
     logs = {k: v for k, v in obs.items() if k.startswith('log/')}
     obs = {k: v for k, v in obs.items() if not k.startswith('log/')}
@@ -238,6 +272,40 @@ class Driver:
       for i in range(self.length):
         tran = {k: v[i] for k, v in trans.items()}
         [fn(tran, i, **self.kwargs) for fn in self.callbacks]
+
+  def _step_workers(self, host):
+    """One step of every env process through shared memory (see
+    `_attach_shared_slab`).  Returns the per-env leftovers (keys that are not in
+    the observation slab, e.g. 'log/*'), usually empty dicts."""
+    for key, (_, slab) in self._act_slab.items():
+      slab[...] = host[key]
+    self._seq += 1
+    seq = self._seq
+    self._ctrl[0] = seq
+    for wake in self._wake:
+      wake.release()
+    done, deadline, spins = self._done, None, 0
+    while True:
+      state = done == seq
+      if state.all():
+        break
+      if (done < 0).any():
+        break
+      spins += 1
+      if spins > 2000:                 # ~ms: stop burning the core
+        time.sleep(0.0002)
+        if deadline is None:
+          deadline = time.time() + 600
+        elif time.time() > deadline:
+          [proc.kill() for proc in self.procs]
+          raise RuntimeError('env workers did not answer within 600 s')
+    results = []
+    for i in range(self.length):
+      if done[i] < 0 or self._extra[i]:
+        results.append(self._receive(self.pipes[i]))    # raises on ('error', e)
+      else:
+        results.append({})
+    return results
 
   def _to_device(self, value):
     if torch.is_tensor(value):
@@ -294,12 +362,33 @@ class Driver:
       raise
 
 
-def _env_server(envid, pipe, ctor):
-  """Worker process: ('step', act) -> ('result', obs) (driver.py:101-137).
-  After ('attach', layout, n) the observation keys named in `layout` are written
-  into row `envid` of the shared slabs and only the rest travels back."""
+def _env_server(envid, pipe, ctor, wake=None):
+  """Worker process.  Pipe protocol as the reference's (driver.py:101-137):
+  ('step', act) -> ('result', obs), 'obs_space', 'act_space'.  After
+  ('attach', obs layout, n, act layout, ctrl name) it switches to the shared
+  memory protocol: wait on `wake`, read its action row, step, write the
+  observation row, publish `done[envid] = seq`."""
   env = None
   blocks, slabs = [], {}
+
+  def attach(layout, n):
+    out = {}
+    for key, (name, shape, dtype) in layout.items():
+      block = shared_memory.SharedMemory(name=name)
+      blocks.append(block)
+      out[key] = np.ndarray((n, *shape), dtype, buffer=block.buf)
+    return out
+
+  def put(obs):
+    rest = {}
+    for key, value in obs.items():
+      slab = slabs.get(key)
+      if slab is None:
+        rest[key] = value
+      else:
+        slab[envid] = value
+    return rest
+
   try:
     env = cloudpickle.loads(ctor)()
     while True:
@@ -311,23 +400,31 @@ def _env_server(envid, pipe, ctor):
         return
       if msg == 'step':
         obs = env.step(args[0])
-        if slabs:
-          rest = {}
-          for key, value in obs.items():
-            slab = slabs.get(key)
-            if slab is None:
-              rest[key] = value
-            else:
-              slab[envid] = value
-          obs = rest
-        pipe.send(('result', obs))
+        pipe.send(('result', put(obs) if slabs else obs))
       elif msg == 'attach':
-        layout, n = args
-        for key, (name, shape, dtype) in layout.items():
-          block = shared_memory.SharedMemory(name=name)
-          blocks.append(block)
-          slabs[key] = np.ndarray((n, *shape), dtype, buffer=block.buf)
+        slabs.update(attach(args[0], args[1]))
+        fast = len(args) > 2 and wake is not None
+        if fast:
+          acts = attach(args[2], args[1])
+          ctrl_block = shared_memory.SharedMemory(name=args[3])
+          blocks.append(ctrl_block)
+          ctrl = np.ndarray(2 + 2 * args[1], np.int64, buffer=ctrl_block.buf)
+          done, extra = ctrl[2: 2 + args[1]], ctrl[2 + args[1]:]
         pipe.send(('result', True))
+        while fast:
+          wake.acquire()
+          seq = int(ctrl[0])
+          try:
+            action = {k: v[envid].copy() for k, v in acts.items()}
+            rest = put(env.step(action))
+            if rest:
+              pipe.send(('result', rest))
+            extra[envid] = 1 if rest else 0
+            done[envid] = seq
+          except Exception as e:
+            pipe.send(('error', e))
+            done[envid] = -1
+            raise
       elif msg == 'obs_space':
         pipe.send(('result', env.obs_space))
       elif msg == 'act_space':

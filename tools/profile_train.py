@@ -1,0 +1,36 @@
+"""Host cost of the pieces of one train step (GPU box)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.argv = [sys.argv[0]]
+import bench
+import embodied_amd as emb
+
+args = bench.parse(); args.capacity = 20000
+device = torch.device('cuda', 0)
+_, env, replay, driver, policy = bench.build_path(args, 0, device)
+driver.reset()
+for _ in range(500):
+  driver(policy, steps=args.envs)
+stream = iter(emb.streams.Consec(emb.streams.Stateless(replay.sample, 16, 'train'),
+                                 length=64, consec=1, prefix=1, strict=True, contiguous=True))
+value = torch.randn(16, 65, device=device)
+
+def timeit(name, fn, iters=2000):
+  for _ in range(50): fn()
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(iters): fn()
+  host = (time.perf_counter() - t0) / iters * 1e6
+  torch.cuda.synchronize()
+  print(f'{name:30s} host {host:7.2f} us', flush=True)
+
+timeit('replay.sample(16)', lambda: replay.sample(16))
+timeit('next(Consec(sample))', lambda: next(stream))
+b = next(stream)
+timeit('scans.gae', lambda: emb.scans.gae(b['reward'], value, b['is_last'], b['is_terminal']))
+timeit('_alloc_batch', lambda: replay._alloc_batch(16, 65))
+timeit('torch.full consec', lambda: torch.full((16, 65), 0, dtype=torch.int32, device=device))
+import cProfile, pstats
+prof = cProfile.Profile(); prof.enable()
+for _ in range(2000): next(stream)
+prof.disable(); pstats.Stats(prof).sort_stats('tottime').print_stats(10)
