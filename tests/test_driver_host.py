@@ -190,3 +190,27 @@ def test_parallel_workers_match_serial(shared_obs):
     assert w0 == w1 and set(t0) == set(t1)
     for k in t0:
       assert np.array_equal(t0[k], t1[k]) and t0[k].dtype == t1[k].dtype, k
+
+
+class _Flaky(dummy.Dummy):
+  def step(self, action):
+    obs = super().step(action)
+    obs['log/steps'] = np.float32(self.count)
+    if self.count == 3:
+      raise ValueError('simulator crashed')
+    return obs
+
+
+def test_worker_extras_and_errors_in_shared_memory_mode():
+  """'log/*' keys are not in the observation slab and still arrive; an
+  exception inside an env process surfaces in the parent (driver.py:89-99)."""
+  agent = make_agent()
+  driver = emb.Driver([lambda: _Flaky('disc', length=10)] * 2, parallel=True)
+  assert driver._fast
+  driver.reset(agent.init_policy)
+  seen = []
+  driver.on_step(lambda tran, w: seen.append(float(tran['log/steps'])))
+  with pytest.raises(RuntimeError, match='simulator crashed'):
+    driver(agent.policy, steps=20)
+  driver.close()
+  assert seen[:6] == [0.0, 0.0, 1.0, 1.0, 2.0, 2.0]
