@@ -160,6 +160,13 @@ class Driver:
     [self._receive(pipe) for pipe in self.pipes]
     self._fast = True
 
+  def __del__(self):
+    try:
+      if getattr(self, 'parallel', False) and getattr(self, '_shared', None):
+        self.close()
+    except Exception:
+      pass
+
   def close(self):
     if self.batch_env is not None:
       getattr(self.batch_env, 'close', lambda: None)()
