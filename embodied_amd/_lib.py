@@ -144,6 +144,7 @@ SIGNATURES = {
     'emb_rows_gather': [p, i64, p, i64, p, p],
     'emb_rows_scatter': [p, i64, p, i64, p, p],
     'emb_window': [p, p, i64, i64, i64, i64, i64, p],
+    'emb_window_keys': [i32, p, p, p, i64, i64, i64, i64, p],
     'emb_scan_gae': [p, p, p, p, i64, i64, f32, f32, p, p, p],
     'emb_scan_lambda': [p, p, p, p, i64, i64, f32, f32, p, p],
     'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],

@@ -57,6 +57,28 @@ def window(value, start, count):
   return out
 
 
+def window_batch(batch, start, count):
+  """`{k: v[:, start:start+count]}` for a dict of device tensors with ONE kernel
+  launch for all keys (`emb_window_keys`)."""
+  import ctypes as C
+  names = list(batch)
+  first = batch[names[0]]
+  total = first.shape[1]
+  if start == 0 and count == total:
+    return {k: (v if v.is_contiguous() else v.contiguous()) for k, v in batch.items()}
+  srcs = [batch[k] if batch[k].is_contiguous() else batch[k].contiguous() for k in names]
+  outs = [torch.empty((v.shape[0], count, *v.shape[2:]), dtype=v.dtype, device=v.device)
+          for v in srcs]
+  n = len(names)
+  rowbytes = (C.c_int64 * n)(*[
+      v.element_size() * int(np.prod(v.shape[2:], dtype=np.int64)) for v in srcs])
+  api.emb_window_keys(
+      n, (C.c_void_p * n)(*[v.data_ptr() for v in srcs]),
+      (C.c_void_p * n)(*[v.data_ptr() for v in outs]), rowbytes, first.shape[0],
+      total, start, count, _lib.raw_stream(first.device))
+  return dict(zip(names, outs))
+
+
 class Consec(base.Stream):
   """Sequence windowing (streams.py:89-150): a source batch of
   `consec * length + prefix` steps is served as `consec` windows
@@ -93,9 +115,12 @@ class Consec(base.Stream):
     count = self.length + self.prefix
     first = self.current['is_first']
     if torch.is_tensor(first):
-      # Device batches are always materialised contiguously (one kernel per
-      # key); `contiguous` only matters for numpy views.
-      chunk = {k: window(v, start, count) for k, v in self.current.items()}
+      # Device batches are always materialised contiguously (one kernel for all
+      # keys); `contiguous` only matters for numpy views.
+      if all(torch.is_tensor(v) and v.is_cuda for v in self.current.values()):
+        chunk = window_batch(self.current, start, count)
+      else:
+        chunk = {k: window(v, start, count) for k, v in self.current.items()}
       chunk['consec'] = torch.full(
           chunk['is_first'].shape, self.index, dtype=torch.int32,
           device=first.device)

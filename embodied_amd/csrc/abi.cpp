@@ -895,6 +895,57 @@ int32_t emb_window(const void* src, void* dst, int64_t batch, int64_t total, int
   });
 }
 
+int32_t emb_window_keys(int32_t n_keys, const void* const* src, void* const* dst,
+                        const int64_t* rowbytes, int64_t batch, int64_t total, int64_t start,
+                        int64_t count, void* stream) {
+  return guarded([&] {
+    need(n_keys >= 1 && src && dst && rowbytes && batch >= 0 && start >= 0 && count >= 0 &&
+         start + count <= total, "window_keys: bad arguments");
+    if (batch == 0 || count == 0) return;
+    need(batch * total <= INT32_MAX, "window_keys: batch too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // A window is a gather whose "pool" is the source batch: sequence b is the
+    // single span {b * total + start, count}.  All keys move in one launch.
+    std::vector<int32_t> spans(3 * batch), rows;
+    for (int64_t b = 0; b < batch; ++b) {
+      spans[3 * b] = static_cast<int32_t>(b * total + start);
+      spans[3 * b + 1] = static_cast<int32_t>(count);
+      spans[3 * b + 2] = 0;
+    }
+    for (int lo = 0; lo < n_keys; lo += emb::kMaxKeys) {
+      emb::MovePlan plan;
+      for (int k = lo; k < std::min(n_keys, lo + emb::kMaxKeys); ++k) {
+        need(src[k] && dst[k] && rowbytes[k] > 0, "window_keys: bad key");
+        plan.key[plan.n_keys++] = {const_cast<uint8_t*>(static_cast<const uint8_t*>(src[k])),
+                                   static_cast<uint8_t*>(dst[k]), rowbytes[k]};
+      }
+      plan.seq_len = static_cast<int32_t>(count);
+      plan.n_rows = static_cast<int32_t>(batch * count);
+      plan.spans_host = spans.data();
+      plan.n_seq = static_cast<int32_t>(batch);
+      if (emb::plan_fits_inline(plan)) {
+        HIP_OK(emb::launch_gather(plan, s));
+        continue;
+      }
+      if (rows.empty()) {
+        rows.resize(batch * count);
+        for (int64_t b = 0; b < batch; ++b)
+          for (int64_t j = 0; j < count; ++j)
+            rows[b * count + j] = static_cast<int32_t>(b * total + start + j);
+      }
+      plan.spans_host = nullptr;
+      plan.n_seq = 0;
+      std::lock_guard<std::mutex> lock(g_ring_mu);
+      auto lease = global_ring().acquire(rows.size() * sizeof(int32_t), s);
+      std::memcpy(lease.host, rows.data(), rows.size() * sizeof(int32_t));
+      global_ring().upload(lease, rows.size() * sizeof(int32_t), s);
+      plan.rows = reinterpret_cast<const int32_t*>(lease.device);
+      HIP_OK(emb::launch_gather(plan, s));
+      global_ring().retire(lease, s);
+    }
+  });
+}
+
 int32_t emb_scan_gae(const void* rew, const void* val, const void* last, const void* term, int64_t B,
                      int64_t T, float live_scale, float lam, void* adv, void* tar, void* stream) {
   return guarded([&] {

@@ -244,6 +244,11 @@ int32_t emb_rows_scatter(void* table, int64_t rowbytes, const int32_t* ids, int6
  * dst (B, count, rowbytes) = src[:, start:start+count].                      */
 int32_t emb_window(const void* src, void* dst, int64_t batch, int64_t total, int64_t start,
                    int64_t count, int64_t rowbytes, void* stream);
+/* The same for every key of a batch in ONE launch: src[k] (B, total, rowbytes[k])
+ * -> dst[k] (B, count, rowbytes[k]).                                          */
+int32_t emb_window_keys(int32_t n_keys, const void* const* src, void* const* dst,
+                        const int64_t* rowbytes, int64_t batch, int64_t total, int64_t start,
+                        int64_t count, void* stream);
 
 /* ---- return scans, float32 on device ------------------------------------- */
 /* PPO GAE (ppo/agent.py:188-201): rew,val (B,T) f32; last,term (B,T) u8 ->

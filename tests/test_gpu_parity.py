@@ -515,3 +515,18 @@ def test_more_keys_than_one_launch_holds(emb):
   ours.update(upd)
   ref.update({k: v.cpu().numpy() for k, v in upd.items()})
   assert_same({k: v.cpu().numpy() for k, v in ours.sample(8).items()}, ref.sample(8), 'many-keys-upd')
+
+
+def test_window_batch_all_keys_one_launch(emb):
+  from embodied_amd.core import streams
+  for B in (4, 300):                      # 300 sequences: row table via the ring
+    batch = {
+        'image': torch.randint(0, 255, (B, 9, 6, 4), dtype=torch.uint8, device='cuda'),
+        'vec': torch.randn(B, 9, 300, device='cuda'),
+        'flag': torch.rand(B, 9, device='cuda') < 0.5,
+        'id': torch.randint(0, 255, (B, 9, 20), dtype=torch.uint8, device='cuda'),
+    }
+    for start, count in ((0, 9), (2, 4), (5, 4), (8, 1)):
+      out = streams.window_batch(batch, start, count)
+      for k, v in batch.items():
+        assert torch.equal(out[k], v[:, start:start + count]) and out[k].is_contiguous()
