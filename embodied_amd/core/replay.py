@@ -380,6 +380,54 @@ class Replay:
           self._handle, _lib.ptr(rows), rows.size, length, ptrs, self._stream())
     return self._finish(out)
 
+  def sample_windows(self, batch, length, consec, prefix=0, mode='train'):
+    """`sample` + `Consec` windowing in one pass over the pool
+    (replay.py:121-127 + streams.py:120-140): returns `consec` dicts, window w =
+    steps [w*length, w*length + length + prefix) of each sampled sequence, each
+    key contiguous.  The wide keys are gathered straight into their windows (the
+    overlapping prefix rows are read twice from HBM instead of copying every
+    window again); only the two 1-byte flag keys take the annotate-then-slice
+    route, because the reference annotates the full sequence before slicing."""
+    assert mode in _lib.MODES, mode
+    assert consec * length + prefix == self.length, (consec, length, prefix, self.length)
+    limiters.wait(
+        lambda: len(self._native), f'Replay buffer {self.name} is empty')
+    width = length + prefix
+    with self._lock:
+      self._flush()
+      rows, _ = self.sample_index(batch, mode)
+      index = (np.arange(consec)[:, None] * length + np.arange(width)[None, :]).reshape(-1)
+      tiled = np.ascontiguousarray(
+          rows[:, index].reshape(batch, consec, width).transpose(1, 0, 2))
+      flags = [k for k in ('is_first', 'is_last') if k in self._keyid]
+      out, wide, narrow = {}, (C.c_void_p * len(self._keys))(), (C.c_void_p * len(self._keys))()
+      full = {}
+      for i, key in enumerate(self._keys):
+        if key.name in flags:
+          full[key.name] = torch.empty(
+              (batch, self.length, *key.shape), dtype=key.dtype, device=self.device)
+          narrow[i] = full[key.name].data_ptr()
+        else:
+          out[key.name] = torch.empty(
+              (consec, batch, width, *key.shape), dtype=key.dtype, device=self.device)
+          wide[i] = out[key.name].data_ptr()
+      stream = self._stream()
+      api.emb_replay_gather_rows(
+          self._handle, _lib.ptr(tiled), tiled.size, width, wide, stream)
+      if flags:
+        api.emb_replay_gather_rows(
+            self._handle, _lib.ptr(rows), rows.size, self.length, narrow, stream)
+    windows = []
+    for w in range(consec):
+      win = {}
+      for key in self._keys:
+        if key.name in full:
+          win[key.name] = full[key.name][:, w * length: w * length + width].contiguous()
+        else:
+          win[key.name] = out[key.name][w]
+      windows.append(self._finish(win))
+    return windows
+
   # ----------------------------------------------------------------- update --
 
   def update(self, data):

@@ -96,6 +96,8 @@ class Consec(base.Stream):
     self.index = 0
     self.current = None
     self.it = None
+    self._fused = False
+    self.windows = None
 
   def __iter__(self):
     self.it = iter(self.source)
@@ -104,6 +106,21 @@ class Consec(base.Stream):
   def __next__(self):
     if self.index >= self.consec:
       self.index = 0
+    fused = self._fused_source() if self.consec > 1 else None
+    if fused is not None:
+      if self.index == 0:
+        replay, batch, mode = fused
+        self.windows = replay.sample_windows(
+            batch, self.length, self.consec, self.prefix, mode)
+      chunk = dict(self.windows[self.index])
+      first = chunk['is_first']
+      if torch.is_tensor(first):
+        chunk['consec'] = torch.full(
+            first.shape, self.index, dtype=torch.int32, device=first.device)
+      else:
+        chunk['consec'] = np.full(first.shape, self.index, np.int32)
+      self.index += 1
+      return chunk
     if self.index == 0:
       self.current = next(self.it)
       have = self.current['is_first'].shape[1]
@@ -131,6 +148,25 @@ class Consec(base.Stream):
         chunk = {k: np.ascontiguousarray(v) for k, v in chunk.items()}
     self.index += 1
     return chunk
+
+  def _fused_source(self):
+    """(replay, batch, mode) if the source is `Stateless(replay.sample, batch,
+    mode)` over this package's Replay with matching lengths: then sampling and
+    windowing run as one gather (`Replay.sample_windows`)."""
+    if self._fused is not False:
+      return self._fused
+    self._fused = None
+    fn = getattr(self.source, 'nextfn', None)
+    target = getattr(getattr(fn, 'func', None), '__self__', None)
+    from . import replay as replaylib
+    if (isinstance(target, replaylib.Replay)
+        and getattr(fn.func, '__func__', None) is replaylib.Replay.sample
+        and not fn.keywords and 1 <= len(fn.args) <= 2
+        and 'is_first' in (target._keyid or {'is_first': 0})
+        and target.length == self.consec * self.length + self.prefix):
+      mode = fn.args[1] if len(fn.args) > 1 else 'train'
+      self._fused = (target, fn.args[0], mode)
+    return self._fused
 
   def save(self):
     return {'source': self.source.save(), 'index': self.index}

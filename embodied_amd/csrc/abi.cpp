@@ -759,12 +759,14 @@ int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n
     if (n_rows == 0) return;
     KeyList list;
     for (size_t k = 0; k < rep->keys.size(); ++k) {
-      need(dst[k] && rep->keys[k].pool, "gather_rows: null buffer");
+      if (!dst[k]) continue;                       // key not wanted in this gather
+      need(rep->keys[k].pool, "gather_rows: key has no pool");
       if (static_cast<int>(k) == rep->key_is_first) list.key_is_first = static_cast<int>(list.key.size());
       if (static_cast<int>(k) == rep->key_is_last) list.key_is_last = static_cast<int>(list.key.size());
       list.push(rep->keys[k].pool, dst[k], rep->keys[k].rowbytes);
     }
     list.seq_len = static_cast<int32_t>(seq_len);
+    if (list.key.empty()) return;
     run_move_all(rep, list, rows, n_rows, nullptr, true, static_cast<hipStream_t>(stream));
   });
 }

@@ -196,7 +196,8 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
                           int32_t n_keys, const int32_t* key_ids, const void* const* src,
                           void* stream);
 /* Move rows given an explicit host row table (multi-GPU owner-side gather,
- * load from disk).                                                           */
+ * fused sample+windowing, load from disk).  gather: a NULL dst[k] skips key k;
+ * the flag annotation applies per `seq_len` rows.                             */
 int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n_rows,
                                int64_t seq_len, void* const* dst, void* stream);
 int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t n_rows,

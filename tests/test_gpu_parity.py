@@ -530,3 +530,25 @@ def test_window_batch_all_keys_one_launch(emb):
       out = streams.window_batch(batch, start, count)
       for k, v in batch.items():
         assert torch.equal(out[k], v[:, start:start + count]) and out[k].is_contiguous()
+
+
+@pytest.mark.parametrize('consec,length,prefix', [(2, 3, 1), (4, 16, 1), (3, 5, 0), (2, 6, 3)])
+def test_fused_sample_windows_equal_sample_then_slice(emb, consec, length, prefix):
+  """Replay.sample_windows (one pass over the pool) == annotate the full
+  sequence, then slice (what replay.py:121-127 + streams.py:120-140 do), for
+  windows that cross chunk boundaries and episode boundaries."""
+  L = consec * length + prefix
+  a = emb.Replay(length=L, capacity=300, chunksize=7, seed=8)
+  b = np_oracle.Replay(L, 300, 7, seed=8)
+  for t in range(150):
+    for w in range(2):
+      a.add(scenarios.synth_step(t, w), w)
+      b.add(scenarios.synth_step(t, w), w)
+  stream = iter(emb.streams.Consec(
+      emb.streams.Stateless(a.sample, 5, 'train'), length, consec, prefix, strict=True,
+      contiguous=True))
+  want = np_oracle.Consec(lambda: b.sample(5), length, consec, prefix)
+  assert stream._fused_source() is not None
+  for _ in range(2 * consec + 1):
+    got = {k: v.cpu().numpy() for k, v in next(stream).items()}
+    assert_same(got, next(want), 'fused-windows')
