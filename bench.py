@@ -46,6 +46,9 @@ def parse():
   p.add_argument('--cpu-seconds', type=float, default=15.0)
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--prefetch', type=int, default=1, help='train batches gathered per launch')
+  p.add_argument('--consec', type=int, default=1,
+                 help='consec_train (ppo/configs.yaml:13): windows served per sampled sequence; '
+                      'sampling and windowing are one gather launch')
   p.add_argument('--workload', default='ppo', choices=['ppo', 'dreamer'],
                  help='ppo = BASELINE configs[1] (default); dreamer = configs[2]: 1M-step '
                       'uniform replay, train_ratio 32, 40 KB/step latents written back')
@@ -78,7 +81,7 @@ class Ratio:
 def build_path(args, rank, device):
   import embodied_amd as emb
   from embodied_amd.envs import synthetic
-  L = args.length + args.context
+  L = args.consec * args.length + args.context
   dreamer = args.workload == 'dreamer'
   replay = emb.Replay(
       length=L, capacity=args.capacity, chunksize=1024, online=not dreamer, seed=0,
@@ -143,12 +146,12 @@ def main():
   assert world == args.gpus or world == 1, (world, args.gpus)
 
   emb, env, replay, driver, policy = build_path(args, rank, device)
-  B, T, L = args.batch, args.length, args.length + args.context
+  B, T, L = args.batch, args.length, args.consec * args.length + args.context
   stream = iter(emb.streams.Consec(
       emb.streams.Stateless(replay.sample, B * args.prefetch, 'train'),
-      length=T, consec=1, prefix=args.context, strict=True, contiguous=True))
+      length=T, consec=args.consec, prefix=args.context, strict=True, contiguous=True))
   should_train = Ratio(args.train_ratio / (B * T))
-  value = torch.randn(B * args.prefetch, L, device=device)
+  value = torch.randn(B * args.prefetch, T + args.context, device=device)
   imag_rew = torch.randn(B * T, 16, device=device)
   imag_flags = torch.zeros(B * T, 16, dtype=torch.bool, device=device)
   grads = torch.zeros(args.grad_numel, device=device) if use_dist else None
@@ -240,11 +243,15 @@ def main():
   env_steps = (counters['env_steps'] - base['env_steps']) * world
   train_steps = (counters['train_steps'] - base['train_steps']) * world
   S = sum(k.rowbytes for k in replay._keys)
-  algo_bytes = 2 * B * args.prefetch * L * S      # read B*L*S + write B*L*S
+  # read B*L*S + write B*L*S per sampled batch; with consec > 1 the windows are
+  # gathered directly (prefix rows read once per window) and the 1-byte flag
+  # keys take a second, tiny launch: normalise per sample, not per launch.
+  algo_bytes = 2 * B * args.prefetch * args.consec * (T + args.context) * S
+  samples = max(1, (counters['train_steps'] - base['train_steps']) // (args.prefetch * args.consec))
   roofline = None
   traffic, traffic_source = pmc_traffic(algo_bytes)
   if launches:
-    avg_s = gather_ms / launches / 1e3
+    avg_s = gather_ms / (launches if args.consec == 1 else samples) / 1e3
     achieved = algo_bytes / avg_s / 1e9
     roofline = {
         'bound': 'hbm', 'kernel': 'gather_kernel (Replay.sample)',
@@ -279,7 +286,7 @@ def main():
                 f'B={B}, T={T}, train_ratio={args.train_ratio}, '
                 f'{"lambda-return" if args.workload == "dreamer" else "GAE"}'),
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
-            'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch,
+            'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
             'parallelism': (f'env-sharded x{world}, {args.exchange} all-gather + '
                             f'{args.grad_numel * 4 >> 20} MiB grad all-reduce (RCCL)')
                            if use_dist else 'single',

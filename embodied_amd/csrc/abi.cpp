@@ -767,7 +767,29 @@ int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n
     }
     list.seq_len = static_cast<int32_t>(seq_len);
     if (list.key.empty()) return;
-    run_move_all(rep, list, rows, n_rows, nullptr, true, static_cast<hipStream_t>(stream));
+    // Sequences that are at most two contiguous runs of pool rows (windows that
+    // cross one chunk boundary) travel as {row0, count0, row1} in the kernel
+    // arguments instead of a row table in device memory.
+    rep->spans.clear();
+    if (n_rows % seq_len == 0) {
+      const int64_t n_seq = n_rows / seq_len;
+      rep->spans.resize(3 * n_seq);
+      bool ok = true;
+      for (int64_t q = 0; q < n_seq && ok; ++q) {
+        const int32_t* r = rows + q * seq_len;
+        int64_t cut = seq_len;
+        for (int64_t j = 1; j < seq_len; ++j)
+          if (r[j] != r[j - 1] + 1) { cut = j; break; }
+        for (int64_t j = cut + 1; j < seq_len && ok; ++j) ok = r[j] == r[j - 1] + 1;
+        ok = ok && r[0] >= 0 && (cut == seq_len || r[cut] >= 0);
+        rep->spans[3 * q] = r[0];
+        rep->spans[3 * q + 1] = static_cast<int32_t>(cut);
+        rep->spans[3 * q + 2] = cut < seq_len ? r[cut] : 0;
+      }
+      if (!ok) rep->spans.clear();
+    }
+    run_move_all(rep, list, rows, n_rows, nullptr, true, static_cast<hipStream_t>(stream),
+                 &rep->spans);
   });
 }
 
