@@ -46,6 +46,9 @@ def parse():
   p.add_argument('--cpu-seconds', type=float, default=15.0)
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--prefetch', type=int, default=1, help='train batches gathered per launch')
+  p.add_argument('--reuse-outputs', type=int, default=0,
+                 help='Replay(reuse_outputs=K): sampled batches rotate through K output sets '
+                      '(0 = fresh tensors per sample, as the reference returns fresh arrays)')
   p.add_argument('--consec', type=int, default=1,
                  help='consec_train (ppo/configs.yaml:13): windows served per sampled sequence; '
                       'sampling and windowing are one gather launch')
@@ -85,7 +88,7 @@ def build_path(args, rank, device):
   dreamer = args.workload == 'dreamer'
   replay = emb.Replay(
       length=L, capacity=args.capacity, chunksize=1024, online=not dreamer, seed=0,
-      device=device, replica=rank)
+      device=device, replica=rank, reuse_outputs=args.reuse_outputs)
   n = args.envs
   if args.host_envs:
     fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]

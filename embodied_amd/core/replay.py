@@ -60,7 +60,7 @@ class Replay:
       self, length, capacity=None, directory=None, chunksize=1024,
       online=False, selector=None, save_wait=False, name='unnamed', seed=0,
       device='cuda', numpy=False, slots=None, stage_rows=256, replica=0,
-      owners=1, owner=0, workers_per_owner=0):
+      owners=1, owner=0, workers_per_owner=0, reuse_outputs=0):
     self.length = int(length)
     self.capacity = capacity and int(capacity)
     self.chunksize = int(chunksize)
@@ -115,6 +115,11 @@ class Replay:
     self._multistream = False
     self._workers_np = None
     self._replica = int(replica)
+    # reuse_outputs=K: `sample` hands out K rotating sets of output tensors per
+    # batch shape instead of fresh ones (a batch stays valid for K-1 further
+    # samples): no allocations, and the gather writes into cache-warm lines.
+    self._reuse = int(reuse_outputs)
+    self._out_ring = {}
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
 
   def __del__(self):
@@ -345,6 +350,16 @@ class Replay:
     return self._finish(out)
 
   def _alloc_batch(self, batch, length):
+    if self._reuse:
+      ring = self._out_ring.setdefault((batch, length), [[], 0])
+      if len(ring[0]) < self._reuse:
+        ring[0].append(self._new_batch(batch, length))
+      out, ptrs = ring[0][ring[1] % len(ring[0])]
+      ring[1] += 1
+      return dict(out), ptrs
+    return self._new_batch(batch, length)
+
+  def _new_batch(self, batch, length):
     out, ptrs = {}, (C.c_void_p * len(self._keys))()
     for i, key in enumerate(self._keys):
       out[key.name] = torch.empty(

@@ -552,3 +552,18 @@ def test_fused_sample_windows_equal_sample_then_slice(emb, consec, length, prefi
   for _ in range(2 * consec + 1):
     got = {k: v.cpu().numpy() for k, v in next(stream).items()}
     assert_same(got, next(want), 'fused-windows')
+
+
+def test_reuse_outputs_rotates_buffers_and_keeps_values(emb):
+  a = emb.Replay(length=4, capacity=40, chunksize=8, seed=2, reuse_outputs=2)
+  b = emb.Replay(length=4, capacity=40, chunksize=8, seed=2)
+  for t in range(30):
+    a.add(scenarios.synth_step(t, 0), 0)
+    b.add(scenarios.synth_step(t, 0), 0)
+  ptrs = []
+  for _ in range(4):
+    x, y = a.sample(3), b.sample(3)
+    ptrs.append(x['image'].data_ptr())
+    assert_same({k: v.cpu().numpy() for k, v in x.items()},
+                {k: v.cpu().numpy() for k, v in y.items()}, 'reuse')
+  assert ptrs[0] == ptrs[2] and ptrs[1] == ptrs[3] and ptrs[0] != ptrs[1]
