@@ -343,6 +343,28 @@ template <> __device__ __forceinline__ __hip_bfloat16 cvt<__hip_bfloat16>(uint8_
 template <typename Out>
 struct alignas(4 * sizeof(Out)) Quad { Out v[4]; };
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Streaming store of one Quad (4, 8 or 16 bytes): the policy batch is consumed
+// by another kernel, keeping it dirty in this XCD's L2 only delays the next
+// kernel boundary.
+template <typename Out>
+__device__ __forceinline__ void store_quad(Out* dst, const Quad<Out>& q) {
+  if constexpr (sizeof(Quad<Out>) == 4) {
+    uint32_t w;
+    __builtin_memcpy(&w, &q, 4);
+    __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(dst));
+  } else if constexpr (sizeof(Quad<Out>) == 8) {
+    u32x2 w;
+    __builtin_memcpy(&w, &q, 8);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2*>(dst));
+  } else {
+    u32x4 w;
+    __builtin_memcpy(&w, &q, 16);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst));
+  }
+}
+
 // Each lane owns 4 consecutive pixels of one frame: it reads their 4*C bytes as
 // C dwords (coalesced across lanes) and writes, per channel, one 4-element
 // vector.  Output is (N, C, P) channels-first or (N, P, C) as stored.
@@ -369,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void obs_stack_kernel(
         Quad<Out> o;
 #pragma unroll
         for (int p = 0; p < 4; ++p) o.v[p] = cvt<Out>(byte_at(p * C + c), scale, offset);
-        *reinterpret_cast<Quad<Out>*>(out + c * pixels + q * 4) = o;
+        store_quad(out + c * pixels + q * 4, o);
       }
     } else {
 #pragma unroll
@@ -377,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void obs_stack_kernel(
         Quad<Out> o;
 #pragma unroll
         for (int p = 0; p < 4; ++p) o.v[p] = cvt<Out>(byte_at(j * 4 + p), scale, offset);
-        *reinterpret_cast<Quad<Out>*>(out + (q * C + j) * 4) = o;
+        store_quad(out + (q * C + j) * 4, o);
       }
     }
   }
@@ -638,14 +660,15 @@ __global__ __launch_bounds__(kThreads) void synth_env_kernel(
   const bool done = !restart && count >= length;
   const uint32_t salt = static_cast<uint32_t>((env0 + e) * 131 + static_cast<int64_t>(count) * 7);
   // byte i of the frame = (salt + i) & 0xFF, written 16 bytes per lane.
-  uint4* out = reinterpret_cast<uint4*>(image + e * frame_bytes);
+  u32x4* out = reinterpret_cast<u32x4*>(image + e * frame_bytes);
   const int64_t vecs = frame_bytes >> 4;
   auto word = [salt](int64_t byte0) {
     const uint32_t x = salt + static_cast<uint32_t>(byte0);
     return (x & 0xFF) | (((x + 1) & 0xFF) << 8) | (((x + 2) & 0xFF) << 16) | (((x + 3) & 0xFF) << 24);
   };
   for (int64_t i = threadIdx.x; i < vecs; i += kThreads)
-    out[i] = make_uint4(word(i * 16), word(i * 16 + 4), word(i * 16 + 8), word(i * 16 + 12));
+    __builtin_nontemporal_store(
+        u32x4{word(i * 16), word(i * 16 + 4), word(i * 16 + 8), word(i * 16 + 12)}, out + i);
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     counters[2 * e] = count;
