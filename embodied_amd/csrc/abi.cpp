@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -192,6 +193,15 @@ class LaunchTimer {
   int64_t launches_ = 0;
   double total_ms_ = 0;
 };
+
+// HIP_FORCE_DEV_KERNARG=0: the runtime leaves kernel arguments in host memory.
+bool host_kernargs() {
+  static const bool value = [] {
+    const char* e = std::getenv("HIP_FORCE_DEV_KERNARG");
+    return e && e[0] == '0';
+  }();
+  return value;
+}
 
 std::mutex g_ring_mu;
 TableRing& global_ring() {
@@ -626,15 +636,29 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     rep->ring.upload(lease, total, stream);
     plan.rows = reinterpret_cast<const int32_t*>(lease.device);
   }
-  rep->order_before(gather, stream);
-  if (gather) {
-    hipEvent_t start, stop;
-    rep->timer.next(&start, &stop);
-    HIP_OK(emb::launch_gather(plan, stream, start, stop));
-  } else {
-    HIP_OK(emb::launch_scatter(plan, stream));
+  emb::MoveLaunch launch;
+  HIP_OK(emb::prepare_move(plan, &launch));
+  // Processes that keep kernel arguments in host memory (HIP_FORCE_DEV_KERNARG=0,
+  // cheaper launches) pay PCIe latency on every wave's argument reads: for big
+  // moves hand the kernel a device copy of its arguments instead.
+  TableRing::Lease args_lease{-1, nullptr, nullptr};
+  const void* device_args = nullptr;
+  if (host_kernargs()) {
+    int64_t bytes = 0;
+    for (int k = 0; k < plan.n_keys; ++k) bytes += plan.key[k].rowbytes * n_rows;
+    if (bytes >= (4 << 20)) {
+      args_lease = rep->ring.acquire(emb::move_args_bytes(), stream);
+      std::memcpy(args_lease.host, launch.args, emb::move_args_bytes());
+      rep->ring.upload(args_lease, emb::move_args_bytes(), stream);
+      device_args = args_lease.device;
+    }
   }
+  rep->order_before(gather, stream);
+  hipEvent_t start = nullptr, stop = nullptr;
+  if (gather) rep->timer.next(&start, &stop);
+  HIP_OK(emb::launch_move(launch, gather, device_args, stream, start, stop));
   rep->order_after(gather, stream);
+  if (args_lease.slot >= 0) rep->ring.retire(args_lease, stream);
   if (lease.slot >= 0) rep->ring.retire(lease, stream);
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdint>
 
 namespace emb {
@@ -43,6 +44,20 @@ struct MovePlan {
 // True if this plan's tables fit the kernel-argument block (else the caller
 // must provide `rows` in device-visible memory).
 bool plan_fits_inline(const MovePlan& plan);
+
+// A prepared launch: the kernel's argument block (opaque) and its grid.
+constexpr size_t kMoveArgsBytes = 4096;
+struct MoveLaunch {
+  alignas(16) unsigned char args[kMoveArgsBytes];
+  uint32_t blocks = 0;
+  uint32_t threads = 0;
+};
+hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out);
+size_t move_args_bytes();
+// device_args == nullptr: arguments by value.  Otherwise a device-visible copy
+// of launch.args[0 .. move_args_bytes()) that the kernel reads through a pointer.
+hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device_args,
+                       hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 // pool[rows[r]] -> batch[r]   (Replay.sample: replay.py:255-292 on device)
 // start/stop (optional): events stamped with the dispatch's own begin/end

@@ -93,6 +93,27 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   const uint32_t off0 = base - r0 * upr;
   const uint32_t L = static_cast<uint32_t>(a.seq_len);
   const uint32_t seq0 = r0 / L, t0 = r0 - seq0 * L;
+  // The workgroup's units span at most kRows consecutive batch rows when rows
+  // are long (the usual case: one 28 KB frame = 1764 units): resolve those rows
+  // ONCE per wave with wave-uniform (scalar) reads of the inline span table and
+  // let the lanes select, instead of every lane reading the table.
+  constexpr int kRows = 3;
+  const bool few_rows = a.rows_mode == 2 &&
+                        (off0 + blockDim.x * U - 1) / upr < static_cast<uint32_t>(kRows);
+  int32_t row_tab[kRows];
+  if (few_rows) {
+    uint32_t seq = seq0, t = t0;
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      if (r0 + i < static_cast<uint32_t>(a.n_rows)) {
+        const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
+        row_tab[i] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
+      } else {
+        row_tab[i] = -1;
+      }
+      if (++t >= L) { t = 0; ++seq; }
+    }
+  }
   uint32_t r[U], off[U];
   int32_t row[U];
 #pragma unroll
@@ -103,6 +124,8 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
     off[j] = x;
     if (base + j * blockDim.x + threadIdx.x >= total) {
       row[j] = -1;
+    } else if (few_rows) {
+      row[j] = dr == 0 ? row_tab[0] : dr == 1 ? row_tab[1] : row_tab[2];
     } else if (a.rows_mode == 2) {
       uint32_t seq = seq0, t = t0 + dr;
       while (t >= L) { t -= L; ++seq; }
@@ -135,7 +158,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
 // pool[rows[r]] -> batch[r] for every key of the replay in ONE launch, with
 // the is_first / is_last annotation of replay.py:277-292 applied in flight.
 template <int U, int NT>
-__global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) {
+__device__ __forceinline__ void gather_body(const MoveArgs& a) {
   const int k = find_key(a, blockIdx.x);
   const KeyDesc key = a.key[k];
   const int local = blockIdx.x - a.first_block[k];
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) {
 
 // batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
 template <int U, int NT>
-__global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) {
+__device__ __forceinline__ void scatter_body(const MoveArgs& a) {
   const int k = find_key(a, blockIdx.x);
   const KeyDesc key = a.key[k];
   const int local = blockIdx.x - a.first_block[k];
@@ -191,6 +214,24 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) {
     return;
   }
   copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
+}
+
+// Each mover exists twice: arguments by value in the kernel-argument segment
+// (default), or read through a pointer to a copy in device memory.  The second
+// form is for processes that keep kernel arguments in host memory
+// (HIP_FORCE_DEV_KERNARG=0: cheaper launches, but every wave's argument reads
+// then cross PCIe, which costs a 58 MB gather a third of its speed).
+template <int U, int NT>
+__global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) { gather_body<U, NT>(a); }
+template <int U, int NT>
+__global__ __launch_bounds__(1024) void gather_kernel_indirect(const MoveArgs* __restrict__ a) {
+  gather_body<U, NT>(*a);
+}
+template <int U, int NT>
+__global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) { scatter_body<U, NT>(a); }
+template <int U, int NT>
+__global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* __restrict__ a) {
+  scatter_body<U, NT>(*a);
 }
 
 // Tuning knobs, read once: EMB_MOVE_VARIANT="U,NT,remap,threads" = 16-byte units
@@ -235,8 +276,12 @@ int inline_words_needed(const MovePlan& plan) {
   return words <= kInlineWords ? static_cast<int>(words) : -1;
 }
 
-hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream,
-                           hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+static_assert(sizeof(MoveArgs) <= kMoveArgsBytes, "MoveLaunch::args too small");
+
+}  // namespace
+
+hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
+  out->blocks = 0;
   const int inline_need = inline_words_needed(plan);
   const bool use_inline = inline_need > 0 && (plan.spans_host || plan.rows_host);
   if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || (!plan.rows && !use_inline))
@@ -245,7 +290,7 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
   const MoveVariant& variant = move_variant();
   const int unroll = variant.unroll;
   const int threads = variant.threads;
-  MoveArgs a;
+  MoveArgs& a = *reinterpret_cast<MoveArgs*>(out->args);
   a.n_keys = plan.n_keys;
   a.n_rows = plan.n_rows;
   a.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;
@@ -294,11 +339,26 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
     if (blocks > INT32_MAX) return hipErrorInvalidValue;
   }
   a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
-  const dim3 grid(static_cast<uint32_t>(blocks)), block(threads);
-#define EMB_MOVE(U_, NT_)                                                        \
-  do {                                                                           \
-    if (gather) hipExtLaunchKernelGGL((gather_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);  \
-    else hipExtLaunchKernelGGL((scatter_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);        \
+  out->blocks = static_cast<uint32_t>(blocks);
+  out->threads = static_cast<uint32_t>(threads);
+  return hipSuccess;
+}
+
+size_t move_args_bytes() { return sizeof(MoveArgs); }
+
+hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device_args,
+                       hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  if (launch.blocks == 0) return hipSuccess;
+  const MoveVariant& variant = move_variant();
+  const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
+  const MoveArgs* ap = static_cast<const MoveArgs*>(device_args);
+  const dim3 grid(launch.blocks), block(launch.threads);
+#define EMB_MOVE(U_, NT_)                                                                      \
+  do {                                                                                         \
+    if (gather && ap) hipExtLaunchKernelGGL((gather_kernel_indirect<U_, NT_>), grid, block, 0, stream, start, stop, 0, ap); \
+    else if (gather) hipExtLaunchKernelGGL((gather_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);            \
+    else if (ap) hipExtLaunchKernelGGL((scatter_kernel_indirect<U_, NT_>), grid, block, 0, stream, start, stop, 0, ap);     \
+    else hipExtLaunchKernelGGL((scatter_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);                       \
   } while (0)
 #define EMB_MOVE_NT(U_)                                                          \
   switch (variant.nt) {                                                          \
@@ -317,6 +377,8 @@ hipError_t plan_and_launch(const MovePlan& plan, bool gather, hipStream_t stream
 #undef EMB_MOVE
   return hipGetLastError();
 }
+
+namespace {
 
 // ---------------------------------------------------------------- windowing --
 
@@ -684,13 +746,17 @@ __global__ __launch_bounds__(kThreads) void synth_env_kernel(
 
 hipError_t launch_gather(const MovePlan& plan, hipStream_t stream, hipEvent_t start,
                          hipEvent_t stop) {
-  return plan_and_launch(plan, true, stream, start, stop);
+  MoveLaunch launch;
+  const hipError_t e = prepare_move(plan, &launch);
+  return e != hipSuccess ? e : launch_move(launch, true, nullptr, stream, start, stop);
 }
 
 bool plan_fits_inline(const MovePlan& plan) { return inline_words_needed(plan) > 0; }
 
 hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream) {
-  return plan_and_launch(plan, false, stream);
+  MoveLaunch launch;
+  const hipError_t e = prepare_move(plan, &launch);
+  return e != hipSuccess ? e : launch_move(launch, false, nullptr, stream, nullptr, nullptr);
 }
 
 hipError_t launch_window(const uint8_t* src, uint8_t* dst, int64_t batch, int64_t total,

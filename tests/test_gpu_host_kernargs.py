@@ -1,0 +1,22 @@
+"""The movers' indirect-argument kernels: a process that keeps kernel arguments
+in host memory (HIP_FORCE_DEV_KERNARG=0) must produce the same bytes.  The
+setting is read at HIP start-up, so the parity cases run in a child process."""
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def test_parity_with_kernel_arguments_in_host_memory():
+  env = dict(os.environ, HIP_FORCE_DEV_KERNARG='0')
+  res = subprocess.run(
+      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-m', 'gpu', '-q', '-x',
+       '-k', 'golden or full_size or large_tables or update_roundtrip or sharded'],
+      cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+  assert ' passed' in res.stdout
