@@ -148,6 +148,7 @@ SIGNATURES = {
     'emb_scan_gae': [p, p, p, p, i64, i64, f32, f32, p, p, p],
     'emb_scan_lambda': [p, p, p, p, i64, i64, f32, f32, p, p],
     'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],
+    'emb_abstract_traj': [p, p, i64, i64, i32, p, p, p],
     'emb_synth_env_step': [p, p, p, p, p, i64, i64, i64, i64, p, p, p],
 }
 

@@ -1025,6 +1025,16 @@ int32_t emb_scan_director(const void* rew, const void* cont, const void* value, 
   });
 }
 
+int32_t emb_abstract_traj(const void* reward, const void* cont, int64_t T, int64_t B, int32_t k,
+                          void* reward_out, void* cont_out, void* stream) {
+  return guarded([&] {
+    need(cont && (reward || !reward_out) && T >= 1 && B >= 0 && k >= 1, "abstract_traj: bad arguments");
+    HIP_OK(emb::launch_abstract_traj(static_cast<const float*>(reward), static_cast<const float*>(cont),
+                                     T, B, k, static_cast<float*>(reward_out),
+                                     static_cast<float*>(cont_out), static_cast<hipStream_t>(stream)));
+  });
+}
+
 int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_last, void* is_terminal,
                            int64_t n, int64_t frame_bytes, int64_t env0, int64_t episode_len,
                            const void* reset, void* counters, void* stream) {

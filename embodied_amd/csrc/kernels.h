@@ -105,6 +105,11 @@ hipError_t launch_director_score(const float* rew, const float* cont,
                                  float discount, float lam, float* ret,
                                  hipStream_t stream);
 
+// Director manager-step abstraction (director/hierarchy.py:240-256), time-major:
+// reward (T-1, B), cont (T, B) -> reward_out (T/k - 1, B), cont_out (T/k, B).
+hipError_t launch_abstract_traj(const float* reward, const float* cont, int64_t T, int64_t B,
+                                int k, float* reward_out, float* cont_out, hipStream_t stream);
+
 // Synthetic vector env (bench/test input): counter-hash frames written straight
 // into HBM, SURVEY.md 8d.
 hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first,

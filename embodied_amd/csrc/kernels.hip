@@ -702,6 +702,28 @@ __global__ __launch_bounds__(kThreads) void director_score_kernel(
   }
 }
 
+// Director manager steps (director/hierarchy.py:240-256), time-major: for every
+// window j of k steps and column b:  w_i = prod_{i'<=i} cont[jk+i'],
+// reward_out[j-1] = mean_i(shifted_reward[jk+i] * w_i)  (j >= 1; the reward is
+// shifted by one step: shifted[0] = 0, shifted[t] = reward[t-1]),
+// cont_out[j] = prod_i cont[jk+i].  Lane = column (coalesced), k is small.
+__global__ __launch_bounds__(kThreads) void abstract_traj_kernel(
+    const float* __restrict__ reward, const float* __restrict__ cont, int64_t T, int64_t B,
+    int k, float* __restrict__ reward_out, float* __restrict__ cont_out) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (b >= B) return;
+  float w = 1.f, acc = 0.f;
+  for (int i = 0; i < k; ++i) {
+    const int64_t t = j * k + i;
+    w *= cont[t * B + b];
+    const float r = (t == 0 || !reward) ? 0.f : reward[(t - 1) * B + b];
+    acc += r * w;
+  }
+  if (cont_out) cont_out[j * B + b] = w;
+  if (reward_out && j >= 1) reward_out[(j - 1) * B + b] = acc / static_cast<float>(k);
+}
+
 // ------------------------------------------------------------ synthetic env --
 
 // Device-resident stand-in for N simulators: the episode logic
@@ -828,6 +850,16 @@ hipError_t launch_director_score(const float* rew, const float* cont, const floa
   if (B <= 0 || T < 2) return hipSuccess;
   hipLaunchKernelGGL(director_score_kernel, dim3(static_cast<uint32_t>((B + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, stream, rew, cont, value, T, B, discount, lam, ret);
+  return hipGetLastError();
+}
+
+hipError_t launch_abstract_traj(const float* reward, const float* cont, int64_t T, int64_t B,
+                                int k, float* reward_out, float* cont_out, hipStream_t stream) {
+  if (B <= 0 || T <= 0) return hipSuccess;
+  if (k < 1 || T % k != 0) return hipErrorInvalidValue;
+  const dim3 grid(static_cast<uint32_t>((B + kThreads - 1) / kThreads), static_cast<uint32_t>(T / k));
+  hipLaunchKernelGGL(abstract_traj_kernel, grid, dim3(kThreads), 0, stream, reward, cont, T, B, k,
+                     reward_out, cont_out);
   return hipGetLastError();
 }
 

@@ -104,7 +104,23 @@ def split_traj(x, k, is_reward=False):
 
 
 def abstract_traj(x, cont, k, kind='first'):
-  """Director manager steps (director/hierarchy.py:240-256)."""
+  """Director manager steps (director/hierarchy.py:240-256), time-major.
+  kind 'reward': x (T-1,B) -> cumprod(cont)-weighted window means (T/k-1,B);
+  'cont': x = cont (T,B) -> window products (T/k,B) — both one kernel
+  (`emb_abstract_traj`); anything else: first step of every window (a view)."""
+  if kind in ('reward', 'cont') and torch.is_tensor(cont) and cont.is_cuda and cont.dim() == 2:
+    dev = cont.device
+    c = _f32(cont, dev)
+    T, B = c.shape
+    if kind == 'reward':
+      r = _f32(x, dev)
+      assert r.shape == (T - 1, B), (r.shape, c.shape)
+      out = torch.empty((T // k - 1, B), dtype=torch.float32, device=dev)
+      api.emb_abstract_traj(r.data_ptr(), c.data_ptr(), T, B, k, out.data_ptr(), None, _stream(c))
+    else:
+      out = torch.empty((T // k, B), dtype=torch.float32, device=dev)
+      api.emb_abstract_traj(None, c.data_ptr(), T, B, k, None, out.data_ptr(), _stream(c))
+    return out
   fold = lambda a: a.reshape((a.shape[0] // k, k) + tuple(a.shape[1:]))
   if kind == 'reward':
     w = torch.cumprod(fold(cont), 1)

@@ -265,6 +265,13 @@ int32_t emb_scan_lambda(const void* last, const void* term, const void* rew, con
 int32_t emb_scan_director(const void* rew, const void* cont, const void* value, int64_t T,
                           int64_t B, float discount, float lam, void* ret, void* stream);
 
+/* Director manager steps (director/hierarchy.py:240-256), time-major: windows
+ * of k steps; reward (T-1,B) f32 [shifted by one step inside], cont (T,B) f32 ->
+ * reward_out (T/k-1,B) = mean of cumprod(cont)-weighted rewards per window,
+ * cont_out (T/k,B) = product of cont per window.  Either output may be NULL.  */
+int32_t emb_abstract_traj(const void* reward, const void* cont, int64_t T, int64_t B, int32_t k,
+                          void* reward_out, void* cont_out, void* stream);
+
 /* ---- synthetic vector env (benchmark / test input) ---------- */
 /* Episode logic of embodied/envs/dummy.py:38-48 for n device-resident envs;
  * counters = device int32[2n] state; reset = device u8[n] or NULL.           */
