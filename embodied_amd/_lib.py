@@ -209,6 +209,22 @@ def raw_stream(device):
   return torch._C._cuda_getCurrentRawStream(index)
 
 
+_TEMPLATES = {}
+
+
+def empty(shape, dtype, device):
+  """torch.empty(shape, dtype, device) at about half the host cost:
+  empty_like of a cached zero-stride one-element template (same contiguous
+  result)."""
+  key = (tuple(shape), dtype, device)
+  template = _TEMPLATES.get(key)
+  if template is None:
+    if len(_TEMPLATES) > 4096:
+      _TEMPLATES.clear()
+    template = _TEMPLATES[key] = torch.empty(1, dtype=dtype, device=device).expand(*key[0])
+  return torch.empty_like(template)
+
+
 def ptr(array):
   """Address of a numpy array's buffer (None -> NULL)."""
   return None if array is None else array.ctypes.data

@@ -120,6 +120,7 @@ class Replay:
     # samples): no allocations, and the gather writes into cache-warm lines.
     self._reuse = int(reuse_outputs)
     self._out_ring = {}
+    self._templates = {}
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
 
   def __del__(self):
@@ -360,11 +361,18 @@ class Replay:
     return self._new_batch(batch, length)
 
   def _new_batch(self, batch, length):
+    # torch.empty_like on a zero-stride, one-element template is about twice as
+    # cheap on the host as torch.empty(shape, dtype, device) and yields the same
+    # contiguous tensor.
+    templates = self._templates.get((batch, length))
+    if templates is None:
+      templates = self._templates[(batch, length)] = [
+          torch.empty(1, dtype=key.dtype, device=self.device).expand(
+              batch, length, *key.shape) for key in self._keys]
     out, ptrs = {}, (C.c_void_p * len(self._keys))()
     for i, key in enumerate(self._keys):
-      out[key.name] = torch.empty(
-          (batch, length, *key.shape), dtype=key.dtype, device=self.device)
-      ptrs[i] = out[key.name].data_ptr()
+      tensor = out[key.name] = torch.empty_like(templates[i])
+      ptrs[i] = tensor.data_ptr()
     return out, ptrs
 
   def _finish(self, out):

@@ -57,11 +57,11 @@ class SyntheticBatchEnv:
   def _alloc(self):
     n, dev = self.n, self.device
     return {
-        'image': torch.empty((n, *self.shape), dtype=torch.uint8, device=dev),
-        'reward': torch.empty(n, dtype=torch.float32, device=dev),
-        'is_first': torch.empty(n, dtype=torch.bool, device=dev),
-        'is_last': torch.empty(n, dtype=torch.bool, device=dev),
-        'is_terminal': torch.empty(n, dtype=torch.bool, device=dev),
+        'image': _lib.empty((n, *self.shape), torch.uint8, dev),
+        'reward': _lib.empty((n,), torch.float32, dev),
+        'is_first': _lib.empty((n,), torch.bool, dev),
+        'is_last': _lib.empty((n,), torch.bool, dev),
+        'is_terminal': _lib.empty((n,), torch.bool, dev),
     }
 
   def step(self, acts):

@@ -28,7 +28,7 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
   n = total if ids is None else len(ids)
   first = layout == 'channels_first'
   shape = (n, c, h, w) if first else (n, h, w, c)
-  out = torch.empty(shape, dtype=dtype, device=frames.device)
+  out = _lib.empty(shape, dtype, frames.device)
   api.emb_obs_stack(
       frames.data_ptr(), _lib.ptr(ids), n, h * w, c,
       _lib.LAYOUT_CHANNELS_FIRST if first else _lib.LAYOUT_SAME, _OUT[dtype],

@@ -52,8 +52,8 @@ def gae(rew, val, last, term, hor=200, lam=0.8):
   last, term = _flag(last, dev), _flag(term, dev)
   B, T = rew.shape
   assert val.shape == last.shape == term.shape == (B, T)
-  adv = torch.empty((B, T - 1), dtype=torch.float32, device=dev)
-  tar = torch.empty_like(adv)
+  adv = _lib.empty((B, T - 1), torch.float32, dev)
+  tar = _lib.empty((B, T - 1), torch.float32, dev)
   api.emb_scan_gae(
       rew.data_ptr(), val.data_ptr(), last.data_ptr(), term.data_ptr(), B, T,
       float(np.float32(1 - 1 / hor)), float(np.float32(lam)), adv.data_ptr(),
@@ -70,7 +70,7 @@ def lambda_return(last, term, rew, val, boot, disc, lam):
   B, T = rew.shape
   assert boot.shape == last.shape == term.shape == (B, T)
   assert val is None or tuple(val.shape) == (B, T)
-  ret = torch.empty((B, T - 1), dtype=torch.float32, device=dev)
+  ret = _lib.empty((B, T - 1), torch.float32, dev)
   api.emb_scan_lambda(
       last.data_ptr(), term.data_ptr(), rew.data_ptr(), boot.data_ptr(), B, T,
       float(np.float32(disc)), float(np.float32(lam)), ret.data_ptr(),
@@ -84,7 +84,7 @@ def director_score(rew, cont, value, horizon=333, lam=0.95):
   rew, cont, value = _f32(rew, dev), _f32(cont, dev), _f32(value, dev)
   T, B = value.shape
   assert cont.shape == (T, B) and rew.shape == (T - 1, B)
-  ret = torch.empty((T - 1, B), dtype=torch.float32, device=dev)
+  ret = _lib.empty((T - 1, B), torch.float32, dev)
   api.emb_scan_director(
       rew.data_ptr(), cont.data_ptr(), value.data_ptr(), T, B,
       float(np.float32(1 - 1 / horizon)), float(np.float32(lam)),
