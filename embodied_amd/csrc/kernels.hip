@@ -80,9 +80,11 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
                                           int nblocks) {
   const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
   const uint32_t total = upr * static_cast<uint32_t>(a.n_rows);
-  // Workgroup b runs on XCD b % 8 (observed; speed only): give every XCD one
-  // contiguous eighth of the batch so its L2 / TLB sees few distinct source
-  // sequences.  EMB_MOVE_VARIANT's third field = 0 turns the remap off.
+  // Optional (EMB_MOVE_VARIANT's third field = 1; off by default): workgroup b
+  // runs on XCD b % 8, so this gives every XCD one contiguous eighth of the
+  // batch.  Measured on MI355X it is 0.2-0.3 us SLOWER at batch 16 inside the
+  // benchmark and 2-3 % slower at batch 256: the plain order already spreads
+  // each frame over all XCDs' memory channels, which a streaming copy prefers.
   int vlocal = local;
   const int per_xcd = nblocks >> 3;
   if (a.xcd_remap && local < (per_xcd << 3)) vlocal = (local & 7) * per_xcd + (local >> 3);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* 
 struct MoveVariant { int unroll; int nt; int remap; int threads; };
 const MoveVariant& move_variant() {
   static const MoveVariant variant = [] {
-    MoveVariant v{2, 3, 1, 256};
+    MoveVariant v{2, 3, 0, 256};
     if (const char* s = std::getenv("EMB_MOVE_VARIANT"))
       std::sscanf(s, "%d,%d,%d,%d", &v.unroll, &v.nt, &v.remap, &v.threads);
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 2;
