@@ -218,7 +218,9 @@ def main():
   counters['env_steps'] = fill * args.envs
   for _ in range(args.warmup):
     one_step()
-  replay.profile(True)
+  # EMB_BENCH_NO_TIMER=1: no dispatch stamps (roofline is then null) -- for a
+  # rocprofv3 run that sees the gather without the timed-dispatch perturbation.
+  replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1')
   replay.profile_read(reset=True)
   base = dict(counters)
 
