@@ -9,7 +9,6 @@
 #include <memory>
 #include <mutex>
 #include <string>
-#include <unordered_set>
 #include <vector>
 
 #include "kernels.h"
@@ -237,6 +236,9 @@ struct emb_replay {
   TableRing ring;
   LaunchTimer timer;
   std::vector<int32_t> rows, spans;
+  std::vector<std::pair<int32_t, int32_t>> runs;   // update: [first, last) pool rows per run
+  std::vector<uint32_t> stamp;                     // update: last-writer-wins marks per pool row
+  uint32_t stamp_epoch = 0;
   std::vector<emb::StepId> ids;
   // Actor and learner on different HIP streams: pool writes (add/update) and
   // pool reads (sample) are ordered across streams with one event each way.
@@ -758,21 +760,53 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
     need(B >= 0 && T >= 1 && stepids, "update: bad arguments");
     if (B == 0) return;
     KeyList list = list_subset(rep, n_keys, key_ids, src);
+    list.seq_len = static_cast<int32_t>(T);
     rep->rows.resize(B * T);
+    rep->spans.resize(3 * B);
+    bool compact = true;    // every window resolved into at most two runs of pool rows
     for (int64_t i = 0; i < B; ++i) {
       emb::ReplayIndex::Pos pos;
-      if (rep->index->parse_stepid(stepids + i * EMB_STEPID_BYTES, &pos))
-        rep->index->rows(pos, T, rep->rows.data() + i * T);
-      else
+      if (rep->index->parse_stepid(stepids + i * EMB_STEPID_BYTES, &pos) &&
+          rep->index->rows(pos, T, rep->rows.data() + i * T)) {
+        compact = compact && rep->index->two_spans(pos, T, rep->spans.data() + 3 * i);
+      } else {
         for (int64_t j = 0; j < T; ++j) rep->rows[i * T + j] = -1;
+        compact = false;
+      }
     }
     // The reference applies batch rows one after another (replay.py:139-149),
     // so when sampled windows overlap the LAST writer of a step wins.  One
-    // launch has no order: drop all but the last occurrence of every pool row.
-    std::unordered_set<int32_t> seen;
-    for (int64_t i = B * T - 1; i >= 0; --i)
-      if (rep->rows[i] >= 0 && !seen.insert(rep->rows[i]).second) rep->rows[i] = -1;
-    run_move_all(rep, list, rep->rows.data(), B * T, nullptr, false, static_cast<hipStream_t>(stream));
+    // launch has no order.  Usual case: no two windows share a pool row (checked
+    // on the sorted runs) and the windows travel as spans in the kernel
+    // arguments.  Otherwise drop all but the last occurrence of every pool row.
+    if (compact) {
+      auto& runs = rep->runs;
+      runs.clear();
+      for (int64_t i = 0; i < B; ++i) {
+        const int32_t* sp = rep->spans.data() + 3 * i;
+        runs.emplace_back(sp[0], sp[0] + sp[1]);
+        if (sp[1] < T) runs.emplace_back(sp[2], sp[2] + static_cast<int32_t>(T) - sp[1]);
+      }
+      std::sort(runs.begin(), runs.end());
+      for (size_t i = 1; i < runs.size() && compact; ++i) compact = runs[i].first >= runs[i - 1].second;
+    }
+    if (!compact) {
+      rep->spans.clear();
+      const size_t pool_rows = static_cast<size_t>(rep->index->config().n_slots * rep->index->config().chunksize);
+      if (rep->stamp.size() < pool_rows) rep->stamp.resize(pool_rows, 0);
+      if (++rep->stamp_epoch == 0) {       // wrapped: start over
+        std::fill(rep->stamp.begin(), rep->stamp.end(), 0u);
+        rep->stamp_epoch = 1;
+      }
+      for (int64_t i = B * T - 1; i >= 0; --i) {
+        const int32_t row = rep->rows[i];
+        if (row < 0) continue;
+        if (rep->stamp[row] == rep->stamp_epoch) rep->rows[i] = -1;
+        else rep->stamp[row] = rep->stamp_epoch;
+      }
+    }
+    run_move_all(rep, list, rep->rows.data(), B * T, nullptr, false, static_cast<hipStream_t>(stream),
+                 &rep->spans);
   });
 }
 
