@@ -567,3 +567,36 @@ def test_reuse_outputs_rotates_buffers_and_keeps_values(emb):
     assert_same({k: v.cpu().numpy() for k, v in x.items()},
                 {k: v.cpu().numpy() for k, v in y.items()}, 'reuse')
   assert ptrs[0] == ptrs[2] and ptrs[1] == ptrs[3] and ptrs[0] != ptrs[1]
+
+
+@pytest.mark.parametrize('chunksize,T,stride', [
+    (16, 6, 6),    # windows of one or two runs, disjoint: spans in the kernel arguments
+    (4, 10, 10),   # three or more runs per window: explicit row table
+    (16, 6, 3),    # overlapping windows: the last writer of a step wins
+    (1024, 64, 64),  # BASELINE shape (B=16, T=64), disjoint
+])
+def test_update_table_forms_match_oracle(emb, chunksize, T, stride):
+  """Replay.update (replay.py:129-149, 216-235) takes three routes to the same
+  scatter: per-window spans, a row table, and a de-duplicated row table."""
+  L = T + 1
+  n_steps = 17 * stride + L + 5
+  ours = emb.Replay(length=L, capacity=10 * n_steps, chunksize=chunksize, seed=3)
+  ref = np_oracle.Replay(L, 10 * n_steps, chunksize, seed=3)
+  wide = lambda t: (np.arange(520, dtype=np.float32) + t)      # 2080-byte rows: the 16-byte-unit mover
+  for t in range(n_steps):
+    s = dict(scenarios.synth_step(t, 0), wide=wide(t))
+    ours.add(s, 0)
+    ref.add(s, 0)
+  full = {k: v.cpu().numpy() for k, v in ours.sample(1).items()}
+  assert_same(full, ref.sample(1), 'first')
+  # Item i starts at step i (single worker, nothing evicted yet).
+  ids = [ref.rows(*ref.items[b * stride], T, ['stepid'])['stepid'] for b in range(16)]
+  stepid = np.stack(ids)
+  gen = np.random.default_rng(0)
+  upd = {'stepid': stepid,
+         'wide': gen.standard_normal((16, T, 520)).astype(np.float32),
+         'reward': gen.standard_normal((16, T)).astype(np.float32),
+         'is_terminal': gen.random((16, T)) < 0.5}
+  ours.update({k: torch.as_tensor(v).cuda() for k, v in upd.items()})
+  ref.update(dict(upd))
+  assert_same({k: v.cpu().numpy() for k, v in ours.sample(24).items()}, ref.sample(24), 'after')
