@@ -157,7 +157,7 @@ def main():
   value = torch.randn(B * args.prefetch, T + args.context, device=device)
   imag_rew = torch.randn(B * T, 16, device=device)
   imag_flags = torch.zeros(B * T, 16, dtype=torch.bool, device=device)
-  grads = torch.zeros(args.grad_numel, device=device) if use_dist else None
+  grads = torch.zeros(args.grad_numel, device=device) if use_dist and args.grad_numel else None
   counters = {'env_steps': 0, 'train_steps': 0}
   pending = []
 
@@ -197,7 +197,8 @@ def main():
         gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
         pending.append(dist.all_gather_into_tensor(gathered, send, async_op=True))
         state_keep[:] = [gathered, send]
-      pending.append(dist.all_reduce(grads, async_op=True))
+      if args.grad_numel:
+        pending.append(dist.all_reduce(grads, async_op=True))
     counters['train_steps'] += args.prefetch
     return adv
 

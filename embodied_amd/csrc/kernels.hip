@@ -160,10 +160,10 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
 // pool[rows[r]] -> batch[r] for every key of the replay in ONE launch, with
 // the is_first / is_last annotation of replay.py:277-292 applied in flight.
 template <int U, int NT>
-__device__ __forceinline__ void gather_body(const MoveArgs& a) {
-  const int k = find_key(a, blockIdx.x);
+__device__ __forceinline__ void gather_block(const MoveArgs& a, int block) {
+  const int k = find_key(a, block);
   const KeyDesc key = a.key[k];
-  const int local = blockIdx.x - a.first_block[k];
+  const int local = block - a.first_block[k];
   const int unit = a.unit[k];
   if (unit == 0) {
     move_wide<true, U, NT>(a, key, local, a.first_block[k + 1] - a.first_block[k]);
@@ -194,10 +194,10 @@ __device__ __forceinline__ void gather_body(const MoveArgs& a) {
 
 // batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
 template <int U, int NT>
-__device__ __forceinline__ void scatter_body(const MoveArgs& a) {
-  const int k = find_key(a, blockIdx.x);
+__device__ __forceinline__ void scatter_block(const MoveArgs& a, int block) {
+  const int k = find_key(a, block);
   const KeyDesc key = a.key[k];
-  const int local = blockIdx.x - a.first_block[k];
+  const int local = block - a.first_block[k];
   const int unit = a.unit[k];
   if (unit == 0) {
     move_wide<false, U, NT>(a, key, local, a.first_block[k + 1] - a.first_block[k]);
@@ -216,6 +216,24 @@ __device__ __forceinline__ void scatter_body(const MoveArgs& a) {
     return;
   }
   copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
+}
+
+// A launch has first_block[n_keys] virtual blocks.  Normally the grid is exactly
+// that; with EMB_MOVE_VARIANT's fifth field = w > 0 the grid is capped at
+// w workgroups per CU and every workgroup walks the virtual blocks with a
+// grid stride (no second round of wave launches).  Measured on MI355X: equal at
+// B=16 and 7-8 % SLOWER at B=64/256 with w=8 or 16 (the dispatcher overlaps one
+// workgroup's stores with the next one's loads better than this loop does), so
+// it stays off.
+template <int U, int NT>
+__device__ __forceinline__ void gather_body(const MoveArgs& a) {
+  const int total = a.first_block[a.n_keys];
+  for (int block = blockIdx.x; block < total; block += gridDim.x) gather_block<U, NT>(a, block);
+}
+template <int U, int NT>
+__device__ __forceinline__ void scatter_body(const MoveArgs& a) {
+  const int total = a.first_block[a.n_keys];
+  for (int block = blockIdx.x; block < total; block += gridDim.x) scatter_block<U, NT>(a, block);
 }
 
 // Each mover exists twice: arguments by value in the kernel-argument segment
@@ -242,12 +260,13 @@ __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* 
 // U=2 beats 4/8 by 10-15 %, workgroup size 64..512 is within noise, 1024 is
 // slower; non-temporal loads+stores are ~3 % faster than plain ones inside the
 // benchmark (cold output lines) and equal in a tight loop.
-struct MoveVariant { int unroll; int nt; int remap; int threads; };
+struct MoveVariant { int unroll; int nt; int remap; int threads; int persist; };
 const MoveVariant& move_variant() {
   static const MoveVariant variant = [] {
-    MoveVariant v{2, 3, 0, 256};
+    MoveVariant v{2, 3, 0, 256, 0};
     if (const char* s = std::getenv("EMB_MOVE_VARIANT"))
-      std::sscanf(s, "%d,%d,%d,%d", &v.unroll, &v.nt, &v.remap, &v.threads);
+      std::sscanf(s, "%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.remap, &v.threads, &v.persist);
+    if (v.persist < 0 || v.persist > 64) v.persist = 0;
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 2;
     if (v.nt < 0 || v.nt > 3) v.nt = 3;
     if (v.threads != 64 && v.threads != 128 && v.threads != 512 && v.threads != 1024) v.threads = 256;
@@ -342,6 +361,7 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
   }
   a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
   out->blocks = static_cast<uint32_t>(blocks);
+  if (variant.persist > 0 && blocks > 256ll * variant.persist) out->blocks = 256u * variant.persist;
   out->threads = static_cast<uint32_t>(threads);
   return hipSuccess;
 }
