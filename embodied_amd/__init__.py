@@ -12,6 +12,8 @@ from .core.replay import Replay
 from .core import limiters
 from .core import selectors
 from .core import streams
+from .core import wrappers
+from .core.wrappers import Wrapper
 from .core import replay
 from . import scans
 from . import ops

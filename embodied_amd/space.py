@@ -20,15 +20,19 @@ class Space:
     self._rng = np.random.default_rng()
 
   def _bound(self, value, sign):
-    if value is None:
-      if np.issubdtype(self._dtype, np.floating):
-        value = sign * np.inf
-      elif np.issubdtype(self._dtype, np.integer):
-        info = np.iinfo(self._dtype)
-        value = info.min if sign < 0 else info.max
-      else:
-        value = sign > 0
-    return np.broadcast_to(np.asarray(value, self._dtype), self._shape)
+    # Bounds given by the caller are kept as given (only broadcast): wrappers
+    # compute with them, and e.g. NormalizeAction's output dtype follows the
+    # bounds' dtype.  Defaults: +-inf (float64) for floats, the dtype's own
+    # range for integers, False/True for bool.
+    if value is not None:
+      return np.broadcast_to(np.asarray(value), self._shape)
+    if np.issubdtype(self._dtype, np.floating):
+      return np.broadcast_to(np.asarray(sign * np.inf), self._shape)
+    if np.issubdtype(self._dtype, np.integer):
+      info = np.iinfo(self._dtype)
+      return np.broadcast_to(
+          np.asarray(info.min if sign < 0 else info.max, self._dtype), self._shape)
+    return np.broadcast_to(np.asarray(sign > 0), self._shape)
 
   @property
   def dtype(self):

@@ -27,7 +27,7 @@ def main():
   ns = adapters.reference_ns()
   outdir = ROOT / 'tests' / 'golden'
   outdir.mkdir(exist_ok=True)
-  for name, fn in scenarios.SCENARIOS.items():
+  for name, fn in {**scenarios.SCENARIOS, **scenarios.HOST_SCENARIOS}.items():
     result = fn(ns)
     result = {k.replace('/', '__'): np.asarray(v) for k, v in result.items()}
     np.savez_compressed(outdir / f'{name}.npz', **result)

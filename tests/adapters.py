@@ -61,6 +61,8 @@ def reference_ns():
   ns.SampleTree = emb.selectors.SampleTree
   ns.Driver = lambda envs: emb.Driver(
       [(lambda e=e: e) for e in envs], parallel=False)
+  ns.wrappers = emb.core.wrappers
+  ns.Space = elements.Space
   ns.tonp = _tonp
   ns.like = lambda template, array: np.asarray(array)
   ns.consec = lambda rep, batch, length, consec, prefix: iter(
@@ -82,6 +84,9 @@ def product_ns(device='cuda'):
   ns.Prioritized = emb.selectors.Prioritized
   ns.Mixture = emb.selectors.Mixture
   ns.SampleTree = emb.selectors.SampleTree
+  from embodied_amd.core import wrappers
+  ns.wrappers = wrappers
+  ns.Space = emb.Space
   ns.Driver = lambda envs: emb.Driver(
       [(lambda e=e: e) for e in envs], parallel=False, device=device)
   ns.tonp = _tonp

@@ -434,3 +434,163 @@ SCENARIOS = {
     'stream_consec': stream_consec,
     'driver_script': driver_script,
 }
+
+
+# ----------------------------------------------------------------- wrappers --
+# Host-only scenarios (no HBM path, no oracle restatement): the product is
+# compared with the golden vectors recorded from the reference directly.
+
+
+class _ScriptedEnv:
+  """Continuous-control env whose spaces use every dtype family the boundary
+  unifies, and that records the actions it really received."""
+
+  def __init__(self, Space, episode=7):
+    self._Space = Space
+    self._episode = episode
+    self._t = 0
+    self.received = []
+
+  @property
+  def obs_space(self):
+    S = self._Space
+    return {
+        'image': S(np.uint8, (2, 2, 1)),
+        'vec': S(np.float64, (3,)),
+        'count': S(np.int64, ()),
+        'reward': S(np.float32, ()),
+        'is_first': S(bool, ()),
+        'is_last': S(bool, ()),
+        'is_terminal': S(bool, ()),
+    }
+
+  @property
+  def act_space(self):
+    S = self._Space
+    return {
+        'action': S(np.float64, (2,), np.array([-2.0, 0.0]), np.array([2.0, 10.0])),
+        'free': S(np.float32, (2,)),
+        'choice': S(np.int64, (), 0, 4),
+        'reset': S(bool, ()),
+    }
+
+  def step(self, action):
+    if action['reset']:
+      self._t = 0
+    else:
+      self._t += 1
+    self.received.append({k: np.array(v) for k, v in action.items()})
+    last = self._t >= self._episode
+    return {
+        'image': np.full((2, 2, 1), self._t % 256, np.uint8),
+        'vec': np.asarray(action['action']).sum() + np.arange(3, dtype=np.float64) * self._t,
+        'count': np.int64(self._t * 1000),
+        'reward': np.float32(0.5 * self._t),
+        'is_first': self._t == 0,
+        'is_last': last,
+        'is_terminal': last and self._t % 2 == 1,
+    }
+
+
+def _space_record(spaces):
+  out = {}
+  for key, space in spaces.items():
+    out[f'{key}/dtype'] = np.frombuffer(np.dtype(space.dtype).str.encode().ljust(4), np.uint8).copy()
+    out[f'{key}/shape'] = np.array(space.shape, np.int64)
+    low, high = np.asarray(space.low), np.asarray(space.high)
+    if np.issubdtype(space.dtype, np.integer):
+      # How an out-of-range bound is stored is the Space type's business (the
+      # reference takes Space from the un-vendored `elements`): compare the
+      # bounds as far as the dtype can represent them.
+      info = np.iinfo(space.dtype)
+      low, high = np.clip(low, info.min, info.max), np.clip(high, info.min, info.max)
+    out[f'{key}/low'] = np.asarray(low, np.float64)
+    out[f'{key}/high'] = np.asarray(high, np.float64)
+    out[f'{key}/discrete'] = np.array(bool(space.discrete))
+  return out
+
+
+def wrappers_chain(ns):
+  """The reference's own `wrap_env` chain (ppo/main.py:249-258) plus TimeLimit
+  and ActionRepeat: spaces seen outside, actions seen inside, observations, and
+  which exception each malformed action raises."""
+  W = ns.wrappers
+  out = {}
+  base = _ScriptedEnv(ns.Space)
+  env = base
+  for name, space in base.act_space.items():
+    if not space.discrete:
+      env = W.NormalizeAction(env, name)
+  env = W.UnifyDtypes(env)
+  env = W.CheckSpaces(env)
+  for name, space in env.act_space.items():
+    if not space.discrete:
+      env = W.ClipAction(env, name)
+  for k, v in _space_record(env.obs_space).items():
+    out[f'obs_space/{k}'] = v
+  for k, v in _space_record(env.act_space).items():
+    out[f'act_space/{k}'] = v
+  rng = np.random.default_rng(11)
+  seen = []
+  for t in range(12):
+    action = {
+        'action': rng.uniform(-1.6, 1.6, 2).astype(np.float32),   # beyond [-1, 1]: clipped
+        'free': rng.uniform(-3, 3, 2).astype(np.float32),         # unbounded dims pass... then clip
+        'choice': np.int32(rng.integers(0, 4)),
+        'reset': bool(t == 0 or t == 9),
+    }
+    seen.append(env.step(action))
+  for key in seen[0]:
+    out[f'obs/{key}'] = np.stack([np.asarray(o[key]) for o in seen])
+    out[f'obs_dtype/{key}'] = np.frombuffer(
+        np.asarray(seen[-1][key]).dtype.str.encode().ljust(4), np.uint8).copy()
+  for key in base.received[0]:
+    out[f'inner/{key}'] = np.stack([r[key] for r in base.received])
+    out[f'inner_dtype/{key}'] = np.frombuffer(
+        base.received[-1][key].dtype.str.encode().ljust(4), np.uint8).copy()
+  # Malformed actions at the CheckSpaces level (below ClipAction: address it directly).
+  checker = W.CheckSpaces(W.UnifyDtypes(_ScriptedEnv(ns.Space)))
+  good = {'action': np.zeros(2, np.float32), 'free': np.zeros(2, np.float32),
+          'choice': np.int32(1), 'reset': True}
+  bad = [
+      {**good, 'action': np.zeros(3, np.float32)},            # shape
+      {**good, 'action': np.array([5.0, 0.0], np.float32)},   # range
+      {**good, 'choice': np.float32(1.5)},                    # dtype kind
+      {**good, 'choice': 'one'},                              # foreign type
+      good,
+  ]
+  codes = []
+  for action in bad:
+    try:
+      checker.step(dict(action))
+      codes.append(0)
+    except TypeError:
+      codes.append(1)
+    except ValueError:
+      codes.append(2)
+  out['check_codes'] = np.array(codes)
+  # TimeLimit (soft and hard) around ActionRepeat.
+  for hard in (True, False):
+    inner = _ScriptedEnv(ns.Space, episode=100)
+    env = W.TimeLimit(W.ActionRepeat(inner, 3), duration=4, reset=hard)
+    rows = []
+    for t in range(14):
+      obs = env.step({'action': np.zeros(2), 'free': np.zeros(2, np.float32),
+                      'choice': np.int64(0), 'reset': t == 0})
+      rows.append([obs['count'], obs['reward'], obs['is_first'], obs['is_last']])
+    tag = 'hard' if hard else 'soft'
+    out[f'limit_{tag}/rows'] = np.array(rows, np.float64)
+    out[f'limit_{tag}/inner_resets'] = np.array([bool(r['reset']) for r in inner.received])
+  try:
+    env.no_such_attribute
+    out['missing_attr'] = np.array(0)
+  except ValueError:
+    out['missing_attr'] = np.array(2)
+  except AttributeError:
+    out['missing_attr'] = np.array(1)
+  return out
+
+
+HOST_SCENARIOS = {
+    'wrappers_chain': wrappers_chain,
+}
