@@ -160,6 +160,10 @@ def main():
   grads = torch.zeros(args.grad_numel, device=device) if use_dist and args.grad_numel else None
   counters = {'env_steps': 0, 'train_steps': 0}
   pending = []
+  comm = None
+  if use_dist:
+    from embodied_amd import distributed as D
+    comm = D.CommThread(device)
 
   def train_step():
     if not use_dist and args.workload == 'dreamer':
@@ -184,8 +188,8 @@ def main():
       flat, batch, layout = D.sample_packed(replay, B * args.prefetch)
       adv, tar = emb.scans.gae(
           batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
-      for work in pending:
-        work.wait()
+      for future in pending:
+        future.result().wait()
       pending.clear()
       if args.exchange == 'trajectories' or (args.exchange == 'online' and layout.online.any()):
         send = flat
@@ -193,12 +197,14 @@ def main():
         send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
       else:
         send = None
+      # The collectives are issued from the comm thread (c10d releases the GIL
+      # while it enqueues), in the same order on every rank.
       if send is not None:
         gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
-        pending.append(dist.all_gather_into_tensor(gathered, send, async_op=True))
+        pending.append(comm.submit(lambda g=gathered, s=send: D.async_all_gather(g, s)))
         state_keep[:] = [gathered, send]
       if args.grad_numel:
-        pending.append(dist.all_reduce(grads, async_op=True))
+        pending.append(comm.submit(lambda: D.async_all_reduce(grads)))
     counters['train_steps'] += args.prefetch
     return adv
 
@@ -226,8 +232,8 @@ def main():
   base = dict(counters)
 
   def fence():
-    for work in pending:
-      work.wait()
+    for future in pending:
+      future.result().wait()
     pending.clear()
     torch.cuda.synchronize(device)
     if use_dist:
@@ -300,6 +306,7 @@ def main():
         'roofline': roofline, 'cpu_baseline': cpu,
     }))
   if use_dist:
+    comm.close()
     dist.destroy_process_group()
 
 

@@ -67,6 +67,12 @@ class PackedLayout:
       self.entries.append((name, dtype, tuple(shape), offset, nbytes))
       offset += -(-nbytes // ALIGN) * ALIGN
     self.nbytes = offset
+    self.index = {e[0]: e for e in self.entries}
+
+  def view(self, flat, name):
+    """Typed (B, L, ...) view of one key inside a 1-D packed buffer."""
+    _, dtype, shape, offset, nbytes = self.index[name]
+    return flat[offset: offset + nbytes].view(dtype).view(self.batch, self.length, *shape)
 
   def views(self, flat, lead=None):
     """Typed views into `flat` ((nbytes,) or (world, nbytes) uint8)."""
@@ -83,9 +89,54 @@ class PackedLayout:
     return out
 
 
+class PackedViews(dict):
+  """Per-key views of a packed batch, made on first access (a view costs ~3
+  tensor ops on the host; a train step usually touches a few keys)."""
+
+  def __init__(self, flat, layout):
+    super().__init__()
+    self._flat, self._layout = flat, layout
+
+  def __missing__(self, name):
+    value = self[name] = self._layout.view(self._flat, name)
+    return value
+
+  def keys(self):
+    return self._layout.index.keys()
+
+  def __iter__(self):
+    return iter(self._layout.index)
+
+  def __len__(self):
+    return len(self._layout.index)
+
+  def __contains__(self, name):
+    return name in self._layout.index
+
+  def items(self):
+    return [(name, self[name]) for name in self._layout.index]
+
+  def values(self):
+    return [self[name] for name in self._layout.index]
+
+
+class SampleInfo:
+  """What `sample_packed` knows about one packed batch."""
+  __slots__ = ('layout', 'online', 'nbytes', 'entries', 'batch', 'length')
+
+  def __init__(self, layout, online):
+    self.layout, self.online = layout, online
+    self.nbytes, self.entries = layout.nbytes, layout.entries
+    self.batch, self.length = layout.batch, layout.length
+
+  def views(self, flat, lead=None):
+    return self.layout.views(flat, lead)
+
+
 def sample_packed(replay, batch, mode='train'):
-  """`replay.sample` into one packed buffer: returns (flat uint8, dict of
-  views).  The gather kernel writes each key at its offset directly."""
+  """`replay.sample` into one packed buffer: returns (flat uint8, per-key views,
+  info with `.online` flags and the layout).  The gather kernel writes each key
+  at its offset directly."""
   import ctypes as C
   from . import _lib
   from ._lib import api
@@ -93,18 +144,88 @@ def sample_packed(replay, batch, mode='train'):
   limiters.wait(lambda: len(replay._native), f'Replay buffer {replay.name} is empty')
   with replay._lock:
     replay._flush()
-    layout = PackedLayout(
-        [(k.name, k.dtype, k.shape) for k in replay._keys], batch, replay.length)
-    flat = torch.empty(layout.nbytes, dtype=torch.uint8, device=replay.device)
-    views = layout.views(flat)
-    ptrs = (C.c_void_p * len(replay._keys))(
-        *[views[k.name].data_ptr() for k in replay._keys])
+    cache = replay.__dict__.setdefault('_packed_layouts', {})
+    layout = cache.get(batch)
+    if layout is None:
+      layout = cache[batch] = PackedLayout(
+          [(k.name, k.dtype, k.shape) for k in replay._keys], batch, replay.length)
+      layout.offsets = [layout.index[k.name][3] for k in replay._keys]
+      layout.ptrs = (C.c_void_p * len(replay._keys))()
+    flat = _lib.empty((layout.nbytes,), torch.uint8, replay.device)
+    base, ptrs = flat.data_ptr(), layout.ptrs
+    for i, offset in enumerate(layout.offsets):
+      ptrs[i] = base + offset
     online = np.zeros(batch, np.uint8)
     api.emb_replay_sample(
         replay._handle, batch, _lib.MODES[mode], ptrs, _lib.ptr(online), None,
         replay._stream())
-  layout.online = online.astype(bool)
-  return flat, views, layout
+  return flat, PackedViews(flat, layout), SampleInfo(layout, online.astype(bool))
+
+
+def _default_pg():
+  from torch.distributed import distributed_c10d
+  return distributed_c10d._get_default_group()
+
+
+def async_all_gather(out, tensor):
+  """Async all-gather into one flat tensor; returns a Work handle.  Calls the
+  process group's own method: no Python-side argument checking, the GIL is
+  released for the whole call (what matters when issued from CommThread)."""
+  pg = _default_pg()
+  try:
+    return pg._allgather_base(out, tensor)
+  except AttributeError:
+    return dist.all_gather_into_tensor(out, tensor, async_op=True)
+
+
+def async_all_reduce(tensor):
+  """Async in-place sum over ranks; returns a Work handle."""
+  pg = _default_pg()
+  try:
+    return pg.allreduce([tensor])
+  except AttributeError:
+    return dist.all_reduce(tensor, async_op=True)
+
+
+class CommThread:
+  """Issues collectives from a helper thread so their host cost (tens of
+  microseconds each inside c10d, with the GIL released) does not sit on the
+  thread that steps the envs.  One thread, FIFO: every rank issues the same
+  collectives in the same order.  `submit(fn)` returns a future whose result is
+  whatever `fn` returned (an async Work handle).  Drain (`wait_all`) before
+  issuing any collective from another thread."""
+
+  def __init__(self, device=None):
+    import concurrent.futures
+    import queue
+    import threading
+    self._Future = concurrent.futures.Future
+    self._queue = queue.SimpleQueue()
+    self._device = device
+    self._thread = threading.Thread(target=self._loop, name='emb_comm', daemon=True)
+    self._thread.start()
+
+  def _loop(self):
+    if self._device is not None and torch.device(self._device).type == 'cuda':
+      torch.cuda.set_device(self._device)     # current device is per thread
+    while True:
+      item = self._queue.get()
+      if item is None:
+        return
+      fn, future = item
+      try:
+        future.set_result(fn())
+      except BaseException as e:              # hand every failure to the waiter
+        future.set_exception(e)
+
+  def submit(self, fn):
+    future = self._Future()
+    self._queue.put((fn, future))
+    return future
+
+  def close(self):
+    self._queue.put(None)
+    self._thread.join(timeout=10)
 
 
 def all_gather_packed(flat, layout):

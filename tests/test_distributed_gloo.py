@@ -104,3 +104,44 @@ def test_replicated_index_draws_agree_world2():
   out = run2(_index_job)
   assert out[0][0] and out[1][0]
   assert out[0][1] == out[1][1]
+
+
+def _comm_thread_job(rank, world, D):
+  """The bench's pattern: async collectives issued from the comm thread, waited
+  for one step later, drained before a collective on the calling thread."""
+  import torch.distributed as dist
+  comm = D.CommThread('cpu')
+  grads = torch.zeros(257)
+  pending, sums, gathers = [], [], []
+  for step in range(6):
+    for future in pending:
+      future.result().wait()
+    pending.clear()
+    if step:
+      sums.append(float(grads[0]))
+      gathers.append(out.clone())
+    grads.fill_(float((rank + 1) * (step + 1)))
+    send = torch.full((5,), rank * 10 + step, dtype=torch.uint8)
+    out = torch.empty(world * 5, dtype=torch.uint8)
+    pending.append(comm.submit(lambda o=out, s=send: D.async_all_gather(o, s)))
+    pending.append(comm.submit(lambda: D.async_all_reduce(grads)))
+  for future in pending:
+    future.result().wait()
+  bad = comm.submit(lambda: 1 / 0)
+  try:
+    bad.result()
+    raised = False
+  except ZeroDivisionError:
+    raised = True
+  comm.close()
+  final = D.max_over_ranks(float(rank), 'cpu')       # calling-thread collective after the drain
+  return sums, [g.tolist() for g in gathers], raised, final
+
+
+def test_comm_thread_issues_collectives_in_order_world2():
+  out = run2(_comm_thread_job)
+  for rank in (0, 1):
+    sums, gathers, raised, final = out[rank]
+    assert sums == [3.0 * (s + 1) for s in range(5)]
+    assert gathers == [[s] * 5 + [10 + s] * 5 for s in range(5)]
+    assert raised and final == 1.0

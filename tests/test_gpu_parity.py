@@ -600,3 +600,33 @@ def test_update_table_forms_match_oracle(emb, chunksize, T, stride):
   ours.update({k: torch.as_tensor(v).cuda() for k, v in upd.items()})
   ref.update(dict(upd))
   assert_same({k: v.cpu().numpy() for k, v in ours.sample(24).items()}, ref.sample(24), 'after')
+
+
+def test_sample_packed_equals_sample(emb):
+  """distributed.sample_packed (one buffer, all keys at aligned offsets, lazy
+  views) returns what Replay.sample returns for the same draws, and flags the
+  windows that came from the online queue."""
+  from embodied_amd import distributed as D
+  def fill(rep):
+    for t in range(40):
+      for w in range(3):
+        rep.add(scenarios.synth_step(t, w), w)
+  a = emb.Replay(length=5, capacity=60, chunksize=8, online=True, seed=2)
+  b = emb.Replay(length=5, capacity=60, chunksize=8, online=True, seed=2)
+  fill(a)
+  fill(b)
+  for _ in range(4):                       # online windows first, then uniform draws
+    flat, views, info = D.sample_packed(a, 6)
+    want = b.sample(6)
+    rows, online = None, info.online
+    assert set(views.keys()) == set(want) and len(views) == len(want)
+    assert_same({k: views[k].cpu().numpy() for k in want},
+                {k: v.cpu().numpy() for k, v in want.items()}, 'packed')
+    assert flat.numel() == info.nbytes and flat.dtype == torch.uint8
+    full = D.all_gather_packed(flat, info)        # world 1: a (1, B, L, ...) view
+    assert torch.equal(full['image'][0], want['image'])
+  assert online.dtype == bool and online.shape == (6,)
+  c = emb.Replay(length=5, capacity=60, chunksize=8, online=True, seed=2)
+  fill(c)
+  _, _, first = D.sample_packed(c, 6)
+  assert first.online.all()                # 3 workers x 8 windows are queued
