@@ -100,6 +100,8 @@ def micro(kind, iters=400, capacity=100000, batch=None):
       big_b.copy_(big_a)
     elif kind == 'sync':
       torch.cuda.synchronize()
+    elif kind == 'emb_scatter':          # one vectorised insert (ours, a scatter launch)
+      driver(policy, steps=args.envs)
     elif kind == 'fill_then_big':      # tiny launch, then an untimed big gather
       tiny.fill_(1.0)
       replay.profile(False)
