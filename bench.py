@@ -159,7 +159,7 @@ def main():
   imag_flags = torch.zeros(B * T, 16, dtype=torch.bool, device=device)
   grads = torch.zeros(args.grad_numel, device=device) if use_dist and args.grad_numel else None
   counters = {'env_steps': 0, 'train_steps': 0}
-  pending = []
+  pending, marks = [], []
   comm = None
   if use_dist:
     from embodied_amd import distributed as D
@@ -205,6 +205,12 @@ def main():
         state_keep[:] = [gathered, send]
       if args.grad_numel:
         pending.append(comm.submit(lambda: D.async_all_reduce(grads)))
+      # When the links are the bottleneck the host could queue train steps far
+      # ahead of the GPU (one gathered buffer each): stay within 8 train steps.
+      marks.append(torch.cuda.Event())
+      marks[-1].record()
+      if len(marks) > 8:
+        marks.pop(0).synchronize()
     counters['train_steps'] += args.prefetch
     return adv
 
