@@ -101,7 +101,8 @@ def build_path(args, rank, device):
         n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device, ring=4)
     driver = emb.Driver(batch_env=env, device=device)
   driver.on_step(replay.add)
-  actions = torch.randint(0, 6, (4096, n), dtype=torch.int32, device=device)
+  # 4096 pre-drawn action rows (the stub policy hands them out in turn).
+  actions = list(torch.randint(0, 6, (4096, n), dtype=torch.int32, device=device).unbind(0))
   state = {'tick': 0}
   if dreamer:   # replay-context latents every policy step (dreamerv3/rssm.py:40-43)
     deter = torch.zeros((n, 8192), dtype=torch.float32, device=device)

@@ -128,6 +128,7 @@ SIGNATURES = {
     'emb_replay_free_slots': [p, p],
     'emb_replay_stats': [p, p, i32],
     'emb_replay_add': [p, i64, p, p, p],
+    'emb_replay_add_masked': [p, i64, p, p, i32, p, p, p, p, p],
     'emb_replay_sample': [p, i64, i32, p, p, p, p],
     'emb_replay_update': [p, i64, i64, p, i32, p, p, p],
     'emb_replay_gather_rows': [p, p, i64, i64, p, p],

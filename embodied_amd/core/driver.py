@@ -92,6 +92,7 @@ class Driver:
         self.act_space = self.envs[0].act_space
     self.callbacks = []
     self.batch_callbacks = []
+    self._sinks = []          # per registered callback: its Replay if it is a bare Replay.add
     self.acts = None
     self.carry = None
     self._slab = {}
@@ -199,12 +200,15 @@ class Driver:
         and getattr(callback, '__func__', None) is replaylib.Replay.add):
       self.batch_callbacks.append(
           lambda trans, workers, **kw: owner.add_batch(trans, workers))
+      self._sinks.append(owner)
     else:
       self.callbacks.append(callback)
+      self._sinks.append(None)
 
   def on_batch(self, callback):
     """fn(trans, workers, **kwargs) once per step with (N, ...) values."""
     self.batch_callbacks.append(callback)
+    self._sinks.append(None)
 
   def __call__(self, policy, steps=0, episodes=0):
     step, episode = 0, 0
@@ -263,10 +267,19 @@ class Driver:
     self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
     assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
     is_last = obs['is_last']
-    acts = {k: mask_actions(self._to_device(v), is_last) for k, v in acts.items()}
-    # Device flags are never mutated in place: `reset` may alias is_last.
-    self.acts = {**acts, 'reset': is_last}
-    self._dispatch({**obs, **acts, **outs, **logs})
+    acts = {k: self._to_device(v) for k, v in acts.items()}
+    if len(self._sinks) == 1 and self._sinks[0] is not None and not logs:
+      # The only consumer of the step is one Replay: the mask rides in its
+      # insert launch (the pool rows and the next step's actions both receive
+      # value * ~is_last) instead of taking a launch of its own.
+      acts = self._sinks[0].add_batch(
+          {**obs, **acts, **outs}, self._workers, mask=(tuple(acts), is_last))
+      self.acts = {**acts, 'reset': is_last}
+    else:
+      acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
+      # Device flags are never mutated in place: `reset` may alias is_last.
+      self.acts = {**acts, 'reset': is_last}
+      self._dispatch({**obs, **acts, **outs, **logs})
     step += self.length
     if self._count_episodes:
       episode += int(is_last.sum().item())

@@ -36,6 +36,11 @@ _TORCH_OF = {
     np.dtype(np.uint32): torch.uint32, np.dtype(np.uint64): torch.uint64,
 }
 _ITEMSIZE = {torch.bfloat16: 2}
+_DTYPE_CODE = {
+    torch.uint8: _lib.U8, torch.int8: _lib.I8, torch.int16: _lib.I16, torch.int32: _lib.I32,
+    torch.int64: _lib.I64, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16,
+    torch.float32: _lib.F32, torch.float64: _lib.F64, torch.bool: _lib.BOOL,
+}
 
 
 def _itemsize(dtype):
@@ -121,6 +126,7 @@ class Replay:
     self._reuse = int(reuse_outputs)
     self._out_ring = {}
     self._templates = {}
+    self._mask_plans = {}
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
 
   def __del__(self):
@@ -284,9 +290,13 @@ class Replay:
     torch.cuda.current_stream(self.device).synchronize()
     self._staged = 0
 
-  def add_batch(self, steps, workers):
+  def add_batch(self, steps, workers, mask=None):
     """N steps, one per listed worker, from (N, ...) arrays or device tensors:
-    one host call, one scatter launch.  Equivalent to N `add` calls in order."""
+    one host call, one scatter launch.  Equivalent to N `add` calls in order.
+
+    `mask=(names, is_last)` fuses the Driver's action mask into the insert
+    (driver.py:72-74): the listed keys are stored as `value * ~is_last` in their
+    own dtype and the masked tensors are returned (dict name -> tensor)."""
     if workers is not self._workers_seen:
       self._workers_np = np.ascontiguousarray(workers, np.int64)
       self._workers_seen = workers
@@ -321,13 +331,35 @@ class Replay:
         seen += 1
       if seen + 1 != len(keys):
         raise KeyError(f'replay step keys {sorted(steps)} differ from the first step')
+      masked = None
+      if mask is not None:
+        names, flags = mask
+        plan = self._mask_plans.get(names)
+        if plan is None:
+          ids = (C.c_int32 * len(names))(*[keyid[name] for name in names])
+          codes = (C.c_int32 * len(names))(*[_DTYPE_CODE[keys[keyid[name]].dtype] for name in names])
+          plan = self._mask_plans[names] = (ids, codes, (C.c_void_p * len(names))())
+        ids, codes, outs = plan
+        masked = {}
+        for j, name in enumerate(names):
+          out = masked[name] = _lib.empty((n, *keys[ids[j]].shape), keys[ids[j]].dtype, device)
+          outs[j] = out.data_ptr()
+        if flags.device != device or not flags.is_contiguous():
+          flags = flags.to(device).contiguous()
+        keep.append(flags)
       while True:
         try:
-          api.emb_replay_add(self._handle, n, _lib.ptr(workers), ptrs, self._stream())
+          if masked is None:
+            api.emb_replay_add(self._handle, n, _lib.ptr(workers), ptrs, self._stream())
+          else:
+            api.emb_replay_add_masked(
+                self._handle, n, _lib.ptr(workers), ptrs, len(ids), ids, codes, outs,
+                flags.data_ptr(), self._stream())
           break
         except _lib.PoolFull:
           self._grow(2 * n)
       self._reraise()
+    return masked
 
   # ----------------------------------------------------------------- sample --
 

@@ -692,8 +692,15 @@ struct KeyList {
   std::vector<emb::KeyDesc> key;
   int key_is_first = -1, key_is_last = -1, key_stepid = -1;
   int32_t seq_len = 1;
+  // Masked insert: per key a DType code (-1 = plain copy) and the buffer that
+  // also receives the masked value; mask_flags = is_last of the rows.
+  std::vector<int8_t> mask_dtype;
+  std::vector<uint8_t*> mask_out;
+  const uint8_t* mask_flags = nullptr;
   void push(uint8_t* pool, const void* batch, int64_t rowbytes) {
     key.push_back({pool, const_cast<uint8_t*>(static_cast<const uint8_t*>(batch)), rowbytes});
+    mask_dtype.push_back(-1);
+    mask_out.push_back(nullptr);
   }
 };
 
@@ -707,7 +714,15 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
     emb::MovePlan plan;
     plan.seq_len = list.seq_len;
     plan.is_first_pool = first_pool;
-    for (int k = lo; k < hi; ++k) plan.key[plan.n_keys++] = list.key[k];
+    for (int k = lo; k < hi; ++k) {
+      if (list.mask_flags && list.mask_dtype[k] >= 0) {
+        plan.mask_bits |= 1u << plan.n_keys;
+        plan.mask_dtype[plan.n_keys] = list.mask_dtype[k];
+        plan.mask_out[plan.n_keys] = list.mask_out[k];
+        plan.mask_flags = list.mask_flags;
+      }
+      plan.key[plan.n_keys++] = list.key[k];
+    }
     if (list.key_is_first >= lo && list.key_is_first < hi) plan.key_is_first = list.key_is_first - lo;
     if (list.key_is_last >= lo && list.key_is_last < hi) plan.key_is_last = list.key_is_last - lo;
     const int sid = (ids && list.key_stepid >= lo && list.key_stepid < hi) ? list.key_stepid - lo : -1;
@@ -715,29 +730,52 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
   }
 }
 
+static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const void* const* src,
+                       int32_t n_masked, const int32_t* masked_keys, const int32_t* masked_dtypes,
+                       void* const* masked_out, const void* is_last, hipStream_t stream) {
+  need(n >= 0 && workers && src, "add: bad arguments");
+  need(!rep->keys.empty(), "add: call emb_replay_set_keys first");
+  need(n_masked == 0 || (masked_keys && masked_dtypes && is_last), "add: bad mask arguments");
+  if (n == 0) return;
+  KeyList list;
+  for (size_t k = 0; k < rep->keys.size(); ++k) {
+    need(rep->keys[k].pool, "add: key has no pool");
+    if (static_cast<int>(k) == rep->key_stepid) {
+      list.key_stepid = static_cast<int>(list.key.size());
+      list.push(rep->keys[k].pool, nullptr, rep->keys[k].rowbytes);
+      continue;
+    }
+    need(src[k], "add: null source buffer");
+    list.push(rep->keys[k].pool, src[k], rep->keys[k].rowbytes);
+  }
+  for (int32_t j = 0; j < n_masked; ++j) {
+    const int32_t k = masked_keys[j];
+    need(k >= 0 && k < static_cast<int32_t>(rep->keys.size()) && k != rep->key_stepid,
+         "add: masked key id out of range");
+    need(masked_dtypes[j] >= 0 && masked_dtypes[j] <= emb::kBool, "add: bad masked dtype");
+    list.mask_dtype[k] = static_cast<int8_t>(masked_dtypes[j]);
+    list.mask_out[k] = masked_out ? static_cast<uint8_t*>(masked_out[j]) : nullptr;
+    list.mask_flags = static_cast<const uint8_t*>(is_last);
+  }
+  rep->rows.resize(n);
+  rep->ids.resize(n);
+  add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());
+  run_move_all(rep, list, rep->rows.data(), n, list.key_stepid >= 0 ? rep->ids.data() : nullptr,
+               false, stream);
+}
+
 int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers, const void* const* src,
                        void* stream) {
-  REP_OP({
-    need(n >= 0 && workers && src, "add: bad arguments");
-    need(!rep->keys.empty(), "add: call emb_replay_set_keys first");
-    if (n == 0) return;
-    KeyList list;
-    for (size_t k = 0; k < rep->keys.size(); ++k) {
-      need(rep->keys[k].pool, "add: key has no pool");
-      if (static_cast<int>(k) == rep->key_stepid) {
-        list.key_stepid = static_cast<int>(list.key.size());
-        list.push(rep->keys[k].pool, nullptr, rep->keys[k].rowbytes);
-        continue;
-      }
-      need(src[k], "add: null source buffer");
-      list.push(rep->keys[k].pool, src[k], rep->keys[k].rowbytes);
-    }
-    rep->rows.resize(n);
-    rep->ids.resize(n);
-    add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());
-    run_move_all(rep, list, rep->rows.data(), n, list.key_stepid >= 0 ? rep->ids.data() : nullptr,
-                 false, static_cast<hipStream_t>(stream));
-  });
+  REP_OP(add_locked(rep, n, workers, src, 0, nullptr, nullptr, nullptr, nullptr,
+                    static_cast<hipStream_t>(stream)));
+}
+
+int32_t emb_replay_add_masked(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                              const void* const* src, int32_t n_masked, const int32_t* masked_keys,
+                              const int32_t* masked_dtypes, void* const* masked_out,
+                              const void* is_last, void* stream) {
+  REP_OP(add_locked(rep, n, workers, src, n_masked, masked_keys, masked_dtypes, masked_out, is_last,
+                    static_cast<hipStream_t>(stream)));
 }
 
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,

@@ -39,6 +39,14 @@ struct MovePlan {
   // 20-byte step ids) come from host memory through the kernel arguments.
   int32_t inline_key = -1;
   const uint8_t* inline_bytes = nullptr;
+  // Scatter only (Driver mask fused into the insert, driver.py:72-74): keys in
+  // mask_bits are written as value * !mask_flags[r] in mask_dtype[k] (a DType
+  // code), to the pool row and, if mask_out[k] is set, to that (n_rows,
+  // rowbytes) buffer as well (the masked actions the next env step receives).
+  uint32_t mask_bits = 0;
+  int8_t mask_dtype[kMaxKeys] = {};
+  uint8_t* mask_out[kMaxKeys] = {};
+  const uint8_t* mask_flags = nullptr;
 };
 
 // True if this plan's tables fit the kernel-argument block (else the caller

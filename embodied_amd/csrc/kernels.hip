@@ -32,6 +32,10 @@ struct MoveArgs {
   int32_t inline_key, inline_key_word0;
   const uint8_t* is_first_pool;
   const int32_t* rows;
+  uint32_t mask_bits;               // scatter: keys written as value * !mask_flags[r]
+  int8_t mask_dtype[kMaxKeys];
+  uint8_t* mask_out[kMaxKeys];
+  const uint8_t* mask_flags;
   uint32_t inline_words[kInlineWords];
 };
 static_assert(sizeof(MoveArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -192,6 +196,50 @@ __device__ __forceinline__ void gather_block(const MoveArgs& a, int block) {
   copy_bytes(src, dst, unit);
 }
 
+// One element of a masked key: value * keep in the key's own dtype — a real
+// multiply, so -x -> -0.0 and NaN stays NaN exactly as numpy's
+// `value * mask.astype(value.dtype)` (driver.py:84-87) — to the pool row and to
+// the masked-action buffer.
+template <typename T>
+__device__ __forceinline__ void put_masked(const uint8_t* src, uint8_t* pool, uint8_t* out, bool keep) {
+  const T v = *reinterpret_cast<const T*>(src) * static_cast<T>(keep ? 1 : 0);
+  if (pool) *reinterpret_cast<T*>(pool) = v;
+  if (out) *reinterpret_cast<T*>(out) = v;
+}
+
+__device__ __forceinline__ void put_masked_bf16(const uint8_t* src, uint8_t* pool, uint8_t* out, bool keep) {
+  // Widen to f32 (exact), multiply, narrow: the product is x, +-0 or NaN.
+  const float x = __uint_as_float(static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(src)) << 16);
+  const uint16_t v = static_cast<uint16_t>(__float_as_uint(x * (keep ? 1.f : 0.f)) >> 16);
+  if (pool) *reinterpret_cast<uint16_t*>(pool) = v;
+  if (out) *reinterpret_cast<uint16_t*>(out) = v;
+}
+
+__device__ __forceinline__ void scatter_masked(const MoveArgs& a, int k, const KeyDesc& key, int local) {
+  const int es = a.unit[k];                       // element size of the key's dtype
+  const int64_t epr = key.rowbytes / es;
+  const int64_t e = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
+  if (e >= epr * a.n_rows) return;
+  const int64_t r = e / epr;
+  const int64_t off = (e - r * epr) * es;
+  const int64_t row = row_of(a, static_cast<uint32_t>(r));
+  const bool keep = a.mask_flags[r] == 0;
+  const uint8_t* src = key.batch + r * key.rowbytes + off;
+  uint8_t* pool = row >= 0 ? key.pool + row * key.rowbytes + off : nullptr;
+  uint8_t* out = a.mask_out[k] ? a.mask_out[k] + r * key.rowbytes + off : nullptr;
+  switch (a.mask_dtype[k]) {
+    case kU8: case kBool: put_masked<uint8_t>(src, pool, out, keep); break;
+    case kI8: put_masked<int8_t>(src, pool, out, keep); break;
+    case kI16: put_masked<int16_t>(src, pool, out, keep); break;
+    case kI32: put_masked<int32_t>(src, pool, out, keep); break;
+    case kI64: put_masked<int64_t>(src, pool, out, keep); break;
+    case kF16: put_masked<_Float16>(src, pool, out, keep); break;
+    case kBF16: put_masked_bf16(src, pool, out, keep); break;
+    case kF32: put_masked<float>(src, pool, out, keep); break;
+    default: put_masked<double>(src, pool, out, keep); break;
+  }
+}
+
 // batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
 template <int U, int NT>
 __device__ __forceinline__ void scatter_block(const MoveArgs& a, int block) {
@@ -199,6 +247,10 @@ __device__ __forceinline__ void scatter_block(const MoveArgs& a, int block) {
   const KeyDesc key = a.key[k];
   const int local = block - a.first_block[k];
   const int unit = a.unit[k];
+  if ((a.mask_bits >> k) & 1u) {
+    scatter_masked(a, k, key, local);
+    return;
+  }
   if (unit == 0) {
     move_wide<false, U, NT>(a, key, local, a.first_block[k + 1] - a.first_block[k]);
     return;
@@ -286,6 +338,16 @@ int pick_unit(const KeyDesc& key) {
   return 1;
 }
 
+int dtype_size(int dtype) {
+  switch (dtype) {
+    case kU8: case kI8: case kBool: return 1;
+    case kI16: case kF16: case kBF16: return 2;
+    case kI32: case kF32: return 4;
+    case kI64: case kF64: return 8;
+    default: return 0;
+  }
+}
+
 // Words of kernel-argument space the plan's tables need, or -1 if they cannot
 // go inline.
 int inline_words_needed(const MovePlan& plan) {
@@ -344,9 +406,20 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
     return hipErrorInvalidValue;
   }
   a.xcd_remap = variant.remap;
+  a.mask_bits = plan.mask_bits;
+  a.mask_flags = plan.mask_flags;
+  if (plan.mask_bits && !plan.mask_flags) return hipErrorInvalidValue;
   int64_t blocks = 0;
   for (int k = 0; k < plan.n_keys; ++k) {
     a.key[k] = plan.key[k];
+    a.mask_dtype[k] = plan.mask_dtype[k];
+    a.mask_out[k] = plan.mask_out[k];
+    const bool masked = (plan.mask_bits >> k) & 1u;
+    if (masked) {
+      const int es = dtype_size(plan.mask_dtype[k]);
+      if (es == 0 || plan.key[k].rowbytes % es || k == a.inline_key) return hipErrorInvalidValue;
+      a.unit[k] = es;
+    } else
     a.unit[k] = (k == a.inline_key) ? 4 : pick_unit(plan.key[k]);
     a.first_block[k] = static_cast<int32_t>(blocks);
     if (a.unit[k] == 0) {

@@ -190,6 +190,17 @@ int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset);
  *         columns to overwrite, src[j] = device (B, T, rowbytes).  Replay.update */
 int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers,
                        const void* const* src, void* stream);
+/* Replay.add with the Driver's action mask fused in (driver.py:72-74,84-87 +
+ * replay.py:77-118): the n_masked keys masked_keys[j] (replay key ids, dtype
+ * codes masked_dtypes[j] = EMB_U8 .. EMB_BOOL) are stored as src * !is_last[row] in
+ * their own dtype (a real multiply: -x -> -0.0, NaN stays NaN), and the same
+ * masked values are written to masked_out[j] (device (n, rowbytes), may be
+ * NULL): the actions the next env step receives.  is_last = device uint8/bool
+ * (n).  One launch instead of mask + insert. */
+int32_t emb_replay_add_masked(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                              const void* const* src, int32_t n_masked,
+                              const int32_t* masked_keys, const int32_t* masked_dtypes,
+                              void* const* masked_out, const void* is_last, void* stream);
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
                           uint8_t* online_out, uint8_t* first_stepids_out, void* stream);
 int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t* stepids,

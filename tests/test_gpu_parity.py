@@ -641,3 +641,53 @@ def test_sample_packed_equals_sample(emb):
   fill(c)
   _, _, first = D.sample_packed(c, 6)
   assert first.online.all()                # 3 workers x 8 windows are queued
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.int32, torch.int64])
+def test_mask_fused_into_insert_equals_mask_then_insert(emb, dtype):
+  """Driver with one Replay sink: the action mask (driver.py:72-74, 84-87) rides
+  in the insert launch.  Same replay contents and same actions handed to the
+  next env step as mask kernel + insert, bit for bit (-0.0 and NaN included)."""
+  from embodied_amd.envs import synthetic
+
+  def run(fused):
+    env = synthetic.SyntheticBatchEnv(6, shape=(8, 8, 4), episode_len=4)
+    rep = emb.Replay(length=5, capacity=300, chunksize=16, seed=1)
+    driver = emb.Driver(batch_env=env, device='cuda')
+    driver.on_step(rep.add)
+    if not fused:
+      driver.on_batch(lambda trans, workers, **kw: None)     # a second consumer: separate mask launch
+    base = torch.tensor([[-1.5, 2.0, float('nan')], [0.0, -0.0, 3.0], [1, -2, 3],
+                         [-4, 5, -6], [7, -8, 9], [-1, 1, -1]], device='cuda')
+    seen = []
+
+    def policy(carry, obs):
+      scale = 1 + carry % 3                      # signs (and NaN) stay where they are
+      act = (base * scale).to(dtype) if dtype.is_floating_point else (base.nan_to_num() * scale).to(dtype)
+      seen.append({k: v.clone() for k, v in driver.acts.items()})
+      return carry + 1, {'action': act, 'aux': act[:, 0].contiguous()}, {'logp': act[:, 1].float()}
+
+    driver.reset(lambda n: 0)
+    driver(policy, steps=6 * 30)
+    batch = {k: v.cpu() for k, v in rep.sample(16).items()}
+    return batch, [{k: v.cpu() for k, v in a.items()} for a in seen]
+
+  got, got_acts = run(True)
+  want, want_acts = run(False)
+  for key in want:
+    a, b = got[key], want[key]
+    assert a.dtype == b.dtype and a.shape == b.shape, key
+    assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), key     # bit for bit
+  assert len(got_acts) == len(want_acts)
+  for a, b in zip(got_acts[1:], want_acts[1:]):
+    for key in b:
+      assert torch.equal(a[key].contiguous().view(torch.uint8), b[key].contiguous().view(torch.uint8)), key
+  if dtype.is_floating_point:
+    acts = got['action'].float()
+    ended = got['is_last']
+    assert ended.any()
+    masked = acts[ended]
+    assert (masked.nan_to_num(nan=1.0).abs() == masked.nan_to_num(nan=1.0).abs()).all()
+    zero_or_nan = (masked == 0) | masked.isnan()
+    assert zero_or_nan.all()
+    assert torch.signbit(masked[masked == 0]).any()          # -x * 0 = -0.0 survives
