@@ -108,3 +108,49 @@ def test_dreamer_config_full_size_uniform_with_write_back(emb):
   assert torch.equal(after['dyn/stoch'][:, :T], stoch)
   assert not after['dyn/deter'][:, T:].any()                          # the 65th step is not written
   assert torch.equal(after['image'], before['image'])
+
+
+def test_crafter_config_256_envs_over_8_owners(emb):
+  """configs[3] shape: 256 envs in 8 blocks of 32, 64x64x3 frames, L=65.  Eight
+  'ranks' run in one process (the all-reduce of the packed batches is their
+  sum): the merged batch equals what ONE replay over all 256 envs returns, each
+  rank touching only its own block's rows."""
+  from embodied_amd import distributed as D
+  world, per, L, B, cap = 8, 32, 65, 16, 20_000
+  kw = dict(chunksize=1024, seed=7)
+  flats = {}
+  shards = [
+      D.ShardedReplay(L, cap, per, rank=r, world=world,
+                      reduce=lambda flat, r=r: flats.__setitem__(r, flat.clone()), **kw)
+      for r in range(world)]
+  single = emb.Replay(L, cap, **kw)
+  n = world * per
+  ids = torch.arange(n, dtype=torch.int32, device='cuda')
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  for tick in range(cap // n + 2 * L):
+    step = {
+        'image': torch.randint(0, 255, (n, 64, 64, 3), dtype=torch.uint8, device='cuda', generator=gen),
+        'reward': torch.randn(n, device='cuda', generator=gen),
+        'is_first': (ids + tick) % 97 == 0,
+        'is_last': (ids + tick) % 97 == 96,
+        'env': ids,
+        'tick': torch.full((n,), tick, dtype=torch.int32, device='cuda'),
+    }
+    single.add_batch(step, list(range(n)))
+    for r, shard in enumerate(shards):
+      shard.add_batch({k: v[r * per:(r + 1) * per] for k, v in step.items()})
+  assert len(single) == cap and all(len(s) == cap for s in shards)
+  for _ in range(3):
+    want = single.sample(B)
+    for shard in shards:
+      shard.sample(B)
+    merged = sum(flats[r] for r in range(world))
+    layout = D.PackedLayout(
+        [(k.name, k.dtype, k.shape) for k in shards[0].replay._keys], B, L)
+    got = layout.views(merged)
+    for key in want:
+      assert torch.equal(got[key], want[key]), key
+    owners = (want['env'][:, 0] // per).tolist()
+    for r in range(world):                       # a rank fills exactly the sequences it owns
+      mine = layout.views(flats[r])['image'].flatten(1).any(1).tolist()
+      assert mine == [o == r for o in owners]
