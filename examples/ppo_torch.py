@@ -12,7 +12,6 @@ import pathlib
 import sys
 import types
 
-import numpy as np
 import torch
 import torch.nn as nn
 

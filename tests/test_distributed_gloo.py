@@ -3,7 +3,6 @@ import os
 import socket
 
 import numpy as np
-import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -109,7 +108,6 @@ def test_replicated_index_draws_agree_world2():
 def _comm_thread_job(rank, world, D):
   """The bench's pattern: async collectives issued from the comm thread, waited
   for one step later, drained before a collective on the calling thread."""
-  import torch.distributed as dist
   comm = D.CommThread('cpu')
   grads = torch.zeros(257)
   pending, sums, gathers = [], [], []

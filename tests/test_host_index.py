@@ -3,7 +3,6 @@ against the golden vectors recorded from the reference and against the oracle.
 No GPU: payload bytes are kept in numpy by a test-side pool so that only the
 C++ integer/float64 bookkeeping is under test here."""
 import ctypes as C
-import types
 
 import numpy as np
 import pytest

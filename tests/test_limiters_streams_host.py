@@ -1,6 +1,5 @@
 """Host-side pieces: limiters and numpy streams (no GPU)."""
 import threading
-import time
 
 import numpy as np
 import pytest

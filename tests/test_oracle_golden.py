@@ -1,6 +1,5 @@
 """Pin the CPU oracle against golden vectors recorded from the real reference
 (oracle/gen_golden.py).  CPU only."""
-import numpy as np
 import pytest
 
 from tests import adapters, scenarios

@@ -4,7 +4,6 @@ durations (the script itself only issues the calls)."""
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
