@@ -33,15 +33,19 @@ for _ in range(iters):
   obs = env.step(acts); t = lap('env.step', t)
   carry, a, outs = policy((), obs); t = lap('policy', t)
   is_last = obs['is_last']
-  a = {k: mask_actions(v, is_last) for k, v in a.items()}; t = lap('mask', t)
-  acts = {**a, 'reset': is_last}
   trans = {**obs, **a, **outs}; t = lap('dicts', t)
-  replay.add_batch(trans, workers); t = lap('add_batch', t)
+  # the Driver's only consumer is the replay: mask + insert are one launch
+  a = replay.add_batch(trans, workers, mask=(tuple(a), is_last)); t = lap('add_batch(mask)', t)
+  acts = {**a, 'reset': is_last}
 torch.cuda.synchronize()
 total = sum(T.values())
 for k, v in T.items():
-  print(f'{k:12s} {v / iters * 1e6:7.2f} us')
-print(f'{"total":12s} {total / iters * 1e6:7.2f} us')
+  print(f'{k:16s} {v / iters * 1e6:7.2f} us')
+print(f'{"total":16s} {total / iters * 1e6:7.2f} us')
+t0 = time.perf_counter()
+for _ in range(iters):
+  mask_actions(acts['action'], is_last)
+print(f'{"separate mask":16s} {(time.perf_counter() - t0) / iters * 1e6:7.2f} us (not on the fused path)')
 
 # inside add_batch: the C call alone
 import ctypes as C
