@@ -112,7 +112,11 @@ class Replay:
     self._one_worker = np.zeros(1, np.int64)
     self._one_row = np.zeros(1, np.int32)
     self._one_sid = np.zeros((1, _lib.STEPID_BYTES), np.uint8)
+    # ndarray.ctypes.data costs ~1.2 us per access: addresses of the persistent
+    # buffers are taken once.
+    self._one_ptrs = (_lib.ptr(self._one_worker), _lib.ptr(self._one_row), _lib.ptr(self._one_sid))
     self._new_chunks = C.c_int32()
+    self._new_chunks_ref = C.byref(self._new_chunks)
     self._saved = set()
     self._updates = 0
     self._workers_seen = None
@@ -257,8 +261,7 @@ class Replay:
       while True:
         try:
           api.emb_replay_add_index(
-              self._handle, 1, _lib.ptr(self._one_worker), _lib.ptr(self._one_row),
-              _lib.ptr(self._one_sid), C.byref(self._new_chunks))
+              self._handle, 1, *self._one_ptrs, self._new_chunks_ref)
           break
         except _lib.PoolFull:
           self._flush()
@@ -299,8 +302,9 @@ class Replay:
     own dtype and the masked tensors are returned (dict name -> tensor)."""
     if workers is not self._workers_seen:
       self._workers_np = np.ascontiguousarray(workers, np.int64)
+      self._workers_ptr = _lib.ptr(self._workers_np)
       self._workers_seen = workers
-    workers = self._workers_np
+    workers, workers_ptr = self._workers_np, self._workers_ptr
     n = len(workers)
     with self._lock:
       if self._keys is None:
@@ -350,10 +354,10 @@ class Replay:
       while True:
         try:
           if masked is None:
-            api.emb_replay_add(self._handle, n, _lib.ptr(workers), ptrs, self._stream())
+            api.emb_replay_add(self._handle, n, workers_ptr, ptrs, self._stream())
           else:
             api.emb_replay_add_masked(
-                self._handle, n, _lib.ptr(workers), ptrs, len(ids), ids, codes, outs,
+                self._handle, n, workers_ptr, ptrs, len(ids), ids, codes, outs,
                 flags.data_ptr(), self._stream())
           break
         except _lib.PoolFull:
@@ -372,10 +376,9 @@ class Replay:
     with self._lock:
       self._flush()
       out, ptrs = self._alloc_batch(batch, self.length)
-      first = np.empty((batch, _lib.STEPID_BYTES), np.uint8)
+      first = (C.c_uint8 * (batch * _lib.STEPID_BYTES))()
       api.emb_replay_sample(
-          self._handle, batch, _lib.MODES[mode], ptrs, None, _lib.ptr(first),
-          self._stream())
+          self._handle, batch, _lib.MODES[mode], ptrs, None, first, self._stream())
       self._reraise()
       # Host copy of stepid[:, 0] rides on the tensor object so `update` with
       # the same tensor needs no device read-back (a sync).
@@ -499,7 +502,10 @@ class Replay:
         stepid = stepid.detach().cpu().numpy()
       stepid = np.ascontiguousarray(stepid, np.uint8)
       first = np.ascontiguousarray(stepid[:, 0])
-    B = len(first)
+    if isinstance(first, np.ndarray):
+      B, first_ptr = len(first), _lib.ptr(first)
+    else:                                  # the ctypes buffer `sample` attached
+      B, first_ptr = len(first) // _lib.STEPID_BYTES, first
     with self._lock:
       self._flush()
       if priority is not None:
@@ -532,8 +538,7 @@ class Replay:
           ids[j] = self._keyid[name]
           ptrs[j] = value.data_ptr()
         api.emb_replay_update(
-            self._handle, B, T, _lib.ptr(first), len(data), ids, ptrs,
-            self._stream())
+            self._handle, B, T, first_ptr, len(data), ids, ptrs, self._stream())
       # replay.py:134: every call counts B*T steps, written or not.
       self._updates += steps
 

@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <memory>
 #include <stdexcept>
@@ -69,7 +70,7 @@ class ReplayIndex {
 
   const ReplayConfig& config() const { return cfg_; }
   Selector& selector() { return *selector_; }
-  int64_t size() const { return static_cast<int64_t>(items_.size()); }
+  int64_t size() const { return next_item_ - first_item_; }
   // Free slots of the tightest owner (what bounds the next insert).
   int64_t free_slots() const {
     size_t least = free_[0].size();
@@ -138,15 +139,14 @@ class ReplayIndex {
     *stepid = make_stepid(uid, index);
     const int64_t row = chunk.slot * cfg_.chunksize + index;
     chunk.fill += 1;
-    w->pending.emplace_back(uid, index);
+    w->pending.push(Pos(uid, index));
     chunk.refs += 1;
     index += 1;
     if (index < cfg_.chunksize) w->cursor.second = index;
     else rotate(chunk, *w);
-    if (static_cast<int64_t>(w->pending.size()) >= cfg_.length) {
+    if (w->pending.count >= cfg_.length) {
       metrics_[kInserts] += 1;
-      const Pos start = w->pending.front();
-      w->pending.pop_front();
+      const Pos start = w->pending.pop();
       insert_item(start);
       if (cfg_.online && w->steps_seen % cfg_.length == 0) fresh_.push_back(start);
     }
@@ -221,11 +221,14 @@ class ReplayIndex {
     return true;
   }
 
+  // 16-byte big-endian chunk uid | 4-byte big-endian row (replay.py:90-91).
   StepId make_stepid(uint64_t uid, int64_t index) const {
     StepId s;
-    for (int i = 0; i < 8; ++i) s.b[i] = static_cast<uint8_t>(cfg_.uid_hi >> (56 - 8 * i));
-    for (int i = 0; i < 8; ++i) s.b[8 + i] = static_cast<uint8_t>(uid >> (56 - 8 * i));
-    for (int i = 0; i < 4; ++i) s.b[16 + i] = static_cast<uint8_t>(static_cast<uint32_t>(index) >> (24 - 8 * i));
+    const uint64_t hi = __builtin_bswap64(cfg_.uid_hi), lo = __builtin_bswap64(uid);
+    const uint32_t row = __builtin_bswap32(static_cast<uint32_t>(index));
+    std::memcpy(s.b, &hi, 8);
+    std::memcpy(s.b + 8, &lo, 8);
+    std::memcpy(s.b + 16, &row, 4);
     return s;
   }
 
@@ -307,10 +310,29 @@ class ReplayIndex {
     return chunks_[c.uid] = c;
   }
 
+  // The last `length` steps of a worker: a fixed ring (a deque would allocate
+  // and free a block every few dozen steps).
+  struct PosRing {
+    std::vector<Pos> slot;
+    int64_t head = 0, count = 0;
+    void push(const Pos& p) {
+      int64_t at = head + count;
+      if (at >= static_cast<int64_t>(slot.size())) at -= static_cast<int64_t>(slot.size());
+      slot[at] = p;
+      ++count;
+    }
+    Pos pop() {
+      const Pos p = slot[head];
+      if (++head == static_cast<int64_t>(slot.size())) head = 0;
+      --count;
+      return p;
+    }
+  };
+
   struct Worker {
     Pos cursor;                 // (open chunk uid, next row)
     Chunk* open = nullptr;      // cached node of the open chunk
-    std::deque<Pos> pending;    // steps not yet the start of an item
+    PosRing pending;            // steps not yet the start of an item
     int64_t steps_seen = 0;     // online mode
   };
 
@@ -323,6 +345,7 @@ class ReplayIndex {
   Worker& make_worker(int64_t id) {
     auto& slot = workers_[id];
     slot = std::make_unique<Worker>();
+    slot->pending.slot.resize(static_cast<size_t>(cfg_.length));
     if (id >= 0 && id < 65536) {
       if (id >= static_cast<int64_t>(dense_.size())) dense_.resize(id + 1, nullptr);
       dense_[id] = slot.get();
