@@ -58,17 +58,22 @@ class SelectorCallbacks(C.Structure):
       ('prioritize', PRIORITIZE_FN)]
 
 
+def _run_builder():
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('_emb_build', HERE / 'build.py')
+  builder = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(builder)
+  builder.build(verbose=False)
+  return builder
+
+
 def _load():
   if not PATH.exists():
     # Git-ignored artefact: compile it in-tree on first use (hipcc cross-compiles
     # gfx950 without a GPU).  No hipcc -> no library -> ImportError, never a
     # CPU fallback.
     try:
-      import importlib.util
-      spec = importlib.util.spec_from_file_location('_emb_build', HERE / 'build.py')
-      builder = importlib.util.module_from_spec(spec)
-      spec.loader.exec_module(builder)
-      builder.build(verbose=False)
+      _run_builder()
     except Exception as e:
       raise ImportError(
           f'{PATH} is missing and could not be built ({e}). embodied_amd has no '
@@ -196,6 +201,64 @@ class _Api:
 
 
 api = _Api()
+
+
+def _load_fastcall():
+  """csrc/fastcall.c: the same exported functions called by address with cheap
+  argument conversion (ctypes spends 1-2 us on a 10-12 argument call).  None if
+  the shim is not built: `fast` then is the ctypes binding."""
+  import importlib.machinery
+  import importlib.util
+  import sysconfig
+  path = HERE / ('_emb_fastcall' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+  if os.environ.get('EMB_NO_FASTCALL') == '1':
+    return None
+  try:
+    if not path.exists() and 'EMB_LIB_PATH' not in os.environ:
+      _run_builder().build_fastcall(verbose=False)
+    if not path.exists() or path.stat().st_size == 0:
+      return None
+    loader = importlib.machinery.ExtensionFileLoader('_emb_fastcall', str(path))
+    spec = importlib.util.spec_from_loader('_emb_fastcall', loader)
+    module = importlib.util.module_from_spec(spec)
+    loader.exec_module(module)
+    return module
+  except Exception:
+    return None
+
+
+class _FastApi:
+  """`fast.emb_xxx(...)`: hot entry points through the call shim.  Arguments:
+  Python ints (addresses, sizes, handles as `.value`), None, floats, ctypes
+  arrays.  Same status handling as `api`."""
+
+  SHAPES = {
+      'emb_synth_env_step': 'ints', 'emb_mask_actions': 'ints',
+      'emb_replay_add': 'ints', 'emb_replay_add_masked': 'ints',
+      'emb_replay_sample': 'ints', 'emb_replay_update': 'ints',
+      'emb_replay_gather_rows': 'ints', 'emb_replay_scatter_rows': 'ints',
+      'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',
+  }
+
+  def __init__(self, module):
+    self.module = module
+    for name, shape in self.SHAPES.items():
+      if module is None:
+        setattr(self, name, getattr(api, name))
+        continue
+      addr = C.cast(getattr(lib, name), C.c_void_p).value
+      setattr(self, name, self._wrap(getattr(module, shape), addr))
+
+  @staticmethod
+  def _wrap(invoke, addr):
+    def call(*args):
+      status = invoke(addr, *args)
+      if status:
+        check(status)
+    return call
+
+
+fast = _FastApi(_load_fastcall())
 
 
 def raw_stream(device):

@@ -12,6 +12,7 @@ import pathlib
 import shutil
 import subprocess
 import sys
+import sysconfig
 
 HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
@@ -19,6 +20,9 @@ OUT = HERE / 'libembodied_hip.so'
 OBJ = HERE / 'build'
 SOURCES = ['kernels.hip', 'abi.cpp']
 ARCH = 'gfx950'
+# CPython call shim for the hottest entry points (csrc/fastcall.c): plain C,
+# links against nothing; the package falls back to ctypes without it.
+FASTCALL = HERE / ('_emb_fastcall' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
 
 
 def hipcc():
@@ -29,9 +33,9 @@ def hipcc():
 
 
 def stale():
-  if not OUT.exists():
+  if not OUT.exists() or not FASTCALL.exists():
     return True
-  built = OUT.stat().st_mtime
+  built = min(OUT.stat().st_mtime, FASTCALL.stat().st_mtime)
   deps = list(CSRC.glob('*')) + [HERE.parent / 'include' / 'embodied_hip.h']
   return any(p.stat().st_mtime > built for p in deps)
 
@@ -69,7 +73,29 @@ def build(force=False, verbose=True):
   os.replace(tmp, OUT)
   if verbose:
     print(f'built {OUT}')
+  build_fastcall(verbose)
   return OUT
+
+
+def build_fastcall(verbose=True):
+  """gcc -shared of csrc/fastcall.c against this interpreter's headers."""
+  gcc = shutil.which('gcc') or shutil.which('cc')
+  include = sysconfig.get_paths().get('include')
+  if not gcc or not include or not (pathlib.Path(include) / 'Python.h').exists():
+    if verbose:
+      print('no C compiler / Python.h: _emb_fastcall not built (ctypes binding only)', file=sys.stderr)
+    FASTCALL.touch()        # an empty file: "tried", import fails, ctypes is used
+    return None
+  tmp = FASTCALL.with_name(FASTCALL.name + '.tmp')
+  cmd = [gcc, '-O2', '-shared', '-fPIC', '-Wall', f'-I{include}', str(CSRC / 'fastcall.c'),
+         '-o', str(tmp)]
+  res = subprocess.run(cmd, capture_output=True, text=True)
+  if res.returncode:
+    raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
+  os.replace(tmp, FASTCALL)
+  if verbose:
+    print(f'built {FASTCALL}')
+  return FASTCALL
 
 
 if __name__ == '__main__':

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._lib import api
+from .._lib import api, fast
 from . import replay as replaylib
 
 _DTYPE_CODE = {
@@ -44,7 +44,7 @@ def mask_actions(value, is_last):
       value = value.contiguous()
     out = torch.empty_like(value)
     n = value.shape[0]
-    api.emb_mask_actions(
+    fast.emb_mask_actions(
         value.data_ptr(), out.data_ptr(), n, value.numel() // max(n, 1),
         _DTYPE_CODE[value.dtype], is_last.data_ptr(),
         _lib.raw_stream(value.device))

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._lib import api
+from .._lib import api, fast
 from . import limiters
 from . import selectors as selectorlib
 
@@ -103,6 +103,7 @@ class Replay:
     self._handle = C.c_void_p()
     api.emb_replay_create(
         C.byref(cfg), self._native._handle, int(seed), C.byref(self._handle))
+    self._h = self._handle.value      # plain int for the call shim
     self._keys = None
     self._keyid = {}
     self._lock = threading.RLock()
@@ -354,10 +355,10 @@ class Replay:
       while True:
         try:
           if masked is None:
-            api.emb_replay_add(self._handle, n, workers_ptr, ptrs, self._stream())
+            fast.emb_replay_add(self._h, n, workers_ptr, ptrs, self._stream())
           else:
-            api.emb_replay_add_masked(
-                self._handle, n, workers_ptr, ptrs, len(ids), ids, codes, outs,
+            fast.emb_replay_add_masked(
+                self._h, n, workers_ptr, ptrs, len(ids), ids, codes, outs,
                 flags.data_ptr(), self._stream())
           break
         except _lib.PoolFull:
@@ -377,8 +378,8 @@ class Replay:
       self._flush()
       out, ptrs = self._alloc_batch(batch, self.length)
       first = (C.c_uint8 * (batch * _lib.STEPID_BYTES))()
-      api.emb_replay_sample(
-          self._handle, batch, _lib.MODES[mode], ptrs, None, first, self._stream())
+      fast.emb_replay_sample(
+          self._h, batch, _lib.MODES[mode], ptrs, None, first, self._stream())
       self._reraise()
       # Host copy of stepid[:, 0] rides on the tensor object so `update` with
       # the same tensor needs no device read-back (a sync).
@@ -537,8 +538,8 @@ class Replay:
           keep.append(value)
           ids[j] = self._keyid[name]
           ptrs[j] = value.data_ptr()
-        api.emb_replay_update(
-            self._handle, B, T, first_ptr, len(data), ids, ptrs, self._stream())
+        fast.emb_replay_update(
+            self._h, B, T, first_ptr, len(data), ids, ptrs, self._stream())
       # replay.py:134: every call counts B*T steps, written or not.
       self._updates += steps
 

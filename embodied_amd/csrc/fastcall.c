@@ -1,0 +1,161 @@
+/* _emb_fastcall: a thin CPython call shim for the hottest entry points of
+ * libembodied_hip.so.
+ *
+ * The library's boundary is the C ABI in include/embodied_hip.h and the
+ * package binds it with ctypes (embodied_amd/_lib.py).  ctypes spends 1-2 us
+ * converting the arguments of a 10-12 argument call; a vectorised Driver step
+ * makes three such calls in ~35 us of host time.  This module calls the SAME
+ * exported functions through their addresses (taken from the ctypes handle),
+ * converting arguments itself: Python int / None / objects with the buffer
+ * protocol (ctypes arrays) -> 64-bit integer registers, Python float -> float.
+ * It links against nothing but libpython and knows three call shapes:
+ *
+ *   ints(addr, a0 .. aN)            every argument is a pointer or an integer
+ *   obs_stack(addr, 11 args)        emb_obs_stack  (two floats at 7, 8)
+ *   scan(addr, 10 or 11 args)       emb_scan_gae / emb_scan_lambda (floats at 6, 7)
+ *
+ * On x86-64 SysV an int32 parameter reads the low half of the 64-bit register
+ * or stack slot it is passed in, so integer-class arguments are all passed as
+ * uint64_t.  The GIL is released around the call, as ctypes does.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+
+typedef uint64_t u64;
+
+/* Python int (signed or unsigned 64-bit), None -> 0, or a buffer -> its address. */
+static int as_u64(PyObject* o, u64* out) {
+  if (PyLong_CheckExact(o)) {
+    int overflow = 0;
+    long long v = PyLong_AsLongLongAndOverflow(o, &overflow);
+    if (!overflow) {
+      if (v == -1 && PyErr_Occurred()) return -1;
+      *out = (u64)v;
+      return 0;
+    }
+    unsigned long long u = PyLong_AsUnsignedLongLong(o);
+    if (u == (unsigned long long)-1 && PyErr_Occurred()) return -1;
+    *out = (u64)u;
+    return 0;
+  }
+  if (o == Py_None) {
+    *out = 0;
+    return 0;
+  }
+  if (PyBool_Check(o) || PyLong_Check(o)) {
+    long long v = PyLong_AsLongLong(o);
+    if (v == -1 && PyErr_Occurred()) return -1;
+    *out = (u64)v;
+    return 0;
+  }
+  if (PyObject_CheckBuffer(o)) {
+    Py_buffer view;
+    if (PyObject_GetBuffer(o, &view, PyBUF_SIMPLE) < 0) return -1;
+    *out = (u64)(uintptr_t)view.buf;
+    PyBuffer_Release(&view);       /* the caller keeps the object alive over the call */
+    return 0;
+  }
+  PyErr_Format(PyExc_TypeError, "fastcall: cannot pass %s as a pointer or integer",
+               Py_TYPE(o)->tp_name);
+  return -1;
+}
+
+static int as_float(PyObject* o, float* out) {
+  double v = PyFloat_AsDouble(o);
+  if (v == -1.0 && PyErr_Occurred()) return -1;
+  *out = (float)v;
+  return 0;
+}
+
+#define MAX_INTS 14
+
+static PyObject* call_ints(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs < 1 || nargs > MAX_INTS + 1) {
+    PyErr_SetString(PyExc_TypeError, "fastcall.ints(addr, up to 14 arguments)");
+    return NULL;
+  }
+  u64 a[MAX_INTS + 1] = {0};
+  for (Py_ssize_t i = 0; i < nargs; ++i)
+    if (as_u64(args[i], &a[i]) < 0) return NULL;
+  void* fn = (void*)(uintptr_t)a[0];
+  int32_t status;
+  const int n = (int)nargs - 1;
+  Py_BEGIN_ALLOW_THREADS
+  /* Extra trailing arguments are harmless in this ABI: pass all 14 slots. */
+  (void)n;
+  status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(
+      a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14]);
+  Py_END_ALLOW_THREADS
+  return PyLong_FromLong(status);
+}
+
+/* emb_obs_stack(src, env_ids, n, pixels, channels, layout, out_dtype, scale, offset, dst, stream) */
+static PyObject* call_obs_stack(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 12) {
+    PyErr_SetString(PyExc_TypeError, "fastcall.obs_stack(addr, 11 arguments)");
+    return NULL;
+  }
+  u64 a[12];
+  float f[2];
+  for (int i = 0; i < 12; ++i) {
+    if (i == 8 || i == 9) {
+      if (as_float(args[i], &f[i - 8]) < 0) return NULL;
+    } else if (as_u64(args[i], &a[i]) < 0) {
+      return NULL;
+    }
+  }
+  void* fn = (void*)(uintptr_t)a[0];
+  int32_t status;
+  Py_BEGIN_ALLOW_THREADS
+  status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, float, float, u64, u64))fn)(
+      a[1], a[2], a[3], a[4], a[5], a[6], a[7], f[0], f[1], a[10], a[11]);
+  Py_END_ALLOW_THREADS
+  return PyLong_FromLong(status);
+}
+
+/* emb_scan_gae(rew, val, last, term, B, T, live_scale, lam, adv, tar, stream)      11
+ * emb_scan_lambda(last, term, rew, boot, B, T, disc, lam, ret, stream)             10 */
+static PyObject* call_scan(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 11 && nargs != 12) {
+    PyErr_SetString(PyExc_TypeError, "fastcall.scan(addr, 10 or 11 arguments)");
+    return NULL;
+  }
+  u64 a[12] = {0};
+  float f[2];
+  for (Py_ssize_t i = 0; i < nargs; ++i) {
+    if (i == 7 || i == 8) {
+      if (as_float(args[i], &f[i - 7]) < 0) return NULL;
+    } else if (as_u64(args[i], &a[i]) < 0) {
+      return NULL;
+    }
+  }
+  void* fn = (void*)(uintptr_t)a[0];
+  int32_t status;
+  Py_BEGIN_ALLOW_THREADS
+  if (nargs == 12)
+    status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, float, float, u64, u64, u64))fn)(
+        a[1], a[2], a[3], a[4], a[5], a[6], f[0], f[1], a[9], a[10], a[11]);
+  else
+    status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, float, float, u64, u64))fn)(
+        a[1], a[2], a[3], a[4], a[5], a[6], f[0], f[1], a[9], a[10]);
+  Py_END_ALLOW_THREADS
+  return PyLong_FromLong(status);
+}
+
+static PyMethodDef methods[] = {
+    {"ints", (PyCFunction)(void (*)(void))call_ints, METH_FASTCALL,
+     "ints(addr, *args) -> status: call an int32 f(pointers/integers...)"},
+    {"obs_stack", (PyCFunction)(void (*)(void))call_obs_stack, METH_FASTCALL,
+     "obs_stack(addr, *11 args) -> status"},
+    {"scan", (PyCFunction)(void (*)(void))call_scan, METH_FASTCALL,
+     "scan(addr, *10 or 11 args) -> status"},
+    {NULL, NULL, 0, NULL},
+};
+
+static struct PyModuleDef module = {
+    PyModuleDef_HEAD_INIT, "_emb_fastcall",
+    "Low-overhead calls into libembodied_hip.so by function address.", -1, methods,
+};
+
+PyMODINIT_FUNC PyInit__emb_fastcall(void) { return PyModule_Create(&module); }

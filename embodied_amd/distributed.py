@@ -156,8 +156,8 @@ def sample_packed(replay, batch, mode='train'):
     for i, offset in enumerate(layout.offsets):
       ptrs[i] = base + offset
     online = np.zeros(batch, np.uint8)
-    api.emb_replay_sample(
-        replay._handle, batch, _lib.MODES[mode], ptrs, _lib.ptr(online), None,
+    _lib.fast.emb_replay_sample(
+        replay._h, batch, _lib.MODES[mode], ptrs, _lib.ptr(online), None,
         replay._stream())
   return flat, PackedViews(flat, layout), SampleInfo(layout, online.astype(bool))
 

@@ -10,7 +10,7 @@ import torch
 
 from ..space import Space
 from .. import _lib
-from .._lib import api
+from .._lib import api, fast
 
 
 class SyntheticBatchEnv:
@@ -72,7 +72,7 @@ class SyntheticBatchEnv:
     else:
       obs = self._alloc()
     reset = acts['reset']
-    api.emb_synth_env_step(
+    fast.emb_synth_env_step(
         obs['image'].data_ptr(), obs['reward'].data_ptr(),
         obs['is_first'].data_ptr(), obs['is_last'].data_ptr(),
         obs['is_terminal'].data_ptr(), n, self.frame_bytes, self.env0,

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import api
+from ._lib import api, fast
 
 _OUT = {torch.uint8: _lib.U8, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16,
         torch.float32: _lib.F32}
@@ -29,7 +29,7 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
   first = layout == 'channels_first'
   shape = (n, c, h, w) if first else (n, h, w, c)
   out = _lib.empty(shape, dtype, frames.device)
-  api.emb_obs_stack(
+  fast.emb_obs_stack(
       frames.data_ptr(), _lib.ptr(ids), n, h * w, c,
       _lib.LAYOUT_CHANNELS_FIRST if first else _lib.LAYOUT_SAME, _OUT[dtype],
       float(scale), float(offset), out.data_ptr(), _stream(frames))

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import api
+from ._lib import api, fast
 
 
 def _stream(t):
@@ -54,7 +54,7 @@ def gae(rew, val, last, term, hor=200, lam=0.8):
   assert val.shape == last.shape == term.shape == (B, T)
   adv = _lib.empty((B, T - 1), torch.float32, dev)
   tar = _lib.empty((B, T - 1), torch.float32, dev)
-  api.emb_scan_gae(
+  fast.emb_scan_gae(
       rew.data_ptr(), val.data_ptr(), last.data_ptr(), term.data_ptr(), B, T,
       float(np.float32(1 - 1 / hor)), float(np.float32(lam)), adv.data_ptr(),
       tar.data_ptr(), _stream(rew))
@@ -71,7 +71,7 @@ def lambda_return(last, term, rew, val, boot, disc, lam):
   assert boot.shape == last.shape == term.shape == (B, T)
   assert val is None or tuple(val.shape) == (B, T)
   ret = _lib.empty((B, T - 1), torch.float32, dev)
-  api.emb_scan_lambda(
+  fast.emb_scan_lambda(
       last.data_ptr(), term.data_ptr(), rew.data_ptr(), boot.data_ptr(), B, T,
       float(np.float32(disc)), float(np.float32(lam)), ret.data_ptr(),
       _stream(rew))

@@ -46,3 +46,36 @@ def test_replay_refuses_cpu_device():
   import embodied_amd
   with pytest.raises(RuntimeError, match='no CPU fallback'):
     embodied_amd.Replay(length=2, capacity=4, device='cpu')
+
+
+def test_call_shim_reaches_the_same_exports():
+  """csrc/fastcall.c calls the exported functions by address: same status
+  handling as the ctypes binding, ints / None / ctypes arrays as arguments."""
+  import ctypes as C
+  import numpy as np
+  import pytest
+  from embodied_amd import _lib
+  assert _lib.fast.module is not None, 'the call shim builds wherever gcc and Python.h exist'
+  table = np.zeros(16, np.uint8)
+  p = table.ctypes.data
+  _lib.fast.emb_mask_actions(p, p, 0, 1, _lib.I32, p, None)           # n = 0: returns OK, no launch
+  _lib.fast.emb_mask_actions((C.c_uint8 * 4)(), p, 0, 1, _lib.I32, p, None)
+  with pytest.raises(ValueError, match='scan_gae'):
+    _lib.fast.emb_scan_gae(0, 0, 0, 0, 0, 2, 0.5, 0.5, 0, 0, 0)       # null pointers: EMB_ERR_INVALID
+  with pytest.raises(TypeError):
+    _lib.fast.emb_mask_actions(C.byref(C.c_int()), p, 0, 1, _lib.I32, p, None)
+  with pytest.raises(TypeError):
+    _lib.fast.emb_mask_actions('x', p, 0, 1, _lib.I32, p, None)
+
+
+def test_package_works_without_the_call_shim():
+  import os
+  import subprocess
+  import sys
+  code = ('from embodied_amd import _lib; assert _lib.fast.module is None; '
+          'import numpy as np; t = np.zeros(4, np.uint8); p = t.ctypes.data; '
+          '_lib.fast.emb_mask_actions(p, p, 0, 1, _lib.I32, p, None); print("ok")')
+  env = dict(os.environ, EMB_NO_FASTCALL='1')
+  out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  assert out.returncode == 0 and 'ok' in out.stdout, out.stderr
