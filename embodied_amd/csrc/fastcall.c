@@ -82,10 +82,24 @@ static PyObject* call_ints(PyObject* self, PyObject* const* args, Py_ssize_t nar
   int32_t status;
   const int n = (int)nargs - 1;
   Py_BEGIN_ALLOW_THREADS
-  /* Extra trailing arguments are harmless in this ABI: pass all 14 slots. */
-  (void)n;
-  status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(
-      a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14]);
+  switch (n) {      /* the exact arity: no reliance on callee ignoring extras */
+    case 0: status = ((int32_t(*)(void))fn)(); break;
+    case 1: status = ((int32_t(*)(u64))fn)(a[1]); break;
+    case 2: status = ((int32_t(*)(u64, u64))fn)(a[1], a[2]); break;
+    case 3: status = ((int32_t(*)(u64, u64, u64))fn)(a[1], a[2], a[3]); break;
+    case 4: status = ((int32_t(*)(u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4]); break;
+    case 5: status = ((int32_t(*)(u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5]); break;
+    case 6: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6]); break;
+    case 7: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7]); break;
+    case 8: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]); break;
+    case 9: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]); break;
+    case 10: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10]); break;
+    case 11: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11]); break;
+    case 12: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]); break;
+    case 13: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]); break;
+    case 14: status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64, u64))fn)(a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14]); break;
+    default: status = -1; break;
+  }
   Py_END_ALLOW_THREADS
   return PyLong_FromLong(status);
 }
