@@ -156,6 +156,11 @@ SIGNATURES = {
     'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],
     'emb_abstract_traj': [p, p, i64, i64, i32, p, p, p],
     'emb_synth_env_step': [p, p, p, p, p, i64, i64, i64, i64, p, p, p],
+    'emb_comm_unique_id': [p],
+    'emb_comm_init': [p, i32, i32, pp],
+    'emb_comm_allgather_traj': [p, p, p, i64, p],
+    'emb_comm_allreduce_grads': [p, p, i64, i32, p],
+    'emb_comm_destroy': [p],
 }
 
 lib.emb_last_error.restype = C.c_char_p

@@ -2,6 +2,9 @@
 #include "../../include/embodied_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the symbols are taken with dlsym
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -1140,6 +1143,115 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
                                  static_cast<uint8_t*>(is_terminal), n, frame_bytes, env0, episode_len,
                                  static_cast<const uint8_t*>(reset), static_cast<int32_t*>(counters),
                                  static_cast<hipStream_t>(stream)));
+  });
+}
+
+}  // extern "C"
+
+// -------------------------------------------------------------- collectives --
+
+namespace {
+
+struct Rccl {
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+// One RCCL per process: the copy that is already loaded (torch bundles one with
+// the same SONAME) if there is one, else the system's.
+const Rccl& rccl() {
+  static const Rccl table = [] {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) throw std::runtime_error(std::string("cannot load RCCL: ") + dlerror());
+    Rccl t;
+    auto sym = [&](const char* name) {
+      void* p = dlsym(lib, name);
+      if (!p) throw std::runtime_error(std::string("RCCL lacks ") + name);
+      return p;
+    };
+    t.get_unique_id = reinterpret_cast<decltype(t.get_unique_id)>(sym("ncclGetUniqueId"));
+    t.comm_init_rank = reinterpret_cast<decltype(t.comm_init_rank)>(sym("ncclCommInitRank"));
+    t.comm_destroy = reinterpret_cast<decltype(t.comm_destroy)>(sym("ncclCommDestroy"));
+    t.all_gather = reinterpret_cast<decltype(t.all_gather)>(sym("ncclAllGather"));
+    t.all_reduce = reinterpret_cast<decltype(t.all_reduce)>(sym("ncclAllReduce"));
+    t.error_string = reinterpret_cast<decltype(t.error_string)>(sym("ncclGetErrorString"));
+    return t;
+  }();
+  return table;
+}
+
+void rccl_ok(ncclResult_t r, const char* what) {
+  if (r != ncclSuccess)
+    throw std::runtime_error(std::string(what) + ": " + rccl().error_string(r));
+}
+
+}  // namespace
+
+struct emb_comm {
+  ncclComm_t comm = nullptr;
+  int32_t rank = 0, world = 1;
+};
+
+extern "C" {
+
+int32_t emb_comm_unique_id(uint8_t* id_out) {
+  return guarded([&] {
+    need(id_out, "comm_unique_id: null output");
+    static_assert(sizeof(ncclUniqueId) == EMB_COMM_ID_BYTES, "RCCL id size");
+    ncclUniqueId id;
+    rccl_ok(rccl().get_unique_id(&id), "ncclGetUniqueId");
+    std::memcpy(id_out, &id, sizeof(id));
+  });
+}
+
+int32_t emb_comm_init(const uint8_t* id, int32_t rank, int32_t world, emb_comm_t** out) {
+  return guarded([&] {
+    need(id && out && world >= 1 && rank >= 0 && rank < world, "comm_init: bad arguments");
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    auto comm = std::make_unique<emb_comm>();
+    comm->rank = rank;
+    comm->world = world;
+    rccl_ok(rccl().comm_init_rank(&comm->comm, world, uid, rank), "ncclCommInitRank");
+    *out = comm.release();
+  });
+}
+
+int32_t emb_comm_allgather_traj(emb_comm_t* comm, const void* send, void* recv,
+                                int64_t bytes_per_rank, void* stream) {
+  return guarded([&] {
+    need(comm && send && recv && bytes_per_rank >= 0, "comm_allgather_traj: bad arguments");
+    if (bytes_per_rank == 0) return;
+    rccl_ok(rccl().all_gather(send, recv, static_cast<size_t>(bytes_per_rank), ncclUint8, comm->comm,
+                              static_cast<hipStream_t>(stream)),
+            "ncclAllGather");
+  });
+}
+
+int32_t emb_comm_allreduce_grads(emb_comm_t* comm, void* buf, int64_t count, int32_t mean,
+                                 void* stream) {
+  return guarded([&] {
+    need(comm && buf && count >= 0, "comm_allreduce_grads: bad arguments");
+    if (count == 0) return;
+    rccl_ok(rccl().all_reduce(buf, buf, static_cast<size_t>(count), ncclFloat32,
+                              mean ? ncclAvg : ncclSum, comm->comm, static_cast<hipStream_t>(stream)),
+            "ncclAllReduce");
+  });
+}
+
+int32_t emb_comm_destroy(emb_comm_t* comm) {
+  return guarded([&] {
+    if (!comm) return;
+    if (comm->comm) rccl_ok(rccl().comm_destroy(comm->comm), "ncclCommDestroy");
+    delete comm;
   });
 }
 

@@ -381,3 +381,62 @@ class ShardedReplay:
           rep._handle, _lib.ptr(rows), rows.size, rep.length, ptrs, rep._stream())
     self._reduce(flat)
     return views
+
+
+class NativeComm:
+  """The two collectives on RCCL through the library's own C ABI
+  (`emb_comm_*`, include/embodied_hip.h) instead of torch.distributed: for hosts
+  that have no process group.  The 128-byte id made by rank 0 reaches the other
+  ranks through `share(id_bytes) -> id_bytes` (default: a torch.distributed
+  object broadcast if a group exists; world 1 needs none).  Collectives are
+  asynchronous on the caller's current stream."""
+
+  def __init__(self, rank=0, world=1, device=None, share=None):
+    import ctypes as C
+    from . import _lib
+    from ._lib import api
+    self._lib, self._api, self._C = _lib, api, C
+    self.rank, self.world = int(rank), int(world)
+    self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    torch.cuda.set_device(self.device)
+    ident = (C.c_uint8 * 128)()
+    if self.rank == 0:
+      api.emb_comm_unique_id(ident)
+    if self.world > 1:
+      if share is None:
+        def share(data):
+          box = [data]
+          dist.broadcast_object_list(box, src=0)
+          return box[0]
+      ident = (C.c_uint8 * 128).from_buffer_copy(share(bytes(ident)))
+    self._handle = C.c_void_p()
+    api.emb_comm_init(ident, self.rank, self.world, C.byref(self._handle))
+
+  def all_gather(self, flat, out=None):
+    """(nbytes,) uint8 per rank -> (world * nbytes,) uint8 on every rank."""
+    assert flat.dtype == torch.uint8 and flat.is_contiguous() and flat.is_cuda
+    if out is None:
+      out = torch.empty(self.world * flat.numel(), dtype=torch.uint8, device=flat.device)
+    self._api.emb_comm_allgather_traj(
+        self._handle, flat.data_ptr(), out.data_ptr(), flat.numel(),
+        self._lib.raw_stream(flat.device))
+    return out
+
+  def all_reduce(self, grads, mean=True):
+    """In-place sum or mean over ranks of a flat float32 buffer."""
+    assert grads.dtype == torch.float32 and grads.is_contiguous() and grads.is_cuda
+    self._api.emb_comm_allreduce_grads(
+        self._handle, grads.data_ptr(), grads.numel(), int(bool(mean)),
+        self._lib.raw_stream(grads.device))
+    return grads
+
+  def close(self):
+    handle, self._handle = self._handle, None
+    if handle:
+      self._api.emb_comm_destroy(handle)
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

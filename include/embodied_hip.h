@@ -283,6 +283,27 @@ int32_t emb_scan_director(const void* rew, const void* cont, const void* value, 
 int32_t emb_abstract_traj(const void* reward, const void* cont, int64_t T, int64_t B, int32_t k,
                           void* reward_out, void* cont_out, void* stream);
 
+/* ----------------------------------------------------------- collectives --
+ * The two exchange steps of the sharded path on RCCL directly (xGMI inside one
+ * node), for hosts that do not go through torch.distributed:
+ *   trajectories  -> one all-gather of the packed (B, L, S) byte block per rank
+ *   gradients     -> all-reduce (sum or mean) of one flat f32 buffer
+ *                    (embodied/jax/opt.py:52-54's pmean)
+ * RCCL is opened with dlopen at the first call (the library itself does not
+ * link against it).  Rank 0 makes the 128-byte id, the caller hands it to the
+ * other ranks by whatever means it has (file, socket, torch.distributed
+ * store), every rank calls emb_comm_init with the device it uses current.
+ * Collectives are asynchronous on `stream`; buffers are caller-owned.         */
+typedef struct emb_comm emb_comm_t;
+#define EMB_COMM_ID_BYTES 128
+int32_t emb_comm_unique_id(uint8_t* id_out /* [EMB_COMM_ID_BYTES] */);
+int32_t emb_comm_init(const uint8_t* id, int32_t rank, int32_t world, emb_comm_t** out);
+int32_t emb_comm_allgather_traj(emb_comm_t* comm, const void* send, void* recv,
+                                int64_t bytes_per_rank, void* stream);
+int32_t emb_comm_allreduce_grads(emb_comm_t* comm, void* buf, int64_t count, int32_t mean,
+                                 void* stream);
+int32_t emb_comm_destroy(emb_comm_t* comm);
+
 /* ---- synthetic vector env (benchmark / test input) ---------- */
 /* Episode logic of embodied/envs/dummy.py:38-48 for n device-resident envs;
  * counters = device int32[2n] state; reset = device u8[n] or NULL.           */

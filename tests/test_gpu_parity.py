@@ -691,3 +691,20 @@ def test_mask_fused_into_insert_equals_mask_then_insert(emb, dtype):
     zero_or_nan = (masked == 0) | masked.isnan()
     assert zero_or_nan.all()
     assert torch.signbit(masked[masked == 0]).any()          # -x * 0 = -0.0 survives
+
+
+def test_native_rccl_collectives_world1(emb):
+  """emb_comm_* (RCCL opened with dlopen, no torch.distributed): one rank on the
+  one GPU of the test box -- id, communicator, both collectives, teardown.
+  With one rank the all-gather is a copy and sum == mean == identity."""
+  from embodied_amd import distributed as D
+  comm = D.NativeComm(rank=0, world=1)
+  flat = torch.randint(0, 255, (3 << 20,), dtype=torch.uint8, device='cuda')
+  out = comm.all_gather(flat)
+  grads = torch.randn(1 << 20, device='cuda')
+  want = grads.clone()
+  comm.all_reduce(grads, mean=True)
+  comm.all_reduce(grads, mean=False)
+  torch.cuda.synchronize()
+  assert torch.equal(out, flat) and torch.equal(grads, want)
+  comm.close()
