@@ -133,6 +133,10 @@ def main():
   local = int(os.environ.get('LOCAL_RANK', '0'))
   # (LOCAL_RANK wraps so that the multi-rank control flow can be exercised on a
   # box with fewer GPUs: EMB_BENCH_BACKEND=gloo, several ranks on one device.)
+  if rank != 0:
+    # stdout carries exactly one JSON line (rank 0's); whatever other ranks or
+    # their libraries print (RCCL's NCCL_DEBUG=VERSION banner) goes to stderr.
+    os.dup2(sys.stderr.fileno(), sys.stdout.fileno())
   local %= max(torch.cuda.device_count(), 1)
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
@@ -287,6 +291,11 @@ def main():
     cpu = cpu_baseline(args)
 
   if rank == 0:
+    # Libraries that wrote to C stdio (RCCL's version banner) come out first, so
+    # that the JSON line is the last line on stdout.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
     print(json.dumps({
         'metric': 'env steps/sec + learner train-steps/sec, 64 envs 84x84x4 obs, 1/2/4/8 GPU',
         'value': round(env_steps / elapsed, 1),
@@ -311,7 +320,7 @@ def main():
                            if use_dist else 'single',
         },
         'roofline': roofline, 'cpu_baseline': cpu,
-    }))
+    }), flush=True)
   if use_dist:
     comm.close()
     dist.destroy_process_group()
