@@ -168,7 +168,11 @@ def main():
   comm = None
   if use_dist:
     from embodied_amd import distributed as D
-    comm = D.CommThread(device)
+    if os.environ.get('EMB_BENCH_COMM') == 'thread':
+      comm = D.CommThread(device)
+      issue = comm.submit
+    else:
+      issue = D.Done
 
   def train_step():
     if not use_dist and args.workload == 'dreamer':
@@ -202,14 +206,16 @@ def main():
         send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
       else:
         send = None
-      # The collectives are issued from the comm thread (c10d releases the GIL
-      # while it enqueues), in the same order on every rank.
+      # Process-group level async collectives (no Python-side checking), issued
+      # inline in the same order on every rank.  EMB_BENCH_COMM=thread issues
+      # them from a helper thread instead (measured slower: the GIL changes
+      # hands at every library call of the stepping thread).
       if send is not None:
         gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
-        pending.append(comm.submit(lambda g=gathered, s=send: D.async_all_gather(g, s)))
+        pending.append(issue(lambda g=gathered, s=send: D.async_all_gather(g, s)))
         state_keep[:] = [gathered, send]
       if args.grad_numel:
-        pending.append(comm.submit(lambda: D.async_all_reduce(grads)))
+        pending.append(issue(lambda: D.async_all_reduce(grads)))
       # When the links are the bottleneck the host could queue train steps far
       # ahead of the GPU (one gathered buffer each): stay within 8 train steps.
       marks.append(torch.cuda.Event())
@@ -322,7 +328,8 @@ def main():
         'roofline': roofline, 'cpu_baseline': cpu,
     }), flush=True)
   if use_dist:
-    comm.close()
+    if comm is not None:
+      comm.close()
     dist.destroy_process_group()
 
 

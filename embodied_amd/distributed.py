@@ -187,6 +187,18 @@ def async_all_reduce(tensor):
     return dist.all_reduce(tensor, async_op=True)
 
 
+class Done:
+  """`CommThread.submit` without the thread: runs `fn` now; `.result()` returns
+  what it returned."""
+  __slots__ = ('_value',)
+
+  def __init__(self, fn):
+    self._value = fn()
+
+  def result(self):
+    return self._value
+
+
 class CommThread:
   """Issues collectives from a helper thread so their host cost (tens of
   microseconds each inside c10d, with the GIL released) does not sit on the
