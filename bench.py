@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  p.add_argument('--steps', type=int, default=5000)
-  p.add_argument('--warmup', type=int, default=500)
+  p.add_argument('--steps', type=int, default=50000)    # ~2 s timed at ~40 us per step
+  p.add_argument('--warmup', type=int, default=2000)
   p.add_argument('--envs', type=int, default=64)
   p.add_argument('--batch', type=int, default=16)
   p.add_argument('--length', type=int, default=64)
