@@ -10,9 +10,9 @@ O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$O/bench_default.json" 2>/dev/null
-python "$R/bench.py" --workload dreamer --steps 1000 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
+python "$R/bench.py" --workload dreamer --steps 5000 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -o st -- \
-  python "$R/bench.py" --steps 1000 --no-cpu-baseline > "$O/stats_bench.log" 2>&1
+  python "$R/bench.py" --no-cpu-baseline > "$O/stats_bench.log" 2>&1
 cp /tmp/st/st_kernel_stats.csv "$O/kernel_stats.csv"
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter --kernel-trace --output-format csv -d /tmp/p_$counter -o p -- \
