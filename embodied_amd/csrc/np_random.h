@@ -9,7 +9,9 @@
 // numpy itself in tests/test_host_rng.py.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
+#include <stdexcept>
 #include <vector>
 
 namespace emb {
@@ -146,6 +148,18 @@ class NpRandom {
   // Generator.choice(k, p=probs): cdf = cumsum(p); cdf /= cdf[-1];
   // searchsorted(cdf, random(), side='right').  `cdf` is scratch of size k.
   int choice(const double* probs, int k, double* cdf) {
+    // The checks Generator.choice makes before it draws (same messages): a
+    // sample tree whose masses went NaN ends here, as it does in the reference.
+    double check = 0.0;
+    bool negative = false;
+    for (int i = 0; i < k; ++i) {
+      check += probs[i];
+      negative = negative || probs[i] < 0;
+    }
+    if (check != check) throw std::invalid_argument("probabilities contain NaN");
+    if (negative) throw std::invalid_argument("probabilities are not non-negative");
+    if (std::fabs(check - 1.0) > 1.4901161193847656e-08)
+      throw std::invalid_argument("probabilities do not sum to 1");
     double acc = 0.0;
     for (int i = 0; i < k; ++i) {
       acc = (i == 0) ? probs[0] : acc + probs[i];
