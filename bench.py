@@ -55,6 +55,9 @@ def parse():
   p.add_argument('--workload', default='ppo', choices=['ppo', 'dreamer'],
                  help='ppo = BASELINE configs[1] (default); dreamer = configs[2]: 1M-step '
                       'uniform replay, train_ratio 32, 40 KB/step latents written back')
+  p.add_argument('--selector', default='uniform', choices=['uniform', 'prioritized'],
+                 help='prioritized = ppo/configs.yaml:42 (exponent .8, maxfrac .5, initial inf, '
+                      'zero_on_sample) instead of the default fracs.uniform 1.0')
   p.add_argument('--host-envs', action='store_true',
                  help='step 64 numpy envs on the host and upload through the pinned slab '
                       '(PCIe-inclusive rate; never the headline value)')
@@ -86,9 +89,13 @@ def build_path(args, rank, device):
   from embodied_amd.envs import synthetic
   L = args.consec * args.length + args.context
   dreamer = args.workload == 'dreamer'
+  selector = None
+  if args.selector == 'prioritized':
+    selector = emb.selectors.Prioritized(
+        exponent=0.8, maxfrac=0.5, initial=float('inf'), zero_on_sample=True, seed=0)
   replay = emb.Replay(
       length=L, capacity=args.capacity, chunksize=1024, online=not dreamer, seed=0,
-      device=device, replica=rank, reuse_outputs=args.reuse_outputs)
+      selector=selector, device=device, replica=rank, reuse_outputs=args.reuse_outputs)
   n = args.envs
   if args.host_envs:
     fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]
@@ -316,7 +323,8 @@ def main():
                 f'{"dreamerv3_1M_uniform" if args.workload == "dreamer" else "ppo_atari_pong"}_64env: '
                 f'64 {"host (numpy, PCIe upload)" if args.host_envs else "device"} envs/GPU, 84x84x4 u8, '
                 f'Replay(length={L}, capacity={args.capacity}, '
-                f'{"uniform, latents written back" if args.workload == "dreamer" else "online"}), '
+                f'{"uniform, latents written back" if args.workload == "dreamer" else "online"}'
+                f'{", prioritized selector" if args.selector == "prioritized" else ""}), '
                 f'B={B}, T={T}, train_ratio={args.train_ratio}, '
                 f'{"lambda-return" if args.workload == "dreamer" else "GAE"}'),
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,

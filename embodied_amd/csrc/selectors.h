@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "np_random.h"
@@ -174,7 +175,8 @@ class SampleTree {
   double root_mass() const { return root_->mass; }
   const Node* root() const { return root_; }
 
-  void insert(int64_t key, double mass) {
+  // Returns the leaf: it stays the same node until `remove(key)`.
+  Node* insert(int64_t key, double mass) {
     if (leaves_.count(key)) throw std::runtime_error("SampleTree: duplicate key");
     Node* spot;
     if (!tail_) {
@@ -204,6 +206,7 @@ class SampleTree {
     attach(spot, leaf);
     leaves_[key] = leaf;
     tail_ = leaf;
+    return leaf;
   }
 
   void remove(int64_t key) {
@@ -236,6 +239,38 @@ class SampleTree {
     if (it == leaves_.end()) throw std::out_of_range("SampleTree: unknown key");
     it->second->mass = mass;
     resum(it->second->up);
+  }
+
+  // Several leaves at once: set every mass, then re-sum each ancestor (a node
+  // is the fresh sum of its children, so the result is what one `update` per
+  // leaf leaves behind; neighbouring leaves share their ancestors).
+  void update_many(const int64_t* keys, const double* masses, int64_t n) {
+    handles_.resize(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; ++i) {
+      auto it = leaves_.find(keys[i]);
+      if (it == leaves_.end()) throw std::out_of_range("SampleTree: unknown key");
+      handles_[static_cast<size_t>(i)] = it->second;
+    }
+    update_leaves(handles_.data(), masses, n);
+  }
+  void update_leaves(Node* const* leaves, const double* masses, int64_t n) {
+    dirty_.clear();
+    for (int64_t i = 0; i < n; ++i) {
+      leaves[i]->mass = masses[i];
+      if (leaves[i]->up) dirty_.push_back(leaves[i]->up);
+    }
+    while (!dirty_.empty()) {
+      std::sort(dirty_.begin(), dirty_.end());
+      dirty_.erase(std::unique(dirty_.begin(), dirty_.end()), dirty_.end());
+      next_.clear();
+      for (Node* node : dirty_) {
+        double total = 0.0;
+        for (Node* kid : node->kids) total += kid->mass;
+        node->mass = total;
+        if (node->up) next_.push_back(node->up);
+      }
+      dirty_.swap(next_);
+    }
   }
 
   int64_t sample() {
@@ -295,8 +330,21 @@ class SampleTree {
   Node* tail_ = nullptr;
   std::unordered_map<int64_t, Node*> leaves_;
   std::vector<double> mass_, prob_, cdf_;
+  std::vector<Node*> dirty_, next_, handles_;
 };
 
+// Priority-proportional sampling over per-step priorities (selectors.py:128-197).
+//
+// The reference keeps, per item, the list of its step ids, per step id a
+// priority and the list of items that contain it, and re-aggregates an item
+// from its steps' priorities whenever one of them changes.  A Replay feeds this
+// selector sliding windows: item k+1 of a worker stream is item k shifted by
+// one step, and items leave oldest-first.  For that pattern ("stream mode") the
+// steps of a stream live in ONE contiguous array, items are just their start
+// position, "the items that contain step p" is the index range [p-n+1, p], and
+// an insert touches one new step instead of n records.  Anything else -- items
+// with arbitrary step lists, out-of-order removals -- switches the selector to
+// the general representation for good (`migrate`), with identical results.
 class Prioritized : public Selector {
  public:
   Prioritized(double exponent, double initial, bool zero_on_sample,
@@ -305,82 +353,397 @@ class Prioritized : public Selector {
         maxfrac_(maxfrac), tree_(branching, seed) {
     if (maxfrac < 0 || maxfrac > 1) throw std::invalid_argument("maxfrac");
   }
+  ~Prioritized() override {
+    for (Stream* st : streams_) delete st;
+  }
 
   int64_t sample() override {
     const int64_t key = tree_.sample();
-    if (zero_) {
-      const auto steps = items_.at(key);  // copy: prioritize() reads items_
-      std::vector<double> zeros(steps.size(), 0.0);
-      prioritize(steps.data(), zeros.data(), static_cast<int64_t>(steps.size()));
+    if (!zero_) return key;
+    // selectors.py:163-168: the drawn item's steps go to priority 0.
+    if (general_) {
+      begin_touch();
+      for (Step* step : items_.at(key).steps) {
+        set_priority(*step, 0.0);
+        touch_users(*step);
+      }
+      refresh_touched();
+      return key;
     }
+    const auto [st, start] = owner_.at(key);
+    ranges_.clear();
+    for (int64_t pos = start; pos < start + st->n; ++pos) {
+      set_slot(st->steps[pos - st->step0], 0.0);
+      touch_range(st, pos);
+    }
+    refresh_ranges();
     return key;
   }
-  int64_t size() const override { return static_cast<int64_t>(items_.size()); }
+  int64_t size() const override {
+    return static_cast<int64_t>(general_ ? items_.size() : owner_.size());
+  }
 
   void insert(int64_t key, const StepId* steps, int n) override {
     if (n <= 0) throw std::invalid_argument("Prioritized: item without steps");
-    auto& mine = items_[key];
-    mine.assign(steps, steps + n);
-    for (int i = 0; i < n; ++i) {
-      users_[steps[i]].push_back(key);
-      prio_.emplace(steps[i], initial_);
-    }
-    tree_.insert(key, mass_of(key));
+    if (!general_ && !stream_insert(key, steps, n)) migrate();
+    if (general_) general_insert(key, steps, n);
   }
 
   void remove(int64_t key) override {
-    tree_.remove(key);
-    auto it = items_.find(key);
-    for (const StepId& sid : it->second) {
-      auto& group = users_[sid];
-      group.erase(std::find(group.begin(), group.end(), key));
-      if (group.empty()) {
-        users_.erase(sid);
-        prio_.erase(sid);
+    if (!general_) {
+      auto it = owner_.find(key);
+      if (it == owner_.end()) throw std::out_of_range("Prioritized: unknown key");
+      Stream* st = it->second.first;
+      if (st->items[0] == key) {
+        tree_.remove(key);
+        owner_.erase(it);
+        st->items.pop_front();
+        st->leaves.pop_front();
+        st->item0 += 1;
+        // Steps in front of the oldest remaining item belong to no item any
+        // more: their priority goes with them (selectors.py:180-185).
+        const int64_t keep_from = st->items.size() ? st->item0 : st->step0 + static_cast<int64_t>(st->steps.size());
+        while (st->step0 < keep_from) {
+          where_.erase(st->steps[0].id);
+          st->steps.pop_front();
+          st->step0 += 1;
+        }
+        if (!st->items.size()) {
+          streams_.erase(st);
+          delete st;
+        }
+        return;
       }
+      migrate();                      // not the oldest item of its stream
     }
-    items_.erase(it);
+    general_remove(key);
   }
 
   bool can_prioritize() const override { return true; }
 
+  // selectors.py:143-158: set the priorities, then re-aggregate every item that
+  // contains one of the steps -- once per item, whatever the order: a tree
+  // node's mass is always the fresh sum of its children.
   void prioritize(const StepId* steps, const double* prios, int64_t n) override {
-    touched_.clear();
-    for (int64_t i = 0; i < n; ++i) {
-      auto it = users_.find(steps[i]);
-      if (it == users_.end()) continue;  // step no longer in any item
-      prio_[steps[i]] = prios[i];
-      touched_.insert(touched_.end(), it->second.begin(), it->second.end());
+    if (general_) {
+      begin_touch();
+      for (int64_t i = 0; i < n; ++i) {
+        auto it = steps_.find(steps[i]);
+        if (it == steps_.end()) continue;  // step no longer in any item
+        set_priority(it->second, prios[i]);
+        touch_users(it->second);
+      }
+      refresh_touched();
+      return;
     }
-    std::sort(touched_.begin(), touched_.end());
-    touched_.erase(std::unique(touched_.begin(), touched_.end()), touched_.end());
-    for (int64_t key : touched_) tree_.update(key, mass_of(key));
+    ranges_.clear();
+    Stream* st = nullptr;
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      // Rows of consecutive steps: try the slot after the previous one before
+      // hashing the 20-byte id.
+      if (st && pos + 1 < st->step0 + static_cast<int64_t>(st->steps.size()) &&
+          st->steps[pos + 1 - st->step0].id == steps[i]) {
+        pos += 1;
+      } else {
+        auto it = where_.find(steps[i]);
+        if (it == where_.end()) {
+          st = nullptr;
+          continue;                  // step no longer in any item
+        }
+        st = it->second.first;
+        pos = it->second.second;
+      }
+      set_slot(st->steps[pos - st->step0], prios[i]);
+      touch_range(st, pos);
+    }
+    refresh_ranges();
   }
 
  private:
-  // maxfrac * max + (1 - maxfrac) * mean over prio ** exponent (py:187-197).
-  double mass_of(int64_t key) {
-    const auto& steps = items_.at(key);
+  // ---------------------------------------------------------- shared pieces --
+  double powered(double prio) const { return exponent_ != 1.0 ? std::pow(prio, exponent_) : prio; }
+  // maxfrac * max + (1 - maxfrac) * mean over prio ** exponent, summed left to
+  // right like the reference's sum() (selectors.py:187-197).
+  double finish(double total, double top, int64_t count) const {
+    const double mean = total / static_cast<double>(count);
+    if (maxfrac_ != 0.0) return maxfrac_ * top + (1 - maxfrac_) * mean;
+    return mean;
+  }
+
+  // A vector that is appended to at the back and consumed from the front.
+  template <typename T>
+  struct Sliding {
+    std::vector<T> v;
+    size_t off = 0;
+    size_t size() const { return v.size() - off; }
+    T& operator[](int64_t i) { return v[off + static_cast<size_t>(i)]; }
+    const T& operator[](int64_t i) const { return v[off + static_cast<size_t>(i)]; }
+    void push_back(const T& x) { v.push_back(x); }
+    void pop_front() {
+      ++off;
+      if (off >= 256 && off * 2 >= v.size()) {
+        v.erase(v.begin(), v.begin() + static_cast<std::ptrdiff_t>(off));
+        off = 0;
+      }
+    }
+  };
+
+  // ------------------------------------------------------------ stream mode --
+  struct Slot {
+    double prio, powered;
+    StepId id;
+  };
+  struct Stream {
+    int n = 0;              // steps per item
+    int64_t step0 = 0;      // position of steps[0]
+    int64_t item0 = 0;      // start position of items[0]; items[j] starts at item0 + j
+    Sliding<Slot> steps;
+    Sliding<int64_t> items; // keys
+    Sliding<SampleTree::Node*> leaves;   // their tree leaves
+  };
+  struct Range {
+    Stream* st;
+    int64_t lo, hi;         // item start positions, inclusive
+  };
+
+  void set_slot(Slot& slot, double prio) const {
+    slot.prio = prio;
+    slot.powered = powered(prio);
+  }
+  double stream_mass(const Stream& st, int64_t start) const {
     double total = 0.0, top = -INFINITY;
-    for (const StepId& sid : steps) {
-      double v = prio_.at(sid);
-      if (exponent_ != 1.0) v = std::pow(v, exponent_);
+    const int64_t first = start - st.step0;
+    for (int64_t i = first; i < first + st.n; ++i) {
+      const double v = st.steps[i].powered;
       total += v;
       top = (v > top) ? v : top;
     }
-    const double mean = total / static_cast<double>(steps.size());
-    if (maxfrac_ != 0.0) return maxfrac_ * top + (1 - maxfrac_) * mean;
-    return mean;
+    return finish(total, top, st.n);
+  }
+  // Items of `st` that contain the step at `pos`.
+  void touch_range(Stream* st, int64_t pos) {
+    const int64_t last = st->item0 + static_cast<int64_t>(st->items.size()) - 1;
+    const int64_t lo = std::max(st->item0, pos - st->n + 1), hi = std::min(last, pos);
+    if (lo > hi) return;
+    if (!ranges_.empty() && ranges_.back().st == st && lo <= ranges_.back().hi + 1 && hi >= ranges_.back().lo - 1) {
+      ranges_.back().lo = std::min(ranges_.back().lo, lo);
+      ranges_.back().hi = std::max(ranges_.back().hi, hi);
+    } else {
+      ranges_.push_back({st, lo, hi});
+    }
+  }
+  void refresh_ranges() {
+    std::sort(ranges_.begin(), ranges_.end(), [](const Range& a, const Range& b) {
+      return a.st != b.st ? a.st < b.st : a.lo < b.lo;
+    });
+    leaves_.clear();
+    masses_.clear();
+    const Stream* st = nullptr;
+    int64_t done = 0;        // next start position not yet emitted for `st`
+    for (const Range& r : ranges_) {
+      if (r.st != st) {
+        st = r.st;
+        done = r.lo;
+      }
+      for (int64_t start = std::max(done, r.lo); start <= r.hi; ++start) {
+        leaves_.push_back(st->leaves[start - st->item0]);
+        masses_.push_back(stream_mass(*st, start));
+      }
+      done = std::max(done, r.hi + 1);
+    }
+    tree_.update_leaves(leaves_.data(), masses_.data(), static_cast<int64_t>(leaves_.size()));
+  }
+
+  // True if the item was taken in stream mode; false if it does not fit (the
+  // caller migrates).  Nothing is modified when it returns false.
+  bool stream_insert(int64_t key, const StepId* ids, int n) {
+    if (n < 2 || owner_.count(key)) return false;
+    auto newest = where_.find(ids[n - 1]);
+    if (newest != where_.end()) return false;           // the newest step must be new
+    auto prev = where_.find(ids[n - 2]);
+    Stream* st = nullptr;
+    if (prev != where_.end()) {
+      // Next window of an existing stream: ids[n-2] is that stream's newest
+      // step, and ids[0 .. n-3] are the steps before it.
+      st = prev->second.first;
+      const int64_t pos = prev->second.second;
+      const int64_t last = st->step0 + static_cast<int64_t>(st->steps.size()) - 1;
+      if (st->n != n || pos != last) return false;
+      const int64_t start = pos - (n - 2);
+      if (start != st->item0 + static_cast<int64_t>(st->items.size())) return false;
+      for (int i = 0; i < n - 2; ++i)
+        if (!(st->steps[start + i - st->step0].id == ids[i])) return false;
+      Slot slot;
+      slot.id = ids[n - 1];
+      set_slot(slot, initial_);
+      st->steps.push_back(slot);
+      where_.emplace(ids[n - 1], std::make_pair(st, pos + 1));
+      st->items.push_back(key);
+      owner_.emplace(key, std::make_pair(st, start));
+      st->leaves.push_back(tree_.insert(key, stream_mass(*st, start)));
+      return true;
+    }
+    // First window of a new stream: none of its steps may be known, and they
+    // must be distinct.
+    for (int i = 0; i < n - 1; ++i) {
+      if (where_.count(ids[i])) return false;
+      for (int j = i + 1; j < n; ++j)
+        if (ids[i] == ids[j]) return false;
+    }
+    st = new Stream();
+    streams_.insert(st);
+    st->n = n;
+    for (int i = 0; i < n; ++i) {
+      Slot slot;
+      slot.id = ids[i];
+      set_slot(slot, initial_);
+      st->steps.push_back(slot);
+      where_.emplace(ids[i], std::make_pair(st, static_cast<int64_t>(i)));
+    }
+    st->items.push_back(key);
+    owner_.emplace(key, std::make_pair(st, int64_t{0}));
+    st->leaves.push_back(tree_.insert(key, stream_mass(*st, 0)));
+    return true;
+  }
+
+  // Rebuild the general representation from the streams (the tree is shared and
+  // stays as it is).  Items are re-created in key order = insertion order, so
+  // every step's user list has the order the reference's would have.
+  void migrate() {
+    std::vector<int64_t> keys;
+    keys.reserve(owner_.size());
+    for (const auto& kv : owner_) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    std::vector<StepId> ids;
+    for (int64_t key : keys) {
+      const auto [st, start] = owner_.at(key);
+      ids.clear();
+      for (int64_t pos = start; pos < start + st->n; ++pos) ids.push_back(st->steps[pos - st->step0].id);
+      general_link(key, ids.data(), st->n);
+      for (int64_t pos = start; pos < start + st->n; ++pos) {
+        const Slot& slot = st->steps[pos - st->step0];
+        Step& step = steps_.at(slot.id);
+        step.prio = slot.prio;
+        step.powered = slot.powered;
+      }
+    }
+    for (Stream* st : streams_) delete st;
+    streams_.clear();
+    where_.clear();
+    owner_.clear();
+    general_ = true;
+  }
+
+  // ----------------------------------------------------------- general mode --
+  struct Item;
+  // One time step: its priority, priority ** exponent (computed when the
+  // priority is set, not every time an item is aggregated) and the items that
+  // contain it (live ones are users[head:]).
+  struct Step {
+    double prio = 0.0, powered = 0.0;
+    std::vector<Item*> users;
+    size_t head = 0;
+    const StepId* id = nullptr;
+  };
+  struct Item {
+    int64_t key = 0;
+    uint64_t stamp = 0;
+    std::vector<Step*> steps;
+  };
+
+  void set_priority(Step& step, double prio) const {
+    step.prio = prio;
+    step.powered = powered(prio);
+  }
+  double mass_of(const Item& item) const {
+    double total = 0.0, top = -INFINITY;
+    for (const Step* step : item.steps) {
+      const double v = step->powered;
+      total += v;
+      top = (v > top) ? v : top;
+    }
+    return finish(total, top, static_cast<int64_t>(item.steps.size()));
+  }
+  // Item <-> step links; new steps start at the initial priority.
+  Item& general_link(int64_t key, const StepId* steps, int n) {
+    Item& mine = items_[key];
+    mine.key = key;
+    mine.steps.clear();
+    mine.steps.reserve(n);
+    for (int i = 0; i < n; ++i) {
+      auto found = steps_.find(steps[i]);
+      if (found == steps_.end()) {
+        found = steps_.emplace(steps[i], Step()).first;
+        found->second.id = &found->first;
+        set_priority(found->second, initial_);
+      }
+      mine.steps.push_back(&found->second);       // node addresses are stable
+    }
+    for (Step* step : mine.steps) step->users.push_back(&mine);
+    return mine;
+  }
+  void general_insert(int64_t key, const StepId* steps, int n) {
+    tree_.insert(key, mass_of(general_link(key, steps, n)));
+  }
+  void general_remove(int64_t key) {
+    tree_.remove(key);
+    auto it = items_.find(key);
+    Item* gone = &it->second;
+    for (Step* step : gone->steps) {
+      auto& users = step->users;
+      // Oldest item first is the usual eviction order: it sits at `head`.
+      // (An item may list the same step twice: then the step may be gone already.)
+      if (step->head < users.size() && users[step->head] == gone) {
+        ++step->head;
+      } else {
+        users.erase(std::find(users.begin() + static_cast<std::ptrdiff_t>(step->head), users.end(), gone));
+      }
+      if (step->head == users.size()) steps_.erase(*step->id);   // its priority goes with it (selectors.py:180-185)
+    }
+    items_.erase(it);
+  }
+  void begin_touch() {
+    touched_.clear();
+    ++epoch_;
+  }
+  void touch_users(Step& step) {
+    for (size_t i = step.head; i < step.users.size(); ++i) {
+      Item* item = step.users[i];
+      if (item->stamp == epoch_) continue;
+      item->stamp = epoch_;
+      touched_.push_back(item);
+    }
+  }
+  void refresh_touched() {
+    keys_.resize(touched_.size());
+    masses_.resize(touched_.size());
+    for (size_t i = 0; i < touched_.size(); ++i) {
+      keys_[i] = touched_[i]->key;
+      masses_[i] = mass_of(*touched_[i]);
+    }
+    tree_.update_many(keys_.data(), masses_.data(), static_cast<int64_t>(touched_.size()));
   }
 
   double exponent_, initial_;
   bool zero_;
   double maxfrac_;
   SampleTree tree_;
-  std::unordered_map<StepId, double, StepIdHash> prio_;
-  std::unordered_map<StepId, std::vector<int64_t>, StepIdHash> users_;
-  std::unordered_map<int64_t, std::vector<StepId>> items_;
-  std::vector<int64_t> touched_;
+  bool general_ = false;
+  // stream mode
+  std::unordered_set<Stream*> streams_;
+  std::unordered_map<StepId, std::pair<Stream*, int64_t>, StepIdHash> where_;  // id -> stream, position
+  std::unordered_map<int64_t, std::pair<Stream*, int64_t>> owner_;            // key -> stream, start
+  std::vector<Range> ranges_;
+  std::vector<SampleTree::Node*> leaves_;
+  // general mode
+  std::unordered_map<StepId, Step, StepIdHash> steps_;
+  std::unordered_map<int64_t, Item> items_;
+  std::vector<Item*> touched_;
+  uint64_t epoch_ = 0;
+  // both
+  std::vector<int64_t> keys_;
+  std::vector<double> masses_;
 };
 
 class Mixture : public Selector {

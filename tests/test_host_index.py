@@ -246,3 +246,57 @@ def test_random_prioritized_histories_against_oracle(seed):
         prio = gen.random(stepid.shape[:2]) * float(gen.choice([1.0, 10.0, 0.0]))
         ours.update({'stepid': stepid, 'priority': prio})
         ref.update({'stepid': stepid, 'priority': prio})
+
+
+@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('break_at', [None, 40, 140])
+def test_prioritized_window_streams_then_arbitrary_use(seed, break_at):
+  """The selector alone.  Sliding windows over a few streams with oldest-first
+  removal (the representation a Replay gets), then -- from `break_at` on --
+  removals in random order and items with arbitrary step lists, which force
+  the switch to the general representation in mid-history.  Draws and lengths
+  must stay the oracle's throughout."""
+  gen = np.random.default_rng(500 + seed)
+  n = int(gen.integers(2, 6))
+  kw = dict(exponent=float(gen.choice([1.0, 0.7])), maxfrac=float(gen.choice([0.0, 0.3])),
+            initial=float(gen.choice([1.0, 2.5])), zero_on_sample=bool(gen.integers(0, 2)),
+            branching=int(gen.choice([2, 4, 16])), seed=seed)
+  ours, ref = selectors.Prioritized(**kw), np_oracle.Prioritized(**kw)
+  sid = lambda stream, t: np.frombuffer(
+      int(stream + 1).to_bytes(16, 'big') + int(t).to_bytes(4, 'big'), np.uint8)
+  clock = [0, 0, 0]
+  live, key = [], 0
+  for it in range(220):
+    free = break_at is not None and it >= break_at
+    op = gen.random()
+    if op < 0.5 or len(live) < 3:
+      stream = int(gen.integers(0, 3))
+      if free and gen.random() < 0.3:       # arbitrary item: steps from anywhere, repeats allowed
+        steps = [sid(int(gen.integers(0, 3)), int(gen.integers(0, max(clock) + 2))) for _ in range(n)]
+      else:
+        t0 = clock[stream]
+        clock[stream] += 1
+        steps = [sid(stream, t0 + i) for i in range(n)]
+      ours[key] = np.stack(steps)
+      ref[key] = [s.tobytes() for s in steps]
+      live.append((key, stream))
+      key += 1
+    elif op < 0.7:
+      if free:
+        victim = live.pop(int(gen.integers(0, len(live))))[0]
+      else:                                   # oldest item of some stream
+        stream = live[int(gen.integers(0, len(live)))][1]
+        index = next(i for i, (_, s) in enumerate(live) if s == stream)
+        victim = live.pop(index)[0]
+      del ours[victim]
+      del ref[victim]
+    elif op < 0.85:
+      stream = int(gen.integers(0, 3))
+      t0 = int(gen.integers(0, clock[stream] + n + 1))
+      ids = np.stack([sid(stream, t0 + i) for i in range(int(gen.integers(1, 2 * n)))])
+      prios = gen.random(len(ids)) * float(gen.choice([1.0, 5.0, 0.0]))
+      ours.prioritize(ids, prios)
+      ref.prioritize([x.tobytes() for x in ids], list(prios))
+    assert len(ours) == len(ref)
+    if len(ref) and it % 3 == 0:
+      assert ours() == ref(), (seed, break_at, it)

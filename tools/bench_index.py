@@ -12,24 +12,35 @@ from embodied_amd import _lib
 from embodied_amd._lib import api
 
 n, L, cap = 64, 65, 100_000
-cfg = _lib.ReplayConfig(L, cap, 1024, (cap + L) // 1024 + 130, 1, 0, 0, 1, 0)
-h = C.c_void_p()
-api.emb_replay_create(C.byref(cfg), None, 0, C.byref(h))
-workers = np.arange(n, dtype=np.int64)
-rows = np.zeros(n, np.int32)
-sids = np.zeros((n, 20), np.uint8)
-for _ in range(cap // n + 3 * L):
-  api.emb_replay_add_index(h, n, _lib.ptr(workers), _lib.ptr(rows), _lib.ptr(sids), None)
-iters = 20000
-t0 = time.perf_counter()
-for _ in range(iters):
-  api.emb_replay_add_index(h, n, _lib.ptr(workers), _lib.ptr(rows), _lib.ptr(sids), None)
-dt = (time.perf_counter() - t0) / iters
-print(f'add_index({n} workers): {dt * 1e6:.2f} us per call, {dt / n * 1e9:.0f} ns per step')
-out = np.zeros((16, L), np.int32)
-t0 = time.perf_counter()
-for _ in range(iters):
-  api.emb_replay_sample_index(h, 16, 1, _lib.ptr(out), None, None)
-dt = (time.perf_counter() - t0) / iters
-print(f'sample_index(16): {dt * 1e6:.2f} us per call')
-api.emb_replay_destroy(h)
+
+
+def run(kind, iters=3000):
+  cfg = _lib.ReplayConfig(L, cap, 1024, (cap + L) // 1024 + 3 * n + 10, 0, 0, 0, 1, 0)
+  h, sel = C.c_void_p(), C.c_void_p()
+  if kind == 'prioritized':        # ppo/configs.yaml:42: exponent .8, maxfrac .5, initial inf, zero_on_sample
+    api.emb_selector_create_prioritized(0.8, float('inf'), 1, 0.5, 16, 0, C.byref(sel))
+  api.emb_replay_create(C.byref(cfg), sel if kind != 'uniform' else None, 0, C.byref(h))
+  workers = np.arange(n, dtype=np.int64)
+  rows = np.zeros(n, np.int32)
+  sids = np.zeros((n, 20), np.uint8)
+  pw, pr, ps = workers.ctypes.data, rows.ctypes.data, sids.ctypes.data
+  for _ in range(cap // n + 3 * L):
+    api.emb_replay_add_index(h, n, pw, pr, ps, None)
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    api.emb_replay_add_index(h, n, pw, pr, ps, None)
+  add = (time.perf_counter() - t0) / iters
+  out = np.zeros((16, L), np.int32)
+  po = out.ctypes.data
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    api.emb_replay_sample_index(h, 16, 1, po, None, None)
+  draw = (time.perf_counter() - t0) / iters
+  print(f'{kind:12s} add_index({n} workers) {add * 1e6:7.2f} us ({add / n * 1e9:4.0f} ns/step)   '
+        f'sample_index(16) {draw * 1e6:7.2f} us')
+  api.emb_replay_destroy(h)
+
+
+if __name__ == '__main__':
+  run('uniform')
+  run('prioritized')
