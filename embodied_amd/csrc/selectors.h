@@ -373,7 +373,7 @@ class Prioritized : public Selector {
     const auto [st, start] = owner_.at(key);
     ranges_.clear();
     for (int64_t pos = start; pos < start + st->n; ++pos) {
-      set_slot(st->steps[pos - st->step0], 0.0);
+      set_slot(*st, pos, 0.0);
       touch_range(st, pos);
     }
     refresh_ranges();
@@ -402,10 +402,10 @@ class Prioritized : public Selector {
         st->item0 += 1;
         // Steps in front of the oldest remaining item belong to no item any
         // more: their priority goes with them (selectors.py:180-185).
-        const int64_t keep_from = st->items.size() ? st->item0 : st->step0 + static_cast<int64_t>(st->steps.size());
+        const int64_t keep_from = st->items.size() ? st->item0 : st->step0 + st->n_steps();
         while (st->step0 < keep_from) {
-          where_.erase(st->steps[0].id);
-          st->steps.pop_front();
+          where_.erase(st->ids[0]);
+          st->pop_step();
           st->step0 += 1;
         }
         if (!st->items.size()) {
@@ -442,8 +442,7 @@ class Prioritized : public Selector {
     for (int64_t i = 0; i < n; ++i) {
       // Rows of consecutive steps: try the slot after the previous one before
       // hashing the 20-byte id.
-      if (st && pos + 1 < st->step0 + static_cast<int64_t>(st->steps.size()) &&
-          st->steps[pos + 1 - st->step0].id == steps[i]) {
+      if (st && pos + 1 < st->step0 + st->n_steps() && st->ids[pos + 1 - st->step0] == steps[i]) {
         pos += 1;
       } else {
         auto it = where_.find(steps[i]);
@@ -454,7 +453,7 @@ class Prioritized : public Selector {
         st = it->second.first;
         pos = it->second.second;
       }
-      set_slot(st->steps[pos - st->step0], prios[i]);
+      set_slot(*st, pos, prios[i]);
       touch_range(st, pos);
     }
     refresh_ranges();
@@ -490,15 +489,24 @@ class Prioritized : public Selector {
   };
 
   // ------------------------------------------------------------ stream mode --
-  struct Slot {
-    double prio, powered;
-    StepId id;
-  };
   struct Stream {
     int n = 0;              // steps per item
-    int64_t step0 = 0;      // position of steps[0]
+    int64_t step0 = 0;      // position of the first stored step
     int64_t item0 = 0;      // start position of items[0]; items[j] starts at item0 + j
-    Sliding<Slot> steps;
+    // Per step, one array each (the aggregation streams through `powered`).
+    Sliding<double> prio, powered;
+    Sliding<StepId> ids;
+    int64_t n_steps() const { return static_cast<int64_t>(ids.size()); }
+    void push_step(const StepId& id, double p, double pw) {
+      ids.push_back(id);
+      prio.push_back(p);
+      powered.push_back(pw);
+    }
+    void pop_step() {
+      ids.pop_front();
+      prio.pop_front();
+      powered.pop_front();
+    }
     Sliding<int64_t> items; // keys
     Sliding<SampleTree::Node*> leaves;   // their tree leaves
   };
@@ -507,19 +515,41 @@ class Prioritized : public Selector {
     int64_t lo, hi;         // item start positions, inclusive
   };
 
-  void set_slot(Slot& slot, double prio) const {
-    slot.prio = prio;
-    slot.powered = powered(prio);
+  void set_slot(Stream& st, int64_t pos, double prio) const {
+    st.prio[pos - st.step0] = prio;
+    st.powered[pos - st.step0] = powered(prio);
   }
   double stream_mass(const Stream& st, int64_t start) const {
     double total = 0.0, top = -INFINITY;
-    const int64_t first = start - st.step0;
-    for (int64_t i = first; i < first + st.n; ++i) {
-      const double v = st.steps[i].powered;
+    const double* p = &st.powered[start - st.step0];
+    for (int i = 0; i < st.n; ++i) {
+      const double v = p[i];
       total += v;
       top = (v > top) ? v : top;
     }
     return finish(total, top, st.n);
+  }
+  // Masses of the `count` items starting at start, start+1, ...: eight items at
+  // a time, each lane doing its own left-to-right sum (independent add chains
+  // instead of one 65-long dependent chain per item).
+  void stream_masses(const Stream& st, int64_t start, int64_t count, std::vector<double>* out) const {
+    constexpr int kLanes = 8;
+    const double* base = &st.powered[start - st.step0];
+    int64_t done = 0;
+    for (; done + kLanes <= count; done += kLanes) {
+      double total[kLanes], top[kLanes];
+      for (int j = 0; j < kLanes; ++j) total[j] = 0.0, top[j] = -INFINITY;
+      const double* p = base + done;
+      for (int i = 0; i < st.n; ++i) {
+        for (int j = 0; j < kLanes; ++j) {
+          const double v = p[i + j];
+          total[j] += v;
+          top[j] = (v > top[j]) ? v : top[j];
+        }
+      }
+      for (int j = 0; j < kLanes; ++j) out->push_back(finish(total[j], top[j], st.n));
+    }
+    for (; done < count; ++done) out->push_back(stream_mass(st, start + done));
   }
   // Items of `st` that contain the step at `pos`.
   void touch_range(Stream* st, int64_t pos) {
@@ -546,9 +576,10 @@ class Prioritized : public Selector {
         st = r.st;
         done = r.lo;
       }
-      for (int64_t start = std::max(done, r.lo); start <= r.hi; ++start) {
-        leaves_.push_back(st->leaves[start - st->item0]);
-        masses_.push_back(stream_mass(*st, start));
+      const int64_t from = std::max(done, r.lo);
+      if (from <= r.hi) {
+        for (int64_t start = from; start <= r.hi; ++start) leaves_.push_back(st->leaves[start - st->item0]);
+        stream_masses(*st, from, r.hi - from + 1, &masses_);
       }
       done = std::max(done, r.hi + 1);
     }
@@ -568,16 +599,13 @@ class Prioritized : public Selector {
       // step, and ids[0 .. n-3] are the steps before it.
       st = prev->second.first;
       const int64_t pos = prev->second.second;
-      const int64_t last = st->step0 + static_cast<int64_t>(st->steps.size()) - 1;
+      const int64_t last = st->step0 + st->n_steps() - 1;
       if (st->n != n || pos != last) return false;
       const int64_t start = pos - (n - 2);
       if (start != st->item0 + static_cast<int64_t>(st->items.size())) return false;
       for (int i = 0; i < n - 2; ++i)
-        if (!(st->steps[start + i - st->step0].id == ids[i])) return false;
-      Slot slot;
-      slot.id = ids[n - 1];
-      set_slot(slot, initial_);
-      st->steps.push_back(slot);
+        if (!(st->ids[start + i - st->step0] == ids[i])) return false;
+      st->push_step(ids[n - 1], initial_, powered(initial_));
       where_.emplace(ids[n - 1], std::make_pair(st, pos + 1));
       st->items.push_back(key);
       owner_.emplace(key, std::make_pair(st, start));
@@ -595,10 +623,7 @@ class Prioritized : public Selector {
     streams_.insert(st);
     st->n = n;
     for (int i = 0; i < n; ++i) {
-      Slot slot;
-      slot.id = ids[i];
-      set_slot(slot, initial_);
-      st->steps.push_back(slot);
+      st->push_step(ids[i], initial_, powered(initial_));
       where_.emplace(ids[i], std::make_pair(st, static_cast<int64_t>(i)));
     }
     st->items.push_back(key);
@@ -619,13 +644,12 @@ class Prioritized : public Selector {
     for (int64_t key : keys) {
       const auto [st, start] = owner_.at(key);
       ids.clear();
-      for (int64_t pos = start; pos < start + st->n; ++pos) ids.push_back(st->steps[pos - st->step0].id);
+      for (int64_t pos = start; pos < start + st->n; ++pos) ids.push_back(st->ids[pos - st->step0]);
       general_link(key, ids.data(), st->n);
       for (int64_t pos = start; pos < start + st->n; ++pos) {
-        const Slot& slot = st->steps[pos - st->step0];
-        Step& step = steps_.at(slot.id);
-        step.prio = slot.prio;
-        step.powered = slot.powered;
+        Step& step = steps_.at(st->ids[pos - st->step0]);
+        step.prio = st->prio[pos - st->step0];
+        step.powered = st->powered[pos - st->step0];
       }
     }
     for (Stream* st : streams_) delete st;

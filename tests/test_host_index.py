@@ -300,3 +300,24 @@ def test_prioritized_window_streams_then_arbitrary_use(seed, break_at):
     assert len(ours) == len(ref)
     if len(ref) and it % 3 == 0:
       assert ours() == ref(), (seed, break_at, it)
+
+
+def test_prioritized_long_windows_against_oracle():
+  """Windows long enough (L = 20) for the eight-items-at-a-time aggregation and
+  for windows that span chunk boundaries, with zero-on-sample and priority
+  write-backs."""
+  kw = dict(exponent=0.8, maxfrac=0.5, initial=np.inf, zero_on_sample=True, seed=3)
+  ours = HostReplay(20, 150, 16, False, selector=selectors.Prioritized(**kw), n_slots=256)
+  ref = np_oracle.Replay(20, 150, 16, False, selector=np_oracle.Prioritized(**kw))
+  gen = np.random.default_rng(9)
+  for t in range(140):
+    for w in range(3):
+      step = {'t': np.int32(t), 'w': np.int32(w)}
+      ours.add(step, w)
+      ref.add(step, w)
+    if t >= 25 and t % 6 == 0:
+      got, want = ours.sample(4), ref.sample(4)
+      assert_same(got, want, f't{t}')
+      prio = gen.random(want['stepid'].shape[:2]) * 3
+      ours.update({'stepid': want['stepid'], 'priority': prio})
+      ref.update({'stepid': want['stepid'], 'priority': prio})
