@@ -321,3 +321,41 @@ def test_prioritized_long_windows_against_oracle():
       prio = gen.random(want['stepid'].shape[:2]) * 3
       ours.update({'stepid': want['stepid'], 'priority': prio})
       ref.update({'stepid': want['stepid'], 'priority': prio})
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_sampletree_random_operations_against_oracle(seed):
+  """Fuzz of the b-ary sum tree alone: inserts, removals (tail and interior),
+  mass updates incl. 0 and inf, draws; root sum, leaf depths and every draw
+  must match the oracle's tree (pinned by the golden `sel_sampletree`)."""
+  gen = np.random.default_rng(900 + seed)
+  branching = int(gen.choice([2, 3, 5, 16]))
+  ours, ref = selectors.SampleTree(branching, seed), np_oracle.SampleTree(branching, seed)
+  live, key = [], 0
+  mass = lambda: float(gen.choice([gen.random(), gen.random() * 50, 0.0, np.inf], p=[0.6, 0.3, 0.07, 0.03]))
+  for it in range(400):
+    op = gen.random()
+    if op < 0.5 or len(live) < 2:
+      m = mass()
+      ours.insert(key, m)
+      ref.insert(key, m)
+      live.append(key)
+      key += 1
+    elif op < 0.75:
+      victim = live.pop(int(gen.integers(0, len(live))) if gen.random() < 0.7 else -1)
+      ours.remove(victim)
+      ref.remove(victim)
+    else:
+      k, m = live[int(gen.integers(0, len(live)))], mass()
+      ours.update(k, m)
+      ref.update(k, m)
+    assert len(ours) == len(ref)
+    root = ref.root.mass
+    assert ours.total == root or (np.isnan(root) and np.isnan(ours.total)), (seed, it)
+    if live and it % 4 == 0 and not np.isnan(root):
+      assert ours.sample() == ref.sample(), (seed, it)
+  depths, _ = ours.shape()
+  def leaf_depths(node, d=0):
+    kids = getattr(node, 'kids', None)
+    return [d] if kids is None else [x for kid in kids for x in leaf_depths(kid, d + 1)]
+  assert sorted(depths.tolist()) == sorted(leaf_depths(ref.root)) or not live
