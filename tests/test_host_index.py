@@ -359,3 +359,36 @@ def test_sampletree_random_operations_against_oracle(seed):
     kids = getattr(node, 'kids', None)
     return [d] if kids is None else [x for kid in kids for x in leaf_depths(kid, d + 1)]
   assert sorted(depths.tolist()) == sorted(leaf_depths(ref.root)) or not live
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_random_mixture_histories_against_oracle(seed):
+  """Replay over Mixture(uniform, priority): member choice, both members'
+  bookkeeping under eviction, priority feedback reaching the prioritized one."""
+  gen = np.random.default_rng(300 + seed)
+  length, chunksize = int(gen.integers(2, 6)), int(gen.integers(3, 10))
+  capacity, workers = int(gen.integers(6, 30)), int(gen.integers(1, 4))
+  frac = float(gen.choice([0.25, 0.5, 0.75]))
+  pkw = dict(exponent=0.8, maxfrac=0.5, initial=1.0, zero_on_sample=bool(seed % 2), seed=seed + 2)
+  mine = selectors.Mixture(
+      dict(uniform=selectors.Uniform(seed + 1), priority=selectors.Prioritized(**pkw)),
+      dict(uniform=frac, priority=1 - frac), seed=seed + 3)
+  theirs = np_oracle.Mixture(
+      dict(uniform=np_oracle.Uniform(seed + 1), priority=np_oracle.Prioritized(**pkw)),
+      dict(uniform=frac, priority=1 - frac), seed=seed + 3)
+  ours = HostReplay(length, capacity, chunksize, False, selector=mine, n_slots=256)
+  ref = np_oracle.Replay(length, capacity, chunksize, False, selector=theirs)
+  clock = [0] * workers
+  for n in range(400):
+    w = int(gen.integers(0, workers))
+    step = {'t': np.int32(clock[w]), 'w': np.int32(w)}
+    clock[w] += 1
+    ours.add(step, w)
+    ref.add(step, w)
+    if len(ref) and n % 4 == 0:
+      got, want = ours.sample(2), ref.sample(2)
+      assert_same(got, want, f'seed{seed} n{n}')
+      if gen.random() < 0.6:
+        prio = gen.random(want['stepid'].shape[:2]) * 4
+        ours.update({'stepid': want['stepid'], 'priority': prio})
+        ref.update({'stepid': want['stepid'], 'priority': prio})
