@@ -252,6 +252,9 @@ struct emb_replay {
   std::mutex mu;
   std::unique_ptr<emb::ReplayIndex> index;
   std::shared_ptr<emb::Selector> selector;
+  // The selector handle's own lock (emb_selector_* take it): replay operations
+  // hold it too, so direct calls on the handle cannot interleave with them.
+  std::shared_ptr<std::mutex> selector_mu = std::make_shared<std::mutex>();
   std::vector<KeyInfo> keys;
   int key_stepid = -1, key_is_first = -1, key_is_last = -1;
   TableRing ring;
@@ -495,6 +498,7 @@ int32_t emb_replay_create(const emb_replay_config_t* cfg, emb_selector_t* select
     c.workers_per_owner = cfg->workers_per_owner;
     auto rep = std::make_unique<emb_replay>();
     rep->selector = selector ? selector->impl : std::make_shared<emb::Uniform>(seed);
+    if (selector) rep->selector_mu = selector->mu;
     rep->index = std::make_unique<emb::ReplayIndex>(c, rep->selector);
     *out = rep.release();
   });
@@ -509,6 +513,7 @@ int32_t emb_replay_destroy(emb_replay_t* rep) {
   return guarded([&] {                                \
     need(rep, "replay handle is null");               \
     std::lock_guard<std::mutex> lock(rep->mu);        \
+    std::lock_guard<std::mutex> sel_lock(*rep->selector_mu); \
     __VA_ARGS__;                                      \
   })
 
