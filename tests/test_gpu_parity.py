@@ -708,3 +708,61 @@ def test_native_rccl_collectives_world1(emb):
   torch.cuda.synchronize()
   assert torch.equal(out, flat) and torch.equal(grads, want)
   comm.close()
+
+
+@pytest.mark.parametrize('seed', range(5))
+def test_random_schemas_against_oracle(emb, seed):
+  """Random key sets (1..9 keys; u8/i16/i32/i64/f16/f32/f64/bool; scalar to
+  rank-3; rows from 1 B to ~5 KB, aligned and odd), inserts one step at a time
+  and in batches, samples, write-backs of random key subsets: every mover path
+  (1/2/4/8/16-byte units, the wide 16-byte path, inline tables and the ring)
+  against the oracle."""
+  gen = np.random.default_rng(700 + seed)
+  dtypes = [np.uint8, np.int16, np.int32, np.int64, np.float16, np.float32, np.float64, np.bool_]
+  shapes = [(), (1,), (3,), (7,), (16,), (5, 3), (2, 4, 4), (640,), (33, 37), (1283,)]
+  spec = {}
+  for i in range(int(gen.integers(1, 10))):
+    spec[f'k{i}'] = (dtypes[int(gen.integers(0, len(dtypes)))], shapes[int(gen.integers(0, len(shapes)))])
+
+  def value(dtype, shape, lead=()):
+    full = (*lead, *shape)
+    if dtype == np.bool_:
+      return gen.random(full) < 0.5
+    if np.issubdtype(dtype, np.integer):
+      return gen.integers(0, 100, full).astype(dtype)
+    return gen.standard_normal(full).astype(dtype)
+
+  def step(t, lead=()):
+    s = {k: value(d, sh, lead) for k, (d, sh) in spec.items()}
+    s['is_first'] = np.full(lead, t % 9 == 0) if lead else np.bool_(t % 9 == 0)
+    s['is_last'] = np.full(lead, t % 9 == 8) if lead else np.bool_(t % 9 == 8)
+    return s
+
+  workers = int(gen.integers(1, 5))
+  length, chunksize = int(gen.integers(1, 8)), int(gen.integers(2, 40))
+  capacity = int(gen.integers(5, 120))
+  ours = emb.Replay(length, capacity, chunksize=chunksize, seed=seed, stage_rows=int(gen.integers(1, 30)), slots=8)
+  ref = np_oracle.Replay(length, capacity, chunksize, seed=seed)
+  for t in range(120):
+    if gen.random() < 0.5:                      # vectorised insert of all workers
+      s = step(t, (workers,))
+      ours.add_batch({k: torch.as_tensor(v).cuda() for k, v in s.items()}, list(range(workers)))
+      for w in range(workers):
+        ref.add({k: v[w] for k, v in s.items()}, w)
+    else:
+      w = int(gen.integers(0, workers))
+      s = step(t)
+      ours.add(s, w)
+      ref.add(s, w)
+    assert len(ours) == len(ref)
+    if len(ref) and t % 7 == 0:
+      B = int(gen.integers(1, 6))
+      got = ours.sample(B)
+      want = ref.sample(B)
+      assert_same({k: v.cpu().numpy() for k, v in got.items()}, want, f'seed{seed} t{t}')
+      if gen.random() < 0.6:                    # write some keys back over a prefix of the windows
+        T = int(gen.integers(1, length + 1))
+        names = [k for k in spec if gen.random() < 0.5] or [next(iter(spec))]
+        upd = {k: value(*spec[k], (B, T)) for k in names}
+        ours.update({'stepid': got['stepid'][:, :T], **{k: torch.as_tensor(v).cuda() for k, v in upd.items()}})
+        ref.update({'stepid': want['stepid'][:, :T], **upd})
