@@ -381,9 +381,9 @@ int32_t emb_tree_create(int32_t branching, uint64_t seed, emb_tree_t** out) {
 int32_t emb_tree_insert(emb_tree_t* tree, int64_t key, double uprob) { TREE_OP(tree->impl.insert(key, uprob)); }
 int32_t emb_tree_remove(emb_tree_t* tree, int64_t key) { TREE_OP(tree->impl.remove(key)); }
 int32_t emb_tree_update(emb_tree_t* tree, int64_t key, double uprob) { TREE_OP(tree->impl.update(key, uprob)); }
-int32_t emb_tree_sample(emb_tree_t* tree, int64_t* key) { TREE_OP(*key = tree->impl.sample()); }
-int32_t emb_tree_len(emb_tree_t* tree, int64_t* n) { TREE_OP(*n = tree->impl.size()); }
-int32_t emb_tree_root_sum(emb_tree_t* tree, double* total) { TREE_OP(*total = tree->impl.root_mass()); }
+int32_t emb_tree_sample(emb_tree_t* tree, int64_t* key) { TREE_OP(need(key, "tree_sample: null output"); *key = tree->impl.sample()); }
+int32_t emb_tree_len(emb_tree_t* tree, int64_t* n) { TREE_OP(need(n, "tree_len: null output"); *n = tree->impl.size()); }
+int32_t emb_tree_root_sum(emb_tree_t* tree, double* total) { TREE_OP(need(total, "tree_root_sum: null output"); *total = tree->impl.root_mass()); }
 
 int32_t emb_tree_shape(emb_tree_t* tree, int64_t cap, int64_t* depths, int64_t* n_leaves,
                        int64_t* n_nodes) {
@@ -471,10 +471,11 @@ int32_t emb_selector_insert(emb_selector_t* sel, int64_t key, const uint8_t* ste
   SEL_OP(sel->impl->insert(key, reinterpret_cast<const emb::StepId*>(stepids), stepids ? n_steps : 0));
 }
 int32_t emb_selector_remove(emb_selector_t* sel, int64_t key) { SEL_OP(sel->impl->remove(key)); }
-int32_t emb_selector_sample(emb_selector_t* sel, int64_t* key) { SEL_OP(*key = sel->impl->sample()); }
-int32_t emb_selector_len(emb_selector_t* sel, int64_t* n) { SEL_OP(*n = sel->impl->size()); }
+int32_t emb_selector_sample(emb_selector_t* sel, int64_t* key) { SEL_OP(need(key, "selector_sample: null output"); *key = sel->impl->sample()); }
+int32_t emb_selector_len(emb_selector_t* sel, int64_t* n) { SEL_OP(need(n, "selector_len: null output"); *n = sel->impl->size()); }
 int32_t emb_selector_prioritize(emb_selector_t* sel, const uint8_t* stepids, const double* prios, int64_t n) {
-  SEL_OP(sel->impl->prioritize(reinterpret_cast<const emb::StepId*>(stepids), prios, n));
+  SEL_OP(need(n >= 0 && (n == 0 || (stepids && prios)), "selector_prioritize: bad arguments");
+         sel->impl->prioritize(reinterpret_cast<const emb::StepId*>(stepids), prios, n));
 }
 int32_t emb_selector_destroy(emb_selector_t* sel) {
   delete sel;
@@ -620,10 +621,10 @@ int32_t emb_replay_prioritize(emb_replay_t* rep, const uint8_t* stepids, const d
   });
 }
 
-int32_t emb_replay_len(emb_replay_t* rep, int64_t* items) { REP_OP(*items = rep->index->size()); }
-int32_t emb_replay_sampler_len(emb_replay_t* rep, int64_t* n) { REP_OP(*n = rep->selector->size()); }
-int32_t emb_replay_free_slots(emb_replay_t* rep, int64_t* n) { REP_OP(*n = rep->index->free_slots()); }
-int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset) { REP_OP(rep->index->stats(out, reset != 0)); }
+int32_t emb_replay_len(emb_replay_t* rep, int64_t* items) { REP_OP(need(items, "replay_len: null output"); *items = rep->index->size()); }
+int32_t emb_replay_sampler_len(emb_replay_t* rep, int64_t* n) { REP_OP(need(n, "replay_sampler_len: null output"); *n = rep->selector->size()); }
+int32_t emb_replay_free_slots(emb_replay_t* rep, int64_t* n) { REP_OP(need(n, "replay_free_slots: null output"); *n = rep->index->free_slots()); }
+int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset) { REP_OP(need(out, "replay_stats: null output"); rep->index->stats(out, reset != 0)); }
 
 // Launch one gather/scatter.  Small tables travel inside the kernel arguments;
 // larger ones through the pinned ring (one async upload).

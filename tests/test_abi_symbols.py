@@ -79,3 +79,52 @@ def test_package_works_without_the_call_shim():
   out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   assert out.returncode == 0 and 'ok' in out.stdout, out.stderr
+
+
+def test_bad_arguments_are_refused_not_dereferenced():
+  """Null handles, null outputs, negative sizes, unknown keys: every entry point
+  that can be reached without a GPU answers with a status code."""
+  import ctypes as C
+  import numpy as np
+  from embodied_amd import _lib
+  raw = _lib.lib
+  for fn in (raw.emb_tree_sample, raw.emb_tree_len, raw.emb_tree_root_sum, raw.emb_selector_sample,
+             raw.emb_selector_len, raw.emb_replay_len, raw.emb_replay_sampler_len,
+             raw.emb_replay_free_slots):
+    assert fn(None, None) < 0                                   # null handle
+  tree, sel, rep = C.c_void_p(), C.c_void_p(), C.c_void_p()
+  assert raw.emb_tree_create(16, 0, C.byref(tree)) == 0
+  assert raw.emb_selector_create_prioritized(
+      C.c_double(0.8), C.c_double(1.0), 1, C.c_double(0.5), 16, 0, C.byref(sel)) == 0
+  cfg = _lib.ReplayConfig(4, 10, 8, 16, 0, 0, 0, 1, 0)
+  assert raw.emb_replay_create(C.byref(cfg), None, C.c_uint64(0), C.byref(rep)) == 0
+  assert raw.emb_tree_sample(tree, None) < 0 and raw.emb_tree_len(tree, None) < 0
+  assert raw.emb_tree_root_sum(tree, None) < 0
+  key = C.c_int64()
+  assert raw.emb_tree_sample(tree, C.byref(key)) == _lib.ERR_EMPTY         # empty tree
+  assert raw.emb_tree_remove(tree, C.c_int64(5)) == _lib.ERR_NOT_FOUND
+  assert raw.emb_tree_update(tree, C.c_int64(5), C.c_double(1.0)) == _lib.ERR_NOT_FOUND
+  assert raw.emb_selector_sample(sel, None) < 0 and raw.emb_selector_len(sel, None) < 0
+  assert raw.emb_selector_sample(sel, C.byref(key)) == _lib.ERR_EMPTY
+  assert raw.emb_selector_insert(sel, C.c_int64(1), None, 0) < 0            # prioritized item without steps
+  assert raw.emb_selector_remove(sel, C.c_int64(77)) < 0
+  assert raw.emb_selector_prioritize(sel, None, None, C.c_int64(3)) < 0
+  assert raw.emb_replay_len(rep, None) < 0 and raw.emb_replay_stats(rep, None, 0) < 0
+  rows = np.zeros(8, np.int32)
+  assert raw.emb_replay_add_index(rep, C.c_int64(-1), None, None, None, None) < 0
+  assert raw.emb_replay_add_index(rep, C.c_int64(2), None, C.c_void_p(rows.ctypes.data), None, None) < 0
+  assert raw.emb_replay_sample_index(rep, C.c_int64(1), 0, C.c_void_p(rows.ctypes.data), None, None) == _lib.ERR_EMPTY
+  assert raw.emb_replay_sample_index(rep, C.c_int64(1), 9, C.c_void_p(rows.ctypes.data), None, None) < 0   # bad mode
+  assert raw.emb_replay_add(rep, C.c_int64(1), None, None, None) < 0
+  assert raw.emb_replay_sample(rep, C.c_int64(1), 0, None, None, None, None) < 0
+  assert raw.emb_replay_set_keys(rep, 0, None, None, None) < 0
+  assert raw.emb_replay_grow(rep, C.c_int64(1), None) < 0                   # cannot shrink
+  assert raw.emb_rng_create(None, 0, None) < 0
+  assert raw.emb_np_sum(None, C.c_int64(3), None) < 0
+  assert raw.emb_comm_init(None, 0, 1, None) < 0
+  assert raw.emb_scan_gae(None, None, None, None, C.c_int64(1), C.c_int64(4), C.c_float(1), C.c_float(1),
+                          None, None, None) < 0
+  assert b'' != raw.emb_last_error()
+  for destroy, handle in ((raw.emb_tree_destroy, tree), (raw.emb_selector_destroy, sel),
+                          (raw.emb_replay_destroy, rep)):
+    assert destroy(handle) == 0
