@@ -766,3 +766,23 @@ def test_random_schemas_against_oracle(emb, seed):
         upd = {k: value(*spec[k], (B, T)) for k in names}
         ours.update({'stepid': got['stepid'][:, :T], **{k: torch.as_tensor(v).cuda() for k, v in upd.items()}})
         ref.update({'stepid': want['stepid'][:, :T], **upd})
+
+
+def test_very_large_rows(emb):
+  """4 MB per step (a 1024x1024x4 frame): 262 144 16-byte units per row, several
+  workgroups per row, window rows from two chunks."""
+  gen = np.random.default_rng(0)
+  ours = emb.Replay(length=3, capacity=6, chunksize=4, seed=0, slots=12)
+  ref = np_oracle.Replay(3, 6, 4, seed=0)
+  for t in range(11):
+    step = {'frame': gen.integers(0, 255, (1024, 1024, 4), dtype=np.uint8), 'x': np.float32(t),
+            'is_first': t == 0, 'is_last': False}
+    ours.add(step, 0)
+    ref.add(step, 0)
+  for _ in range(2):
+    got, want = ours.sample(3), ref.sample(3)
+    assert_same({k: v.cpu().numpy() for k, v in got.items()}, want, 'large rows')
+  new = torch.randint(0, 255, (3, 2, 1024, 1024, 4), dtype=torch.uint8, device='cuda')
+  ours.update({'stepid': got['stepid'][:, :2], 'frame': new})
+  ref.update({'stepid': want['stepid'][:, :2], 'frame': new.cpu().numpy()})
+  assert_same({k: v.cpu().numpy() for k, v in ours.sample(3).items()}, ref.sample(3), 'large rows upd')
