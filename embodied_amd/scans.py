@@ -54,6 +54,8 @@ def gae(rew, val, last, term, hor=200, lam=0.8):
   assert val.shape == last.shape == term.shape == (B, T)
   adv = _lib.empty((B, T - 1), torch.float32, dev)
   tar = _lib.empty((B, T - 1), torch.float32, dev)
+  if B == 0 or T < 2:
+    return adv, tar                   # nothing to scan: (B, 0) results
   fast.emb_scan_gae(
       rew.data_ptr(), val.data_ptr(), last.data_ptr(), term.data_ptr(), B, T,
       float(np.float32(1 - 1 / hor)), float(np.float32(lam)), adv.data_ptr(),
@@ -71,6 +73,8 @@ def lambda_return(last, term, rew, val, boot, disc, lam):
   assert boot.shape == last.shape == term.shape == (B, T)
   assert val is None or tuple(val.shape) == (B, T)
   ret = _lib.empty((B, T - 1), torch.float32, dev)
+  if B == 0 or T < 2:
+    return ret
   fast.emb_scan_lambda(
       last.data_ptr(), term.data_ptr(), rew.data_ptr(), boot.data_ptr(), B, T,
       float(np.float32(disc)), float(np.float32(lam)), ret.data_ptr(),
@@ -85,6 +89,8 @@ def director_score(rew, cont, value, horizon=333, lam=0.95):
   T, B = value.shape
   assert cont.shape == (T, B) and rew.shape == (T - 1, B)
   ret = _lib.empty((T - 1, B), torch.float32, dev)
+  if B == 0 or T < 2:
+    return ret
   api.emb_scan_director(
       rew.data_ptr(), cont.data_ptr(), value.data_ptr(), T, B,
       float(np.float32(1 - 1 / horizon)), float(np.float32(lam)),

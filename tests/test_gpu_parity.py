@@ -786,3 +786,32 @@ def test_very_large_rows(emb):
   ours.update({'stepid': got['stepid'][:, :2], 'frame': new})
   ref.update({'stepid': want['stepid'][:, :2], 'frame': new.cpu().numpy()})
   assert_same({k: v.cpu().numpy() for k, v in ours.sample(3).items()}, ref.sample(3), 'large rows upd')
+
+
+def test_empty_and_degenerate_calls(emb):
+  """Zero-size requests are answered with zero-size results, not launches:
+  sample(0), add_batch of no workers, update of no rows, length-1 windows,
+  capacity 1."""
+  rep = emb.Replay(length=1, capacity=1, chunksize=2, seed=0)
+  ref = np_oracle.Replay(1, 1, 2, seed=0)
+  for t in range(7):
+    s = {'x': np.float32(t), 'is_first': t == 0, 'is_last': False}
+    rep.add(s, 0)
+    ref.add(s, 0)
+    assert len(rep) == len(ref) == 1
+    assert_same({k: v.cpu().numpy() for k, v in rep.sample(2).items()}, ref.sample(2), f'cap1 t{t}')
+  empty = rep.sample(0)
+  assert empty['x'].shape == (0, 1) and empty['stepid'].shape == (0, 1, 20)
+  assert rep.add_batch({'x': torch.zeros(0, device='cuda'), 'is_first': torch.zeros(0, dtype=torch.bool, device='cuda'),
+                        'is_last': torch.zeros(0, dtype=torch.bool, device='cuda')}, []) is None
+  rep.update({'stepid': torch.zeros((0, 1, 20), dtype=torch.uint8, device='cuda'),
+              'x': torch.zeros((0, 1), device='cuda')})
+  assert len(rep) == 1
+  # scans on minimal shapes
+  one = torch.zeros((1, 2), device='cuda')
+  flags = torch.zeros((1, 2), dtype=torch.bool, device='cuda')
+  adv, tar = emb.scans.gae(one + 1, one, flags, flags)
+  assert adv.shape == (1, 1) and tar.shape == (1, 1)
+  single = torch.zeros((3, 1), device='cuda')
+  adv, _ = emb.scans.gae(single, single, single.bool(), single.bool())
+  assert adv.shape == (3, 0)
