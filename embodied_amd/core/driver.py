@@ -44,6 +44,8 @@ def mask_actions(value, is_last):
       value = value.contiguous()
     out = torch.empty_like(value)
     n = value.shape[0]
+    if value.numel() == 0:
+      return out
     fast.emb_mask_actions(
         value.data_ptr(), out.data_ptr(), n, value.numel() // max(n, 1),
         _DTYPE_CODE[value.dtype], is_last.data_ptr(),

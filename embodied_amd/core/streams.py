@@ -51,6 +51,8 @@ def window(value, start, count):
       (value.shape[0], count, *value.shape[2:]), dtype=value.dtype,
       device=value.device)
   rowbytes = value.element_size() * int(np.prod(value.shape[2:], dtype=np.int64))
+  if out.numel() == 0:
+    return out
   api.emb_window(
       value.data_ptr(), out.data_ptr(), value.shape[0], value.shape[1], start,
       count, rowbytes, _lib.raw_stream(value.device))

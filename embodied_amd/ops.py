@@ -29,6 +29,8 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
   first = layout == 'channels_first'
   shape = (n, c, h, w) if first else (n, h, w, c)
   out = _lib.empty(shape, dtype, frames.device)
+  if out.numel() == 0:
+    return out                       # no envs / empty frames: nothing to launch
   fast.emb_obs_stack(
       frames.data_ptr(), _lib.ptr(ids), n, h * w, c,
       _lib.LAYOUT_CHANNELS_FIRST if first else _lib.LAYOUT_SAME, _OUT[dtype],
@@ -42,6 +44,8 @@ def rows_gather(table, ids):
   ids = np.ascontiguousarray(ids, np.int32)
   out = torch.empty((len(ids), *table.shape[1:]), dtype=table.dtype, device=table.device)
   rowbytes = table.element_size() * int(np.prod(table.shape[1:], dtype=np.int64))
+  if out.numel() == 0:
+    return out
   api.emb_rows_gather(table.data_ptr(), rowbytes, _lib.ptr(ids), len(ids),
                       out.data_ptr(), _stream(table))
   return out
@@ -53,6 +57,8 @@ def rows_scatter(table, ids, rows):
   ids = np.ascontiguousarray(ids, np.int32)
   rows = rows.to(table.device, table.dtype).contiguous()
   rowbytes = table.element_size() * int(np.prod(table.shape[1:], dtype=np.int64))
+  if rows.numel() == 0:
+    return table
   api.emb_rows_scatter(table.data_ptr(), rowbytes, _lib.ptr(ids), len(ids),
                        rows.data_ptr(), _stream(table))
   return table

@@ -815,3 +815,15 @@ def test_empty_and_degenerate_calls(emb):
   single = torch.zeros((3, 1), device='cuda')
   adv, _ = emb.scans.gae(single, single, single.bool(), single.bool())
   assert adv.shape == (3, 0)
+
+
+def test_odd_argument_probe(emb):
+  """tools/edge_cases.py: empty env batches, zero-width rows, empty id lists,
+  zero-length windows, huge / negative worker ids, one-env Driver."""
+  import importlib.util
+  import pathlib
+  path = pathlib.Path(__file__).resolve().parent.parent / 'tools' / 'edge_cases.py'
+  spec = importlib.util.spec_from_file_location('_edge_cases', path)
+  module = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(module)
+  assert module.FAILED == []
