@@ -827,3 +827,27 @@ def test_odd_argument_probe(emb):
   module = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(module)
   assert module.FAILED == []
+
+
+def test_numpy_facade_roundtrip_with_priorities(emb):
+  """Replay(numpy=True): host arrays out, host arrays back in for update and
+  priority (what a reference-style agent does), prioritized selector."""
+  kw = dict(exponent=0.8, maxfrac=0.5, initial=1.0, zero_on_sample=False, seed=1)
+  ours = emb.Replay(length=4, capacity=40, chunksize=8, numpy=True,
+                    selector=emb.selectors.Prioritized(**kw))
+  ref = np_oracle.Replay(4, 40, 8, selector=np_oracle.Prioritized(**kw))
+  gen = np.random.default_rng(5)
+  for t in range(30):
+    for w in range(2):
+      s = scenarios.synth_step(t, w)
+      ours.add(s, w)
+      ref.add(s, w)
+    if t >= 6 and t % 3 == 0:
+      got, want = ours.sample(5), ref.sample(5)
+      assert all(isinstance(v, np.ndarray) for v in got.values())
+      assert_same(got, want, f't{t}')
+      upd = {'stepid': got['stepid'], 'priority': gen.random((5, 4)),
+             'reward': gen.standard_normal((5, 4)).astype(np.float32)}
+      ours.update(dict(upd))
+      ref.update(dict(upd))
+  assert_same(ours.sample(8), ref.sample(8), 'final')
