@@ -851,3 +851,33 @@ def test_numpy_facade_roundtrip_with_priorities(emb):
       ours.update(dict(upd))
       ref.update(dict(upd))
   assert_same(ours.sample(8), ref.sample(8), 'final')
+
+
+def test_save_load_with_prioritized_selector(emb, tmp_path):
+  """Restoring chunk files re-inserts items chunk by chunk (replay.py:347-359):
+  windows arrive out of stream order, which the prioritized selector must take
+  (general representation) -- then inserts continue and draws stay valid."""
+  kw = dict(exponent=0.8, maxfrac=0.5, initial=np.inf, zero_on_sample=True, seed=2)
+  a = emb.Replay(length=5, capacity=60, chunksize=8, directory=tmp_path, save_wait=True,
+                 selector=emb.selectors.Prioritized(**kw))
+  for t in range(40):
+    for w in range(2):
+      a.add(scenarios.synth_step(t, w), w)
+  a.save()
+  b = emb.Replay(length=5, capacity=60, chunksize=8, directory=tmp_path,
+                 selector=emb.selectors.Prioritized(**kw))
+  b.load()
+  assert len(b) > 0
+  for t in range(40, 60):
+    for w in range(2):
+      b.add(scenarios.synth_step(t, w), w)
+  assert len(b) == 60
+  for _ in range(5):
+    batch = b.sample(6)
+    step, worker = batch['step'].cpu().numpy(), batch['worker'].cpu().numpy()
+    assert (np.diff(step, axis=1) == 1).all() and (worker == worker[:, :1]).all()
+    img = batch['image'].cpu().numpy()
+    for i in range(6):
+      want = scenarios.synth_step(int(step[i, 0]), int(worker[i, 0]))['image']
+      assert (img[i, 0] == want).all()
+    b.update({'stepid': batch['stepid'], 'priority': torch.rand(6, 5, device='cuda')})
