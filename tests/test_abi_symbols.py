@@ -128,3 +128,31 @@ def test_bad_arguments_are_refused_not_dereferenced():
   for destroy, handle in ((raw.emb_tree_destroy, tree), (raw.emb_selector_destroy, sel),
                           (raw.emb_replay_destroy, rep)):
     assert destroy(handle) == 0
+
+
+def test_plain_c_program_against_the_abi(tmp_path):
+  """examples/c_abi_demo.c: gcc -std=c99 against include/embodied_hip.h, linked
+  with the shared library, no Python in the process.  It must print the index
+  streams SURVEY.md Appendix C captured from the reference."""
+  import os
+  import pathlib
+  import shutil
+  import subprocess
+  import pytest
+  root = pathlib.Path(__file__).resolve().parent.parent
+  gcc = shutil.which('gcc')
+  if not gcc:
+    pytest.skip('no gcc')
+  exe = tmp_path / 'demo'
+  build = subprocess.run(
+      [gcc, '-std=c99', '-Wall', '-Werror', f'-I{root / "include"}', str(root / 'examples' / 'c_abi_demo.c'),
+       f'-L{root / "embodied_amd"}', '-lembodied_hip', '-o', str(exe)], capture_output=True, text=True)
+  assert build.returncode == 0, build.stderr
+  import torch
+  paths = [str(root / 'embodied_amd'), os.path.join(os.path.dirname(torch.__file__), 'lib'), '/opt/rocm/lib']
+  env = dict(os.environ, LD_LIBRARY_PATH=':'.join(paths + [os.environ.get('LD_LIBRARY_PATH', '')]))
+  run = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+  assert run.returncode == 0, run.stderr
+  lines = run.stdout.strip().splitlines()
+  assert lines[0] == 'uniform: 8 6 5 2 3 0 0 0 1 8 6 9 5 6 9 7'
+  assert lines[1] == 'replay: 50 items; sampled workers 0 1 2 2'
