@@ -24,11 +24,15 @@ def _worker(rank, world, port, fn, out):
     torch.distributed.destroy_process_group()
 
 
-def run2(fn):
+def run_world(fn, world):
   manager = mp.Manager()
   out = manager.dict()
-  mp.spawn(_worker, args=(2, _free_port(), fn, out), nprocs=2, join=True)
+  mp.spawn(_worker, args=(world, _free_port(), fn, out), nprocs=world, join=True)
   return dict(out)
+
+
+def run2(fn):
+  return run_world(fn, 2)
 
 
 def _gather_job(rank, world, D):
@@ -143,3 +147,17 @@ def test_comm_thread_issues_collectives_in_order_world2():
     assert sums == [3.0 * (s + 1) for s in range(5)]
     assert gathers == [[s] * 5 + [10 + s] * 5 for s in range(5)]
     assert raised and final == 1.0
+
+
+def test_all_gather_and_all_reduce_world4():
+  """Four ranks: rank order in the gathered buffers, env blocks, the mean."""
+  out = run_world(_gather_job, 4)
+  for rank in range(4):
+    got, packed, grads, block, mx = out[rank]
+    for k in got:
+      want = np.concatenate([_expected(r)[k] for r in range(4)], 0)
+      assert np.array_equal(got[k], want), k
+      assert np.array_equal(packed[k].reshape(want.shape), want), k
+    assert np.allclose(grads, 2.5)
+    assert block == list(range(rank * 16, rank * 16 + 16))
+    assert mx == 3.5
