@@ -285,3 +285,76 @@ def test_schema_is_fixed_by_the_first_step(Replay):
   seq = one(replay)
   assert seq['a'].dtype == np.float32 and seq['b'].dtype == np.int32
   assert seq['a'].tolist() == [1.0, 2.0] and seq['b'][1].tolist() == [1, 2, 3]
+
+
+@pytest.mark.parametrize('length,workers,capacity', [
+    (1, 1, 1), (2, 1, 2), (5, 1, 10), (1, 2, 2), (5, 3, 15), (2, 7, 20)])
+def test_worker_delay(Replay, length, workers, capacity):
+  """Workers that finish at different times (tests/test_replay.py:137-150):
+  streams run dry one after another while the others keep inserting."""
+  replay = Replay(length, capacity)
+  rng = np.random.default_rng(seed=0)
+  streams = [iter(range(10)) for _ in range(workers)]
+  added = 0
+  while streams:
+    worker = int(rng.integers(0, len(streams)))
+    try:
+      replay.add({'step': next(streams[worker])}, worker)
+      added += 1
+    except StopIteration:
+      del streams[worker]
+  assert added == 10 * workers
+  assert 0 < len(replay) <= capacity
+
+
+@pytest.mark.parametrize('length,capacity,chunksize', [
+    (1, 1, 128), (3, 10, 128), (5, 100, 128), (5, 25, 2)])
+def test_restore_noclear(Replay, tmp_path, length, capacity, chunksize):
+  """Loading a checkpoint into a replay that kept running
+  (tests/test_replay.py:177-193): nothing breaks; where the old items must
+  have displaced the new ones, only old payload is sampled."""
+  replay = Replay(length, capacity, directory=tmp_path, chunksize=chunksize, save_wait=True)
+  for _ in range(30):
+    replay.add({'foo': 13})
+  num_items = np.clip(30 - length + 1, 0, capacity)
+  assert len(replay) == num_items
+  data = replay.save()
+  for _ in range(30):
+    replay.add({'foo': 42})
+  replay.load(data)
+  assert 0 < len(replay) <= capacity
+  for _ in range(len(replay)):
+    seq = one(replay)
+    assert len(seq['foo']) == length and set(np.unique(seq['foo'])) <= {13, 42}
+    if capacity < num_items:
+      assert (seq['foo'] == 13).all()
+
+
+@pytest.mark.parametrize('workers', [1, 2, 5])
+@pytest.mark.parametrize('length,capacity,chunksize', [(1, 1, 1), (3, 10, 5), (5, 100, 12)])
+def test_restore_chunks_workers(Replay, tmp_path, workers, length, capacity, chunksize):
+  """Chunk files per worker: how many are written, how many steps they hold
+  after pruning, and that loading brings every item back
+  (tests/test_replay.py:252-278)."""
+  capacity *= workers
+  replay = Replay(length, capacity, directory=tmp_path, chunksize=chunksize, save_wait=True)
+  for step in range(50):
+    for worker in range(workers):
+      replay.add({'step': step}, worker)
+  num_items = np.clip((50 - length + 1) * workers, 0, capacity)
+  assert len(replay) == num_items
+  data = replay.save()
+  filenames = list(pathlib.Path(tmp_path).glob('*.npz'))
+  lengths = [int(x.stem.split('-')[3]) for x in filenames]
+  stored_steps = min(capacity // workers + length - 1, 50)
+  total_chunks = int(np.ceil(50 / chunksize))
+  pruned_chunks = int(np.floor((50 - stored_steps) / chunksize))
+  assert len(filenames) == (total_chunks - pruned_chunks) * workers
+  last_chunk_empty = total_chunks * chunksize - 50
+  saved_steps = (total_chunks - pruned_chunks) * chunksize - last_chunk_empty
+  assert sum(lengths) == saved_steps * workers
+  replay = Replay(length, capacity, directory=tmp_path, chunksize=chunksize)
+  replay.load(data)
+  assert len(replay) == num_items
+  for _ in range(len(replay)):
+    assert len(one(replay)['step']) == length
