@@ -393,3 +393,64 @@ def test_random_mixture_histories_against_oracle(seed):
         prio = gen.random(want['stepid'].shape[:2]) * 4
         ours.update({'stepid': want['stepid'], 'priority': prio})
         ref.update({'stepid': want['stepid'], 'priority': prio})
+
+
+@pytest.mark.parametrize('branching', [2, 3, 5, 10])
+def test_sampletree_draw_statistics_like_reference_tests(branching):
+  """tests/test_sampletree.py:60-173 re-expressed against the native tree: the
+  only survivor is always drawn; equal masses are drawn about equally at any
+  scale; draw frequencies follow the masses after inserts and after updates;
+  zero-mass entries are never drawn unless every entry is zero; infinite
+  masses are the only ones drawn."""
+  import collections
+  tree = selectors.SampleTree(branching)
+  for key in (12, 123, 42):
+    tree.insert(key, 1.0)
+  tree.remove(12)
+  tree.remove(42)
+  assert {tree.sample() for _ in range(10)} == {123}
+
+  for inserts in (2, 10):
+    for mass in (1e-5, 1.0, 1e5):
+      tree = selectors.SampleTree(branching, seed=0)
+      keys = list(range(inserts))
+      for key in keys:
+        tree.insert(key, mass)
+      for key in keys[::3]:
+        tree.remove(key)
+      keys = [k for k in keys if k % 3]
+      counts = collections.Counter(tree.sample() for _ in range(100 * len(keys)))
+      assert set(counts) == set(keys)
+      assert all(c / (100 * len(keys)) > 0.5 / len(keys) for c in counts.values())
+
+  masses = {0: 0, 1: 3, 2: 1, 3: 1, 4: 2, 5: 2}
+  total = sum(masses.values())
+  def check(tree):
+    counts = collections.Counter(tree.sample() for _ in range(100 * len(masses)))
+    assert 0 not in counts and counts
+    for key, count in counts.items():
+      assert 0.7 * masses[key] / total < count / (100 * len(masses)) < 1.3 * masses[key] / total
+  for scale in (1e-5, 1, 1e5):
+    tree = selectors.SampleTree(branching, seed=0)
+    for key, mass in masses.items():
+      tree.insert(key, scale * mass)
+    check(tree)
+  tree = selectors.SampleTree(branching, seed=0)
+  for key in masses:
+    tree.insert(key, 100)
+  for key, mass in masses.items():
+    tree.update(key, mass)
+  check(tree)
+
+  tree = selectors.SampleTree(branching, seed=0)
+  for index in range(100):
+    tree.insert(index, 1.0 if index % 3 == 0 else 0.0)
+  assert all(tree.sample() % 3 == 0 for _ in range(1000))
+  tree = selectors.SampleTree(branching, seed=0)
+  for index in range(100):
+    tree.insert(index, 0.0)
+  assert all(0 <= tree.sample() < 100 for _ in range(1000))
+  tree = selectors.SampleTree(branching, seed=0)
+  for index in range(100):
+    tree.insert(index, np.inf if index % 3 == 0 else 1.0)
+  assert all(tree.sample() % 3 == 0 for _ in range(1000))
