@@ -159,7 +159,7 @@ class LaunchTimer {
     if (!enabled) return;
     if (discard && pairs_.size() >= 256) used_ %= 256;
     if (used_ == pairs_.size()) {
-      if (pairs_.size() >= 8192) collect();
+      if (pairs_.size() >= 32768) collect();   // bounds the events held; reading them waits for the launches
       if (used_ == pairs_.size()) {
         hipEvent_t a, b;
         HIP_OK(hipEventCreate(&a));
