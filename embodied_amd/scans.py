@@ -15,6 +15,21 @@ def _stream(t):
   return _lib.raw_stream(t.device)
 
 
+_ROUNDED = {}
+
+
+def _round32(x):
+  """x rounded to float32 (what the float32 reference computes with), as a
+  Python float; the handful of hyper-parameter values is remembered."""
+  try:
+    return _ROUNDED[x]
+  except KeyError:
+    if len(_ROUNDED) > 1024:
+      _ROUNDED.clear()
+    value = _ROUNDED[x] = float(np.float32(x))
+    return value
+
+
 def _f32(x, device):
   if torch.is_tensor(x) and x.dtype == torch.float32 and x.device == device and x.is_contiguous():
     return x
@@ -58,7 +73,7 @@ def gae(rew, val, last, term, hor=200, lam=0.8):
     return adv, tar                   # nothing to scan: (B, 0) results
   fast.emb_scan_gae(
       rew.data_ptr(), val.data_ptr(), last.data_ptr(), term.data_ptr(), B, T,
-      float(np.float32(1 - 1 / hor)), float(np.float32(lam)), adv.data_ptr(),
+      _round32(1 - 1 / hor), _round32(lam), adv.data_ptr(),
       tar.data_ptr(), _stream(rew))
   return adv, tar
 
@@ -77,7 +92,7 @@ def lambda_return(last, term, rew, val, boot, disc, lam):
     return ret
   fast.emb_scan_lambda(
       last.data_ptr(), term.data_ptr(), rew.data_ptr(), boot.data_ptr(), B, T,
-      float(np.float32(disc)), float(np.float32(lam)), ret.data_ptr(),
+      _round32(disc), _round32(lam), ret.data_ptr(),
       _stream(rew))
   return ret
 
@@ -93,7 +108,7 @@ def director_score(rew, cont, value, horizon=333, lam=0.95):
     return ret
   api.emb_scan_director(
       rew.data_ptr(), cont.data_ptr(), value.data_ptr(), T, B,
-      float(np.float32(1 - 1 / horizon)), float(np.float32(lam)),
+      _round32(1 - 1 / horizon), _round32(lam),
       ret.data_ptr(), _stream(rew))
   return ret
 
