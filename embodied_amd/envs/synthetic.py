@@ -81,10 +81,18 @@ class SyntheticBatchEnv:
     return obs
 
 
+_RAMPS = {}
+
+
 def host_frame(env, count, frame_bytes):
-  """Byte i of env `env`'s frame at episode step `count`."""
-  salt = (env * 131 + count * 7) & 0xFFFFFFFF
-  return ((salt + np.arange(frame_bytes, dtype=np.int64)) & 0xFF).astype(np.uint8)
+  """Byte i of env `env`'s frame at episode step `count`:
+  (env*131 + count*7 + i) & 0xFF -- a uint8 ramp plus a uint8 salt (uint8
+  addition wraps modulo 256)."""
+  ramp = _RAMPS.get(frame_bytes)
+  if ramp is None:
+    ramp = _RAMPS[frame_bytes] = (np.arange(frame_bytes, dtype=np.int64) & 0xFF).astype(np.uint8)
+  salt = np.uint8((env * 131 + count * 7) & 0xFF)
+  return ramp + salt
 
 
 class HostSyntheticEnv:
