@@ -299,6 +299,28 @@ def main():
         'launches': launches,
     }
 
+  # Outside the timed region, for context: the same kernel with more sequences
+  # per launch (the reference's prefetch depth is 1, so B=16 is the faithful
+  # headline; these show what the kernel does when a launch is not ~15 us).
+  if roofline and rank == 0 and world == 1 and args.consec == 1 and not args.host_envs:
+    try:
+      larger = {}
+      for big in (64, 256):
+        torch.cuda.synchronize(device)
+        replay.profile_read(reset=True)
+        for _ in range(20):
+          replay.sample(big, 'report')
+        torch.cuda.synchronize(device)
+        count, ms = replay.profile_read(reset=True)
+        if count:
+          us = ms / count * 1e3
+          gbs = 2 * big * L * S / (us * 1e-6) / 1e9
+          larger[str(big)] = {'avg_launch_us': round(us, 2), 'achieved': round(gbs, 1),
+                              'frac': round(gbs / HBM_PEAK_GBS, 4)}
+      roofline['larger_batches_per_launch'] = larger
+    except Exception as e:     # context only: never lose the headline over it
+      roofline['larger_batches_per_launch'] = {'error': str(e)[:200]}
+
   cpu = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ppo' and not args.host_envs:
     cpu = cpu_baseline(args)
