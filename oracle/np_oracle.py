@@ -13,10 +13,13 @@ Parity pinning (see tests/test_oracle_golden.py, oracle/gen_golden.py):
   * selectors / Replay / Driver / Consec are pinned against golden vectors
     produced by running the real reference modules in the build container
     (`tests/golden/*.npz`, generator committed).
-  * The return scans (GAE, lambda-return, Director score) live in JAX code that
-    cannot be imported here (no jax): for those **parity is unpinned by the
-    reference**; they are cross-checked against an independent float64 closed
-    form only.
+  * The return scans (GAE, lambda-return, Director score, split/abstract_traj)
+    live in JAX code that cannot be imported here (no jax).  They are pinned
+    against fixtures made by EXECUTING the reference's own function text under
+    numpy stand-ins for `jnp`/`f32`/`sg`/`chex` (`oracle/gen_scan_golden.py`,
+    `oracle/shims/jaxlike.py` -> `tests/golden/scan_*.npz`): this oracle equals
+    them bit for bit in float32 (`tests/test_scan_golden.py`).  numpy stands in
+    for XLA's float32 arithmetic there (FMA contraction may differ at ~1e-7).
 
 Integer PRNG: the reference draws through `numpy.random.default_rng`; so does
 this oracle (numpy is the actual third-party dependency).  The product restates
@@ -687,7 +690,8 @@ def stack_obs(per_env_obs):
 
 # ----------------------------------------------------------------------------
 # Return scans (float32, sequential from the last step backwards).
-# Reference code is JAX and cannot run here: PARITY UNPINNED by the reference.
+# The reference code is JAX; pinned by executing its source under numpy
+# stand-ins (oracle/gen_scan_golden.py, tests/test_scan_golden.py).
 # ----------------------------------------------------------------------------
 
 f32 = np.float32
