@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
   if not force and not stale():
     return OUT
   flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall',
-           '-Wno-unused-function', '-x', 'hip']
+           '-Wno-unused-function', '-Wno-pass-failed', '-x', 'hip']
 
   def compile_one(name):
     obj = OBJ / (name + '.o')

@@ -59,6 +59,7 @@ struct MoveLaunch {
   alignas(16) unsigned char args[kMoveArgsBytes];
   uint32_t blocks = 0;
   uint32_t threads = 0;
+  bool span = false;       // persistent span mover (wide keys of a span table)
 };
 hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out);
 size_t move_args_bytes();

@@ -10,6 +10,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,13 @@ struct MoveArgs {
   int8_t mask_dtype[kMaxKeys];
   uint8_t* mask_out[kMaxKeys];
   const uint8_t* mask_flags;
+  // Span mode (rows_mode 2): the wide keys are moved by `wide_workers`
+  // persistent workgroups walking `wtile0[n_wide]` tiles (see move_wide_spans);
+  // those keys own no virtual blocks.
+  int32_t wide_workers, n_wide;
+  uint32_t wtile0[kMaxKeys + 1];
+  uint32_t tiles_per_seq[kMaxKeys];
+  uint8_t wide_key[kMaxKeys];
   uint32_t inline_words[kInlineWords];
 };
 static_assert(sizeof(MoveArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -158,6 +166,89 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
     u32x4* dst = reinterpret_cast<u32x4*>(kGather ? batch : pool) + off[j];
     if (NT & 2) __builtin_nontemporal_store(buf[j], dst);
     else *dst = buf[j];
+  }
+}
+
+// Span mode: every sequence is one or two contiguous runs of pool rows
+// ({row0, n0, row1}: rows row0..row0+n0-1, then row1..), so per wide key a
+// sequence is a flat run of L * rowbytes/16 units with ONE split point and no
+// row structure at all.  `wide_workers` workgroups (a couple per CU) walk the
+// tiles of blockDim.x * U units with a grid stride, and every lane issues the
+// NEXT tile's loads before it stores the current one: loads and stores of one
+// workgroup overlap and the launch has a single ramp instead of one per
+// 8 KB workgroup.  Measured on MI355X (tools/gather_lab.hip, B=16, L=65,
+// 28 224-byte rows, cold 2.8 GB pool): 10.0-10.2 us against 10.1 us for a
+// plain contiguous copy of the same bytes and 13.8 us for the flat
+// one-tile-per-workgroup mover above.
+template <bool kGather, int U, int NT>
+__device__ __forceinline__ void move_wide_spans(const MoveArgs& a) {
+  const uint32_t tile = blockDim.x * U;
+  const uint32_t L = static_cast<uint32_t>(a.seq_len);
+  const uint32_t ntiles = a.wtile0[a.n_wide];
+  const uint32_t stride = static_cast<uint32_t>(a.wide_workers);
+  struct Where {
+    const u32x4* p0; const u32x4* p1;   // pool runs, both indexed by the unit number
+    const u32x4* b;                     // batch side of the sequence
+    uint32_t split, total, u0;
+  };
+  auto locate = [&](uint32_t ti) {
+    int k = 0;
+    while (k + 1 < a.n_wide && ti >= a.wtile0[k + 1]) ++k;
+    const KeyDesc& key = a.key[a.wide_key[k]];
+    const uint32_t local = ti - a.wtile0[k];
+    const uint32_t tps = a.tiles_per_seq[k];
+    const uint32_t seq = local / tps, piece = local - seq * tps;
+    const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
+    const uint32_t row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
+    const uint32_t row1 = a.inline_words[3 * seq + 2];
+    Where w;
+    w.split = n0 * upr;
+    w.total = L * upr;
+    w.u0 = piece * tile + threadIdx.x;
+    w.p0 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row0) * upr;
+    w.p1 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row1) * upr - w.split;
+    w.b = reinterpret_cast<const u32x4*>(key.batch) + static_cast<uint64_t>(seq) * w.total;
+    return w;
+  };
+  auto issue = [&](const Where& w, u32x4* v) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t u = w.u0 + j * blockDim.x;
+      if (u < w.total) {
+        const u32x4* src = kGather ? (u < w.split ? w.p0 : w.p1) + u : w.b + u;
+        v[j] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+  };
+  auto put = [&](const Where& w, const u32x4* v) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t u = w.u0 + j * blockDim.x;
+      if (u < w.total) {
+        u32x4* dst = const_cast<u32x4*>(kGather ? w.b + u : (u < w.split ? w.p0 : w.p1) + u);
+        if (NT & 2) __builtin_nontemporal_store(v[j], dst);
+        else *dst = v[j];
+      }
+    }
+  };
+  uint32_t i = blockIdx.x;
+  if (i >= ntiles) return;
+  u32x4 cur[U], nxt[U];
+  Where wc = locate(i);
+  issue(wc, cur);
+  for (;;) {
+    const uint32_t n = i + stride;
+    Where wn = wc;
+    if (n < ntiles) {
+      wn = locate(n);
+      issue(wn, nxt);
+    }
+    put(wc, cur);
+    if (n >= ntiles) break;
+#pragma unroll
+    for (int j = 0; j < U; ++j) cur[j] = nxt[j];
+    wc = wn;
+    i = n;
   }
 }
 
@@ -306,6 +397,29 @@ __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* 
   scatter_body<U, NT>(*a);
 }
 
+// Span-mode launch: the first `wide_workers` workgroups are the persistent wide
+// movers, the rest are the virtual blocks of the narrow keys.
+template <bool kGather, int U, int NT>
+__global__ __launch_bounds__(1024) void span_move_kernel(const MoveArgs a) {
+  if (static_cast<int>(blockIdx.x) < a.wide_workers) {
+    move_wide_spans<kGather, U, NT>(a);
+    return;
+  }
+  const int block = static_cast<int>(blockIdx.x) - a.wide_workers;
+  if (kGather) gather_block<2, NT>(a, block);
+  else scatter_block<2, NT>(a, block);
+}
+template <bool kGather, int U, int NT>
+__global__ __launch_bounds__(1024) void span_move_kernel_indirect(const MoveArgs* __restrict__ a) {
+  if (static_cast<int>(blockIdx.x) < a->wide_workers) {
+    move_wide_spans<kGather, U, NT>(*a);
+    return;
+  }
+  const int block = static_cast<int>(blockIdx.x) - a->wide_workers;
+  if (kGather) gather_block<2, NT>(*a, block);
+  else scatter_block<2, NT>(*a, block);
+}
+
 // Tuning knobs, read once: EMB_MOVE_VARIANT="U,NT,remap,threads" = 16-byte units
 // per lane, non-temporal hints (bit0 loads, bit1 stores), XCD remap on/off and
 // workgroup size.  Defaults from the MI355X sweep (tools/bench_gather.py):
@@ -326,6 +440,32 @@ const MoveVariant& move_variant() {
   }();
   return variant;
 }
+
+// Span-mode mover (move_wide_spans): EMB_SPAN_VARIANT="U,NT,threads,W" = units
+// per lane per tile (2|4), non-temporal hints, workgroup size (256|512|1024)
+// and persistent workgroups per CU; W=0 turns the path off (flat mover for
+// everything).  Defaults from tools/gather_lab.hip on MI355X.
+//
+// The persistent mover wins while the launch is ramp-dominated and loses to
+// the flat mover's many short-lived workgroups once every worker has more than
+// a few tiles (MI355X, S0 rows, kernel us persistent / flat: B=8 7.2 / 8.7,
+// B=16 11.0 / 13.4, B=32 23.1 / 22.5, B=64 44.0 / 40.5, B=128 85.8 / 77.0), so
+// it is used up to `max_mb` MB of wide payload per launch (fifth field).
+struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; };
+const SpanVariant& span_variant() {
+  static const SpanVariant variant = [] {
+    SpanVariant v{4, 3, 512, 2, 40};
+    if (const char* s = std::getenv("EMB_SPAN_VARIANT"))
+      std::sscanf(s, "%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb);
+    if (v.unroll != 2 && v.unroll != 4) v.unroll = 4;
+    if (v.nt < 0 || v.nt > 3) v.nt = 3;
+    if (v.threads != 256 && v.threads != 512 && v.threads != 1024) v.threads = 512;
+    if (v.per_cu < 0 || v.per_cu > 16) v.per_cu = 2;
+    return v;
+  }();
+  return variant;
+}
+constexpr int kCUs = 256;
 
 int pick_unit(const KeyDesc& key) {
   const uint64_t mix = reinterpret_cast<uint64_t>(key.pool) |
@@ -371,9 +511,23 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
     return hipErrorInvalidValue;
   if (plan.n_rows == 0) return hipSuccess;
   const MoveVariant& variant = move_variant();
-  const int unroll = variant.unroll;
-  const int threads = variant.threads;
+  const SpanVariant& sv = span_variant();
+  // Span tables (sample, windowing, write-back) with at least one wide key go
+  // to the persistent span mover; everything else to the flat mover.
+  bool span_path = false;
+  if (use_inline && plan.spans_host && sv.per_cu > 0 && plan.seq_len >= 1) {
+    int64_t wide_bytes = 0;
+    for (int k = 0; k < plan.n_keys; ++k)
+      if (!((plan.mask_bits >> k) & 1u) && k != plan.inline_key && pick_unit(plan.key[k]) == 0)
+        wide_bytes += plan.key[k].rowbytes * static_cast<int64_t>(plan.n_rows);
+    span_path = wide_bytes > 0 && wide_bytes <= static_cast<int64_t>(sv.max_mb) * 1000000;
+  }
+  const int unroll = span_path ? sv.unroll : variant.unroll;
+  const int threads = span_path ? sv.threads : variant.threads;
+  out->span = span_path;
   MoveArgs& a = *reinterpret_cast<MoveArgs*>(out->args);
+  a.wide_workers = 0;
+  a.n_wide = 0;
   a.n_keys = plan.n_keys;
   a.n_rows = plan.n_rows;
   a.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;
@@ -422,7 +576,17 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
     } else
     a.unit[k] = (k == a.inline_key) ? 4 : pick_unit(plan.key[k]);
     a.first_block[k] = static_cast<int32_t>(blocks);
-    if (a.unit[k] == 0) {
+    if (a.unit[k] == 0 && span_path) {
+      // tiles of threads * unroll units per sequence; no virtual blocks
+      const int64_t per_seq = static_cast<int64_t>(a.seq_len) * (plan.key[k].rowbytes >> 4);
+      const int64_t tps = (per_seq + threads * unroll - 1) / (threads * unroll);
+      const int64_t first = a.n_wide ? a.wtile0[a.n_wide] : 0;
+      if (per_seq > UINT32_MAX / 2 || first + tps * plan.n_seq > UINT32_MAX / 2) return hipErrorInvalidValue;
+      a.wide_key[a.n_wide] = static_cast<uint8_t>(k);
+      a.tiles_per_seq[a.n_wide] = static_cast<uint32_t>(tps);
+      a.wtile0[a.n_wide] = static_cast<uint32_t>(first);
+      a.wtile0[++a.n_wide] = static_cast<uint32_t>(first + tps * plan.n_seq);
+    } else if (a.unit[k] == 0) {
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes >> 4);
       if (units > UINT32_MAX / 2) return hipErrorInvalidValue;
       blocks += (units + threads * unroll - 1) / (threads * unroll);
@@ -434,7 +598,13 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
   }
   a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
   out->blocks = static_cast<uint32_t>(blocks);
-  if (variant.persist > 0 && blocks > 256ll * variant.persist) out->blocks = 256u * variant.persist;
+  if (span_path) {
+    a.wide_workers = static_cast<int32_t>(std::min<int64_t>(a.wtile0[a.n_wide], int64_t(kCUs) * sv.per_cu));
+    if (blocks + a.wide_workers > INT32_MAX) return hipErrorInvalidValue;
+    out->blocks = static_cast<uint32_t>(blocks + a.wide_workers);
+  } else if (variant.persist > 0 && blocks > 256ll * variant.persist) {
+    out->blocks = 256u * variant.persist;
+  }
   out->threads = static_cast<uint32_t>(threads);
   return hipSuccess;
 }
@@ -448,6 +618,26 @@ hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device
   const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
   const MoveArgs* ap = static_cast<const MoveArgs*>(device_args);
   const dim3 grid(launch.blocks), block(launch.threads);
+  if (launch.span) {
+    const SpanVariant& sv = span_variant();
+#define EMB_SPAN(G_, U_, NT_)                                                                       \
+  do {                                                                                              \
+    if (ap) hipExtLaunchKernelGGL((span_move_kernel_indirect<G_, U_, NT_>), grid, block, 0, stream, start, stop, 0, ap); \
+    else hipExtLaunchKernelGGL((span_move_kernel<G_, U_, NT_>), grid, block, 0, stream, start, stop, 0, a);             \
+  } while (0)
+#define EMB_SPAN_NT(G_, U_)                                                      \
+  switch (sv.nt) {                                                               \
+    case 0: EMB_SPAN(G_, U_, 0); break;                                          \
+    case 1: EMB_SPAN(G_, U_, 1); break;                                          \
+    case 2: EMB_SPAN(G_, U_, 2); break;                                          \
+    default: EMB_SPAN(G_, U_, 3); break;                                         \
+  }
+    if (gather) { if (sv.unroll == 2) { EMB_SPAN_NT(true, 2) } else { EMB_SPAN_NT(true, 4) } }
+    else { if (sv.unroll == 2) { EMB_SPAN_NT(false, 2) } else { EMB_SPAN_NT(false, 4) } }
+#undef EMB_SPAN_NT
+#undef EMB_SPAN
+    return hipGetLastError();
+  }
 #define EMB_MOVE(U_, NT_)                                                                      \
   do {                                                                                         \
     if (gather && ap) hipExtLaunchKernelGGL((gather_kernel_indirect<U_, NT_>), grid, block, 0, stream, start, stop, 0, ap); \

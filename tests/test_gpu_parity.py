@@ -881,3 +881,43 @@ def test_save_load_with_prioritized_selector(emb, tmp_path):
       want = scenarios.synth_step(int(step[i, 0]), int(worker[i, 0]))['image']
       assert (img[i, 0] == want).all()
     b.update({'stepid': batch['stepid'], 'priority': torch.rand(6, 5, device='cuda')})
+
+
+@pytest.mark.parametrize('chunksize,L,batches', [
+    (16, 7, (1, 3, 16)),        # most windows cross a chunk boundary: two runs per sequence
+    (64, 65, (1, 5)),           # BASELINE length, windows of 1-2 runs
+    (8, 9, (2, 40)),            # windows of 2-3 chunks: NOT span-shaped, falls back to row tables
+])
+def test_span_mover_several_wide_keys_match_oracle(emb, chunksize, L, batches):
+  """The persistent span mover (kernels.hip move_wide_spans: sample, windowing
+  and write-back of keys with >= 2 KB rows) against the oracle: three wide keys
+  of different row sizes next to the narrow ones, tiles that straddle the run
+  split and the end of a sequence, gather and scatter directions."""
+  n_workers, n_steps = 3, 6 * chunksize + L
+  ours = emb.Replay(length=L, capacity=4 * n_steps, chunksize=chunksize, seed=5)
+  ref = np_oracle.Replay(L, 4 * n_steps, chunksize, seed=5)
+  gen = np.random.default_rng(1)
+  def step(t, w):
+    return dict(
+        scenarios.synth_step(t, w),
+        a=gen.standard_normal(520).astype(np.float32),          # 2080 B = 130 units
+        b=gen.integers(0, 255, (48, 48, 3), dtype=np.uint8),    # 6912 B = 432 units
+        c=gen.standard_normal(1028).astype(np.float16))         # 2056 B: 8-byte units, narrow path
+  for t in range(n_steps):
+    for w in range(n_workers):
+      s = step(t, w)
+      ours.add(s, w)
+      ref.add(s, w)
+  for batch in batches:
+    got = {k: v.cpu().numpy() for k, v in ours.sample(batch).items()}
+    assert_same(got, ref.sample(batch), f'sample {batch}')
+  # write-back of two wide keys over sampled windows (span-shaped when disjoint)
+  want = ref.sample(4)
+  got = ours.sample(4)
+  upd = {'stepid': want['stepid'][:, :L - 1],
+         'a': gen.standard_normal((4, L - 1, 520)).astype(np.float32),
+         'b': gen.integers(0, 255, (4, L - 1, 48, 48, 3), dtype=np.uint8)}
+  assert np.array_equal(got['stepid'].cpu().numpy(), want['stepid'])
+  ours.update({k: torch.as_tensor(v).cuda() for k, v in upd.items()})
+  ref.update(dict(upd))
+  assert_same({k: v.cpu().numpy() for k, v in ours.sample(12).items()}, ref.sample(12), 'after update')

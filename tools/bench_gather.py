@@ -17,6 +17,9 @@ p.add_argument('--iters', type=int, default=50)
 p.add_argument('--variants', default='', help='unused: set EMB_MOVE_VARIANT=U,NT,remap,threads per process')
 p.add_argument('--batches', default='16,64,256')
 p.add_argument('--sleep-us', type=float, default=0, help='host idle time between samples')
+p.add_argument('--tight', action='store_true',
+               help='also time the C entry point with preallocated outputs (no Python allocation '
+                    'between launches: the GPU stays busy, as in tools/gather_lab.hip mode A)')
 args = p.parse_args()
 
 n, L = 64, 65
@@ -71,3 +74,28 @@ for variant in [os.environ.get('EMB_MOVE_VARIANT', 'default')]:
     nbytes = 2 * B * L * S
     print(f'variant {variant:5s} B={B:4d} kernel {us:8.2f} us  {nbytes / us / 1e3:8.1f} GB/s (r+w)  '
           f'frac {nbytes / us / 1e3 / 8000:.3f}  wall/call {wall:8.1f} us', flush=True)
+
+if args.tight:
+  import ctypes as C
+  from embodied_amd import _lib
+  from embodied_amd._lib import fast
+  for B in map(int, args.batches.split(',')):
+    outs = [rep._new_batch(B, L) for _ in range(4)]
+    first = (C.c_uint8 * (B * _lib.STEPID_BYTES))()
+    stream = rep._stream()
+    mode = _lib.MODES['train']
+    for i in range(10):
+      fast.emb_replay_sample(rep._h, B, mode, outs[i % 4][1], None, first, stream)
+    torch.cuda.synchronize()
+    rep.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.iters * 4):
+      fast.emb_replay_sample(rep._h, B, mode, outs[i % 4][1], None, first, stream)
+    host = (time.perf_counter() - t0) / (args.iters * 4) * 1e6
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / (args.iters * 4) * 1e6
+    launches, ms = rep.profile_read(reset=True)
+    us = ms / launches * 1e3
+    nbytes = 2 * B * L * S
+    print(f'tight   B={B:4d} kernel {us:8.2f} us  {nbytes / us / 1e3:8.1f} GB/s (r+w)  '
+          f'frac {nbytes / us / 1e3 / 8000:.3f}  host/call {host:6.1f} us  wall/call {wall:8.1f} us', flush=True)

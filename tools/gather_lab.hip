@@ -10,6 +10,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <cstdint>
 #include <cstdio>
@@ -243,7 +244,7 @@ int main(int argc, char** argv) {
   CHECK(hipEventCreate(&w1));
   const double mb = 2.0 * batch_bytes / 1e6;
   std::printf("B=%d L=%u rowbytes=%u  r+w bytes per launch %.2f MB  ring=%d iters=%d\n", B, L, rowbytes, mb, ring, iters);
-  std::printf("%-34s %9s %9s %9s | %9s | %9s\n", "variant", "A mean", "A med", "A min", "B thru", "C mean");
+  std::printf("%-34s %9s %9s %9s | %9s | %9s | %9s\n", "variant", "A mean", "A med", "A min", "B thru", "C mean", "D idle");
   for (auto& l : ls) {
     for (int i = 0; i < 10; ++i) l.go(i, stream, nullptr, nullptr);
     CHECK(hipStreamSynchronize(stream));
@@ -274,8 +275,22 @@ int main(int argc, char** argv) {
       for (int i = 0; i < batchn; ++i) { float ms; CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tc.push_back(ms * 1e3f); }
     }
     double meanC = 0; for (float t : tc) meanC += t; meanC /= tc.size();
-    std::printf("%-34s %9.2f %9.2f %9.2f | %9.2f | %9.2f   (A: %.0f GB/s r+w)\n", l.name.c_str(), meanA, medA, minA,
-                msB * 1e3 / iters, meanC, mb / meanA * 1e3);
+    // D: stamped, GPU idle between launches (sync + 15 us of host spinning)
+    double meanD = 0;
+    {
+      const int nd = std::min(iters, 100);
+      for (int i = 0; i < nd; ++i) {
+        l.go(i, stream, ev[0], ev[1]);
+        CHECK(hipStreamSynchronize(stream));
+        float ms; CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        meanD += ms * 1e3;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 15.0) {}
+      }
+      meanD /= nd;
+    }
+    std::printf("%-34s %9.2f %9.2f %9.2f | %9.2f | %9.2f | %9.2f  (A: %.0f GB/s r+w)\n", l.name.c_str(), meanA, medA, minA,
+                msB * 1e3 / iters, meanC, meanD, mb / meanA * 1e3);
     std::fflush(stdout);
   }
   // hipMemcpyAsync D2D of the same bytes (throughput only)
