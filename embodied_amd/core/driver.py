@@ -372,16 +372,23 @@ class Driver:
     return out
 
   def _receive(self, pipe):
+    """The payload of a worker's ('result', payload) reply.  Anything else — an
+    ('error', e) reply, a dead pipe, an unknown tag — ends the run: every
+    worker is killed before the exception propagates (driver.py:89-99)."""
+    failure = None
     try:
-      msg, arg = pipe.recv()
-      if msg == 'error':
-        raise RuntimeError(arg)
-      assert msg == 'result'
-      return arg
-    except Exception:
-      print('Terminating workers due to an exception.')
-      [proc.kill() for proc in self.procs]
-      raise
+      tag, payload = pipe.recv()
+    except Exception as e:                      # EOF / broken pipe: worker is gone
+      failure = e
+    else:
+      if tag == 'result':
+        return payload
+      failure = RuntimeError(payload) if tag == 'error' else RuntimeError(
+          f'env worker sent an unexpected {tag!r} message')
+    print('Terminating workers due to an exception.')
+    for proc in self.procs:
+      proc.kill()
+    raise failure
 
 
 def _env_server(envid, pipe, ctor, wake=None):
@@ -411,48 +418,56 @@ def _env_server(envid, pipe, ctor, wake=None):
         slab[envid] = value
     return rest
 
+  def serve_shared(layout, n, act_layout=None, ctrl_name=None):
+    """'attach': from now on observations go into the shared slab; with action
+    slabs and a control block the whole step protocol does."""
+    slabs.update(attach(layout, n))
+    if act_layout is None or wake is None:
+      pipe.send(('result', True))
+      return
+    acts = attach(act_layout, n)
+    ctrl_block = shared_memory.SharedMemory(name=ctrl_name)
+    blocks.append(ctrl_block)
+    ctrl = np.ndarray(2 + 2 * n, np.int64, buffer=ctrl_block.buf)
+    done, extra = ctrl[2: 2 + n], ctrl[2 + n:]
+    pipe.send(('result', True))
+    while True:
+      wake.acquire()
+      seq = int(ctrl[0])
+      try:
+        rest = put(env.step({k: v[envid].copy() for k, v in acts.items()}))
+        if rest:
+          pipe.send(('result', rest))
+        extra[envid] = 1 if rest else 0
+        done[envid] = seq
+      except Exception as e:
+        pipe.send(('error', e))
+        done[envid] = -1
+        raise
+
+  def step(action):
+    obs = env.step(action)
+    pipe.send(('result', put(obs) if slabs else obs))
+
+  handlers = {
+      'step': step,
+      'attach': serve_shared,
+      'obs_space': lambda: pipe.send(('result', env.obs_space)),
+      'act_space': lambda: pipe.send(('result', env.act_space)),
+  }
   try:
     env = cloudpickle.loads(ctor)()
     while True:
-      if not pipe.poll(0.1):
+      if not pipe.poll(0.1):                    # also notices a vanished parent
         continue
       try:
-        msg, *args = pipe.recv()
+        request = pipe.recv()
       except EOFError:
         return
-      if msg == 'step':
-        obs = env.step(args[0])
-        pipe.send(('result', put(obs) if slabs else obs))
-      elif msg == 'attach':
-        slabs.update(attach(args[0], args[1]))
-        fast = len(args) > 2 and wake is not None
-        if fast:
-          acts = attach(args[2], args[1])
-          ctrl_block = shared_memory.SharedMemory(name=args[3])
-          blocks.append(ctrl_block)
-          ctrl = np.ndarray(2 + 2 * args[1], np.int64, buffer=ctrl_block.buf)
-          done, extra = ctrl[2: 2 + args[1]], ctrl[2 + args[1]:]
-        pipe.send(('result', True))
-        while fast:
-          wake.acquire()
-          seq = int(ctrl[0])
-          try:
-            action = {k: v[envid].copy() for k, v in acts.items()}
-            rest = put(env.step(action))
-            if rest:
-              pipe.send(('result', rest))
-            extra[envid] = 1 if rest else 0
-            done[envid] = seq
-          except Exception as e:
-            pipe.send(('error', e))
-            done[envid] = -1
-            raise
-      elif msg == 'obs_space':
-        pipe.send(('result', env.obs_space))
-      elif msg == 'act_space':
-        pipe.send(('result', env.act_space))
-      else:
-        raise ValueError(f'Invalid message {msg}')
+      handler = handlers.get(request[0])
+      if handler is None:
+        raise ValueError(f'Invalid message {request[0]}')
+      handler(*request[1:])
   except (ConnectionResetError, BrokenPipeError):
     print('Connection to driver lost')
   except Exception as e:

@@ -1,12 +1,12 @@
 """Batch streams (reference: embodied/core/streams.py): `Stateless` wraps a
 sampling function, `Consec` serves one long sampled batch as consecutive
-overlapping windows, `Prefetch` runs a source one batch ahead in a thread.
+overlapping windows, `Prefetch` runs a source some batches ahead in a thread.
 
 Batches may be dicts of numpy arrays or of torch device tensors; for device
-tensors the window copy is the `emb_window` kernel (one launch per key).
+tensors the window copy is one `emb_window_keys` launch for all keys, and over
+this package's `Replay.sample` the sampling and the windowing are one gather.
 """
-import functools
-import queue
+import collections
 import threading
 
 import numpy as np
@@ -18,24 +18,28 @@ from . import base
 
 
 class Stateless(base.Stream):
-  """streams.py:12-29."""
+  """An endless stream that calls `fn(*args, **kwargs)` for every batch; an
+  iterator may be given instead of a function (streams.py:12-29).  It carries
+  no state of its own: `save()` is None and `load` ignores its argument."""
 
-  def __init__(self, nextfn, *args, **kwargs):
-    if not callable(nextfn) and hasattr(nextfn, '__next__'):
-      nextfn = nextfn.__next__
-    self.nextfn = functools.partial(nextfn, *args, **kwargs)
+  def __init__(self, fn, *args, **kwargs):
+    if not callable(fn):
+      if not hasattr(fn, '__next__'):
+        raise TypeError(f'Stateless needs a callable or an iterator, got {type(fn).__name__}')
+      fn = fn.__next__
+    self.fn, self.args, self.kwargs = fn, args, kwargs
 
   def __iter__(self):
     return self
 
   def __next__(self):
-    return self.nextfn()
+    return self.fn(*self.args, **self.kwargs)
 
   def save(self):
     return None
 
   def load(self, data):
-    pass
+    del data
 
 
 def window(value, start, count):
@@ -85,71 +89,87 @@ class Consec(base.Stream):
   """Sequence windowing (streams.py:89-150): a source batch of
   `consec * length + prefix` steps is served as `consec` windows
   `[:, i*length : i*length + length + prefix]`, each with an int32 `consec` key
-  holding the window number; the prefix columns of successive windows overlap."""
+  holding the window number; the prefix columns of successive windows overlap.
+
+  State (`save`/`load`): the source's state and the number of the next window.
+  """
 
   def __init__(
       self, source, length, consec, prefix=0, strict=True, contiguous=False):
     self.source = source
-    self.length = length
-    self.consec = consec
-    self.prefix = prefix
+    self.length, self.consec, self.prefix = length, consec, prefix
     self.strict = strict
     self.contiguous = contiguous
-    self.index = 0
-    self.current = None
-    self.it = None
-    self._fused = False
-    self.windows = None
+    self.index = 0            # next window of the current source batch
+    self.current = None       # the source batch being served (unfused route)
+    self.windows = None       # its windows, already cut (fused route)
+    self._batches = None
+    self._fused = False       # not probed yet
+    self._numbers = {}        # (shape, window number, device) -> constant tensor
 
   def __iter__(self):
-    self.it = iter(self.source)
+    self._batches = iter(self.source)
     return self
 
   def __next__(self):
-    if self.index >= self.consec:
-      self.index = 0
+    number = 0 if self.index >= self.consec else self.index
     fused = self._fused_source() if self.consec > 1 else None
     if fused is not None:
-      if self.index == 0:
-        replay, batch, mode = fused
-        self.windows = replay.sample_windows(
-            batch, self.length, self.consec, self.prefix, mode)
-      chunk = dict(self.windows[self.index])
-      first = chunk['is_first']
-      if torch.is_tensor(first):
-        chunk['consec'] = torch.full(
-            first.shape, self.index, dtype=torch.int32, device=first.device)
-      else:
-        chunk['consec'] = np.full(first.shape, self.index, np.int32)
-      self.index += 1
-      return chunk
-    if self.index == 0:
-      self.current = next(self.it)
+      chunk = self._next_fused(number, *fused)
+    else:
+      chunk = self._next_sliced(number)
+    self.index = number + 1
+    return chunk
+
+  def _next_fused(self, number, replay, batch, mode):
+    if number == 0:
+      self.windows = replay.sample_windows(
+          batch, self.length, self.consec, self.prefix, mode)
+    chunk = dict(self.windows[number])
+    chunk['consec'] = self._number(chunk['is_first'], number)
+    return chunk
+
+  def _next_sliced(self, number):
+    if number == 0:
+      self.current = next(self._batches)
       have = self.current['is_first'].shape[1]
       need = self.length * self.consec + self.prefix
-      assert need <= have, (self.length, self.consec, self.prefix, have)
-      if self.strict:
-        assert need == have, (self.consec, self.length, self.prefix, have)
-    start = self.index * self.length
-    count = self.length + self.prefix
-    first = self.current['is_first']
-    if torch.is_tensor(first):
+      if have < need or (self.strict and have != need):
+        raise AssertionError(
+            f'Consec(length={self.length}, consec={self.consec}, prefix={self.prefix}) needs '
+            f'{"exactly" if self.strict else "at least"} {need} steps per sequence, got {have}')
+    start, count = number * self.length, self.length + self.prefix
+    batch = self.current
+    if torch.is_tensor(batch['is_first']):
       # Device batches are always materialised contiguously (one kernel for all
       # keys); `contiguous` only matters for numpy views.
-      if all(torch.is_tensor(v) and v.is_cuda for v in self.current.values()):
-        chunk = window_batch(self.current, start, count)
+      if all(torch.is_tensor(v) and v.is_cuda for v in batch.values()):
+        chunk = window_batch(batch, start, count)
       else:
-        chunk = {k: window(v, start, count) for k, v in self.current.items()}
-      chunk['consec'] = torch.full(
-          chunk['is_first'].shape, self.index, dtype=torch.int32,
-          device=first.device)
+        chunk = {k: window(v, start, count) for k, v in batch.items()}
     else:
-      chunk = {k: v[:, start: start + count] for k, v in self.current.items()}
-      chunk['consec'] = np.full(chunk['is_first'].shape, self.index, np.int32)
+      chunk = {k: v[:, start: start + count] for k, v in batch.items()}
       if self.contiguous:
         chunk = {k: np.ascontiguousarray(v) for k, v in chunk.items()}
-    self.index += 1
+    chunk['consec'] = self._number(chunk['is_first'], number)
     return chunk
+
+  def _number(self, like, number):
+    """The `consec` key: int32, shaped like `is_first`, filled with the window
+    number.  numpy batches get a fresh array; device batches share one constant
+    tensor per (shape, number) — filling a new one is a kernel launch and ~5 us
+    of host time per train step (treat it as read-only, like any batch key the
+    agent does not own)."""
+    if not torch.is_tensor(like):
+      return np.full(like.shape, number, np.int32)
+    key = (tuple(like.shape), number, like.device)
+    const = self._numbers.get(key)
+    if const is None:
+      if len(self._numbers) > 64:
+        self._numbers.clear()
+      const = self._numbers[key] = torch.full(
+          like.shape, number, dtype=torch.int32, device=like.device)
+    return const
 
   def _fused_source(self):
     """(replay, batch, mode) if the source is `Stateless(replay.sample, batch,
@@ -158,16 +178,17 @@ class Consec(base.Stream):
     if self._fused is not False:
       return self._fused
     self._fused = None
-    fn = getattr(self.source, 'nextfn', None)
-    target = getattr(getattr(fn, 'func', None), '__self__', None)
     from . import replay as replaylib
-    if (isinstance(target, replaylib.Replay)
-        and getattr(fn.func, '__func__', None) is replaylib.Replay.sample
-        and not fn.keywords and 1 <= len(fn.args) <= 2
+    src = self.source
+    fn = getattr(src, 'fn', None)
+    target = getattr(fn, '__self__', None)
+    if (isinstance(src, Stateless) and isinstance(target, replaylib.Replay)
+        and getattr(fn, '__func__', None) is replaylib.Replay.sample
+        and not src.kwargs and 1 <= len(src.args) <= 2
         and 'is_first' in (target._keyid or {'is_first': 0})
         and target.length == self.consec * self.length + self.prefix):
-      mode = fn.args[1] if len(fn.args) > 1 else 'train'
-      self._fused = (target, fn.args[0], mode)
+      mode = src.args[1] if len(src.args) > 1 else 'train'
+      self._fused = (target, src.args[0], mode)
     return self._fused
 
   def save(self):
@@ -178,54 +199,95 @@ class Consec(base.Stream):
     self.index = data['index']
 
 
+class _Failed:
+  """What the producer thread leaves in the buffer when the source raised."""
+
+  def __init__(self, error):
+    self.error = error
+
+
 class Prefetch(base.Stream):
-  """`amount`-deep pipeline: a daemon thread pulls from the source and applies
-  `transform` ahead of the consumer (streams.py:32-86)."""
+  """Keeps up to `amount` transformed batches ready ahead of the consumer
+  (streams.py:32-86; the agent's `stream()` uses it to overlap batch
+  preparation with the train step).
+
+  A producer thread fills a buffer while it holds fewer than `amount` batches.
+  Every batch travels with the source's state taken right after it was drawn;
+  `save()` returns the state that belongs to the last batch HANDED OUT, so a
+  restore replays exactly the batches the consumer has not seen.  `load(state)`
+  drops whatever was prepared ahead, lets a batch that is being prepared finish
+  (it is dropped as well), restores the source and resumes.  An exception in
+  the source or the transform reaches the consumer as RuntimeError on the
+  `next()` that would have returned that batch.
+  """
 
   def __init__(self, source, transform=None, amount=1):
     self.source = iter(source) if hasattr(source, '__iter__') else source()
-    self.transform = transform or (lambda x: x)
-    self.state = self._getstate()
-    self.requests = threading.Semaphore(amount)
-    self.amount = amount
-    self.queue = queue.Queue()
-    self.worker = threading.Thread(target=self._worker, daemon=True)
-    self.started = False
+    self.amount = int(amount)
+    self._transform = transform
+    self._state = self._snapshot()
+    self._cond = threading.Condition()
+    self._ready = collections.deque()
+    self._busy = False       # the producer is drawing / transforming a batch
+    self._epoch = 0          # bumped by load(): batches of older epochs are dropped
+    self._thread = None
 
   def __iter__(self):
-    assert not self.started
-    self.worker.start()
-    self.started = True
+    if self._thread is not None:
+      raise AssertionError('Prefetch can be iterated once')
+    self._thread = threading.Thread(target=self._produce, name='prefetch', daemon=True)
+    self._thread.start()
     return self
 
   def __next__(self):
-    assert self.started
-    result = self.queue.get()
-    self.requests.release()
-    if isinstance(result, BaseException):
-      raise RuntimeError(str(result)) from result
-    data, self.state = result
+    if self._thread is None:
+      raise AssertionError('call iter() on a Prefetch before next()')
+    with self._cond:
+      while not self._ready:
+        self._cond.wait()
+      item = self._ready.popleft()
+      if isinstance(item, _Failed):
+        self._ready.appendleft(item)          # stays failed
+        raise RuntimeError(str(item.error)) from item.error
+      self._cond.notify_all()
+    data, self._state = item
     return data
 
   def save(self):
-    return self.state
+    return self._state
 
   def load(self, state):
-    if self.started:
-      for _ in range(self.amount):
-        self.queue.get()
-    self.source.load(state)
-    if self.started:
-      self.requests.release(self.amount)
+    with self._cond:
+      self._epoch += 1
+      self._ready.clear()
+      while self._busy:
+        self._cond.wait()
+      self._ready.clear()
+      self.source.load(state)
+      self._state = self._snapshot()
+      self._cond.notify_all()
 
-  def _worker(self):
-    try:
-      while True:
-        self.requests.acquire()
-        data = self.transform(next(self.source))
-        self.queue.put((data, self._getstate()))
-    except BaseException as e:
-      self.queue.put(e)
+  def _produce(self):
+    while True:
+      with self._cond:
+        while len(self._ready) >= self.amount:
+          self._cond.wait()
+        epoch, self._busy = self._epoch, True
+      try:
+        data = next(self.source)
+        if self._transform is not None:
+          data = self._transform(data)
+        item = (data, self._snapshot())
+      except BaseException as error:      # incl. StopIteration: the consumer must hear of it
+        item = _Failed(error)
+      with self._cond:
+        self._busy = False
+        if epoch == self._epoch:
+          self._ready.append(item)
+        self._cond.notify_all()
+        if isinstance(item, _Failed) and epoch == self._epoch:
+          return
 
-  def _getstate(self):
-    return self.source.save() if hasattr(self.source, 'save') else None
+  def _snapshot(self):
+    save = getattr(self.source, 'save', None)
+    return save() if save is not None else None

@@ -89,6 +89,62 @@ def test_prefetch_propagates_errors_and_state():
     next(pre)
 
 
+class Counting:
+  """A source with state: yields {'n': 1}, {'n': 2}, ..."""
+
+  def __init__(self):
+    self.n = 0
+    self.drawn = []
+
+  def __iter__(self):
+    return self
+
+  def __next__(self):
+    self.n += 1
+    self.drawn.append(self.n)
+    return {'n': self.n}
+
+  def save(self):
+    return self.n
+
+  def load(self, n):
+    self.n = n
+
+
+@pytest.mark.parametrize('amount', [1, 3])
+def test_prefetch_runs_at_most_amount_ahead_and_restores(amount):
+  import time
+  src = Counting()
+  pre = streams.Prefetch(src, amount=amount)
+  with pytest.raises(AssertionError):
+    next(pre)                                   # not started
+  it = iter(pre)
+  assert [next(it)['n'] for _ in range(4)] == [1, 2, 3, 4]
+  time.sleep(0.05)                              # let the producer run as far as it may
+  assert src.drawn[-1] == 4 + amount            # exactly `amount` batches ahead
+  assert pre.save() == 4                        # state of the last batch handed out
+  pre.load(2)                                   # rewind: prepared batches are dropped
+  assert pre.save() == 2
+  assert [next(it)['n'] for _ in range(3)] == [3, 4, 5]
+  assert pre.save() == 5
+  with pytest.raises(AssertionError):
+    iter(pre)                                   # one consumer
+
+
+def test_stateless_takes_functions_and_iterators():
+  calls = []
+  def draw(batch, mode='train'):
+    calls.append((batch, mode))
+    return len(calls)
+  s = streams.Stateless(draw, 16, mode='report')
+  assert iter(s) is s and [next(s), next(s)] == [1, 2]
+  assert calls == [(16, 'report')] * 2
+  assert s.save() is None and s.load(None) is None
+  assert list(zip(range(3), streams.Stateless(iter('abc')))) == [(0, 'a'), (1, 'b'), (2, 'c')]
+  with pytest.raises(TypeError):
+    streams.Stateless(3)
+
+
 def test_recency_selector_prefers_recent_items():
   """Not pinned by the reference (its Recency cannot draw); checks the intent:
   draw frequency follows uprobs over age, deleted items are never returned."""

@@ -293,6 +293,70 @@ int main(int argc, char** argv) {
                 msB * 1e3 / iters, meanC, meanD, mb / meanA * 1e3);
     std::fflush(stdout);
   }
+
+  // ---- pipeline study: what a kernel BEFORE the gather does to the gather's
+  // stamped window.  pre = what runs just before each stamped launch.
+  {
+    hipStream_t other;
+    CHECK(hipStreamCreateWithFlags(&other, hipStreamNonBlocking));
+    hipEvent_t pe0, pe1, marker;
+    CHECK(hipEventCreate(&pe0)); CHECK(hipEventCreate(&pe1));
+    CHECK(hipEventCreateWithFlags(&marker, hipEventDisableTiming));
+    uint8_t* big_a; uint8_t* big_b;
+    CHECK(hipMalloc(&big_a, 8 << 20)); CHECK(hipMalloc(&big_b, 8 << 20));
+    const char* pres[] = {"none", "tiny", "tiny stamped", "tiny stop-only", "tiny + event record",
+                          "tiny on other stream", "8MB copy kernel", "two tiny", "tiny, then gather twice (2nd)"};
+    std::printf("\n%-34s", "pipeline study (stamped mean us)");
+    for (auto* p : pres) std::printf(" | %s", p);
+    std::printf("\n");
+    for (auto& l : ls) {
+      if (l.name != "copy_flat U4 NT3 T256" && l.name != "gather_persist U4 NT3 T512 W2" &&
+          l.name != "gather_span U1 NT3 T256") continue;
+      std::printf("%-34s", l.name.c_str());
+      for (int pre = 0; pre < 9; ++pre) {
+        std::vector<float> tc;
+        for (int done = 0; done < iters; done += batchn) {
+          for (int i = 0; i < batchn; ++i) {
+            switch (pre) {
+              case 0: break;
+              case 1: hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, tiny); break;
+              case 2: hipExtLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, pe0, pe1, 0, tiny); break;
+              case 3: hipExtLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, nullptr, pe1, 0, tiny); break;
+              case 4: hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, tiny);
+                      CHECK(hipEventRecord(marker, stream)); break;
+              case 5: hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, other, tiny); break;
+              case 6: hipLaunchKernelGGL((copy_flat<4, 3>), dim3((8 << 20) / 16 / 1024), dim3(256), 0, stream,
+                                         reinterpret_cast<const u32x4*>(big_a), reinterpret_cast<u32x4*>(big_b), (8u << 20) / 16); break;
+              case 7: hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, tiny);
+                      hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, tiny); break;
+              case 8: hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, tiny);
+                      l.go(done + i + 17, stream, nullptr, nullptr); break;
+            }
+            l.go(done + i, stream, ev[2 * i], ev[2 * i + 1]);
+          }
+          CHECK(hipStreamSynchronize(stream));
+          CHECK(hipStreamSynchronize(other));
+          for (int i = 0; i < batchn; ++i) { float ms; CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tc.push_back(ms * 1e3f); }
+        }
+        double m = 0; for (float t : tc) m += t; m /= tc.size();
+        std::printf(" | %6.2f", m);
+      }
+      std::printf("\n");
+      // wall-clock cost per (tiny + gather) pair vs gather alone, unstamped
+      for (int pre = 0; pre < 2; ++pre) {
+        CHECK(hipEventRecord(w0, stream));
+        for (int i = 0; i < iters; ++i) {
+          if (pre) hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, stream, tiny);
+          l.go(i, stream, nullptr, nullptr);
+        }
+        CHECK(hipEventRecord(w1, stream));
+        CHECK(hipStreamSynchronize(stream));
+        float msw; CHECK(hipEventElapsedTime(&msw, w0, w1));
+        std::printf("    unstamped wall per iteration, %s: %.2f us\n", pre ? "tiny + gather" : "gather only", msw * 1e3 / iters);
+      }
+    }
+  }
+
   // hipMemcpyAsync D2D of the same bytes (throughput only)
   CHECK(hipEventRecord(w0, stream));
   for (int i = 0; i < iters; ++i) CHECK(hipMemcpyAsync(out[i % ring], pool + (i % nslots) * batch_bytes, batch_bytes, hipMemcpyDeviceToDevice, stream));
