@@ -20,6 +20,14 @@ import os
 import sys
 import time
 
+# Kernel arguments in host memory instead of device memory (a HIP runtime
+# setting, read when HIP starts): every launch is ~1.6 us cheaper for the host
+# (4.6 -> 3.0 us on MI355X), and the step is launch-bound.  Waves then read
+# their arguments across PCIe, which is why the big movers get a device copy
+# of their argument block (abi.cpp run_move).  Set HIP_FORCE_DEV_KERNARG=1 for
+# the runtime's default placement; DESIGN.md 4 has both sets of numbers.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
+
 import numpy as np
 import torch
 
@@ -44,6 +52,12 @@ def parse():
                       'batch whenever it holds fresh on-policy windows (every trajectory crosses '
                       'xGMI once; re-sampled windows are not re-sent); trajectories = every batch')
   p.add_argument('--cpu-seconds', type=float, default=15.0)
+  p.add_argument('--sustained-seconds', type=float, default=10.0,
+                 help='after the headline region: the same loop for this long (SURVEY 8d asks for '
+                      'wall-clock rates over >= 10 s windows); reported as `sustained`, 0 = skip')
+  p.add_argument('--prewarm-train-steps', type=int, default=200,
+                 help='train steps run after the fill and before --warmup, so that a short '
+                      '--warmup still times a warm train path')
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--prefetch', type=int, default=1, help='train batches gathered per launch')
   p.add_argument('--reuse-outputs', type=int, default=0,
@@ -115,11 +129,15 @@ def build_path(args, rank, device):
     deter = torch.zeros((n, 8192), dtype=torch.float32, device=device)
     stoch = torch.zeros((n, 32, 64), dtype=torch.float32, device=device)
 
+  # The agent owns its input staging: two policy-batch buffers used in turn.
+  staging = [torch.empty((n, 4, 84, 84), dtype=torch.bfloat16, device=device) for _ in range(2)]
+
   def policy(carry, obs, **kw):
     # obs stack/transpose into the policy batch (N, C, H, W) bf16 in [0, 1]:
     # what the agent does first with the frames (jax/agent.py:230).
     batch = emb.ops.obs_stack(
-        obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+        obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255,
+        out=staging[state['tick'] & 1])
     state['tick'] += 1
     state['policy_batch'] = batch
     outs = {'dyn/deter': deter, 'dyn/stoch': stoch} if dreamer else {}
@@ -128,8 +146,30 @@ def build_path(args, rank, device):
   return emb, env, replay, driver, policy
 
 
+def launch_ranks(args):
+  """`python bench.py --gpus N` without a launcher: start N local ranks, one per
+  GPU, under torch.distributed.run and become that process (rank 0 prints the
+  JSON line).  Reference shape: embodied/jax/internal.py:96-105."""
+  import socket
+  backend = os.environ.get('EMB_BENCH_BACKEND', 'nccl')
+  have = torch.cuda.device_count()
+  if backend == 'nccl' and have < args.gpus:
+    raise SystemExit(f'bench.py --gpus {args.gpus}: this node has {have} GPU(s); RCCL needs one '
+                     'GPU per rank (EMB_BENCH_BACKEND=gloo runs the control flow on fewer)')
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+         os.path.abspath(__file__), *sys.argv[1:]]
+  sys.stdout.flush()
+  os.execv(sys.executable, cmd)
+
+
 def main():
   args = parse()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    launch_ranks(args)
   if args.workload == 'dreamer':      # dreamerv3/configs.yaml:11,15,40-42 (size overridden to 1e6)
     if args.capacity == 100_000:
       args.capacity = 1_000_000
@@ -158,7 +198,8 @@ def main():
     dist.init_process_group(
         backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
         **({'device_id': device} if backend == 'nccl' else {}))
-  assert world == args.gpus or world == 1, (world, args.gpus)
+  assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+  rccl_ranks = dist.get_world_size() if use_dist else 1
 
   emb, env, replay, driver, policy = build_path(args, rank, device)
   B, T, L = args.batch, args.length, args.consec * args.length + args.context
@@ -247,11 +288,16 @@ def main():
   for _ in range(fill):
     driver(policy, steps=args.envs)
   counters['env_steps'] = fill * args.envs
-  for _ in range(args.warmup):
-    one_step()
   # EMB_BENCH_NO_TIMER=1: no dispatch stamps (roofline is then null) -- for a
   # rocprofv3 run that sees the gather without the timed-dispatch perturbation.
+  # Switched on before the warm-up so that the stamps' events exist by then.
   replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1')
+  # The fill runs no train step: warm the train path (allocator, online queue,
+  # caches) whatever --warmup says, then the caller's warmup steps.
+  for _ in range(args.prewarm_train_steps):
+    train_step()
+  for _ in range(args.warmup):
+    one_step()
   replay.profile_read(reset=True)
   base = dict(counters)
 
@@ -276,6 +322,43 @@ def main():
     elapsed = float(t.item())
 
   launches, gather_ms = replay.profile_read(reset=True)
+  headline = dict(counters)
+
+  # The same loop for >= --sustained-seconds more (the headline region is as
+  # long as --steps says; this window is long whatever the caller chose).
+  sustained = None
+  if args.sustained_seconds > 0:
+    fence()
+    s_start = time.perf_counter()
+    s_steps = 0
+    while True:
+      for _ in range(256):
+        one_step()
+      s_steps += 256
+      go_on = time.perf_counter() - s_start < args.sustained_seconds
+      if use_dist:          # every rank must leave the loop after the same step
+        flag = torch.tensor([1.0 if go_on else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        go_on = bool(flag.item())
+      if not go_on:
+        break
+    fence()
+    s_elapsed = time.perf_counter() - s_start
+    if use_dist:
+      t = torch.tensor([s_elapsed], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      s_elapsed = float(t.item())
+    s_launches, s_ms = replay.profile_read(reset=True)
+    sustained = {
+        'seconds': round(s_elapsed, 3), 'steps': s_steps,
+        'env_steps_per_s': round(s_steps * args.envs * world / s_elapsed, 1),
+        'train_steps_per_s': round(
+            (counters['train_steps'] - headline['train_steps']) * world / s_elapsed, 2),
+        'ms_per_step': round(s_elapsed / s_steps * 1e3, 5),
+        'gather_avg_us': round(s_ms / s_launches * 1e3, 2) if s_launches else None,
+        'gather_launches': s_launches,
+    }
+  counters.update(headline)
   env_steps = (counters['env_steps'] - base['env_steps']) * world
   train_steps = (counters['train_steps'] - base['train_steps']) * world
   S = sum(k.rowbytes for k in replay._keys)
@@ -299,13 +382,18 @@ def main():
         'launches': launches,
     }
 
-  # Outside the timed region, for context: the same kernel with more sequences
-  # per launch (the reference's prefetch depth is 1, so B=16 is the faithful
-  # headline; these show what the kernel does when a launch is not ~15 us).
+  # Outside the timed region, measured context (no credit): SURVEY 8d's
+  # batches-per-launch sweep 1 / 8 / 64 (the reference's prefetch depth is 1, so
+  # one batch of B=16 per launch is the faithful headline), and a plain
+  # device-to-device copy of one batch's bytes out of the same pool — what a
+  # kernel with no gather structure at all achieves on this box, read cold.
   if roofline and rank == 0 and world == 1 and args.consec == 1 and not args.host_envs:
     try:
-      larger = {}
-      for big in (64, 256):
+      sweep = {}
+      for per_launch in (1, 8, 64):
+        big = B * per_launch
+        for _ in range(3):
+          replay.sample(big, 'report')
         torch.cuda.synchronize(device)
         replay.profile_read(reset=True)
         for _ in range(20):
@@ -315,11 +403,13 @@ def main():
         if count:
           us = ms / count * 1e3
           gbs = 2 * big * L * S / (us * 1e-6) / 1e9
-          larger[str(big)] = {'avg_launch_us': round(us, 2), 'achieved': round(gbs, 1),
-                              'frac': round(gbs / HBM_PEAK_GBS, 4)}
-      roofline['larger_batches_per_launch'] = larger
+          sweep[str(per_launch)] = {
+              'sequences': big, 'avg_launch_us': round(us, 2), 'achieved': round(gbs, 1),
+              'frac': round(gbs / HBM_PEAK_GBS, 4), 'read_frac': round(gbs / 2 / HBM_PEAK_GBS, 4)}
+      roofline['batches_per_launch_sweep'] = sweep
+      roofline['plain_copy_same_bytes'] = plain_copy_reference(replay, B * L, device)
     except Exception as e:     # context only: never lose the headline over it
-      roofline['larger_batches_per_launch'] = {'error': str(e)[:200]}
+      roofline['batches_per_launch_sweep'] = {'error': str(e)[:200]}
 
   cpu = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ppo' and not args.host_envs:
@@ -336,7 +426,9 @@ def main():
         'value': round(env_steps / elapsed, 1),
         'unit': 'env_steps/s',
         'train_steps_per_s': round(train_steps / elapsed, 2),
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'n_gpus': world, 'rccl_ranks': rccl_ranks,
+        'backend': (dist.get_backend() if use_dist else None),
+        'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 5),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'u8', 'data': 'synthetic',
@@ -351,16 +443,44 @@ def main():
                 f'{"lambda-return" if args.workload == "dreamer" else "GAE"}'),
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
+            'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
             'parallelism': (f'env-sharded x{world}, {args.exchange} all-gather + '
                             f'{args.grad_numel * 4 >> 20} MiB grad all-reduce (RCCL)')
                            if use_dist else 'single',
         },
+        'sustained': sustained,
         'roofline': roofline, 'cpu_baseline': cpu,
     }), flush=True)
   if use_dist:
     if comm is not None:
       comm.close()
     dist.destroy_process_group()
+
+
+def plain_copy_reference(replay, rows, device, iters=200):
+  """Back-to-back torch copies of `rows` image rows from rotating (cold) places
+  of the replay's image pool into one output buffer: us per copy (events around
+  the loop, i.e. throughput — a tight loop keeps the GPU busy) and r+w GB/s."""
+  key = max(replay._keys, key=lambda k: k.rowbytes)
+  nbytes = rows * key.rowbytes
+  pool = key.pool
+  slots = max(1, pool.numel() // nbytes - 1)
+  out = torch.empty(nbytes, dtype=torch.uint8, device=device)
+  srcs = [pool[(i * 7919 % slots) * nbytes:][:nbytes] for i in range(iters)]
+  for src in srcs[:10]:
+    out.copy_(src)
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for src in srcs:
+    out.copy_(src)
+  e1.record()
+  torch.cuda.synchronize(device)
+  us = e0.elapsed_time(e1) / iters * 1e3
+  return {'bytes_one_way': nbytes, 'us_per_copy': round(us, 2),
+          'achieved': round(2 * nbytes / us / 1e3, 1),
+          'frac': round(2 * nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
+          'how': 'torch copy_ of the image key\'s share of one batch, cold source, '
+                 'throughput over back-to-back launches'}
 
 
 def pmc_traffic(algo_bytes):

@@ -316,7 +316,7 @@ class Replay:
         self._flush()
       keyid, keys, device = self._keyid, self._keys, self.device
       ptrs = self._batch_ptrs
-      keep, seen = [], 0
+      keep, seen, vals = [], 0, {}
       for name, value in steps.items():
         i = keyid.get(name)
         if i is None:
@@ -324,15 +324,19 @@ class Replay:
             continue
           raise KeyError(f'replay step key {name!r} was not in the first step')
         key = keys[i]
-        if not torch.is_tensor(value):
-          value = torch.from_numpy(np.ascontiguousarray(value))
-        if value.shape[1:] != key.shape or value.shape[0] != n:
-          raise ValueError((name, tuple(value.shape), (n, *key.shape)))
-        if (value.dtype != key.dtype or value.device != device
-            or not value.is_contiguous()):
+        # Usual case first: a contiguous tensor of the key's dtype on this device.
+        if not (type(value) is torch.Tensor and value.dtype is key.dtype
+                and value.device == device and value.is_contiguous()):
+          if not torch.is_tensor(value):
+            value = torch.from_numpy(np.ascontiguousarray(value))
+          if value.shape[1:] != key.shape or value.shape[0] != n:
+            raise ValueError((name, tuple(value.shape), (n, *key.shape)))
           value = value.to(device, key.dtype, non_blocking=True).contiguous()
-        keep.append(value)
+          keep.append(value)
+        elif value.shape[1:] != key.shape or value.shape[0] != n:
+          raise ValueError((name, tuple(value.shape), (n, *key.shape)))
         ptrs[i] = value.data_ptr()
+        vals[name] = value
         seen += 1
       if seen + 1 != len(keys):
         raise KeyError(f'replay step keys {sorted(steps)} differ from the first step')
@@ -347,7 +351,7 @@ class Replay:
         ids, codes, outs = plan
         masked = {}
         for j, name in enumerate(names):
-          out = masked[name] = _lib.empty((n, *keys[ids[j]].shape), keys[ids[j]].dtype, device)
+          out = masked[name] = torch.empty_like(vals[name])
           outs[j] = out.data_ptr()
         if flags.device != device or not flags.is_contiguous():
           flags = flags.to(device).contiguous()

@@ -154,23 +154,31 @@ class LaunchTimer {
   bool enabled = false;
   bool discard = false;   // stamps only, never read: a small ring of pairs reused in turn
   // Next (start, stop) pair for hipExtLaunchKernelGGL, or nulls when disabled.
+  // Pairs come from a fixed pool created when stamping is switched on (event
+  // creation is far too slow to happen inside a timed region); when the pool is
+  // used up the stamps are read — all but the newest few belong to launches
+  // that finished long ago — and the pool starts over.
   void next(hipEvent_t* start, hipEvent_t* stop) {
     *start = *stop = nullptr;
     if (!enabled) return;
-    if (discard && pairs_.size() >= 256) used_ %= 256;
+    if (pairs_.empty()) reserve(discard ? 256 : kPool);
     if (used_ == pairs_.size()) {
-      if (pairs_.size() >= 32768) collect();   // bounds the events held; reading them waits for the launches
-      if (used_ == pairs_.size()) {
-        hipEvent_t a, b;
-        HIP_OK(hipEventCreate(&a));
-        HIP_OK(hipEventCreate(&b));
-        pairs_.emplace_back(a, b);
-      }
+      if (discard) used_ = 0;
+      else collect();
     }
     *start = pairs_[used_].first;
     *stop = pairs_[used_].second;
     ++used_;
   }
+  void reserve(size_t n) {
+    while (pairs_.size() < n) {
+      hipEvent_t a, b;
+      HIP_OK(hipEventCreate(&a));
+      HIP_OK(hipEventCreate(&b));
+      pairs_.emplace_back(a, b);
+    }
+  }
+  static constexpr size_t kPool = 2048;
   void collect() {
     for (size_t i = 0; i < used_; ++i) {
       HIP_OK(hipEventSynchronize(pairs_[i].second));
@@ -201,24 +209,27 @@ class LaunchTimer {
 // HIP_FORCE_DEV_KERNARG=0: the runtime leaves kernel arguments in host memory.
 bool host_kernargs() {
   static const bool value = [] {
+    if (const char* o = std::getenv("EMB_ARGS_INDIRECT")) return o[0] == '1';   // A/B override
     const char* e = std::getenv("HIP_FORCE_DEV_KERNARG");
     return e && e[0] == '0';
   }();
   return value;
 }
 
-// Experiment knob (EMB_STAMP_ALL=1, off by default): while a replay's gather
-// launches are being timed, stamp its scatter launches too.  A dispatch that
-// carries stamps completes its own end-of-kernel cache release before the next
-// dispatch begins; an unstamped one leaves that ~1.2 us to the window of the
-// dispatch that follows it.  With the knob on the gather reads 13.8 us instead
-// of 15.0 us inside bench.py -- but an ordinary pipeline has no stamps (rocprofv3
-// with no stamps at all reads 14.6-15.2 us, same as stamping the gathers only),
-// so the default keeps the gather-only stamps.
-bool stamp_all() {
+// While a replay's gather launches are being timed (bench.py's roofline leg),
+// its scatter launches carry a completion stamp too (stop event only, from a
+// small ring, never read).  Why: a dispatch WITHOUT a completion signal leaves
+// its end-of-kernel cache release to the window of the dispatch that follows,
+// so a stamped gather behind an unstamped insert reads ~2 us long
+// (tools/gather_lab.hip "pipeline study": plain copy 10.2 us alone, 12.2 us
+// behind an unstamped tiny kernel, 10.3 us behind one with a stop stamp; wall
+// time per pair is the same).  rocprofv3 gives every dispatch a signal, so this
+// is also what makes the in-process number agree with the profiler's.
+// EMB_STAMP_PRED=0 turns it off.
+bool stamp_predecessors() {
   static const bool value = [] {
-    const char* e = std::getenv("EMB_STAMP_ALL");
-    return e && e[0] == '1';
+    const char* e = std::getenv("EMB_STAMP_PRED");
+    return !(e && e[0] == '0');
   }();
   return value;
 }
@@ -230,6 +241,8 @@ TableRing& global_ring() {
 }
 
 }  // namespace
+
+static size_t emb_timer_pool() { return 2048; }
 
 struct emb_rng {
   std::mutex mu;
@@ -677,17 +690,28 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     for (int k = 0; k < plan.n_keys; ++k) bytes += plan.key[k].rowbytes * n_rows;
     if (bytes >= (4 << 20)) {
       args_lease = rep->ring.acquire(emb::move_args_bytes(), stream);
-      std::memcpy(args_lease.host, launch.args, emb::move_args_bytes());
-      rep->ring.upload(args_lease, emb::move_args_bytes(), stream);
+      // A one-workgroup kernel writes the block (an H2D copy in front of the
+      // mover costs more on both sides); while gathers are timed it carries a
+      // completion stamp like every other predecessor (stamp_predecessors).
+      hipEvent_t none = nullptr, done = nullptr;
+      if (rep->timer.enabled && stamp_predecessors()) {
+        rep->timer_other.enabled = rep->timer_other.discard = true;
+        rep->timer_other.next(&none, &done);
+      }
+      HIP_OK(emb::launch_args_writer(launch, args_lease.device, stream, done));
       device_args = args_lease.device;
     }
   }
   rep->order_before(gather, stream);
   hipEvent_t start = nullptr, stop = nullptr;
   if (gather) rep->timer.next(&start, &stop);
-  else if (rep->timer.enabled && stamp_all()) {
+  else if (rep->timer.enabled && stamp_predecessors() && !host_kernargs()) {
+    // (With host-resident kernel arguments every big gather already follows its
+    // stamped argument-writer launch, and a stamp on each insert would cost
+    // ~10 % of the step rate there; with device-resident arguments it is free.)
     rep->timer_other.enabled = rep->timer_other.discard = true;
     rep->timer_other.next(&start, &stop);
+    start = nullptr;                 // completion stamp only
   }
   HIP_OK(emb::launch_move(launch, gather, device_args, stream, start, stop));
   rep->order_after(gather, stream);
@@ -931,7 +955,16 @@ int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t 
   });
 }
 
-int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) { REP_OP(rep->timer.enabled = enable != 0); }
+int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) {
+  REP_OP({
+    rep->timer.enabled = enable != 0;
+    if (enable) {                       // create the stamp pools now, not inside a timed region
+      rep->timer.reserve(emb_timer_pool());
+      rep->timer_other.discard = true;
+      rep->timer_other.reserve(256);
+    }
+  });
+}
 
 int32_t emb_replay_multistream(emb_replay_t* rep, int32_t enable) { REP_OP(rep->multistream = enable != 0); }
 

@@ -63,6 +63,10 @@ struct MoveLaunch {
 };
 hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out);
 size_t move_args_bytes();
+// Copies launch.args into device memory with a one-workgroup kernel (its own
+// arguments may live in host memory); `stop` (optional) stamps its completion.
+hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t stream,
+                              hipEvent_t stop = nullptr);
 // device_args == nullptr: arguments by value.  Otherwise a device-visible copy
 // of launch.args[0 .. move_args_bytes()) that the kernel reads through a pointer.
 hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device_args,

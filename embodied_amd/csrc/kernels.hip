@@ -20,10 +20,29 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one dwordx4
 
+// Payload pointers that reach a kernel through memory (the indirect-argument
+// movers read their KeyDescs with loads) have no known address space, and the
+// compiler then emits flat_load / flat_store — slower than global_load /
+// global_store and tied to the LDS counter.  Everything the movers touch is
+// device global memory: say so.
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
+template <bool kNonTemporal>
+__device__ __forceinline__ u32x4 load16(const u32x4* p) {
+  const gu32x4* g = (const gu32x4*)p;
+  if constexpr (kNonTemporal) return __builtin_nontemporal_load(g);
+  else return *g;
+}
+template <bool kNonTemporal>
+__device__ __forceinline__ void store16(u32x4* p, u32x4 v) {
+  gu32x4* g = (gu32x4*)p;
+  if constexpr (kNonTemporal) __builtin_nontemporal_store(v, g);
+  else *g = v;
+}
+
 constexpr int kThreads = 256;
 
 // Per-launch plan in kernel-argument memory (< 4 KiB).
-struct MoveArgs {
+struct alignas(16) MoveArgs {
   KeyDesc key[kMaxKeys];
   int32_t first_block[kMaxKeys + 1];
   int32_t unit[kMaxKeys];           // 0: 16-byte flat path; else bytes per lane
@@ -67,17 +86,28 @@ __device__ __forceinline__ int32_t row_of(const MoveArgs& a, uint32_t r) {
 }
 
 template <typename T>
-__device__ __forceinline__ void copy_unit(const uint8_t* s, uint8_t* d) {
-  *reinterpret_cast<T*>(d) = *reinterpret_cast<const T*>(s);
+__device__ __forceinline__ T gload(const void* p) {
+  return *(const __attribute__((address_space(1))) T*)p;
 }
+template <typename T>
+__device__ __forceinline__ void gstore(void* p, T v) {
+  *(__attribute__((address_space(1))) T*)p = v;
+}
+
+template <typename T>
+__device__ __forceinline__ void copy_unit(const uint8_t* s, uint8_t* d) {
+  gstore<T>(d, gload<T>(s));
+}
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void copy_bytes(const uint8_t* s, uint8_t* d, int unit) {
   switch (unit) {
-    case 16: copy_unit<uint4>(s, d); break;
-    case 8: copy_unit<uint2>(s, d); break;
+    case 16: copy_unit<u32x4>(s, d); break;
+    case 8: copy_unit<u32x2_t>(s, d); break;
     case 4: copy_unit<uint32_t>(s, d); break;
     case 2: copy_unit<uint16_t>(s, d); break;
-    default: *d = *s; break;
+    default: copy_unit<uint8_t>(s, d); break;
   }
 }
 
@@ -156,7 +186,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
     const uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
     const uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
     const u32x4* src = reinterpret_cast<const u32x4*>(kGather ? pool : batch) + off[j];
-    buf[j] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+    buf[j] = load16<(NT & 1) != 0>(src);
   }
 #pragma unroll
   for (int j = 0; j < U; ++j) {
@@ -164,8 +194,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
     uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
     uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
     u32x4* dst = reinterpret_cast<u32x4*>(kGather ? batch : pool) + off[j];
-    if (NT & 2) __builtin_nontemporal_store(buf[j], dst);
-    else *dst = buf[j];
+    store16<(NT & 2) != 0>(dst, buf[j]);
   }
 }
 
@@ -216,7 +245,7 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a) {
       const uint32_t u = w.u0 + j * blockDim.x;
       if (u < w.total) {
         const u32x4* src = kGather ? (u < w.split ? w.p0 : w.p1) + u : w.b + u;
-        v[j] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+        v[j] = load16<(NT & 1) != 0>(src);
       }
     }
   };
@@ -226,8 +255,7 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a) {
       const uint32_t u = w.u0 + j * blockDim.x;
       if (u < w.total) {
         u32x4* dst = const_cast<u32x4*>(kGather ? w.b + u : (u < w.split ? w.p0 : w.p1) + u);
-        if (NT & 2) __builtin_nontemporal_store(v[j], dst);
-        else *dst = v[j];
+        store16<(NT & 2) != 0>(dst, v[j]);
       }
     }
   };
@@ -275,13 +303,13 @@ __device__ __forceinline__ void gather_block(const MoveArgs& a, int block) {
   uint8_t* dst = key.batch + r * key.rowbytes + off;
   if (key.rowbytes == 1 && (k == a.key_is_first || k == a.key_is_last)) {
     const int t = static_cast<int>(r % a.seq_len);
-    uint8_t v = *src;
+    uint8_t v = gload<uint8_t>(src);
     if (k == a.key_is_first) {
       if (t == 0) v = 1;
     } else if (a.is_first_pool && t + 1 < a.seq_len) {
-      v |= a.is_first_pool[row_of(a, static_cast<uint32_t>(r + 1))];
+      v |= gload<uint8_t>(a.is_first_pool + row_of(a, static_cast<uint32_t>(r + 1)));
     }
-    *dst = v;
+    gstore<uint8_t>(dst, v);
     return;
   }
   copy_bytes(src, dst, unit);
@@ -293,17 +321,17 @@ __device__ __forceinline__ void gather_block(const MoveArgs& a, int block) {
 // the masked-action buffer.
 template <typename T>
 __device__ __forceinline__ void put_masked(const uint8_t* src, uint8_t* pool, uint8_t* out, bool keep) {
-  const T v = *reinterpret_cast<const T*>(src) * static_cast<T>(keep ? 1 : 0);
-  if (pool) *reinterpret_cast<T*>(pool) = v;
-  if (out) *reinterpret_cast<T*>(out) = v;
+  const T v = gload<T>(src) * static_cast<T>(keep ? 1 : 0);
+  if (pool) gstore<T>(pool, v);
+  if (out) gstore<T>(out, v);
 }
 
 __device__ __forceinline__ void put_masked_bf16(const uint8_t* src, uint8_t* pool, uint8_t* out, bool keep) {
   // Widen to f32 (exact), multiply, narrow: the product is x, +-0 or NaN.
-  const float x = __uint_as_float(static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(src)) << 16);
+  const float x = __uint_as_float(static_cast<uint32_t>(gload<uint16_t>(src)) << 16);
   const uint16_t v = static_cast<uint16_t>(__float_as_uint(x * (keep ? 1.f : 0.f)) >> 16);
-  if (pool) *reinterpret_cast<uint16_t*>(pool) = v;
-  if (out) *reinterpret_cast<uint16_t*>(out) = v;
+  if (pool) gstore<uint16_t>(pool, v);
+  if (out) gstore<uint16_t>(out, v);
 }
 
 __device__ __forceinline__ void scatter_masked(const MoveArgs& a, int k, const KeyDesc& key, int local) {
@@ -314,7 +342,7 @@ __device__ __forceinline__ void scatter_masked(const MoveArgs& a, int k, const K
   const int64_t r = e / epr;
   const int64_t off = (e - r * epr) * es;
   const int64_t row = row_of(a, static_cast<uint32_t>(r));
-  const bool keep = a.mask_flags[r] == 0;
+  const bool keep = gload<uint8_t>(a.mask_flags + r) == 0;
   const uint8_t* src = key.batch + r * key.rowbytes + off;
   uint8_t* pool = row >= 0 ? key.pool + row * key.rowbytes + off : nullptr;
   uint8_t* out = a.mask_out[k] ? a.mask_out[k] + r * key.rowbytes + off : nullptr;
@@ -355,7 +383,7 @@ __device__ __forceinline__ void scatter_block(const MoveArgs& a, int block) {
   if (row < 0) return;
   if (k == a.inline_key) {   // batch bytes of this key ride in the kernel arguments
     const uint32_t w = a.inline_words[a.inline_key_word0 + r * (key.rowbytes >> 2) + (off >> 2)];
-    *reinterpret_cast<uint32_t*>(key.pool + row * key.rowbytes + off) = w;
+    gstore<uint32_t>(key.pool + row * key.rowbytes + off, w);
     return;
   }
   copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
@@ -419,6 +447,19 @@ __global__ __launch_bounds__(1024) void span_move_kernel_indirect(const MoveArgs
   if (kGather) gather_block<2, NT>(*a, block);
   else scatter_block<2, NT>(*a, block);
 }
+
+// Host-resident kernel arguments (HIP_FORCE_DEV_KERNARG=0): one workgroup
+// copies the mover's argument block from the kernel-argument segment into
+// device memory, so that the mover's thousands of waves read it from L2
+// instead of each crossing PCIe.
+// One 16-byte load per lane: the whole block crosses PCIe in a single round
+// trip (word-sized loads took four, ~10 us).
+__global__ __launch_bounds__(256) void args_writer_kernel(const MoveArgs a, u32x4* __restrict__ dst) {
+  const u32x4* src = reinterpret_cast<const u32x4*>(&a);
+  for (uint32_t i = threadIdx.x; i < sizeof(MoveArgs) / 16; i += blockDim.x) dst[i] = src[i];
+}
+static_assert(sizeof(MoveArgs) % 16 == 0 && sizeof(MoveArgs) / 16 <= 256,
+              "argument block is copied as one dwordx4 per lane");
 
 // Tuning knobs, read once: EMB_MOVE_VARIANT="U,NT,remap,threads" = 16-byte units
 // per lane, non-temporal hints (bit0 loads, bit1 stores), XCD remap on/off and
@@ -610,6 +651,14 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
 }
 
 size_t move_args_bytes() { return sizeof(MoveArgs); }
+
+hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t stream,
+                              hipEvent_t stop) {
+  const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
+  hipExtLaunchKernelGGL(args_writer_kernel, dim3(1), dim3(256), 0, stream, nullptr, stop, 0, a,
+                        static_cast<u32x4*>(device_dst));
+  return hipGetLastError();
+}
 
 hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device_args,
                        hipStream_t stream, hipEvent_t start, hipEvent_t stop) {

@@ -16,19 +16,26 @@ def _stream(t):
 
 
 def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
-              scale=1.0, offset=0.0):
+              scale=1.0, offset=0.0, out=None):
   """frames: uint8 (N_total, H, W, C) slab on the GPU.  Returns the policy batch
   (n, C, H, W) [channels_first] or (n, H, W, C) [same] as `dtype`, values
-  `x * scale + offset` for float outputs; batch row j is env `env_ids[j]`."""
+  `x * scale + offset` for float outputs; batch row j is env `env_ids[j]`.
+  `out`: a contiguous tensor of that shape and dtype to write into (an agent
+  that owns its input staging saves the allocation, ~2.5 us of host time)."""
   if not (torch.is_tensor(frames) and frames.is_cuda and frames.dtype == torch.uint8):
     raise RuntimeError('obs_stack needs a uint8 CUDA tensor (no CPU fallback)')
-  frames = frames.contiguous()
+  if not frames.is_contiguous():
+    frames = frames.contiguous()
   total, h, w, c = frames.shape
   ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int32)
   n = total if ids is None else len(ids)
   first = layout == 'channels_first'
   shape = (n, c, h, w) if first else (n, h, w, c)
-  out = _lib.empty(shape, dtype, frames.device)
+  if out is None:
+    out = _lib.empty(shape, dtype, frames.device)
+  elif (out.shape != shape or out.dtype != dtype or out.device != frames.device
+        or not out.is_contiguous()):
+    raise ValueError(f'obs_stack out= must be contiguous {shape} {dtype} on {frames.device}')
   if out.numel() == 0:
     return out                       # no envs / empty frames: nothing to launch
   fast.emb_obs_stack(

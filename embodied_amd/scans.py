@@ -67,8 +67,8 @@ def gae(rew, val, last, term, hor=200, lam=0.8):
   last, term = _flag(last, dev), _flag(term, dev)
   B, T = rew.shape
   assert val.shape == last.shape == term.shape == (B, T)
-  adv = _lib.empty((B, T - 1), torch.float32, dev)
-  tar = _lib.empty((B, T - 1), torch.float32, dev)
+  both = _lib.empty((2, B, T - 1), torch.float32, dev)   # one allocation, two views
+  adv, tar = both.unbind(0)
   if B == 0 or T < 2:
     return adv, tar                   # nothing to scan: (B, 0) results
   fast.emb_scan_gae(
@@ -129,10 +129,15 @@ def abstract_traj(x, cont, k, kind='first'):
   kind 'reward': x (T-1,B) -> cumprod(cont)-weighted window means (T/k-1,B);
   'cont': x = cont (T,B) -> window products (T/k,B) — both one kernel
   (`emb_abstract_traj`); anything else: first step of every window (a view)."""
-  if kind in ('reward', 'cont') and torch.is_tensor(cont) and cont.is_cuda and cont.dim() == 2:
+  if kind in ('reward', 'cont'):
+    if not (torch.is_tensor(cont) and cont.is_cuda and cont.dim() == 2):
+      raise RuntimeError(
+          'abstract_traj reward/cont windows run as a HIP kernel: `cont` must be a (T, B) CUDA '
+          'tensor (no CPU fallback)')
     dev = cont.device
     c = _f32(cont, dev)
     T, B = c.shape
+    assert T % k == 0, (T, k)
     if kind == 'reward':
       r = _f32(x, dev)
       assert r.shape == (T - 1, B), (r.shape, c.shape)
@@ -142,11 +147,4 @@ def abstract_traj(x, cont, k, kind='first'):
       out = torch.empty((T // k, B), dtype=torch.float32, device=dev)
       api.emb_abstract_traj(None, c.data_ptr(), T, B, k, None, out.data_ptr(), _stream(c))
     return out
-  fold = lambda a: a.reshape((a.shape[0] // k, k) + tuple(a.shape[1:]))
-  if kind == 'reward':
-    w = torch.cumprod(fold(cont), 1)
-    x = torch.cat([0 * x[:1], x], 0)
-    return (fold(x) * w).mean(1)[1:]
-  if kind == 'cont':
-    return fold(x).prod(1)
-  return fold(x)[:, 0]
+  return x.reshape((x.shape[0] // k, k) + tuple(x.shape[1:]))[:, 0]   # first step of each window

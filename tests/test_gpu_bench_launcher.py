@@ -1,0 +1,60 @@
+"""`python bench.py --gpus N` must start N ranks itself (the driver runs exactly
+that command form for N = 1, 2, 4, 8).  Two ranks on the test box's one GPU
+with the gloo backend: the control flow is the multi-rank one, only the
+transport differs from RCCL."""
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def run_bench(*flags, env=None):
+  full = dict(os.environ, **(env or {}))
+  for name in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    full.pop(name, None)
+  res = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *flags], cwd=ROOT, env=full,
+                       capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stderr[-3000:]
+  lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, res.stdout[-2000:]        # ONE JSON line, from rank 0
+  return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+  rec = run_bench('--gpus', '2', '--steps', '20', '--warmup', '5',
+                  env={'EMB_BENCH_BACKEND': 'gloo'})
+  assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['backend'] == 'gloo'
+  assert rec['steps'] == 20 and rec['warmup'] == 5
+  assert rec['config']['global_envs'] == 2 * rec['config']['envs_per_gpu']
+  assert rec['scaling'] == 'weak' and rec['value'] > 0
+  assert rec['sustained']['seconds'] >= 2.0
+  assert rec['roofline']['launches'] >= 1          # rank 0's gathers inside the timed region
+
+
+def test_bench_short_run_keeps_its_shape():
+  """The driver's short form on one GPU: the line carries roofline, the
+  sustained window and the CPU baseline; the headline region is exactly --steps."""
+  rec = run_bench('--steps', '20', '--warmup', '5', '--cpu-seconds', '2', '--sustained-seconds', '2')
+  assert rec['n_gpus'] == 1 and rec['steps'] == 20
+  roof = rec['roofline']
+  assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and 0 < roof['frac'] < 1
+  assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+  assert set(roof['batches_per_launch_sweep']) == {'1', '8', '64'}
+  assert rec['sustained']['seconds'] >= 2.0 and rec['sustained']['gather_launches'] > 100
+  assert rec['cpu_baseline']['kind'] == 'port' and rec['cpu_baseline']['cores'] == 1
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+  import torch
+  want = torch.cuda.device_count() + 1
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'EMB_BENCH_BACKEND')}
+  res = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(want)], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=300)
+  assert res.returncode != 0 and 'GPU' in (res.stderr + res.stdout)

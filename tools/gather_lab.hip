@@ -153,6 +153,149 @@ __global__ void gather_persist(const uint8_t* __restrict__ pool, uint8_t* __rest
   }
 }
 
+// ---- persistent, branch-free loads: out-of-range lanes re-read the last unit
+// (clamped index) so that every load is unconditional and the compiler can wait
+// for exactly the older tile (vmcnt(U)) before storing it -------------------
+template <int U, int NT>
+__global__ void gather_persist2(const uint8_t* __restrict__ pool, uint8_t* __restrict__ batch,
+                                uint32_t upr, uint32_t L, uint32_t nseq, const Spans sp) {
+  const uint32_t total = L * upr;
+  const uint32_t tile = blockDim.x * U;
+  const uint32_t tiles_per_seq = (total + tile - 1) / tile;
+  const uint32_t ntiles = tiles_per_seq * nseq;
+  u32x4 cur[U], nxt[U];
+  uint32_t i = blockIdx.x;
+  auto issue = [&](uint32_t ti, u32x4* v) {
+    const uint32_t seq = ti / tiles_per_seq, k = ti - seq * tiles_per_seq;
+    const uint32_t row0 = sp.w[3 * seq], n0 = sp.w[3 * seq + 1], row1 = sp.w[3 * seq + 2];
+    const uint32_t split = n0 * upr;
+    const u32x4* s0 = reinterpret_cast<const u32x4*>(pool) + static_cast<uint64_t>(row0) * upr;
+    const u32x4* s1 = reinterpret_cast<const u32x4*>(pool) + static_cast<uint64_t>(row1) * upr - split;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      uint32_t u = k * tile + j * blockDim.x + threadIdx.x;
+      u = u < total ? u : total - 1;
+      v[j] = ld<NT>((u < split ? s0 : s1) + u);
+    }
+  };
+  auto put = [&](uint32_t ti, const u32x4* v) {
+    const uint32_t seq = ti / tiles_per_seq, k = ti - seq * tiles_per_seq;
+    u32x4* dst = reinterpret_cast<u32x4*>(batch) + static_cast<uint64_t>(seq) * total;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t u = k * tile + j * blockDim.x + threadIdx.x;
+      if (u < total) st<NT>(dst + u, v[j]);
+    }
+  };
+  if (i >= ntiles) return;
+  issue(i, cur);
+  while (i + gridDim.x < ntiles) {           // steady state: the next tile always exists
+    issue(i + gridDim.x, nxt);
+    put(i, cur);
+#pragma unroll
+    for (int j = 0; j < U; ++j) cur[j] = nxt[j];
+    i += gridDim.x;
+  }
+  put(i, cur);
+}
+
+// ---- the same with unconditional (clamped) stores as well: out-of-range
+// lanes rewrite the last unit with the value they re-read ------------------
+template <int U, int NT>
+__global__ void gather_persist3(const uint8_t* __restrict__ pool, uint8_t* __restrict__ batch,
+                                uint32_t upr, uint32_t L, uint32_t nseq, const Spans sp) {
+  const uint32_t total = L * upr;
+  const uint32_t tile = blockDim.x * U;
+  const uint32_t tiles_per_seq = (total + tile - 1) / tile;
+  const uint32_t ntiles = tiles_per_seq * nseq;
+  u32x4 cur[U], nxt[U];
+  uint32_t i = blockIdx.x;
+  auto issue = [&](uint32_t ti, u32x4* v) {
+    const uint32_t seq = ti / tiles_per_seq, k = ti - seq * tiles_per_seq;
+    const uint32_t row0 = sp.w[3 * seq], n0 = sp.w[3 * seq + 1], row1 = sp.w[3 * seq + 2];
+    const uint32_t split = n0 * upr;
+    const u32x4* s0 = reinterpret_cast<const u32x4*>(pool) + static_cast<uint64_t>(row0) * upr;
+    const u32x4* s1 = reinterpret_cast<const u32x4*>(pool) + static_cast<uint64_t>(row1) * upr - split;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      uint32_t u = k * tile + j * blockDim.x + threadIdx.x;
+      u = u < total ? u : total - 1;
+      v[j] = ld<NT>((u < split ? s0 : s1) + u);
+    }
+  };
+  auto put = [&](uint32_t ti, const u32x4* v) {
+    const uint32_t seq = ti / tiles_per_seq, k = ti - seq * tiles_per_seq;
+    u32x4* dst = reinterpret_cast<u32x4*>(batch) + static_cast<uint64_t>(seq) * total;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      uint32_t u = k * tile + j * blockDim.x + threadIdx.x;
+      u = u < total ? u : total - 1;
+      st<NT>(dst + u, v[j]);
+    }
+  };
+  if (i >= ntiles) return;
+  issue(i, cur);
+  while (i + gridDim.x < ntiles) {           // steady state: the next tile always exists
+    issue(i + gridDim.x, nxt);
+    put(i, cur);
+#pragma unroll
+    for (int j = 0; j < U; ++j) cur[j] = nxt[j];
+    i += gridDim.x;
+  }
+  put(i, cur);
+}
+
+// ---- persistent, two register sets used in turn (no copy between them, so
+// nothing forces a wait on the newer tile's loads), loads branch-free --------
+template <int U, int NT, bool kClampStores>
+__global__ void gather_persist4(const uint8_t* __restrict__ pool, uint8_t* __restrict__ batch,
+                                uint32_t upr, uint32_t L, uint32_t nseq, const Spans sp) {
+  const uint32_t total = L * upr;
+  const uint32_t tile = blockDim.x * U;
+  const uint32_t tiles_per_seq = (total + tile - 1) / tile;
+  const uint32_t ntiles = tiles_per_seq * nseq;
+  const uint32_t stride = gridDim.x;
+  u32x4 a[U], b[U];
+  auto issue = [&](uint32_t ti, u32x4* v) {
+    const uint32_t seq = ti / tiles_per_seq, k = ti - seq * tiles_per_seq;
+    const uint32_t row0 = sp.w[3 * seq], n0 = sp.w[3 * seq + 1], row1 = sp.w[3 * seq + 2];
+    const uint32_t split = n0 * upr;
+    const u32x4* s0 = reinterpret_cast<const u32x4*>(pool) + static_cast<uint64_t>(row0) * upr;
+    const u32x4* s1 = reinterpret_cast<const u32x4*>(pool) + static_cast<uint64_t>(row1) * upr - split;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      uint32_t u = k * tile + j * blockDim.x + threadIdx.x;
+      u = u < total ? u : total - 1;
+      v[j] = ld<NT>((u < split ? s0 : s1) + u);
+    }
+  };
+  auto put = [&](uint32_t ti, const u32x4* v) {
+    const uint32_t seq = ti / tiles_per_seq, k = ti - seq * tiles_per_seq;
+    u32x4* dst = reinterpret_cast<u32x4*>(batch) + static_cast<uint64_t>(seq) * total;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      uint32_t u = k * tile + j * blockDim.x + threadIdx.x;
+      if (kClampStores) { u = u < total ? u : total - 1; st<NT>(dst + u, v[j]); }
+      else if (u < total) st<NT>(dst + u, v[j]);
+    }
+  };
+  uint32_t i = blockIdx.x;
+  if (i >= ntiles) return;
+  issue(i, a);
+  for (;;) {
+    uint32_t n = i + stride;
+    if (n >= ntiles) { put(i, a); return; }
+    issue(n, b);
+    put(i, a);
+    i = n;
+    n = i + stride;
+    if (n >= ntiles) { put(i, b); return; }
+    issue(n, a);
+    put(i, b);
+    i = n;
+  }
+}
+
 __global__ void tiny_kernel(float* p) { p[threadIdx.x] += 1.f; }
 
 // ---------------------------------------------------------------------------
@@ -233,6 +376,22 @@ int main(int argc, char** argv) {
   ls.push_back({"gather_persist U" #U_ " NT" #NT_ " T" #TH_ " W" #W_, [=](int it, hipStream_t s, hipEvent_t a, hipEvent_t b) { \
     hipExtLaunchKernelGGL((gather_persist<U_, NT_>), dim3(256 * W_), dim3(TH_), 0, s, a, b, 0, \
                           pool, out[it % ring], upr, L, static_cast<uint32_t>(B), sets[it % nsets]); }})
+#define ADD_PERSIST2(K_, U_, NT_, TH_, W_)                                                       \
+  ls.push_back({#K_ " U" #U_ " NT" #NT_ " T" #TH_ " W" #W_, [=](int it, hipStream_t s, hipEvent_t a, hipEvent_t b) { \
+    hipExtLaunchKernelGGL((K_<U_, NT_>), dim3(256 * W_), dim3(TH_), 0, s, a, b, 0, \
+                          pool, out[it % ring], upr, L, static_cast<uint32_t>(B), sets[it % nsets]); }})
+  ADD_PERSIST2(gather_persist2, 4, 3, 512, 2); ADD_PERSIST2(gather_persist2, 4, 3, 256, 4); ADD_PERSIST2(gather_persist2, 2, 3, 256, 8);
+  ADD_PERSIST2(gather_persist2, 2, 3, 512, 4); ADD_PERSIST2(gather_persist2, 4, 3, 256, 3); ADD_PERSIST2(gather_persist2, 4, 3, 256, 6);
+  ADD_PERSIST2(gather_persist3, 4, 3, 512, 2); ADD_PERSIST2(gather_persist3, 4, 3, 256, 4); ADD_PERSIST2(gather_persist3, 2, 3, 256, 8);
+  ADD_PERSIST2(gather_persist3, 8, 3, 256, 2); ADD_PERSIST2(gather_persist3, 8, 3, 512, 1); ADD_PERSIST2(gather_persist3, 4, 3, 1024, 1);
+#define ADD_PERSIST4(C_, U_, NT_, TH_, W_)                                                       \
+  ls.push_back({"gather_persist4 clamp" #C_ " U" #U_ " NT" #NT_ " T" #TH_ " W" #W_, [=](int it, hipStream_t s, hipEvent_t a, hipEvent_t b) { \
+    hipExtLaunchKernelGGL((gather_persist4<U_, NT_, C_>), dim3(256 * W_), dim3(TH_), 0, s, a, b, 0, \
+                          pool, out[it % ring], upr, L, static_cast<uint32_t>(B), sets[it % nsets]); }})
+  ADD_PERSIST4(false, 4, 3, 512, 2); ADD_PERSIST4(false, 4, 3, 256, 4); ADD_PERSIST4(false, 2, 3, 256, 8); ADD_PERSIST4(false, 2, 3, 256, 4);
+  ADD_PERSIST4(true, 4, 3, 512, 2); ADD_PERSIST4(true, 4, 3, 256, 4); ADD_PERSIST4(true, 2, 3, 256, 8); ADD_PERSIST4(true, 2, 3, 256, 4);
+  ADD_PERSIST4(true, 4, 3, 256, 2); ADD_PERSIST4(true, 8, 3, 256, 2); ADD_PERSIST4(true, 4, 3, 256, 3); ADD_PERSIST4(true, 2, 3, 512, 4);
+  ADD_PERSIST4(true, 4, 3, 128, 8); ADD_PERSIST4(true, 4, 3, 64, 16); ADD_PERSIST4(true, 2, 3, 128, 16); ADD_PERSIST4(true, 4, 3, 1024, 1);
   ADD_PERSIST(2, 3, 256, 4); ADD_PERSIST(2, 3, 256, 8); ADD_PERSIST(4, 3, 256, 2); ADD_PERSIST(4, 3, 256, 4);
   ADD_PERSIST(4, 3, 512, 2); ADD_PERSIST(2, 3, 1024, 1); ADD_PERSIST(4, 3, 1024, 1); ADD_PERSIST(4, 0, 256, 4);
 
