@@ -142,6 +142,8 @@ SIGNATURES = {
     'emb_replay_multistream': [p, i32],
     'emb_replay_profile_read': [p, p, p, i32],
     'emb_replay_complete_all': [p],
+    'emb_replay_open_chunks': [p, p],
+    'emb_replay_reserve_uids': [p, u64],
     'emb_replay_chunks': [p, i64, p, p, p, p, p, p],
     'emb_replay_load_chunk': [p, u64, u64, i64, i64, p],
     'emb_replay_load_items': [p, u64, i64],

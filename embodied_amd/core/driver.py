@@ -99,6 +99,7 @@ class Driver:
     self.carry = None
     self._slab = {}
     self._workers = np.arange(self.length, dtype=np.int64)
+    self._workers.setflags(write=False)     # lets Replay.add_batch keep its converted copy
     self.reset()
 
   # driver.py:34-39

@@ -133,6 +133,8 @@ class Replay:
     self._templates = {}
     self._mask_plans = {}
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
+    if directory and self._owners == 1 and pathlib.Path(directory).is_dir():
+      self._reserve_directory_uids(directory)
 
   def __del__(self):
     handle, self._handle = getattr(self, '_handle', None), None
@@ -217,6 +219,12 @@ class Replay:
       raise _lib.PoolFull(_lib.ERR_POOL_FULL, 'a sharded replay pool cannot grow: raise `slots`')
     new_slots = max(2 * self._slots, self._slots + at_least + 2)
     if self._keys is not None:
+      # The copy below runs on the caller's stream and the old pool goes back to
+      # the allocator: with actor and learner on different streams, write-backs
+      # still queued on the other stream would miss the copy and a gather could
+      # read freed memory.  Growth is rare: drain the device first.
+      if self._multistream:
+        torch.cuda.synchronize(self.device)
       rows = new_slots * self.chunksize
       for key in self._keys:
         bigger = torch.empty(rows * key.rowbytes, dtype=torch.uint8, device=self.device)
@@ -224,6 +232,8 @@ class Replay:
         key.pool = bigger
       pools = (C.c_void_p * len(self._keys))(*[k.pool.data_ptr() for k in self._keys])
       api.emb_replay_grow(self._handle, new_slots, pools)
+      if self._multistream:
+        torch.cuda.synchronize(self.device)     # the copies are done before anyone uses the new pool
     else:
       api.emb_replay_grow(self._handle, new_slots, None)
     self._slots = new_slots
@@ -302,9 +312,14 @@ class Replay:
     (driver.py:72-74): the listed keys are stored as `value * ~is_last` in their
     own dtype and the masked tensors are returned (dict name -> tensor)."""
     if workers is not self._workers_seen:
-      self._workers_np = np.ascontiguousarray(workers, np.int64)
+      self._workers_np = np.array(workers, np.int64, ndmin=1)      # private copy
       self._workers_ptr = _lib.ptr(self._workers_np)
-      self._workers_seen = workers
+      # Remember the caller's object only if it cannot change under us (the
+      # Driver's read-only id array, a tuple): a list or writable array that is
+      # mutated in place must be read again on every call.
+      frozen = isinstance(workers, tuple) or (
+          isinstance(workers, np.ndarray) and not workers.flags.writeable)
+      self._workers_seen = workers if frozen else None
     workers, workers_ptr = self._workers_np, self._workers_ptr
     n = len(workers)
     with self._lock:
@@ -553,6 +568,30 @@ class Replay:
 
   # ------------------------------------------------------------ save / load --
 
+  def _no_sharded_checkpoint(self, what):
+    if self._owners > 1:
+      raise NotImplementedError(
+          f'Replay.{what}: a sharded pool (owners={self._owners}) keeps only one owner\'s rows '
+          'on this rank; checkpoint each rank\'s own Replay instead')
+
+  def _reserve_directory_uids(self, directory):
+    """Never reissue the id of a chunk file that is already in `directory`
+    (a fresh Replay pointed at a used directory, a skipped corrupted file, train
+    and eval replays sharing a directory): move the serial past all of them."""
+    top = 0
+    for path in pathlib.Path(directory).glob('*.npz'):
+      try:
+        _, uid, succ, _ = parse_filename(path.name)
+      except Exception:
+        continue
+      # The successor named in a file name may never have been written (it was
+      # still empty): its id is taken all the same.
+      for taken in (uid, succ):
+        if taken >> 64 == self._replica:
+          top = max(top, taken & _MASK64)
+    if top:
+      api.emb_replay_reserve_uids(self._handle, top + 1)
+
   def _chunk_table(self):
     n = C.c_int64()
     api.emb_replay_chunks(self._handle, 0, None, None, None, None, None, C.byref(n))
@@ -576,11 +615,25 @@ class Replay:
     is the state."""
     if not self.directory:
       return None
+    self._no_sharded_checkpoint('save')
     directory = pathlib.Path(self.directory)
     directory.mkdir(parents=True, exist_ok=True)
     with self._lock:
       self._flush()
-      api.emb_replay_complete_all(self._handle)
+      self._reserve_directory_uids(directory)
+      # Closing the open chunks opens one successor per worker: make room first
+      # (the pool grows lazily, a checkpoint must not die of PoolFull).
+      while True:
+        need, free = C.c_int64(), C.c_int64()
+        api.emb_replay_open_chunks(self._handle, C.byref(need))
+        api.emb_replay_free_slots(self._handle, C.byref(free))
+        if free.value < need.value:
+          self._grow(need.value)
+        try:
+          api.emb_replay_complete_all(self._handle)    # all or nothing
+          break
+        except _lib.PoolFull:
+          self._grow(need.value)
       jobs = []
       for chunk in self._chunk_table():
         if chunk['fill'] <= 0 or chunk['uid'] in self._saved:
@@ -612,6 +665,7 @@ class Replay:
     amount = amount or self.capacity or np.inf
     if not directory:
       return
+    self._no_sharded_checkpoint('load')
     directory = pathlib.Path(directory)
     with self._lock:
       self._flush()
@@ -622,6 +676,14 @@ class Replay:
       loaded_uids = {self._full_uid(c['uid']) for c in table}
       ondisk = sorted((p.name for p in directory.glob('*.npz')), reverse=True)
       ondisk = [x for x in ondisk if parse_filename(x)[1] not in loaded_uids]
+      # Chunk ids are `replica << 64 | serial` here (chunk.py:15-16 draws random
+      # 128-bit UUIDs): files whose upper half is another replica's — or a
+      # reference-written UUID — cannot be addressed by this index.
+      foreign = [x for x in ondisk if parse_filename(x)[1] >> 64 != self._replica]
+      if foreign:
+        print(f'Skipping {len(foreign)} chunk file(s) written under another replica id '
+              f'(this replay is replica {self._replica}): {foreign[0]} ...')
+        ondisk = [x for x in ondisk if x not in set(foreign)]
       if not ondisk:
         return
       counts = count_items(loaded + ondisk, self.length)
@@ -631,8 +693,13 @@ class Replay:
         total += counts[parse_filename(name)[1]]
         if total >= amount:
           break
-      chunks = []
+      chunks, taken = [], set()
       for name in ondisk[:take]:
+        uid = parse_filename(name)[1]
+        if uid in taken:                  # the same chunk saved twice: keep the newest file
+          print(f'Skipping duplicate chunk file {name}')
+          continue
+        taken.add(uid)
         try:
           with np.load(directory / name) as f:
             arrays = {k: f[k] for k in f.files}

@@ -976,6 +976,8 @@ int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* to
 }
 
 int32_t emb_replay_complete_all(emb_replay_t* rep) { REP_OP(rep->index->complete_all()); }
+int32_t emb_replay_open_chunks(emb_replay_t* rep, int64_t* n) { REP_OP(need(n, "open_chunks: null output"); *n = rep->index->open_chunks()); }
+int32_t emb_replay_reserve_uids(emb_replay_t* rep, uint64_t serial) { REP_OP(rep->index->reserve_uids(serial)); }
 
 int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_t* succ,
                           int64_t* fill, int64_t* slot, int64_t* time_ms, int64_t* n) {

@@ -259,16 +259,37 @@ class ReplayIndex {
   const std::unordered_map<uint64_t, Chunk>& chunks() const { return chunks_; }
 
   // Checkpoint support (replay.py:295-359): close every worker's open chunk.
+  // All or nothing: every rotation opens a successor chunk, so the free slots
+  // are counted per owner BEFORE any worker is touched (PoolFull leaves the
+  // index unchanged; the caller grows the pool and retries).
   void complete_all() {
+    std::vector<int64_t> need(cfg_.owners, 0);
+    for (auto& kv : workers_)
+      if (chunks_.at(kv.second->cursor.first).fill > 0) ++need[owner_of(kv.first)];
+    for (int64_t o = 0; o < cfg_.owners; ++o)
+      if (need[o] > static_cast<int64_t>(free_[o].size())) throw PoolFull();
     for (auto& kv : workers_) {
       Worker& w = *kv.second;
       Chunk& chunk = chunks_.at(w.cursor.first);
       if (chunk.fill > 0) rotate(chunk, w);
     }
   }
+  // Open (non-empty) chunks complete_all would close = slots it needs.
+  int64_t open_chunks() const {
+    int64_t n = 0;
+    for (auto& kv : workers_)
+      if (chunks_.at(kv.second->cursor.first).fill > 0) ++n;
+    return n;
+  }
+  // Chunk serials below `serial` are taken (files already on disk).
+  void reserve_uids(uint64_t serial) {
+    if (serial > next_uid_) next_uid_ = serial;
+  }
 
   // Re-create a saved chunk (replay.py:347-359): returns its slot.
   int64_t load_chunk(uint64_t uid, uint64_t succ, int64_t fill, int64_t time_ms = 0) {
+    if (cfg_.owners != 1)
+      throw std::invalid_argument("replay: a sharded pool has no checkpoint path (load_chunk)");
     if (chunks_.count(uid)) throw std::runtime_error("replay: chunk already loaded");
     if (free_[0].empty()) throw PoolFull();
     Chunk c;

@@ -226,8 +226,16 @@ int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable);
 int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* total_ms,
                                 int32_t reset);
 
-/* Checkpoint support (replay.py:294-388): chunk table in/out.                */
+/* Checkpoint support (replay.py:294-388): chunk table in/out.
+ * complete_all closes every worker's open chunk (replay.py:297-299); it needs
+ * one free slot per open chunk (emb_replay_open_chunks) and fails with
+ * EMB_ERR_POOL_FULL, leaving the index unchanged, when they are not there.
+ * reserve_uids: chunk serials below `serial` are not issued (chunk files of an
+ * earlier run in the same directory keep their ids: chunk.py:15-16 draws
+ * random UUIDs, this build counts).                                          */
 int32_t emb_replay_complete_all(emb_replay_t* rep);
+int32_t emb_replay_open_chunks(emb_replay_t* rep, int64_t* n);
+int32_t emb_replay_reserve_uids(emb_replay_t* rep, uint64_t serial);
 int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_t* succ,
                           int64_t* fill, int64_t* slot, int64_t* time_ms, int64_t* n);
 int32_t emb_replay_load_chunk(emb_replay_t* rep, uint64_t uid, uint64_t succ, int64_t fill,

@@ -1,0 +1,143 @@
+"""Checkpoint / pool-growth edge cases found in review (round 1 ADVICE.md):
+save() with a nearly full pool, growth with actor and learner on different
+streams, worker-id lists mutated in place, chunk ids when a directory already
+holds chunk files, sharded pools."""
+import numpy as np
+import pytest
+import torch
+
+from tests import scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def emb():
+  import embodied_amd
+  assert torch.cuda.is_available()
+  return embodied_amd
+
+
+def fill(rep, steps, workers, t0=0):
+  for t in range(t0, t0 + steps):
+    for w in range(workers):
+      rep.add(scenarios.synth_step(t, w), w)
+
+
+def test_save_with_fewer_free_slots_than_workers(emb, tmp_path):
+  """capacity=None: 64 slots that double on demand.  24 workers x 1 open chunk
+  plus their closed ones leave 16 free slots; save() closes every open chunk
+  (one new slot per worker) and must grow the pool instead of raising PoolFull
+  half-way.  Twice in a row, then everything must load back."""
+  import ctypes as C
+  from embodied_amd._lib import api
+  workers = 24
+  rep = emb.Replay(length=3, directory=tmp_path, chunksize=4, save_wait=True, seed=0)
+  fill(rep, 5, workers)                      # 2 chunks per worker: 48 of 64 slots in use
+  free = C.c_int64()
+  api.emb_replay_free_slots(rep._handle, C.byref(free))
+  assert free.value < workers
+  rep.save()
+  fill(rep, 2, workers, t0=5)
+  rep.save()                                 # again: the successors hold rows now
+  assert len(list(tmp_path.glob('*.npz'))) == 3 * workers
+  again = emb.Replay(length=3, directory=tmp_path, chunksize=4, seed=0)
+  again.load()
+  assert len(again) == len(rep) > 0
+  got = again.sample(8)
+  for b in range(8):
+    for j in range(3):
+      want = scenarios.synth_step(int(got['step'][b, j]), int(got['worker'][b, j]))
+      assert np.array_equal(got['image'][b, j].cpu().numpy(), want['image'])
+
+
+def test_worker_list_mutated_in_place_is_reread(emb):
+  rep = emb.Replay(length=2, capacity=64, chunksize=8, seed=0)
+  ids = [0, 1]
+  def batch(t):
+    steps = [scenarios.synth_step(t, w) for w in ids]
+    return {k: torch.as_tensor(np.stack([s[k] for s in steps])).cuda() for k in steps[0]}
+  for t in range(3):
+    rep.add_batch(batch(t), ids)
+  ids[1] = 5                                 # same list object, different env
+  for t in range(3, 6):
+    rep.add_batch(batch(t), ids)
+  seen = set()
+  for _ in range(30):
+    got = rep.sample(4)
+    worker, step = got['worker'].cpu().numpy(), got['step'].cpu().numpy()
+    assert (worker[:, 0] == worker[:, 1]).all() and (step[:, 1] == step[:, 0] + 1).all()
+    seen |= set(worker[:, 0].tolist())
+  assert seen == {0, 1, 5}                   # stale ids would have glued 5's steps onto stream 1
+
+
+def test_fresh_replay_in_a_used_directory_issues_new_chunk_ids(emb, tmp_path):
+  first = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, save_wait=True)
+  fill(first, 9, 2)
+  first.save()
+  names = {p.name for p in tmp_path.glob('*.npz')}
+  second = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, save_wait=True)
+  fill(second, 9, 2, t0=100)                 # load() was never called
+  second.save()
+  both = {p.name for p in tmp_path.glob('*.npz')}
+  assert len(both) == 2 * len(names)
+  uids = [emb.core.replay.parse_filename(n)[1] for n in both]
+  assert len(set(uids)) == len(uids)         # no id issued twice
+  third = emb.Replay(length=2, capacity=1000, directory=tmp_path, chunksize=4)
+  third.load()
+  assert len(third) == len(first) + len(second)
+
+
+def test_load_skips_chunks_of_other_replicas(emb, tmp_path, capsys):
+  a = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, save_wait=True, replica=3)
+  fill(a, 6, 1)
+  a.save()
+  b = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, replica=0)
+  b.load()
+  assert len(b) == 0 and 'another replica' in capsys.readouterr().out
+  c = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, replica=3)
+  c.load()
+  assert len(c) == len(a)
+
+
+def test_sharded_pool_refuses_checkpoints(emb, tmp_path):
+  rep = emb.Replay(length=2, capacity=40, directory=tmp_path, chunksize=4, slots=16,
+                   owners=2, owner=0, workers_per_owner=1)
+  with pytest.raises(NotImplementedError):
+    rep.save()
+  with pytest.raises(NotImplementedError):
+    rep.load()
+
+
+def test_growth_with_actor_and_learner_on_two_streams(emb):
+  """Write-backs queued on the learner's stream must be in the pool after the
+  actor's insert made the pool grow (the copy runs on the actor's stream)."""
+  rep = emb.Replay(length=4, chunksize=8, seed=0)           # 64 slots, grows on demand
+  actor, learner = torch.cuda.Stream(), torch.cuda.Stream()
+  deter = lambda t: np.full(2048, t, np.float32)
+  with torch.cuda.stream(actor):
+    for t in range(40):
+      rep.add({'deter': deter(t), 'is_first': t == 0, 'is_last': False}, 0)
+    batch = rep.sample(3)
+  actor.synchronize()
+  with torch.cuda.stream(learner):
+    big = torch.randn(1 << 26, device='cuda')
+    for _ in range(4):
+      big = big * 1.0001                     # keeps the learner stream busy: the update queues up
+    new = torch.full((3, 4, 2048), -7.0, device='cuda')
+    rep.update({'stepid': batch['stepid'], 'deter': new})
+  with torch.cuda.stream(actor):
+    for t in range(40, 40 + 8 * 70):         # > 64 chunks: forces _grow while the update may be pending
+      rep.add({'deter': deter(t), 'is_first': False, 'is_last': False}, 0)
+  torch.cuda.synchronize()
+  ids = batch['stepid'].cpu().numpy()
+  hits = 0
+  for _ in range(200):
+    got = rep.sample(16)
+    sid = got['stepid'].cpu().numpy()
+    for b in range(16):
+      for j in range(4):
+        if (sid[b, j] == ids.reshape(-1, 20)).all(1).any():
+          assert float(got['deter'][b, j, 0]) == -7.0
+          hits += 1
+  assert hits > 0

@@ -454,3 +454,53 @@ def test_sampletree_draw_statistics_like_reference_tests(branching):
   for index in range(100):
     tree.insert(index, np.inf if index % 3 == 0 else 1.0)
   assert all(tree.sample() % 3 == 0 for _ in range(1000))
+
+
+def test_complete_all_is_all_or_nothing():
+  """Checkpoint support: closing every worker's open chunk needs one free slot
+  per open chunk.  With too few it must fail BEFORE rotating anybody (a save
+  that dies half-way would leave some workers rotated), and succeed after the
+  pool grew."""
+  import ctypes as C
+  rep = HostReplay(length=2, capacity=None, chunksize=4, n_slots=5)
+  for w in range(3):
+    rep.add({'t': np.int32(w)}, w)            # three open chunks, two free slots
+  need, free = C.c_int64(), C.c_int64()
+  api.emb_replay_open_chunks(rep.h, C.byref(need))
+  api.emb_replay_free_slots(rep.h, C.byref(free))
+  assert (need.value, free.value) == (3, 2)
+  def table():
+    n = C.c_int64()
+    api.emb_replay_chunks(rep.h, 0, None, None, None, None, None, C.byref(n))
+    uid, succ = np.zeros(n.value, np.uint64), np.zeros(n.value, np.uint64)
+    fill, slot, tms = (np.zeros(n.value, np.int64) for _ in range(3))
+    api.emb_replay_chunks(rep.h, n.value, _lib.ptr(uid), _lib.ptr(succ), _lib.ptr(fill),
+                          _lib.ptr(slot), _lib.ptr(tms), C.byref(n))
+    return sorted(zip(uid.tolist(), succ.tolist(), fill.tolist()))
+  before = table()
+  with pytest.raises(_lib.PoolFull):
+    api.emb_replay_complete_all(rep.h)
+  assert table() == before                     # nothing was rotated
+  api.emb_replay_grow(rep.h, 8, None)
+  api.emb_replay_complete_all(rep.h)
+  after = table()
+  assert len(after) == len(before) + 3
+  api.emb_replay_open_chunks(rep.h, C.byref(need))
+  assert need.value == 0                       # the successors are empty
+  api.emb_replay_complete_all(rep.h)           # nothing to close: no slots needed
+  assert table() == after
+
+
+def test_reserved_chunk_serials_are_not_reissued():
+  import ctypes as C
+  rep = HostReplay(length=2, capacity=None, chunksize=4, n_slots=6)
+  api.emb_replay_reserve_uids(rep.h, 41)
+  rep.add({'t': np.int32(0)}, 0)
+  n = C.c_int64()
+  uid = np.zeros(4, np.uint64)
+  api.emb_replay_chunks(rep.h, 4, _lib.ptr(uid), None, None, None, None, C.byref(n))
+  assert n.value == 1 and uid[0] == 41
+  api.emb_replay_reserve_uids(rep.h, 7)        # never moves backwards
+  rep.add({'t': np.int32(0)}, 1)
+  api.emb_replay_chunks(rep.h, 4, _lib.ptr(uid), None, None, None, None, C.byref(n))
+  assert sorted(uid[:2].tolist()) == [41, 42]
