@@ -58,3 +58,68 @@ def test_sharded_replay_two_ranks_one_gpu():
     for k in want:
       assert np.array_equal(got0[k], want[k]), k       # rank 0 == single replay
       assert np.array_equal(got1[k], want[k]), k       # rank 1 has the same batch
+
+
+def _crafter_worker(rank, world, port, out):
+  """configs[3]: 256 envs in 8 blocks of 32 (one per rank), 64x64x3 frames,
+  L = 65; the packed batches are merged by a REAL all-reduce between 8 processes
+  (gloo on 127.0.0.1; they share the test box's one GPU)."""
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  import hashlib
+  import embodied_amd as emb
+  from embodied_amd import distributed as D
+  torch.cuda.set_device(0)
+  D.init('gloo')
+  try:
+    per, L, B, cap = 32, 65, 16, 6000
+    kw = dict(chunksize=256, seed=7)
+    shard = D.ShardedReplay(L, cap, per, **kw)
+    single = emb.Replay(L, cap, **kw) if rank == 0 else None
+    n = world * per
+    ids = torch.arange(n, dtype=torch.int32, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(0)        # same frames on every rank
+    for tick in range(cap // n + 2 * L):
+      step = {
+          'image': torch.randint(0, 255, (n, 64, 64, 3), dtype=torch.uint8, device='cuda', generator=gen),
+          'reward': torch.randn(n, device='cuda', generator=gen),
+          'is_first': (ids + tick) % 97 == 0,
+          'is_last': (ids + tick) % 97 == 96,
+          'env': ids,
+          'tick': torch.full((n,), tick, dtype=torch.int32, device='cuda'),
+      }
+      shard.add_batch({k: v[rank * per:(rank + 1) * per] for k, v in step.items()})
+      if single is not None:
+        single.add_batch(step, list(range(n)))
+    assert len(shard) == cap
+    digests = []
+    for _ in range(3):
+      got = shard.sample(B)
+      h = hashlib.sha256()
+      for key in sorted(got):
+        h.update(key.encode() + got[key].cpu().numpy().tobytes())
+      want = None
+      if single is not None:
+        ref = single.sample(B)
+        w = hashlib.sha256()
+        for key in sorted(ref):
+          w.update(key.encode() + ref[key].cpu().numpy().tobytes())
+        want = w.hexdigest()
+        owners = sorted(set((ref['env'][:, 0] // per).tolist()))
+      digests.append((h.hexdigest(), want))
+    out[rank] = (digests, owners if rank == 0 else None)
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def test_crafter_config_256_envs_over_8_real_ranks():
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_crafter_worker, args=(8, _free_port(), out), nprocs=8, join=True)
+  assert sorted(out.keys()) == list(range(8))
+  for i in range(3):
+    want = out[0][0][i][1]
+    assert want is not None
+    for rank in range(8):
+      assert out[rank][0][i][0] == want, (i, rank)     # every rank holds the single-replay batch
+  assert len(out[0][1]) > 1                            # the last batch mixed sequences of several owners

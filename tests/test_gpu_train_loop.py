@@ -147,3 +147,49 @@ def test_actor_learner_split_respects_samples_per_insert(tmp_path):
   got = counters['trains'] * args.batch_size / int(logger.step)
   assert 0.6 * want <= got <= 1.2 * want, (got, want)
   assert replay_box[-1]._multistream
+
+
+def test_train_eval_runs_both_drivers_and_replays(tmp_path):
+  """run.train_eval (embodied/run/train_eval.py:10-18 signature): the train
+  Driver feeds the train Replay and the learner, the eval Driver runs whole
+  episodes in mode='eval' into its own Replay, both report streams are drawn,
+  checkpoints hold both replays."""
+  import embodied_amd as emb
+  from embodied_amd.envs import dummy
+  args = make_args(tmp_path, steps=500, eval_every=0.05, eval_envs=2, eval_eps=2)
+  env0 = dummy.Dummy('disc', size=(8, 8), length=17)
+  modes = []
+
+  class Agent(CheckingAgent):
+    def policy(self, carry, obs, mode='train'):
+      modes.append((mode, len(obs['is_first'])))
+      self.prev = None              # two drivers interleave: continuity is checked in train()
+      return super().policy(carry, obs, mode)
+
+  agent = Agent(env0.obs_space, env0.act_space)
+  replays = {}
+  def make_replay(name, capacity):
+    replays[name] = emb.Replay(
+        length=args.batch_length + 1, capacity=capacity, chunksize=64,
+        directory=tmp_path / name, save_wait=True)
+    return replays[name]
+  make_stream = lambda replay, mode: emb.streams.Consec(
+      emb.streams.Stateless(replay.sample, args.batch_size, mode),
+      length=args.batch_length, consec=1, prefix=1, strict=True, contiguous=True)
+  logger = emb.utils.Logger()
+  emb.run.train_eval(
+      lambda: agent, lambda: make_replay('replay', 500), lambda: make_replay('eval_replay', 100),
+      lambda i: dummy.Dummy('disc', size=(8, 8), length=17 + i),
+      lambda i: dummy.Dummy('disc', size=(8, 8), length=11), make_stream, lambda: logger, args)
+  assert int(logger.step) >= 500
+  train_calls = [n for mode, n in modes if mode == 'train']
+  eval_calls = [n for mode, n in modes if mode == 'eval']
+  assert set(train_calls) == {3} and set(eval_calls) == {2}
+  assert abs(len(train_calls) - int(logger.step) / 3) <= 4          # only train steps count
+  assert len(eval_calls) >= 2 * 12                                  # >= 2 whole episodes per evaluation
+  assert agent.trains > 10 and agent.reports >= 2                   # eval + train report streams
+  assert len(replays['replay']) > 0 and len(replays['eval_replay']) > 0
+  assert agent.saves >= 1
+  assert list((tmp_path / 'replay').glob('*.npz')) and list((tmp_path / 'eval_replay').glob('*.npz'))
+  keys = set().union(*logger.history)
+  assert any(k.startswith('eval/') for k in keys) and any(k.startswith('report/') for k in keys)
