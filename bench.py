@@ -46,11 +46,18 @@ def parse():
   p.add_argument('--capacity', type=int, default=100_000)   # ppo/configs.yaml:39
   p.add_argument('--train-ratio', type=float, default=3.0)  # ppo/configs.yaml:51
   p.add_argument('--grad-numel', type=int, default=10_000_000)   # PPO-sized f32 gradient
-  p.add_argument('--exchange', default='online',
-                 choices=['online', 'trajectories', 'returns', 'none'],
-                 help='N>1: what each train step all-gathers. online (default) = the packed '
-                      'batch whenever it holds fresh on-policy windows (every trajectory crosses '
-                      'xGMI once; re-sampled windows are not re-sent); trajectories = every batch')
+  p.add_argument('--exchange', default='dp_slice',
+                 choices=['dp_slice', 'online', 'trajectories', 'returns', 'none'],
+                 help='N>1: how trajectories cross xGMI.  dp_slice (default) = SURVEY 8e\'s cheaper '
+                      'form: batches holding fresh on-policy windows are cut into one block per rank '
+                      'and exchanged with ONE all-to-all, every rank trains on a slice mixed from '
+                      'all ranks\' envs ((n-1)/n * B*L*S bytes each way per exchanged batch).  '
+                      'online = all-gather of those batches ((n-1) * B*L*S received); trajectories '
+                      '= all-gather of every batch; returns = all-gather of the GAE outputs only')
+  p.add_argument('--grad-dtype', default='bf16', choices=['bf16', 'f32'],
+                 help='N>1: dtype of the flat gradient buffer that is all-reduced every train '
+                      'step (the reference all-reduces f32 leaves, embodied/jax/opt.py:52-54; '
+                      'bf16 halves the bytes on the links)')
   p.add_argument('--cpu-seconds', type=float, default=15.0)
   p.add_argument('--sustained-seconds', type=float, default=10.0,
                  help='after the headline region: the same loop for this long (SURVEY 8d asks for '
@@ -210,7 +217,9 @@ def main():
   value = torch.randn(B * args.prefetch, T + args.context, device=device)
   imag_rew = torch.randn(B * T, 16, device=device)
   imag_flags = torch.zeros(B * T, 16, dtype=torch.bool, device=device)
-  grads = torch.zeros(args.grad_numel, device=device) if use_dist and args.grad_numel else None
+  grad_dtype = torch.bfloat16 if args.grad_dtype == 'bf16' else torch.float32
+  grads = (torch.zeros(args.grad_numel, dtype=grad_dtype, device=device)
+           if use_dist and args.grad_numel else None)
   counters = {'env_steps': 0, 'train_steps': 0}
   pending, marks = [], []
   comm = None
@@ -242,18 +251,38 @@ def main():
       # single RCCL all-gather; both collectives run async on RCCL's stream and
       # are waited for one train step later (the reference returns train outs
       # one step late too: embodied/jax/agent.py:286-294).
-      flat, batch, layout = D.sample_packed(replay, B * args.prefetch)
-      adv, tar = emb.scans.gae(
-          batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
+      rows = B * args.prefetch
+      sliced = (args.exchange == 'dp_slice' and rows % world == 0
+                and replay.online_pending() > 0)
+      if sliced:
+        # Fresh on-policy windows: cut the batch into one block per rank.
+        flat, batch, layout = D.sample_packed(replay, rows, groups=world)
+      else:
+        flat, batch, layout = D.sample_packed(replay, rows)
       for future in pending:
         future.result().wait()
       pending.clear()
-      if args.exchange == 'trajectories' or (args.exchange == 'online' and layout.online.any()):
-        send = flat
-      elif args.exchange == 'returns':
-        send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
+      send = None
+      if sliced:
+        # This rank's slice of the global batch = block `rank` of every rank's
+        # batch; it is complete one train step later (the wait above) and is
+        # what the learner then computes returns on.
+        work, received, views = D.exchange_dp_slices(flat, layout)
+        pending.append(D.Done(lambda w=work: w))
+        state_keep[:] = [flat, received]
+        late, slice_state['views'] = slice_state.get('views'), views
+        source = late if late is not None else batch
+        dense = lambda x: x.reshape(rows, x.shape[-1])
+        adv, tar = emb.scans.gae(
+            dense(source['reward']), value, dense(source['is_last']),
+            dense(source['is_terminal']), hor=200, lam=0.8)
       else:
-        send = None
+        adv, tar = emb.scans.gae(
+            batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
+        if args.exchange == 'trajectories' or (args.exchange == 'online' and layout.online.any()):
+          send = flat
+        elif args.exchange == 'returns':
+          send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
       # Process-group level async collectives (no Python-side checking), issued
       # inline in the same order on every rank.  EMB_BENCH_COMM=thread issues
       # them from a helper thread instead (measured slower: the GIL changes
@@ -266,14 +295,16 @@ def main():
         pending.append(issue(lambda: D.async_all_reduce(grads)))
       # When the links are the bottleneck the host could queue train steps far
       # ahead of the GPU (one gathered buffer each): stay within 8 train steps.
-      marks.append(torch.cuda.Event())
-      marks[-1].record()
-      if len(marks) > 8:
-        marks.pop(0).synchronize()
+      if counters['train_steps'] % 4 == 0:       # one mark per 4 train steps, 8 marks deep
+        marks.append(torch.cuda.Event())
+        marks[-1].record()
+        if len(marks) > 8:
+          marks.pop(0).synchronize()
     counters['train_steps'] += args.prefetch
     return adv
 
   state_keep = []
+  slice_state = {}
 
   def one_step():
     driver(policy, steps=args.envs)            # exactly one vectorised step
@@ -444,8 +475,9 @@ def main():
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
             'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
-            'parallelism': (f'env-sharded x{world}, {args.exchange} all-gather + '
-                            f'{args.grad_numel * 4 >> 20} MiB grad all-reduce (RCCL)')
+            'parallelism': (f'env-sharded x{world}, trajectory exchange {args.exchange} + '
+                            f'{args.grad_numel * (2 if args.grad_dtype == "bf16" else 4) >> 20} MiB '
+                            f'{args.grad_dtype} grad all-reduce per train step (RCCL)')
                            if use_dist else 'single',
         },
         'sustained': sustained,

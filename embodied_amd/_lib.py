@@ -130,11 +130,13 @@ SIGNATURES = {
     'emb_replay_prioritize': [p, p, p, i64],
     'emb_replay_len': [p, p],
     'emb_replay_sampler_len': [p, p],
+    'emb_replay_online_pending': [p, p],
     'emb_replay_free_slots': [p, p],
     'emb_replay_stats': [p, p, i32],
     'emb_replay_add': [p, i64, p, p, p],
     'emb_replay_add_masked': [p, i64, p, p, i32, p, p, p, p, p],
     'emb_replay_sample': [p, i64, i32, p, p, p, p],
+    'emb_replay_sample_grouped': [p, i64, i32, p, i32, i64, p, p, p],
     'emb_replay_update': [p, i64, i64, p, i32, p, p, p],
     'emb_replay_gather_rows': [p, p, i64, i64, p, p],
     'emb_replay_scatter_rows': [p, p, i64, i32, p, p, p],
@@ -242,7 +244,7 @@ class _FastApi:
   SHAPES = {
       'emb_synth_env_step': 'ints', 'emb_mask_actions': 'ints',
       'emb_replay_add': 'ints', 'emb_replay_add_masked': 'ints',
-      'emb_replay_sample': 'ints', 'emb_replay_update': 'ints',
+      'emb_replay_sample': 'ints', 'emb_replay_sample_grouped': 'ints', 'emb_replay_update': 'ints',
       'emb_replay_gather_rows': 'ints', 'emb_replay_scatter_rows': 'ints',
       'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',
   }

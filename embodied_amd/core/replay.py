@@ -118,6 +118,8 @@ class Replay:
     self._one_ptrs = (_lib.ptr(self._one_worker), _lib.ptr(self._one_row), _lib.ptr(self._one_sid))
     self._new_chunks = C.c_int32()
     self._new_chunks_ref = C.byref(self._new_chunks)
+    self._pending_count = C.c_int64()
+    self._pending_ref = C.byref(self._pending_count)
     self._saved = set()
     self._updates = 0
     self._workers_seen = None
@@ -146,6 +148,13 @@ class Replay:
   def __len__(self):
     n = C.c_int64()
     api.emb_replay_len(self._handle, C.byref(n))
+    return n.value
+
+  def online_pending(self):
+    """Fresh on-policy windows queued for the next train-mode samples (online
+    mode, replay.py:114-118)."""
+    n = self._pending_count
+    api.emb_replay_online_pending(self._handle, self._pending_ref)
     return n.value
 
   def _stream(self):

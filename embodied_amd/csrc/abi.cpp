@@ -635,6 +635,7 @@ int32_t emb_replay_prioritize(emb_replay_t* rep, const uint8_t* stepids, const d
 }
 
 int32_t emb_replay_len(emb_replay_t* rep, int64_t* items) { REP_OP(need(items, "replay_len: null output"); *items = rep->index->size()); }
+int32_t emb_replay_online_pending(emb_replay_t* rep, int64_t* n) { REP_OP(need(n, "replay_online_pending: null output"); *n = rep->index->online_pending()); }
 int32_t emb_replay_sampler_len(emb_replay_t* rep, int64_t* n) { REP_OP(need(n, "replay_sampler_len: null output"); *n = rep->selector->size()); }
 int32_t emb_replay_free_slots(emb_replay_t* rep, int64_t* n) { REP_OP(need(n, "replay_free_slots: null output"); *n = rep->index->free_slots()); }
 int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset) { REP_OP(need(out, "replay_stats: null output"); rep->index->stats(out, reset != 0)); }
@@ -725,6 +726,8 @@ struct KeyList {
   std::vector<emb::KeyDesc> key;
   int key_is_first = -1, key_is_last = -1, key_stepid = -1;
   int32_t seq_len = 1;
+  int32_t group = 0;            // gather: destination groups (MovePlan::group)
+  int64_t group_stride = 0;
   // Masked insert: per key a DType code (-1 = plain copy) and the buffer that
   // also receives the masked value; mask_flags = is_last of the rows.
   std::vector<int8_t> mask_dtype;
@@ -746,6 +749,8 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
     const int hi = std::min(total, lo + emb::kMaxKeys);
     emb::MovePlan plan;
     plan.seq_len = list.seq_len;
+    plan.group = list.group;
+    plan.group_stride = list.group_stride;
     plan.is_first_pool = first_pool;
     for (int k = lo; k < hi; ++k) {
       if (list.mask_flags && list.mask_dtype[k] >= 0) {
@@ -811,26 +816,41 @@ int32_t emb_replay_add_masked(emb_replay_t* rep, int64_t n, const int64_t* worke
                     static_cast<hipStream_t>(stream)));
 }
 
+static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* const* dst,
+                          int32_t group, int64_t group_stride, uint8_t* online_out,
+                          uint8_t* first_stepids_out, hipStream_t stream) {
+  need(batch >= 0 && dst, "sample: bad arguments");
+  need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
+  need(group >= 0 && group_stride >= 0 && (group == 0 || group_stride % 16 == 0),
+       "sample: bad destination groups");
+  if (batch == 0) return;
+  const int64_t L = rep->index->config().length;
+  KeyList list;
+  for (size_t k = 0; k < rep->keys.size(); ++k) {
+    need(dst[k] && rep->keys[k].pool, "sample: null buffer");
+    if (static_cast<int>(k) == rep->key_is_first) list.key_is_first = static_cast<int>(list.key.size());
+    if (static_cast<int>(k) == rep->key_is_last) list.key_is_last = static_cast<int>(list.key.size());
+    list.push(rep->keys[k].pool, dst[k], rep->keys[k].rowbytes);
+  }
+  list.seq_len = static_cast<int32_t>(L);
+  list.group = group;
+  list.group_stride = group_stride;
+  rep->rows.resize(batch * L);
+  sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
+  run_move_all(rep, list, rep->rows.data(), batch * L, nullptr, true, stream, &rep->spans);
+}
+
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
                           uint8_t* online_out, uint8_t* first_stepids_out, void* stream) {
-  REP_OP({
-    need(batch >= 0 && dst, "sample: bad arguments");
-    need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
-    if (batch == 0) return;
-    const int64_t L = rep->index->config().length;
-    KeyList list;
-    for (size_t k = 0; k < rep->keys.size(); ++k) {
-      need(dst[k] && rep->keys[k].pool, "sample: null buffer");
-      if (static_cast<int>(k) == rep->key_is_first) list.key_is_first = static_cast<int>(list.key.size());
-      if (static_cast<int>(k) == rep->key_is_last) list.key_is_last = static_cast<int>(list.key.size());
-      list.push(rep->keys[k].pool, dst[k], rep->keys[k].rowbytes);
-    }
-    list.seq_len = static_cast<int32_t>(L);
-    rep->rows.resize(batch * L);
-    sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
-    run_move_all(rep, list, rep->rows.data(), batch * L, nullptr, true,
-                 static_cast<hipStream_t>(stream), &rep->spans);
-  });
+  REP_OP(sample_locked(rep, batch, mode, dst, 0, 0, online_out, first_stepids_out,
+                       static_cast<hipStream_t>(stream)));
+}
+
+int32_t emb_replay_sample_grouped(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
+                                  int32_t group, int64_t group_stride, uint8_t* online_out,
+                                  uint8_t* first_stepids_out, void* stream) {
+  REP_OP(sample_locked(rep, batch, mode, dst, group, group_stride, online_out, first_stepids_out,
+                       static_cast<hipStream_t>(stream)));
 }
 
 static KeyList list_subset(emb_replay* rep, int32_t n_keys, const int32_t* key_ids,

@@ -35,6 +35,11 @@ struct MovePlan {
   const int32_t* rows_host = nullptr;
   const int32_t* spans_host = nullptr;
   int32_t n_seq = 0;
+  // Gather only: batch side cut into groups of `group` sequences whose starts
+  // are `group_stride` bytes apart (every key.batch is then the key's offset
+  // inside group 0); 0 = dense.
+  int32_t group = 0;
+  int64_t group_stride = 0;
   // Scatter only: the batch bytes of this key (4-byte multiple rows, e.g. the
   // 20-byte step ids) come from host memory through the kernel arguments.
   int32_t inline_key = -1;

@@ -60,6 +60,13 @@ struct alignas(16) MoveArgs {
   // persistent workgroups walking `wtile0[n_wide]` tiles (see move_wide_spans);
   // those keys own no virtual blocks.
   int32_t wide_workers, n_wide;
+  // Gather only: the batch side in groups of `group` sequences, `group_stride`
+  // bytes apart (0 = one dense (n_rows, rowbytes) array per key).  Sequence s of
+  // key k starts at key.batch + (s / group) * group_stride + (s % group) * L *
+  // rowbytes: the layout of a packed batch cut into per-destination-rank blocks
+  // (distributed.py, DP-slice exchange).
+  int32_t group;
+  int64_t group_stride;
   uint32_t wtile0[kMaxKeys + 1];
   uint32_t tiles_per_seq[kMaxKeys];
   uint8_t wide_key[kMaxKeys];
@@ -83,6 +90,15 @@ __device__ __forceinline__ int32_t row_of(const MoveArgs& a, uint32_t r) {
   }
   if (a.rows_mode == 1) return static_cast<int32_t>(a.inline_words[r]);
   return a.rows[r];
+}
+
+// Byte offset of batch row r of `key` on the batch side (see MoveArgs::group).
+__device__ __forceinline__ int64_t batch_offset(const MoveArgs& a, const KeyDesc& key, uint32_t r) {
+  if (a.group == 0) return static_cast<int64_t>(r) * key.rowbytes;
+  const uint32_t L = static_cast<uint32_t>(a.seq_len), g = static_cast<uint32_t>(a.group);
+  const uint32_t seq = r / L, t = r - seq * L;
+  const uint32_t grp = seq / g, j = seq - grp * g;
+  return static_cast<int64_t>(grp) * a.group_stride + static_cast<int64_t>(j * L + t) * key.rowbytes;
 }
 
 template <typename T>
@@ -184,7 +200,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   for (int j = 0; j < U; ++j) {
     if (row[j] < 0) continue;
     const uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
-    const uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
+    const uint8_t* batch = key.batch + batch_offset(a, key, r[j]);
     const u32x4* src = reinterpret_cast<const u32x4*>(kGather ? pool : batch) + off[j];
     buf[j] = load16<(NT & 1) != 0>(src);
   }
@@ -192,7 +208,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   for (int j = 0; j < U; ++j) {
     if (row[j] < 0) continue;
     uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
-    uint8_t* batch = key.batch + static_cast<int64_t>(r[j]) * key.rowbytes;
+    uint8_t* batch = key.batch + batch_offset(a, key, r[j]);
     u32x4* dst = reinterpret_cast<u32x4*>(kGather ? batch : pool) + off[j];
     store16<(NT & 2) != 0>(dst, buf[j]);
   }
@@ -236,7 +252,13 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a) {
     w.u0 = piece * tile + threadIdx.x;
     w.p0 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row0) * upr;
     w.p1 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row1) * upr - w.split;
-    w.b = reinterpret_cast<const u32x4*>(key.batch) + static_cast<uint64_t>(seq) * w.total;
+    if (a.group == 0) {
+      w.b = reinterpret_cast<const u32x4*>(key.batch) + static_cast<uint64_t>(seq) * w.total;
+    } else {
+      const uint32_t g = static_cast<uint32_t>(a.group), grp = seq / g, j = seq - grp * g;
+      w.b = reinterpret_cast<const u32x4*>(key.batch + static_cast<int64_t>(grp) * a.group_stride) +
+            static_cast<uint64_t>(j) * w.total;
+    }
     return w;
   };
   auto issue = [&](const Where& w, u32x4* v) {
@@ -300,7 +322,7 @@ __device__ __forceinline__ void gather_block(const MoveArgs& a, int block) {
   const int64_t row = row_of(a, static_cast<uint32_t>(r));
   if (row < 0) return;   // not this rank's sequence (sharded pools): leave as is
   const uint8_t* src = key.pool + row * key.rowbytes + off;
-  uint8_t* dst = key.batch + r * key.rowbytes + off;
+  uint8_t* dst = key.batch + batch_offset(a, key, static_cast<uint32_t>(r)) + off;
   if (key.rowbytes == 1 && (k == a.key_is_first || k == a.key_is_last)) {
     const int t = static_cast<int>(r % a.seq_len);
     uint8_t v = gload<uint8_t>(src);
@@ -569,6 +591,10 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
   MoveArgs& a = *reinterpret_cast<MoveArgs*>(out->args);
   a.wide_workers = 0;
   a.n_wide = 0;
+  a.group = plan.group > 0 ? plan.group : 0;
+  a.group_stride = plan.group_stride;
+  if (a.group && (plan.group_stride % 16 != 0 || plan.mask_bits || plan.inline_key >= 0))
+    return hipErrorInvalidValue;       // gather-side layout only, 16-byte aligned groups
   a.n_keys = plan.n_keys;
   a.n_rows = plan.n_rows;
   a.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;

@@ -154,6 +154,10 @@ class ReplayIndex {
     return row;
   }
 
+  // Windows waiting in the online queue (replay.py:114-118): a train-mode
+  // sample serves these before it asks the selector.
+  int64_t online_pending() const { return static_cast<int64_t>(fresh_.size()); }
+
   // replay.py:151-169: one sequence start.  Stale online entries (first chunk
   // evicted) are dropped and the draw repeated, as the KeyError retry does.
   Pos draw(int mode_train, bool* from_online) {

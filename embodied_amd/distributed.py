@@ -12,6 +12,10 @@ The exchange steps are the two north_star names:
     instead of one per key.
   * `all_reduce_mean`   — all-reduce of one flat gradient buffer
     (embodied/jax/opt.py:52-54's pmean).
+  * `exchange_dp_slices` — SURVEY.md 8e's cheaper form of the trajectory
+    exchange: every rank ends up with ITS slice of the global batch only, one
+    all-to-all of B*L*S bytes per rank instead of an all-gather that hands every
+    rank all (n-1) other batches.
 """
 import os
 
@@ -70,8 +74,12 @@ class PackedLayout:
     self.index = {e[0]: e for e in self.entries}
 
   def view(self, flat, name):
-    """Typed (B, L, ...) view of one key inside a 1-D packed buffer."""
+    """Typed (B, L, ...) view of one key inside a 1-D packed buffer, or
+    (G, B, L, ...) over a (G, nbytes) stack of packed buffers."""
     _, dtype, shape, offset, nbytes = self.index[name]
+    if flat.dim() == 2:
+      return flat[:, offset: offset + nbytes].view(dtype).view(
+          flat.shape[0], self.batch, self.length, *shape)
     return flat[offset: offset + nbytes].view(dtype).view(self.batch, self.length, *shape)
 
   def views(self, flat, lead=None):
@@ -133,33 +141,49 @@ class SampleInfo:
     return self.layout.views(flat, lead)
 
 
-def sample_packed(replay, batch, mode='train'):
+def sample_packed(replay, batch, mode='train', groups=1):
   """`replay.sample` into one packed buffer: returns (flat uint8, per-key views,
   info with `.online` flags and the layout).  The gather kernel writes each key
-  at its offset directly."""
+  at its offset directly.
+
+  `groups` > 1 cuts the batch into that many equal blocks of `batch / groups`
+  sequences, each block a complete packed sub-batch (all keys) of its own:
+  block d is what destination rank d receives in `exchange_dp_slices`.  The
+  views are then shaped (groups, batch / groups, L, ...)."""
   import ctypes as C
   from . import _lib
-  from ._lib import api
   from .core import limiters
+  assert batch % groups == 0, (batch, groups)
   limiters.wait(lambda: len(replay._native), f'Replay buffer {replay.name} is empty')
   with replay._lock:
     replay._flush()
     cache = replay.__dict__.setdefault('_packed_layouts', {})
-    layout = cache.get(batch)
+    layout = cache.get((batch, groups))
     if layout is None:
-      layout = cache[batch] = PackedLayout(
-          [(k.name, k.dtype, k.shape) for k in replay._keys], batch, replay.length)
+      layout = cache[(batch, groups)] = PackedLayout(
+          [(k.name, k.dtype, k.shape) for k in replay._keys], batch // groups, replay.length)
       layout.offsets = [layout.index[k.name][3] for k in replay._keys]
       layout.ptrs = (C.c_void_p * len(replay._keys))()
-    flat = _lib.empty((layout.nbytes,), torch.uint8, replay.device)
+      layout.groups = groups
+      layout.online_ptrs = [np.zeros(batch, np.uint8) for _ in range(4)]   # handed out in turn
+      layout.turn = 0
+    flat = _lib.empty((groups * layout.nbytes,), torch.uint8, replay.device)
     base, ptrs = flat.data_ptr(), layout.ptrs
     for i, offset in enumerate(layout.offsets):
       ptrs[i] = base + offset
-    online = np.zeros(batch, np.uint8)
-    _lib.fast.emb_replay_sample(
-        replay._h, batch, _lib.MODES[mode], ptrs, _lib.ptr(online), None,
-        replay._stream())
-  return flat, PackedViews(flat, layout), SampleInfo(layout, online.astype(bool))
+    layout.turn = (layout.turn + 1) & 3
+    online = layout.online_ptrs[layout.turn]
+    if groups == 1:
+      _lib.fast.emb_replay_sample(
+          replay._h, batch, _lib.MODES[mode], ptrs, _lib.ptr(online), None,
+          replay._stream())
+      views = PackedViews(flat, layout)
+    else:
+      _lib.fast.emb_replay_sample_grouped(
+          replay._h, batch, _lib.MODES[mode], ptrs, batch // groups, layout.nbytes,
+          _lib.ptr(online), None, replay._stream())
+      views = PackedViews(flat.view(groups, layout.nbytes), layout)
+  return flat, views, SampleInfo(layout, online.view(np.bool_))
 
 
 def _default_pg():
@@ -185,6 +209,42 @@ def async_all_reduce(tensor):
     return pg.allreduce([tensor])
   except AttributeError:
     return dist.all_reduce(tensor, async_op=True)
+
+
+def async_all_to_all(out, tensor):
+  """Async equal-split all-to-all: block d of `tensor` goes to rank d, block s
+  of `out` comes from rank s.  Returns a Work handle (`.wait()`)."""
+  pg = _default_pg()
+  if dist.get_backend() == 'gloo' and tensor.is_cuda:
+    # gloo moves host memory only (test transport: the multi-rank control flow
+    # on a box with fewer GPUs than ranks); RCCL takes the device buffers as is.
+    host_in, host_out = tensor.cpu(), torch.empty(out.shape, dtype=out.dtype)
+    pg.alltoall_base(host_out, host_in, [], []).wait()
+    out.copy_(host_out)
+    return _Finished()
+  return pg.alltoall_base(out, tensor, [], [])
+
+
+class _Finished:
+  def wait(self):
+    return True
+
+
+def exchange_dp_slices(flat, info):
+  """All-to-all of a grouped packed batch (`sample_packed(..., groups=world)`):
+  rank r keeps block r of its own batch and receives block r of every other
+  rank's.  Returns (work, received flat, per-key views shaped (world, B/world,
+  L, ...)): this rank's slice of the global batch, mixed from every rank's
+  envs.  Each rank sends and receives (n-1)/n * B*L*S bytes; the all-gather
+  form receives (n-1) * B*L*S."""
+  w = world()
+  out = torch.empty_like(flat)
+  if w == 1:
+    out.copy_(flat)
+    work = _Finished()
+  else:
+    work = async_all_to_all(out, flat)
+  return work, out, PackedViews(out.view(info.layout.groups, info.layout.nbytes), info.layout)
 
 
 class Done:

@@ -175,6 +175,9 @@ int32_t emb_replay_prioritize(emb_replay_t* rep, const uint8_t* stepids, const d
                               int64_t n);
 int32_t emb_replay_len(emb_replay_t* rep, int64_t* items);
 int32_t emb_replay_sampler_len(emb_replay_t* rep, int64_t* n);
+/* Windows queued by online mode (replay.py:114-118) that the next train-mode
+ * samples will serve before the selector is asked.                           */
+int32_t emb_replay_online_pending(emb_replay_t* rep, int64_t* n);
 int32_t emb_replay_free_slots(emb_replay_t* rep, int64_t* n);
 /* out = {items, chunks, streams, inserts, samples, updates} (replay.py:58-74) */
 int32_t emb_replay_stats(emb_replay_t* rep, int64_t out[6], int32_t reset);
@@ -203,6 +206,16 @@ int32_t emb_replay_add_masked(emb_replay_t* rep, int64_t n, const int64_t* worke
                               void* const* masked_out, const void* is_last, void* stream);
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
                           uint8_t* online_out, uint8_t* first_stepids_out, void* stream);
+/* The same with the batch side cut into groups of `group` sequences whose
+ * starts are `group_stride` bytes (a multiple of 16) apart: dst[k] is key k's
+ * place inside group 0, sequence s of key k lands at dst[k] + (s / group) *
+ * group_stride + (s % group) * length * rowbytes[k].  This is the layout of a
+ * packed batch cut into one block per destination rank, so that the DP-slice
+ * exchange of SURVEY.md 8e (the reference assembles per-process slices into the
+ * global batch, embodied/jax/internal.py:145-152) is ONE all-to-all.         */
+int32_t emb_replay_sample_grouped(emb_replay_t* rep, int64_t batch, int32_t mode,
+                                  void* const* dst, int32_t group, int64_t group_stride,
+                                  uint8_t* online_out, uint8_t* first_stepids_out, void* stream);
 int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t* stepids,
                           int32_t n_keys, const int32_t* key_ids, const void* const* src,
                           void* stream);

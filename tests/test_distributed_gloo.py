@@ -161,3 +161,39 @@ def test_all_gather_and_all_reduce_world4():
     assert np.allclose(grads, 2.5)
     assert block == list(range(rank * 16, rank * 16 + 16))
     assert mx == 3.5
+
+
+def _slice_job(rank, world, D):
+  """DP-slice exchange on host buffers: every rank builds a grouped packed
+  batch (block d = what rank d gets) whose bytes name (source rank, block,
+  sequence), exchanges, and returns what it received."""
+  specs = [('image', torch.uint8, (4, 4, 2)), ('reward', torch.float32, ()),
+           ('stepid', torch.uint8, (20,))]
+  g, L = 2, 5
+  layout = D.PackedLayout(specs, g, L)
+  layout.groups = world
+  flat = torch.zeros(world * layout.nbytes, dtype=torch.uint8)
+  views = D.PackedViews(flat.view(world, layout.nbytes), layout)
+  for d in range(world):
+    for j in range(g):
+      views['image'][d, j] = 40 * rank + 8 * d + j
+      views['reward'][d, j] = 40 * rank + 8 * d + j + 0.5
+      views['stepid'][d, j] = 40 * rank + 8 * d + j
+  info = D.SampleInfo(layout, np.zeros(world * g, bool))
+  work, out, got = D.exchange_dp_slices(flat, info)
+  work.wait()
+  return {k: got[k].numpy().copy() for k in ('image', 'reward', 'stepid')}
+
+
+def test_dp_slice_exchange_world2_and_world4():
+  for world in (2, 4):
+    out = run_world(_slice_job, world)
+    for rank in range(world):
+      got = out[rank]
+      assert got['image'].shape == (world, 2, 5, 4, 4, 2)
+      for src in range(world):            # block `rank` of every source rank, in source order
+        for j in range(2):
+          tag = 40 * src + 8 * rank + j
+          assert (got['image'][src, j] == tag).all()
+          assert (got['reward'][src, j] == tag + 0.5).all()
+          assert (got['stepid'][src, j] == tag).all()

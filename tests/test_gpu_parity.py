@@ -921,3 +921,33 @@ def test_span_mover_several_wide_keys_match_oracle(emb, chunksize, L, batches):
   ours.update({k: torch.as_tensor(v).cuda() for k, v in upd.items()})
   ref.update(dict(upd))
   assert_same({k: v.cpu().numpy() for k, v in ours.sample(12).items()}, ref.sample(12), 'after update')
+
+
+@pytest.mark.parametrize('chunksize,L,batch,groups', [
+    (16, 7, 8, 2), (16, 7, 8, 8), (64, 65, 16, 4), (8, 9, 12, 3)])
+def test_grouped_packed_sample_equals_dense_sample(emb, chunksize, L, batch, groups):
+  """distributed.sample_packed(groups=n): the batch cut into one packed block
+  per destination rank (the send buffer of the DP-slice all-to-all) holds the
+  same sequences, in order, as the dense sample of the same draws; exchanged
+  among one rank it comes back unchanged."""
+  from embodied_amd import distributed as D
+  def build():
+    rep = emb.Replay(length=L, capacity=40 * L, chunksize=chunksize, seed=9)
+    gen = np.random.default_rng(0)
+    for t in range(6 * chunksize + L):
+      for w in range(2):
+        rep.add(dict(scenarios.synth_step(t, w),
+                     wide=gen.standard_normal(520).astype(np.float32)), w)
+    return rep
+  a, b = build(), build()
+  for _ in range(2):
+    flat, views, info = D.sample_packed(a, batch, groups=groups)
+    want = b.sample(batch)
+    assert flat.numel() == groups * info.layout.nbytes
+    for key in want:
+      got = views[key]
+      assert got.shape == (groups, batch // groups, *want[key].shape[1:]), key
+      assert torch.equal(got.reshape(want[key].shape), want[key]), key
+  work, out, got = D.exchange_dp_slices(flat, info)     # world 1: a copy
+  work.wait()
+  assert torch.equal(out, flat)

@@ -1,24 +1,41 @@
 #!/bin/bash
 # Reproduce profiles/rNN_* on the GPU box (run from the repo root):
-#   tools/collect_profiles.sh r01
+#   tools/collect_profiles.sh r02
 # Counters are collected in their own passes (never together with a trace domain
 # other than --kernel-trace); FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+# the headline line, un-profiled (bench.py's default: kernel arguments in host memory)
 python "$R/bench.py" > "$O/bench_default.json" 2>/dev/null
-python "$R/bench.py" --workload dreamer --steps 5000 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
+# the runtime's default argument placement, for DESIGN.md 4's A/B
+HIP_FORCE_DEV_KERNARG=1 python "$R/bench.py" --no-cpu-baseline > "$O/bench_device_kernargs.json" 2>/dev/null
+python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 3 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
+# the driver's short form
+python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | grep '^{' > "$O/bench_steps20.json"
+# --stats of the SAME default command
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -o st -- \
-  python "$R/bench.py" --no-cpu-baseline > "$O/stats_bench.log" 2>&1
-cp /tmp/st/st_kernel_stats.csv "$O/kernel_stats.csv"
+  python "$R/bench.py" --no-cpu-baseline > "$O/bench_under_rocprof.json" 2>"$O/stats_bench.log"
+cp /tmp/st/st_kernel_stats.csv "$O/kernel_stats_bench.csv"
+HIP_FORCE_DEV_KERNARG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st1 -o st -- \
+  python "$R/bench.py" --no-cpu-baseline > "$O/bench_device_kernargs_under_rocprof.json" 2>/dev/null
+cp /tmp/st1/st_kernel_stats.csv "$O/kernel_stats_bench_device_kernargs.csv"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st2 -o st -- \
+  python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 0 --no-cpu-baseline > /dev/null 2>&1
+cp /tmp/st2/st_kernel_stats.csv "$O/kernel_stats_dreamer.csv"
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter --kernel-trace --output-format csv -d /tmp/p_$counter -o p -- \
-    python "$R/bench.py" --steps 300 --no-cpu-baseline > /dev/null 2>&1
+    python "$R/bench.py" --steps 300 --sustained-seconds 0 --no-cpu-baseline > /dev/null 2>&1
   python "$R/tools/summarize_pmc.py" /tmp/p_$counter/p_counter_collection.csv > "$O/pmc_$counter.csv"
 done
+python "$R/tools/bench_gather.py" --batches 1,4,8,16,32,64,128,256 --tight > "$O/gather_sweep.txt" 2>&1
+HIP_FORCE_DEV_KERNARG=1 python "$R/tools/bench_gather.py" --batches 1,4,8,16,32,64,128,256 --tight > "$O/gather_sweep_device_kernargs.txt" 2>&1
+"$R/tools/build/gather_lab" 16 200 4 > "$O/gather_lab_B16.txt" 2>&1 || true
+python "$R/tools/profile_step.py" > "$O/profile_step.txt" 2>&1
+python "$R/tools/profile_train.py" 2>&1 | head -8 > "$O/profile_train.txt"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/km -o km -- \
   python "$R/tools/bench_kernels.py" > /dev/null 2>&1
 cp /tmp/km/km_kernel_trace.csv "$O/kernels_micro_trace.csv" 2>/dev/null || true
