@@ -22,11 +22,14 @@ import time
 
 # Kernel arguments in host memory instead of device memory (a HIP runtime
 # setting, read when HIP starts): every launch is ~1.6 us cheaper for the host
-# (4.6 -> 3.0 us on MI355X), and the step is launch-bound.  Waves then read
+# (4.6 -> 3.0 us on MI355X), and the PPO step is launch-bound.  Waves then read
 # their arguments across PCIe, which is why the big movers get a device copy
-# of their argument block (abi.cpp run_move).  Set HIP_FORCE_DEV_KERNARG=1 for
-# the runtime's default placement; DESIGN.md 4 has both sets of numbers.
-os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
+# of their argument block (abi.cpp run_move).  The Dreamer workload is bound by
+# its 144 MB gathers and 84 MB write-backs, not by launches, and keeps the
+# runtime's default.  HIP_FORCE_DEV_KERNARG=1/0 in the environment overrides;
+# DESIGN.md 4 has both sets of numbers.
+if not any('dreamer' in arg for arg in sys.argv[1:]):
+  os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
 
 import numpy as np
 import torch

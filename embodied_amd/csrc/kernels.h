@@ -35,6 +35,9 @@ struct MovePlan {
   const int32_t* rows_host = nullptr;
   const int32_t* spans_host = nullptr;
   int32_t n_seq = 0;
+  // The process keeps kernel arguments in host memory (HIP_FORCE_DEV_KERNARG=0):
+  // prefer the mover with the fewest argument readers.
+  bool args_in_host_memory = false;
   // Gather only: batch side cut into groups of `group` sequences whose starts
   // are `group_stride` bytes apart (every key.batch is then the key's offset
   // inside group 0); 0 = dense.

@@ -583,7 +583,12 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
     for (int k = 0; k < plan.n_keys; ++k)
       if (!((plan.mask_bits >> k) & 1u) && k != plan.inline_key && pick_unit(plan.key[k]) == 0)
         wide_bytes += plan.key[k].rowbytes * static_cast<int64_t>(plan.n_rows);
-    span_path = wide_bytes > 0 && wide_bytes <= static_cast<int64_t>(sv.max_mb) * 1000000;
+    // With kernel arguments in host memory the flat mover's thousands of
+    // workgroups each fetch their plan through a pointer (Dreamer-sized sample,
+    // 3 wide keys, 144 MB: 37 us flat-indirect against 29 us through the span
+    // mover's 512 workgroups), so there the span mover takes every size.
+    span_path = wide_bytes > 0 && (plan.args_in_host_memory ||
+                                   wide_bytes <= static_cast<int64_t>(sv.max_mb) * 1000000);
   }
   const int unroll = span_path ? sv.unroll : variant.unroll;
   const int threads = span_path ? sv.threads : variant.threads;
