@@ -65,6 +65,9 @@ def parse():
   p.add_argument('--sustained-seconds', type=float, default=10.0,
                  help='after the headline region: the same loop for this long (SURVEY 8d asks for '
                       'wall-clock rates over >= 10 s windows); reported as `sustained`, 0 = skip')
+  p.add_argument('--no-context', action='store_true',
+                 help='skip the batches-per-launch sweep and the plain-copy reference after the '
+                      'timed regions (counter passes: only the workload\'s own launches)')
   p.add_argument('--prewarm-train-steps', type=int, default=200,
                  help='train steps run after the fill and before --warmup, so that a short '
                       '--warmup still times a warm train path')
@@ -421,7 +424,8 @@ def main():
   # one batch of B=16 per launch is the faithful headline), and a plain
   # device-to-device copy of one batch's bytes out of the same pool — what a
   # kernel with no gather structure at all achieves on this box, read cold.
-  if roofline and rank == 0 and world == 1 and args.consec == 1 and not args.host_envs:
+  if (roofline and rank == 0 and world == 1 and args.consec == 1 and not args.host_envs
+      and not args.no_context):
     try:
       sweep = {}
       for per_launch in (1, 8, 64):
