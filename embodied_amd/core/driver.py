@@ -98,6 +98,8 @@ class Driver:
     self.acts = None
     self.carry = None
     self._slab = {}
+    self._obs_names, self._obs_has_logs = None, False
+    self._uploaded, self._upload_pending = None, False
     self._workers = np.arange(self.length, dtype=np.int64)
     self._workers.setflags(write=False)     # lets Replay.add_batch keep its converted copy
     self.reset()
@@ -227,6 +229,7 @@ class Driver:
     assert all(len(x) == self.length for x in acts.values())
     host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
     assert all(isinstance(v, np.ndarray) for v in host.values())
+    self._wait_uploads()        # env results overwrite the slab the last upload read
     if self.parallel and self._fast:
       results = self._step_workers(host)
     else:
@@ -264,8 +267,13 @@ class Driver:
     the mask runs unconditionally (a no-op where nothing ended) and episodes
     are counted only when the caller stops on them."""
     obs = self.batch_env.step(self.acts)
-    logs = {k: v for k, v in obs.items() if k.startswith('log/')}
-    if logs:
+    names = tuple(obs)
+    if names != self._obs_names:          # which keys are 'log/*' is looked at once per key set
+      self._obs_names = names
+      self._obs_has_logs = any(k.startswith('log/') for k in names)
+    logs = {}
+    if self._obs_has_logs:
+      logs = {k: v for k, v in obs.items() if k.startswith('log/')}
       obs = {k: v for k, v in obs.items() if not k.startswith('log/')}
     self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
     assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
@@ -368,9 +376,18 @@ class Driver:
         self._host_flags[k] = view.copy()
       out[k] = pinned.to(self.device, non_blocking=True)
     # The slab is overwritten by the next step's env results: uploads must be
-    # done by then.  One event wait per step, not per key.
-    torch.cuda.current_stream(self.device).synchronize()
+    # done by then.  One event per step, waited for right before the slab is
+    # written again (`_wait_uploads`), so the policy call overlaps the copies.
+    if self._uploaded is None:
+      self._uploaded = torch.cuda.Event()
+    self._uploaded.record()
+    self._upload_pending = True
     return out
+
+  def _wait_uploads(self):
+    if self._upload_pending:
+      self._uploaded.synchronize()
+      self._upload_pending = False
 
   def _receive(self, pipe):
     """The payload of a worker's ('result', payload) reply.  Anything else — an

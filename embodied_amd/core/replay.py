@@ -134,6 +134,8 @@ class Replay:
     self._out_ring = {}
     self._templates = {}
     self._mask_plans = {}
+    self._add_plan = None
+    self._stage_busy, self._stage_pending = None, False
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
     if directory and self._owners == 1 and pathlib.Path(directory).is_dir():
       self._reserve_directory_uids(directory)
@@ -288,6 +290,9 @@ class Replay:
           self._grow()
       self._reraise()
       slot = self._staged
+      if self._stage_pending:                 # the last flush still reads the pinned rows
+        self._stage_busy.synchronize()
+        self._stage_pending = False
       for key, data in rows:
         key.stage_np[slot] = data
       self._keys[-1].stage_np[slot] = self._one_sid[0]
@@ -309,8 +314,12 @@ class Replay:
     rows = self._stage_dst[:n].copy()
     api.emb_replay_scatter_rows(
         self._handle, _lib.ptr(rows), n, len(self._keys), ids, ptrs, self._stream())
-    # The pinned rows are reused by the next add: wait for the H2D copies.
-    torch.cuda.current_stream(self.device).synchronize()
+    # The pinned rows are reused by the next staged add: that add waits for the
+    # H2D copies (an event, not a stream drain — the host goes on stepping envs).
+    if self._stage_busy is None:
+      self._stage_busy = torch.cuda.Event()
+    self._stage_busy.record()
+    self._stage_pending = True
     self._staged = 0
 
   def add_batch(self, steps, workers, mask=None):
@@ -340,30 +349,26 @@ class Replay:
         self._flush()
       keyid, keys, device = self._keyid, self._keys, self.device
       ptrs = self._batch_ptrs
-      keep, seen, vals = [], 0, {}
-      for name, value in steps.items():
-        i = keyid.get(name)
-        if i is None:
-          if name.startswith('log/'):
-            continue
-          raise KeyError(f'replay step key {name!r} was not in the first step')
-        key = keys[i]
-        # Usual case first: a contiguous tensor of the key's dtype on this device.
-        if not (type(value) is torch.Tensor and value.dtype is key.dtype
-                and value.device == device and value.is_contiguous()):
+      # Per (key order, n): which pool column each dict position feeds and what a
+      # ready-to-use value looks like there (checked per call, looked up once).
+      order = tuple(steps)
+      plan = self._add_plan
+      if plan is None or plan[0] != order or plan[1] != n:
+        plan = self._add_plan = (order, n, self._plan_columns(order, n))
+      keep, index, Tensor = [], device.index, torch.Tensor
+      for value, (i, dtype, shape, name) in zip(steps.values(), plan[2]):
+        if i < 0:
+          continue                                    # 'log/*': not stored
+        # Usual case: a contiguous tensor of the key's dtype and shape on this GPU.
+        if not (type(value) is Tensor and value.dtype is dtype and value.shape == shape
+                and value.is_contiguous() and value.get_device() == index):
           if not torch.is_tensor(value):
             value = torch.from_numpy(np.ascontiguousarray(value))
-          if value.shape[1:] != key.shape or value.shape[0] != n:
-            raise ValueError((name, tuple(value.shape), (n, *key.shape)))
-          value = value.to(device, key.dtype, non_blocking=True).contiguous()
+          if tuple(value.shape) != shape:
+            raise ValueError((name, tuple(value.shape), shape))
+          value = value.to(device, dtype, non_blocking=True).contiguous()
           keep.append(value)
-        elif value.shape[1:] != key.shape or value.shape[0] != n:
-          raise ValueError((name, tuple(value.shape), (n, *key.shape)))
         ptrs[i] = value.data_ptr()
-        vals[name] = value
-        seen += 1
-      if seen + 1 != len(keys):
-        raise KeyError(f'replay step keys {sorted(steps)} differ from the first step')
       masked = None
       if mask is not None:
         names, flags = mask
@@ -375,7 +380,8 @@ class Replay:
         ids, codes, outs = plan
         masked = {}
         for j, name in enumerate(names):
-          out = masked[name] = torch.empty_like(vals[name])
+          key = keys[ids[j]]
+          out = masked[name] = _lib.empty((n, *key.shape), key.dtype, device)
           outs[j] = out.data_ptr()
         if flags.device != device or not flags.is_contiguous():
           flags = flags.to(device).contiguous()
@@ -393,6 +399,25 @@ class Replay:
           self._grow(2 * n)
       self._reraise()
     return masked
+
+  def _plan_columns(self, order, n):
+    """For every position of a step dict with keys `order`: (pool column or -1,
+    dtype, (n, *shape), name).  Raises like the per-step checks did when the key
+    set differs from the first step's."""
+    columns, seen = [], 0
+    for name in order:
+      i = self._keyid.get(name)
+      if i is None:
+        if name.startswith('log/'):
+          columns.append((-1, None, None, name))
+          continue
+        raise KeyError(f'replay step key {name!r} was not in the first step')
+      key = self._keys[i]
+      columns.append((i, key.dtype, (n, *key.shape), name))
+      seen += 1
+    if seen + 1 != len(self._keys):
+      raise KeyError(f'replay step keys {sorted(order)} differ from the first step')
+    return columns
 
   # ----------------------------------------------------------------- sample --
 

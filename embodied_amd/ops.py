@@ -33,8 +33,8 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
   shape = (n, c, h, w) if first else (n, h, w, c)
   if out is None:
     out = _lib.empty(shape, dtype, frames.device)
-  elif (out.shape != shape or out.dtype != dtype or out.device != frames.device
-        or not out.is_contiguous()):
+  elif not (out.shape == shape and out.dtype is dtype and out.is_contiguous()
+            and out.get_device() == frames.get_device()):
     raise ValueError(f'obs_stack out= must be contiguous {shape} {dtype} on {frames.device}')
   if out.numel() == 0:
     return out                       # no envs / empty frames: nothing to launch
