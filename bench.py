@@ -276,15 +276,11 @@ def main():
         work, received, views = D.exchange_dp_slices(flat, layout)
         pending.append(D.Done(lambda w=work: w))
         state_keep[:] = [flat, received]
-        late, slice_state['views'] = slice_state.get('views'), views
-        source = late if late is not None else batch
-        dense = lambda x: x.reshape(rows, x.shape[-1])
-        adv, tar = emb.scans.gae(
-            dense(source['reward']), value, dense(source['is_last']),
-            dense(source['is_terminal']), hor=200, lam=0.8)
+        late, slice_state['recv'] = slice_state.get('recv'), (received, layout)
+        source, source_info = late if late is not None else (flat, layout)
+        adv, tar = D.gae_packed(source, source_info, value, hor=200, lam=0.8)
       else:
-        adv, tar = emb.scans.gae(
-            batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
+        adv, tar = D.gae_packed(flat, layout, value, hor=200, lam=0.8)
         if args.exchange == 'trajectories' or (args.exchange == 'online' and layout.online.any()):
           send = flat
         elif args.exchange == 'returns':

@@ -156,6 +156,7 @@ SIGNATURES = {
     'emb_window': [p, p, i64, i64, i64, i64, i64, p],
     'emb_window_keys': [i32, p, p, p, i64, i64, i64, i64, p],
     'emb_scan_gae': [p, p, p, p, i64, i64, f32, f32, p, p, p],
+    'emb_scan_gae_grouped': [p, p, p, p, i64, i64, f32, f32, p, p, i64, i64, p],
     'emb_scan_lambda': [p, p, p, p, i64, i64, f32, f32, p, p],
     'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],
     'emb_abstract_traj': [p, p, i64, i64, i32, p, p, p],
@@ -247,6 +248,7 @@ class _FastApi:
       'emb_replay_sample': 'ints', 'emb_replay_sample_grouped': 'ints', 'emb_replay_update': 'ints',
       'emb_replay_gather_rows': 'ints', 'emb_replay_scatter_rows': 'ints',
       'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',
+      'emb_scan_gae_grouped': 'scan',
   }
 
   def __init__(self, module):

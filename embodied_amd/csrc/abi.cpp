@@ -1164,6 +1164,19 @@ int32_t emb_scan_gae(const void* rew, const void* val, const void* last, const v
   });
 }
 
+int32_t emb_scan_gae_grouped(const void* rew, const void* val, const void* last, const void* term,
+                             int64_t B, int64_t T, float live_scale, float lam, void* adv,
+                             void* tar, int64_t group, int64_t group_stride, void* stream) {
+  return guarded([&] {
+    need(rew && val && last && term && adv && tar && B >= 0 && T >= 1 && group >= 0 &&
+             group_stride >= 0 && group_stride % 4 == 0, "scan_gae_grouped: bad arguments");
+    HIP_OK(emb::launch_gae(static_cast<const float*>(rew), static_cast<const float*>(val),
+                           static_cast<const uint8_t*>(last), static_cast<const uint8_t*>(term), B, T,
+                           live_scale, lam, static_cast<float*>(adv), static_cast<float*>(tar),
+                           static_cast<hipStream_t>(stream), group, group_stride));
+  });
+}
+
 int32_t emb_scan_lambda(const void* last, const void* term, const void* rew, const void* boot,
                         int64_t B, int64_t T, float disc, float lam, void* ret, void* stream) {
   return guarded([&] {

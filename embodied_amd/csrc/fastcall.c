@@ -129,13 +129,14 @@ static PyObject* call_obs_stack(PyObject* self, PyObject* const* args, Py_ssize_
 }
 
 /* emb_scan_gae(rew, val, last, term, B, T, live_scale, lam, adv, tar, stream)      11
- * emb_scan_lambda(last, term, rew, boot, B, T, disc, lam, ret, stream)             10 */
+ * emb_scan_lambda(last, term, rew, boot, B, T, disc, lam, ret, stream)             10
+ * emb_scan_gae_grouped(rew, val, last, term, B, T, live, lam, adv, tar, group, group_stride, stream)  13 */
 static PyObject* call_scan(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
-  if (nargs != 11 && nargs != 12) {
-    PyErr_SetString(PyExc_TypeError, "fastcall.scan(addr, 10 or 11 arguments)");
+  if (nargs != 11 && nargs != 12 && nargs != 14) {
+    PyErr_SetString(PyExc_TypeError, "fastcall.scan(addr, 10, 11 or 13 arguments)");
     return NULL;
   }
-  u64 a[12] = {0};
+  u64 a[14] = {0};
   float f[2];
   for (Py_ssize_t i = 0; i < nargs; ++i) {
     if (i == 7 || i == 8) {
@@ -147,7 +148,10 @@ static PyObject* call_scan(PyObject* self, PyObject* const* args, Py_ssize_t nar
   void* fn = (void*)(uintptr_t)a[0];
   int32_t status;
   Py_BEGIN_ALLOW_THREADS
-  if (nargs == 12)
+  if (nargs == 14)   /* emb_scan_gae_grouped: ..., adv, tar, group, group_stride, stream */
+    status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, float, float, u64, u64, u64, u64, u64))fn)(
+        a[1], a[2], a[3], a[4], a[5], a[6], f[0], f[1], a[9], a[10], a[11], a[12], a[13]);
+  else if (nargs == 12)
     status = ((int32_t(*)(u64, u64, u64, u64, u64, u64, float, float, u64, u64, u64))fn)(
         a[1], a[2], a[3], a[4], a[5], a[6], f[0], f[1], a[9], a[10], a[11]);
   else

@@ -113,9 +113,12 @@ hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_e
                             int dtype, const uint8_t* is_last, hipStream_t stream);
 
 // Return scans (float32).  Batch-major (B, T) unless stated.
+// group > 0: rew / last / term are keys of a grouped packed batch (row b starts
+// (b / group) * group_stride_bytes + (b % group) * T * itemsize into its key).
 hipError_t launch_gae(const float* rew, const float* val, const uint8_t* last,
                       const uint8_t* term, int64_t B, int64_t T, float live_scale,
-                      float lam, float* adv, float* tar, hipStream_t stream);
+                      float lam, float* adv, float* tar, hipStream_t stream,
+                      int64_t group = 0, int64_t group_stride_bytes = 0);
 hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term,
                                 const float* rew, const float* boot, int64_t B,
                                 int64_t T, float disc, float lam, float* ret,

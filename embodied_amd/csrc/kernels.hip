@@ -949,14 +949,25 @@ __device__ __forceinline__ void affine_suffix(float& a, float& b, int sl) {
 struct GaeOp {   // ppo/agent.py:188-201
   const float* rew; const float* val; const uint8_t* last; const uint8_t* term;
   int64_t T; float live_scale, lam; float* adv; float* tar;
+  // rew / last / term may come straight out of a grouped packed batch
+  // (distributed.py): row b then starts (b / group) * gs + (b % group) * T
+  // elements into its key (gs_rew in floats, gs_flag in bytes); 0 = dense rows.
+  // `val` (the critic's output) and the results are always dense.
+  int64_t group, gs_rew, gs_flag;
   __device__ float seed(int64_t) const { return 0.f; }
   __device__ void coef(int64_t b, int64_t t, float& a, float& bc, float& keep) const {
     const int64_t i = b * T + t;
-    const bool tm = term[i + 1] != 0;
+    int64_t ir = i, il = i;
+    if (group) {
+      const int64_t g = b / group, j = b - g * group;
+      ir = g * gs_rew + j * T + t;
+      il = g * gs_flag + j * T + t;
+    }
+    const bool tm = term[il + 1] != 0;
     const float live = tm ? 0.f : live_scale;
-    const float cont = (tm || last[i + 1] != 0) ? 0.f : lam;
+    const float cont = (tm || last[il + 1] != 0) ? 0.f : lam;
     keep = val[i];
-    a = rew[i + 1] + live * val[i + 1] - keep;
+    a = rew[ir + 1] + live * val[i + 1] - keep;
     bc = live * cont;
   }
   __device__ void store(int64_t b, int64_t t, float y, float keep) const {
@@ -1197,9 +1208,12 @@ hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_e
 
 hipError_t launch_gae(const float* rew, const float* val, const uint8_t* last,
                       const uint8_t* term, int64_t B, int64_t T, float live_scale, float lam,
-                      float* adv, float* tar, hipStream_t stream) {
+                      float* adv, float* tar, hipStream_t stream, int64_t group,
+                      int64_t group_stride_bytes) {
   if (B <= 0 || T < 2) return hipSuccess;
-  return launch_scan(GaeOp{rew, val, last, term, T, live_scale, lam, adv, tar}, B, T - 1, stream);
+  if (group < 0 || (group && group_stride_bytes % 4 != 0)) return hipErrorInvalidValue;
+  return launch_scan(GaeOp{rew, val, last, term, T, live_scale, lam, adv, tar,
+                           group, group_stride_bytes / 4, group_stride_bytes}, B, T - 1, stream);
 }
 
 hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term, const float* rew,

@@ -186,6 +186,28 @@ def sample_packed(replay, batch, mode='train', groups=1):
   return flat, views, SampleInfo(layout, online.view(np.bool_))
 
 
+def gae_packed(flat, info, value, hor=200, lam=0.8):
+  """`scans.gae` on a packed batch (dense or grouped — sampled locally or
+  delivered by `exchange_dp_slices`) without materialising views or dense copies:
+  the scan kernel reads `reward`, `is_last`, `is_terminal` in place.  `value` is
+  the critic's dense (B, T) float32 output.  Returns adv, tar (B, T-1)."""
+  from . import _lib, scans
+  layout = info.layout
+  groups = getattr(layout, 'groups', 1)
+  B, T = layout.batch * groups, layout.length
+  assert value.shape == (B, T) and value.dtype == torch.float32 and value.is_contiguous()
+  base = flat.data_ptr()
+  index = layout.index
+  both = _lib.empty((2, B, T - 1), torch.float32, flat.device)
+  adv, tar = both.unbind(0)
+  _lib.fast.emb_scan_gae_grouped(
+      base + index['reward'][3], value.data_ptr(), base + index['is_last'][3],
+      base + index['is_terminal'][3], B, T, scans._round32(1 - 1 / hor), scans._round32(lam),
+      adv.data_ptr(), tar.data_ptr(), layout.batch if groups > 1 else 0,
+      layout.nbytes if groups > 1 else 0, _lib.raw_stream(flat.device))
+  return adv, tar
+
+
 def _default_pg():
   from torch.distributed import distributed_c10d
   return distributed_c10d._get_default_group()

@@ -289,6 +289,14 @@ int32_t emb_window_keys(int32_t n_keys, const void* const* src, void* const* dst
 int32_t emb_scan_gae(const void* rew, const void* val, const void* last, const void* term,
                      int64_t B, int64_t T, float live_scale, float lam, void* adv, void* tar,
                      void* stream);
+/* The same with rew / last / term read straight out of a grouped packed batch
+ * (emb_replay_sample_grouped, or the buffer a DP-slice all-to-all delivered):
+ * row b of a key starts (b / group) * group_stride + (b % group) * T * itemsize
+ * bytes into it; val, adv and tar are dense.  group = 0: identical to
+ * emb_scan_gae.                                                               */
+int32_t emb_scan_gae_grouped(const void* rew, const void* val, const void* last, const void* term,
+                             int64_t B, int64_t T, float live_scale, float lam, void* adv,
+                             void* tar, int64_t group, int64_t group_stride, void* stream);
 /* DreamerV3 lambda-return (dreamerv3/agent.py:482-490) -> ret (B,T-1).       */
 int32_t emb_scan_lambda(const void* last, const void* term, const void* rew, const void* boot,
                         int64_t B, int64_t T, float disc, float lam, void* ret, void* stream);

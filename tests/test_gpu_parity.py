@@ -951,3 +951,14 @@ def test_grouped_packed_sample_equals_dense_sample(emb, chunksize, L, batch, gro
   work, out, got = D.exchange_dp_slices(flat, info)     # world 1: a copy
   work.wait()
   assert torch.equal(out, flat)
+  # GAE straight from the packed buffers (dense and grouped) == GAE on dense tensors
+  value = torch.randn(batch, L, device='cuda')
+  want_adv, want_tar = emb.scans.gae(want['reward'], value, want['is_last'], want['is_terminal'])
+  adv, tar = D.gae_packed(flat, info, value)
+  assert torch.equal(adv, want_adv) and torch.equal(tar, want_tar)
+  dense_flat, _, dense_info = D.sample_packed(a, batch)
+  dense_want = b.sample(batch)
+  adv, tar = D.gae_packed(dense_flat, dense_info, value)
+  ref_adv, ref_tar = emb.scans.gae(
+      dense_want['reward'], value, dense_want['is_last'], dense_want['is_terminal'])
+  assert torch.equal(adv, ref_adv) and torch.equal(tar, ref_tar)
