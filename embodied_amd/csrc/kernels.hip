@@ -41,8 +41,26 @@ __device__ __forceinline__ void store16(u32x4* p, u32x4 v) {
 
 constexpr int kThreads = 256;
 
+// What a persistent span-mover workgroup needs before its first load, in one
+// contiguous 160-byte block at the very start of the arguments: a wave copies
+// it into registers with three independent scalar loads (one memory latency)
+// instead of walking four or five dependent ones through the full plan — which
+// matters most when the plan is read through a pointer (host-resident kernel
+// arguments: the device copy starts out cold in every XCD's L2).
+constexpr int kSpanKeys = 4;     // wide keys per span launch (more: flat mover)
+struct alignas(16) SpanHead {
+  int32_t wide_workers, n_wide, seq_len, group;
+  int64_t group_stride;
+  uint32_t ntiles, pad_;
+  uint32_t tile0[kSpanKeys];          // first tile of wide key k; 0xFFFFFFFF beyond n_wide
+  uint32_t tiles_per_seq[kSpanKeys];
+  KeyDesc key[kSpanKeys];
+};
+static_assert(sizeof(SpanHead) == 160, "SpanHead is loaded as 40 dwords");
+
 // Per-launch plan in kernel-argument memory (< 4 KiB).
 struct alignas(16) MoveArgs {
+  SpanHead head;
   KeyDesc key[kMaxKeys];
   int32_t first_block[kMaxKeys + 1];
   int32_t unit[kMaxKeys];           // 0: 16-byte flat path; else bytes per lane
@@ -56,10 +74,9 @@ struct alignas(16) MoveArgs {
   int8_t mask_dtype[kMaxKeys];
   uint8_t* mask_out[kMaxKeys];
   const uint8_t* mask_flags;
-  // Span mode (rows_mode 2): the wide keys are moved by `wide_workers`
-  // persistent workgroups walking `wtile0[n_wide]` tiles (see move_wide_spans);
+  // Span mode (rows_mode 2): the wide keys are moved by `head.wide_workers`
+  // persistent workgroups walking `head.ntiles` tiles (see move_wide_spans);
   // those keys own no virtual blocks.
-  int32_t wide_workers, n_wide;
   // Gather only: the batch side in groups of `group` sequences, `group_stride`
   // bytes apart (0 = one dense (n_rows, rowbytes) array per key).  Sequence s of
   // key k starts at key.batch + (s / group) * group_stride + (s % group) * L *
@@ -67,9 +84,6 @@ struct alignas(16) MoveArgs {
   // (distributed.py, DP-slice exchange).
   int32_t group;
   int64_t group_stride;
-  uint32_t wtile0[kMaxKeys + 1];
-  uint32_t tiles_per_seq[kMaxKeys];
-  uint8_t wide_key[kMaxKeys];
   uint32_t inline_words[kInlineWords];
 };
 static_assert(sizeof(MoveArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -226,22 +240,22 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
 // plain contiguous copy of the same bytes and 13.8 us for the flat
 // one-tile-per-workgroup mover above.
 template <bool kGather, int U, int NT>
-__device__ __forceinline__ void move_wide_spans(const MoveArgs& a) {
+__device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const SpanHead& h) {
   const uint32_t tile = blockDim.x * U;
-  const uint32_t L = static_cast<uint32_t>(a.seq_len);
-  const uint32_t ntiles = a.wtile0[a.n_wide];
-  const uint32_t stride = static_cast<uint32_t>(a.wide_workers);
+  const uint32_t L = static_cast<uint32_t>(h.seq_len);
+  const uint32_t ntiles = h.ntiles;
+  const uint32_t stride = static_cast<uint32_t>(h.wide_workers);
   struct Where {
     const u32x4* p0; const u32x4* p1;   // pool runs, both indexed by the unit number
     const u32x4* b;                     // batch side of the sequence
     uint32_t split, total, u0;
   };
   auto locate = [&](uint32_t ti) {
-    int k = 0;
-    while (k + 1 < a.n_wide && ti >= a.wtile0[k + 1]) ++k;
-    const KeyDesc& key = a.key[a.wide_key[k]];
-    const uint32_t local = ti - a.wtile0[k];
-    const uint32_t tps = a.tiles_per_seq[k];
+    // Which wide key: tile0[] beyond n_wide is 0xFFFFFFFF.
+    const int k = (ti >= h.tile0[1]) + (ti >= h.tile0[2]) + (ti >= h.tile0[3]);
+    const KeyDesc key = h.key[k];
+    const uint32_t tps = h.tiles_per_seq[k];
+    const uint32_t local = ti - h.tile0[k];
     const uint32_t seq = local / tps, piece = local - seq * tps;
     const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
     const uint32_t row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
@@ -252,11 +266,11 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a) {
     w.u0 = piece * tile + threadIdx.x;
     w.p0 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row0) * upr;
     w.p1 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row1) * upr - w.split;
-    if (a.group == 0) {
+    if (h.group == 0) {
       w.b = reinterpret_cast<const u32x4*>(key.batch) + static_cast<uint64_t>(seq) * w.total;
     } else {
-      const uint32_t g = static_cast<uint32_t>(a.group), grp = seq / g, j = seq - grp * g;
-      w.b = reinterpret_cast<const u32x4*>(key.batch + static_cast<int64_t>(grp) * a.group_stride) +
+      const uint32_t g = static_cast<uint32_t>(h.group), grp = seq / g, j = seq - grp * g;
+      w.b = reinterpret_cast<const u32x4*>(key.batch + static_cast<int64_t>(grp) * h.group_stride) +
             static_cast<uint64_t>(j) * w.total;
     }
     return w;
@@ -449,25 +463,36 @@ __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* 
 
 // Span-mode launch: the first `wide_workers` workgroups are the persistent wide
 // movers, the rest are the virtual blocks of the narrow keys.
+// The 160-byte head goes from the argument block to LDS with one 16-byte load
+// per lane of the first ten lanes — a single memory latency however the
+// compiler would have scheduled the individual field reads.
+__device__ __forceinline__ void stage_head(const MoveArgs* a, SpanHead* dst) {
+  if (threadIdx.x < sizeof(SpanHead) / 16)
+    reinterpret_cast<u32x4*>(dst)[threadIdx.x] =
+        reinterpret_cast<const u32x4*>(&a->head)[threadIdx.x];
+  __syncthreads();
+}
+
 template <bool kGather, int U, int NT>
-__global__ __launch_bounds__(1024) void span_move_kernel(const MoveArgs a) {
-  if (static_cast<int>(blockIdx.x) < a.wide_workers) {
-    move_wide_spans<kGather, U, NT>(a);
+__device__ __forceinline__ void span_move_body(const MoveArgs& a) {
+  __shared__ SpanHead head;
+  stage_head(&a, &head);
+  if (static_cast<int>(blockIdx.x) < head.wide_workers) {
+    move_wide_spans<kGather, U, NT>(a, head);
     return;
   }
-  const int block = static_cast<int>(blockIdx.x) - a.wide_workers;
+  const int block = static_cast<int>(blockIdx.x) - head.wide_workers;
   if (kGather) gather_block<2, NT>(a, block);
   else scatter_block<2, NT>(a, block);
 }
+
+template <bool kGather, int U, int NT>
+__global__ __launch_bounds__(1024) void span_move_kernel(const MoveArgs a) {
+  span_move_body<kGather, U, NT>(a);
+}
 template <bool kGather, int U, int NT>
 __global__ __launch_bounds__(1024) void span_move_kernel_indirect(const MoveArgs* __restrict__ a) {
-  if (static_cast<int>(blockIdx.x) < a->wide_workers) {
-    move_wide_spans<kGather, U, NT>(*a);
-    return;
-  }
-  const int block = static_cast<int>(blockIdx.x) - a->wide_workers;
-  if (kGather) gather_block<2, NT>(*a, block);
-  else scatter_block<2, NT>(*a, block);
+  span_move_body<kGather, U, NT>(*a);
 }
 
 // Host-resident kernel arguments (HIP_FORCE_DEV_KERNARG=0): one workgroup
@@ -580,24 +605,30 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
   bool span_path = false;
   if (use_inline && plan.spans_host && sv.per_cu > 0 && plan.seq_len >= 1) {
     int64_t wide_bytes = 0;
+    int wide_keys = 0;
     for (int k = 0; k < plan.n_keys; ++k)
-      if (!((plan.mask_bits >> k) & 1u) && k != plan.inline_key && pick_unit(plan.key[k]) == 0)
+      if (!((plan.mask_bits >> k) & 1u) && k != plan.inline_key && pick_unit(plan.key[k]) == 0) {
         wide_bytes += plan.key[k].rowbytes * static_cast<int64_t>(plan.n_rows);
+        ++wide_keys;
+      }
     // With kernel arguments in host memory the flat mover's thousands of
     // workgroups each fetch their plan through a pointer (Dreamer-sized sample,
     // 3 wide keys, 144 MB: 37 us flat-indirect against 29 us through the span
     // mover's 512 workgroups), so there the span mover takes every size.
-    span_path = wide_bytes > 0 && (plan.args_in_host_memory ||
-                                   wide_bytes <= static_cast<int64_t>(sv.max_mb) * 1000000);
+    span_path = wide_bytes > 0 && wide_keys <= kSpanKeys &&
+                (plan.args_in_host_memory || wide_bytes <= static_cast<int64_t>(sv.max_mb) * 1000000);
   }
   const int unroll = span_path ? sv.unroll : variant.unroll;
   const int threads = span_path ? sv.threads : variant.threads;
   out->span = span_path;
   MoveArgs& a = *reinterpret_cast<MoveArgs*>(out->args);
-  a.wide_workers = 0;
-  a.n_wide = 0;
+  SpanHead& h = a.head;
+  std::memset(&h, 0, sizeof(h));
+  for (int j = 0; j < kSpanKeys; ++j) h.tile0[j] = 0xFFFFFFFFu;
   a.group = plan.group > 0 ? plan.group : 0;
   a.group_stride = plan.group_stride;
+  h.group = a.group;
+  h.group_stride = a.group_stride;
   if (a.group && (plan.group_stride % 16 != 0 || plan.mask_bits || plan.inline_key >= 0))
     return hipErrorInvalidValue;       // gather-side layout only, 16-byte aligned groups
   a.n_keys = plan.n_keys;
@@ -652,12 +683,13 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
       // tiles of threads * unroll units per sequence; no virtual blocks
       const int64_t per_seq = static_cast<int64_t>(a.seq_len) * (plan.key[k].rowbytes >> 4);
       const int64_t tps = (per_seq + threads * unroll - 1) / (threads * unroll);
-      const int64_t first = a.n_wide ? a.wtile0[a.n_wide] : 0;
+      const int64_t first = h.ntiles;
       if (per_seq > UINT32_MAX / 2 || first + tps * plan.n_seq > UINT32_MAX / 2) return hipErrorInvalidValue;
-      a.wide_key[a.n_wide] = static_cast<uint8_t>(k);
-      a.tiles_per_seq[a.n_wide] = static_cast<uint32_t>(tps);
-      a.wtile0[a.n_wide] = static_cast<uint32_t>(first);
-      a.wtile0[++a.n_wide] = static_cast<uint32_t>(first + tps * plan.n_seq);
+      h.key[h.n_wide] = plan.key[k];
+      h.tiles_per_seq[h.n_wide] = static_cast<uint32_t>(tps);
+      h.tile0[h.n_wide] = static_cast<uint32_t>(first);
+      h.ntiles = static_cast<uint32_t>(first + tps * plan.n_seq);
+      ++h.n_wide;
     } else if (a.unit[k] == 0) {
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes >> 4);
       if (units > UINT32_MAX / 2) return hipErrorInvalidValue;
@@ -671,9 +703,10 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
   a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
   out->blocks = static_cast<uint32_t>(blocks);
   if (span_path) {
-    a.wide_workers = static_cast<int32_t>(std::min<int64_t>(a.wtile0[a.n_wide], int64_t(kCUs) * sv.per_cu));
-    if (blocks + a.wide_workers > INT32_MAX) return hipErrorInvalidValue;
-    out->blocks = static_cast<uint32_t>(blocks + a.wide_workers);
+    h.wide_workers = static_cast<int32_t>(std::min<int64_t>(h.ntiles, int64_t(kCUs) * sv.per_cu));
+    h.seq_len = a.seq_len;
+    if (blocks + h.wide_workers > INT32_MAX) return hipErrorInvalidValue;
+    out->blocks = static_cast<uint32_t>(blocks + h.wide_workers);
   } else if (variant.persist > 0 && blocks > 256ll * variant.persist) {
     out->blocks = 256u * variant.persist;
   }
