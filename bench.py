@@ -65,6 +65,9 @@ def parse():
   p.add_argument('--sustained-seconds', type=float, default=10.0,
                  help='after the headline region: the same loop for this long (SURVEY 8d asks for '
                       'wall-clock rates over >= 10 s windows); reported as `sustained`, 0 = skip')
+  p.add_argument('--stamp-every', type=int, default=4,
+                 help='dispatch stamps on one sample gather in this many (a stamped launch costs '
+                      'the host a few microseconds more than a plain one; 1 = every gather)')
   p.add_argument('--no-context', action='store_true',
                  help='skip the batches-per-launch sweep and the plain-copy reference after the '
                       'timed regions (counter passes: only the workload\'s own launches)')
@@ -324,7 +327,11 @@ def main():
   # EMB_BENCH_NO_TIMER=1: no dispatch stamps (roofline is then null) -- for a
   # rocprofv3 run that sees the gather without the timed-dispatch perturbation.
   # Switched on before the warm-up so that the stamps' events exist by then.
-  replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1')
+  # One gather in --stamp-every carries stamps, unless the timed region is too
+  # short for that to leave a usable sample (the driver's --steps 20 has four).
+  expected = args.steps * args.envs * args.train_ratio / (B * T)
+  stamp_every = args.stamp_every if (expected >= 256 and args.consec == 1) else 1
+  replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1', every=stamp_every)
   # The fill runs no train step: warm the train path (allocator, online queue,
   # caches) whatever --warmup says, then the caller's warmup steps.
   for _ in range(args.prewarm_train_steps):
@@ -412,7 +419,7 @@ def main():
         'traffic_source': traffic_source,
         'read_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
         'bytes_per_launch': algo_bytes, 'avg_launch_us': round(avg_s * 1e6, 2),
-        'launches': launches,
+        'launches': launches, 'stamped_one_in': stamp_every,
     }
 
   # Outside the timed region, measured context (no credit): SURVEY 8d's
@@ -423,6 +430,7 @@ def main():
   if (roofline and rank == 0 and world == 1 and args.consec == 1 and not args.host_envs
       and not args.no_context):
     try:
+      replay.profile(True, every=1)
       sweep = {}
       for per_launch in (1, 8, 64):
         big = B * per_launch
@@ -538,13 +546,14 @@ def pmc_traffic(algo_bytes):
 def cpu_baseline(args):
   """The numpy oracle of the same step on this host, single thread: serial
   Driver over 64 host synthetic envs + oracle Replay.add/sample + numpy GAE.
-  Bounded: ~args.cpu_seconds of work on a smaller buffer (capacity 20k)."""
+  Same replay capacity as the GPU leg (filled first, untimed), then
+  ~args.cpu_seconds of timed work."""
   from oracle import np_oracle
   from embodied_amd.envs import synthetic
   L, B, T = args.length + args.context, args.batch, args.length
   envs = [synthetic.HostSyntheticEnv(e) for e in range(args.envs)]
   drv = np_oracle.Driver(envs)
-  rep = np_oracle.Replay(L, 20_000, 1024, online=True, seed=0)
+  rep = np_oracle.Replay(L, args.capacity, 1024, online=True, seed=0)
   drv.on_step(rep.add)
   gen = np.random.default_rng(0)
   val = gen.standard_normal((B, L)).astype(np.float32)
@@ -556,8 +565,10 @@ def cpu_baseline(args):
 
   should_train = Ratio(args.train_ratio / (B * T))
   env_steps = train_steps = 0
-  for _ in range(L + 4):
+  fill_begin = time.perf_counter()
+  while len(rep) < args.capacity and time.perf_counter() - fill_begin < 60:
     drv.step(policy)
+  filled = len(rep)
   begin = time.perf_counter()
   while time.perf_counter() - begin < args.cpu_seconds:
     drv.step(policy)
@@ -572,7 +583,8 @@ def cpu_baseline(args):
       'kind': 'port',
       'train_steps_per_s': round(train_steps / took, 3),
       'sample': f'{env_steps} env steps / {train_steps} train steps in {took:.1f}s, '
-                'numpy oracle, capacity 20000, same envs/shapes/ratio',
+                f'numpy oracle, replay filled to {filled} of {args.capacity} items, '
+                'same envs/shapes/ratio',
       'host_cpus': os.cpu_count(),
   }
 

@@ -770,9 +770,10 @@ class Replay:
 
   # ------------------------------------------------------------- profiling --
 
-  def profile(self, enable=True):
-    """HIP-event timing of this replay's gather launches (bench roofline)."""
-    api.emb_replay_profile(self._handle, int(enable))
+  def profile(self, enable=True, every=1):
+    """HIP-event timing of this replay's gather launches (bench roofline);
+    `every=n` stamps one gather in n."""
+    api.emb_replay_profile(self._handle, int(every) if enable and every > 1 else int(bool(enable)))
 
   def profile_read(self, reset=True):
     launches, ms = C.c_int64(), C.c_double()

@@ -153,6 +153,12 @@ class LaunchTimer {
   }
   bool enabled = false;
   bool discard = false;   // stamps only, never read: a small ring of pairs reused in turn
+  // Stamp one launch in `every` (a stamped launch costs the host a few
+  // microseconds more than a plain one: sampling keeps the timed loop close to
+  // the un-instrumented one).
+  int every = 1;
+  uint64_t tick = 0;
+  bool due() { return enabled && (tick++ % static_cast<uint64_t>(every) == 0); }
   // Next (start, stop) pair for hipExtLaunchKernelGGL, or nulls when disabled.
   // Pairs come from a fixed pool created when stamping is switched on (event
   // creation is far too slow to happen inside a timed region); when the pool is
@@ -685,6 +691,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   // Processes that keep kernel arguments in host memory (HIP_FORCE_DEV_KERNARG=0,
   // cheaper launches) pay PCIe latency on every wave's argument reads: for big
   // moves hand the kernel a device copy of its arguments instead.
+  const bool stamp_this = gather && rep->timer.due();
   TableRing::Lease args_lease{-1, nullptr, nullptr};
   const void* device_args = nullptr;
   if (host_kernargs()) {
@@ -696,7 +703,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
       // mover costs more on both sides); while gathers are timed it carries a
       // completion stamp like every other predecessor (stamp_predecessors).
       hipEvent_t none = nullptr, done = nullptr;
-      if (rep->timer.enabled && stamp_predecessors()) {
+      if (stamp_this && stamp_predecessors()) {
         rep->timer_other.enabled = rep->timer_other.discard = true;
         rep->timer_other.next(&none, &done);
       }
@@ -706,8 +713,8 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   }
   rep->order_before(gather, stream);
   hipEvent_t start = nullptr, stop = nullptr;
-  if (gather) rep->timer.next(&start, &stop);
-  else if (rep->timer.enabled && stamp_predecessors() && !host_kernargs()) {
+  if (stamp_this) rep->timer.next(&start, &stop);
+  else if (!gather && rep->timer.enabled && stamp_predecessors() && !host_kernargs()) {
     // (With host-resident kernel arguments every big gather already follows its
     // stamped argument-writer launch, and a stamp on each insert would cost
     // ~10 % of the step rate there; with device-resident arguments it is free.)
@@ -979,6 +986,8 @@ int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t 
 int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) {
   REP_OP({
     rep->timer.enabled = enable != 0;
+    rep->timer.every = enable > 1 ? enable : 1;      // enable = n > 1: stamp every n-th gather
+    rep->timer.tick = 0;
     if (enable) {                       // create the stamp pools now, not inside a timed region
       rep->timer.reserve(emb_timer_pool());
       rep->timer_other.discard = true;

@@ -234,7 +234,9 @@ int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t 
 int32_t emb_replay_multistream(emb_replay_t* rep, int32_t enable);
 
 /* HIP-event timing of the gather launches issued through this handle (on their
- * own stream): total milliseconds and launch count since the last reset.     */
+ * own stream): total milliseconds and launch count since the last reset.
+ * enable = 1 stamps every gather, n > 1 every n-th one (a stamped launch costs
+ * the host more than a plain one), 0 switches the stamps off.                */
 int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable);
 int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* total_ms,
                                 int32_t reset);
