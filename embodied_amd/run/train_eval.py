@@ -1,5 +1,16 @@
-"""Training with a second, evaluation Driver/Replay pair
-(reference: embodied/run/train_eval.py:10-157; same signature)."""
+"""Training with a second, evaluation Driver/Replay pair.
+
+Same entry point and `args` fields as the reference's
+`embodied.run.train_eval(make_agent, make_replay_train, make_replay_eval,
+make_env_train, make_env_eval, make_stream, make_logger, args)`
+(embodied/run/train_eval.py:10-157).  Two halves share one agent:
+
+* the training half is `run.train`'s: `args.envs` envs feed the train Replay,
+  the learner runs as a Driver callback;
+* the evaluation half (`_Evaluation`) owns `args.eval_envs` envs and the eval
+  Replay: on its own wall-clock schedule it plays `args.eval_eps` whole episodes
+  with `mode='eval'` and draws one report batch from each replay.
+"""
 import pathlib
 from functools import partial as bind
 
@@ -8,67 +19,89 @@ from ..core.driver import Driver
 from .train import _Learner
 
 
+class _Evaluation:
+  """Episodes in eval mode into their own Replay, plus the two report streams."""
+
+  def __init__(self, agent, make_env, replay_eval, replay_train, make_stream, logger, args):
+    self.agent, self.logger = agent, logger
+    self.replays = {'eval': replay_eval, 'report': replay_train}
+    self.episodes = getattr(args, 'eval_eps', 1)
+    count = getattr(args, 'eval_envs', 1)
+    self.driver = Driver(
+        [bind(make_env, index) for index in range(count)],
+        parallel=not args.debug, device=getattr(args, 'device', None))
+    self.driver.on_step(replay_eval.add)
+    self.streams = {
+        'eval': iter(agent.stream(make_stream(replay_eval, 'eval'))),
+        'report': iter(agent.stream(make_stream(replay_train, 'report')))}
+    self.carries = {name: agent.init_report(args.batch_size) for name in self.streams}
+    self.due = utils.LocalClock(getattr(args, 'eval_every', args.report_every), first=True)
+
+  def policy(self, *args, **kwargs):
+    return self.agent.policy(*args, mode='eval', **kwargs)
+
+  def maybe_run(self, step):
+    if not self.due(step):
+      return
+    self.driver.reset(self.agent.init_policy)
+    self.driver(self.policy, episodes=self.episodes)
+    for name, stream in self.streams.items():
+      if len(self.replays[name]):
+        self.carries[name], metrics = self.agent.report(self.carries[name], next(stream))
+        self.logger.add(metrics, prefix=name)
+
+  def close(self):
+    self.driver.close()
+
+
 def train_eval(
     make_agent, make_replay_train, make_replay_eval, make_env_train,
     make_env_eval, make_stream, make_logger, args):
-  agent = make_agent()
-  replay_train = make_replay_train()
-  replay_eval = make_replay_eval()
-  logger = make_logger()
+  agent, logger = make_agent(), make_logger()
+  replays = {'train': make_replay_train(), 'eval': make_replay_eval()}
   step = logger.step
-  logdir = pathlib.Path(args.logdir)
   policy_fps = utils.FPS()
-  should_log = utils.LocalClock(args.log_every)
-  should_eval = utils.LocalClock(getattr(args, 'eval_every', args.report_every), first=True)
-  should_save = utils.LocalClock(args.save_every)
-  device = getattr(args, 'device', None)
+  log_due = utils.LocalClock(args.log_every)
+  save_due = utils.LocalClock(args.save_every)
 
-  fns = [bind(make_env_train, i) for i in range(args.envs)]
-  driver_train = Driver(fns, parallel=not args.debug, device=device)
-  driver_train.on_batch(lambda trans, workers, **kw: (step.increment(args.envs), policy_fps.step(args.envs)))
-  driver_train.on_step(replay_train.add)
+  actors = Driver(
+      [bind(make_env_train, index) for index in range(args.envs)],
+      parallel=not args.debug, device=getattr(args, 'device', None))
 
-  fns = [bind(make_env_eval, i) for i in range(getattr(args, 'eval_envs', 1))]
-  driver_eval = Driver(fns, parallel=not args.debug, device=device)
-  driver_eval.on_step(replay_eval.add)
+  def count(trans, workers, **kw):
+    step.increment(args.envs)
+    policy_fps.step(args.envs)
 
-  stream_train = iter(agent.stream(make_stream(replay_train, 'train')))
-  stream_report = iter(agent.stream(make_stream(replay_train, 'report')))
-  stream_eval = iter(agent.stream(make_stream(replay_eval, 'eval')))
-  carry_report = agent.init_report(args.batch_size)
-  carry_eval = agent.init_report(args.batch_size)
+  actors.on_batch(count)
+  actors.on_step(replays['train'].add)
+  learner = _Learner(
+      agent, replays['train'], iter(agent.stream(make_stream(replays['train'], 'train'))),
+      step, args)
+  actors.on_batch(learner)
+  evaluation = _Evaluation(
+      agent, make_env_eval, replays['eval'], replays['train'], make_stream, logger, args)
 
-  learner = _Learner(agent, replay_train, stream_train, step, args)
-  driver_train.on_batch(learner)
+  checkpoint = utils.Checkpoint(pathlib.Path(args.logdir) / 'checkpoint.pkl')
+  checkpoint.step = step
+  checkpoint.agent = agent
+  checkpoint.replay_train = replays['train']
+  checkpoint.replay_eval = replays['eval']
+  checkpoint.load_or_save()
 
-  cp = utils.Checkpoint(logdir / 'checkpoint.pkl')
-  cp.step = step
-  cp.agent = agent
-  cp.replay_train = replay_train
-  cp.replay_eval = replay_eval
-  cp.load_or_save()
+  def policy(*a, **kw):
+    return agent.policy(*a, mode='train', **kw)
 
-  train_policy = lambda *a, **kw: agent.policy(*a, mode='train', **kw)
-  eval_policy = lambda *a, **kw: agent.policy(*a, mode='eval', **kw)
-  driver_train.reset(agent.init_policy)
+  actors.reset(agent.init_policy)
   while step < args.steps:
-    if should_eval(step):
-      driver_eval.reset(agent.init_policy)
-      driver_eval(eval_policy, episodes=getattr(args, 'eval_eps', 1))
-      if len(replay_eval):
-        carry_eval, mets = agent.report(carry_eval, next(stream_eval))
-        logger.add(mets, prefix='eval')
-      if len(replay_train):
-        carry_report, mets = agent.report(carry_report, next(stream_report))
-        logger.add(mets, prefix='report')
-    driver_train(train_policy, steps=10)
-    if should_log(step):
+    evaluation.maybe_run(step)
+    actors(policy, steps=10)
+    if log_due(step):
       logger.add(learner.metrics.result())
-      logger.add(replay_train.stats(), prefix='replay')
+      logger.add(replays['train'].stats(), prefix='replay')
       logger.add({'fps/policy': policy_fps.result(), 'fps/train': learner.fps.result()})
       logger.write()
-    if should_save(step):
-      cp.save()
+    if save_due(step):
+      checkpoint.save()
   logger.close()
-  driver_train.close()
-  driver_eval.close()
+  actors.close()
+  evaluation.close()

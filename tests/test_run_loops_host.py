@@ -19,29 +19,45 @@ class Sink:
     self.rows.append({(f'{prefix}/{k}' if prefix else k): float(v) for k, v in mapping.items()})
 
 
-def reference_logfn(logger, epstats, n):
-  """One Agg per env, fed one transition at a time: what run/train.py:31-54
-  does (without the uint8 image stacks it keeps for worker 0's video)."""
-  episodes = [emb.utils.Agg() for _ in range(n)]
+class PerEnvEpisodes:
+  """What the reference's per-env `logfn` callback reports (run/train.py:31-54),
+  written as one plain accumulator per env: an episode starts at `is_first`,
+  every step adds its reward to the score and one to the length and remembers the
+  reward, every scalar `log/*` value is tracked for avg / max / sum; at `is_last`
+  score and length go to the logger under `episode/`, and the episode's
+  reward_rate (share of consecutive reward pairs that differ by >= 0.01, only
+  with more than one step) plus the log aggregates go to the episode statistics.
+  (The uint8 image stacks kept for worker 0's video are not part of the path.)"""
 
-  def logfn(tran, worker):
-    episode = episodes[worker]
-    tran['is_first'] and episode.reset()
-    episode.add('score', tran['reward'], agg='sum')
-    episode.add('length', 1, agg='sum')
-    episode.add('rewards', tran['reward'], agg='stack')
+  def __init__(self, logger, epstats, n):
+    self.logger, self.epstats = logger, epstats
+    self.envs = [self._fresh() for _ in range(n)]
+
+  @staticmethod
+  def _fresh():
+    return {'rewards': [], 'logs': {}}
+
+  def __call__(self, tran, worker):
+    if tran['is_first']:
+      self.envs[worker] = self._fresh()
+    env = self.envs[worker]
+    env['rewards'].append(float(tran['reward']))
     for key, value in tran.items():
       if key.startswith('log/'):
         assert np.ndim(value) == 0
-        episode.add(key, value, agg=('avg', 'max', 'sum'))
-    if tran['is_last']:
-      result = episode.result()
-      logger.add({'score': result.pop('score'), 'length': result.pop('length')}, prefix='episode')
-      rew = result.pop('rewards')
-      if len(rew) > 1:
-        result['reward_rate'] = (np.abs(rew[1:] - rew[:-1]) >= 0.01).mean()
-      epstats.add(result)
-  return logfn
+        env['logs'].setdefault(key, []).append(float(value))
+    if not tran['is_last']:
+      return
+    rewards = np.asarray(env['rewards'])
+    self.logger.add({'score': rewards.sum(), 'length': len(rewards)}, prefix='episode')
+    result = {}
+    for key, values in env['logs'].items():
+      result[f'{key}/avg'] = np.mean(values)
+      result[f'{key}/max'] = np.max(values)
+      result[f'{key}/sum'] = np.sum(values)
+    if len(rewards) > 1:
+      result['reward_rate'] = (np.abs(np.diff(rewards)) >= 0.01).mean()
+    self.epstats.add(result)
 
 
 def test_episode_stats_equal_per_env_logfn():
@@ -50,7 +66,7 @@ def test_episode_stats_equal_per_env_logfn():
   ours_log, ours_ep = Sink(), Sink()
   want_log, want_ep = Sink(), Sink()
   stats = EpisodeStats(ours_log, ours_ep)
-  logfn = reference_logfn(want_log, want_ep, n)
+  logfn = PerEnvEpisodes(want_log, want_ep, n)
   is_last = np.zeros(n, bool)
   for t in range(steps):
     is_first = is_last.copy() if t else np.ones(n, bool)
