@@ -413,7 +413,10 @@ def main():
     avg_s = gather_ms / (launches if args.consec == 1 else samples) / 1e3
     achieved = algo_bytes / avg_s / 1e9
     roofline = {
-        'bound': 'hbm', 'kernel': 'gather_kernel (Replay.sample)',
+        'bound': 'hbm',
+        'kernel': ('span_move_kernel<gather> (Replay.sample)' if algo_bytes // 2 <= 40_000_000
+                   or os.environ.get('HIP_FORCE_DEV_KERNARG') == '0'
+                   else 'gather_kernel (Replay.sample)'),
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
         'traffic_source': traffic_source,
