@@ -32,6 +32,21 @@ def hipcc():
   raise RuntimeError('hipcc not found: cannot build libembodied_hip.so')
 
 
+def scratch_users(remarks):
+  """(kernel, bytes per lane) for every kernel the compiler gave scratch memory,
+  from -Rpass-analysis=kernel-resource-usage remarks."""
+  import re
+  out, name = [], None
+  for line in remarks.splitlines():
+    m = re.search(r'Function Name: (\S+)', line)
+    if m:
+      name = m.group(1)
+    m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+    if m and int(m.group(1)) > 0:
+      out.append((name, int(m.group(1))))
+  return out
+
+
 def stale():
   if not OUT.exists() or not FASTCALL.exists():
     return True
@@ -55,12 +70,23 @@ def build(force=False, verbose=True):
 
   def compile_one(name):
     obj = OBJ / (name + '.o')
-    cmd = [cc, *flags, '-c', str(CSRC / name), '-o', str(obj)]
+    extra = ['-Rpass-analysis=kernel-resource-usage'] if name.endswith('.hip') else []
+    cmd = [cc, *flags, *extra, '-c', str(CSRC / name), '-o', str(obj)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode:
       raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
-    if verbose and res.stderr.strip():
-      print(res.stderr, file=sys.stderr)
+    spills = scratch_users(res.stderr)
+    if spills:
+      # A by-value argument block whose address escapes, or a register spill:
+      # either turns a 10 us mover into a 250 us one.  Never ship that silently.
+      raise RuntimeError('kernels that use scratch memory:\n' + '\n'.join(
+          f'  {kernel}: {nbytes} bytes/lane' for kernel, nbytes in spills))
+    import re
+    rest = [l for l in res.stderr.splitlines() if 'kernel-resource-usage' not in l
+            and not re.match(r'^\s*(\d+\s*)?\|', l) and not l.lstrip().startswith('^')
+            and 'remarks generated' not in l]
+    if verbose and any(l.strip() for l in rest):
+      print('\n'.join(rest), file=sys.stderr)
     return obj
 
   with concurrent.futures.ThreadPoolExecutor(len(SOURCES)) as pool:

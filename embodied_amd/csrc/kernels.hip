@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +62,9 @@ static_assert(sizeof(SpanHead) == 160, "SpanHead is loaded as 40 dwords");
 // Per-launch plan in kernel-argument memory (< 4 KiB).
 struct alignas(16) MoveArgs {
   SpanHead head;
+  // Row table / span table / step ids carried in the arguments.  Directly behind
+  // the head: the span mover stages head + the first spans with ONE load per lane.
+  uint32_t inline_words[kInlineWords];
   KeyDesc key[kMaxKeys];
   int32_t first_block[kMaxKeys + 1];
   int32_t unit[kMaxKeys];           // 0: 16-byte flat path; else bytes per lane
@@ -84,9 +88,19 @@ struct alignas(16) MoveArgs {
   // (distributed.py, DP-slice exchange).
   int32_t group;
   int64_t group_stride;
-  uint32_t inline_words[kInlineWords];
 };
 static_assert(sizeof(MoveArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+// What the span mover stages through LDS before anything else: the head and the
+// first spans, contiguous in the arguments.
+constexpr int kStagedSeqs = 72;      // (160 + 72 * 12) / 16 = 64 lanes: one wave, one load each
+struct StagedSpans {
+  SpanHead head;
+  uint32_t spans[3 * kStagedSeqs];
+};
+static_assert(sizeof(StagedSpans) == 64 * 16, "one 16-byte load per lane of one wave");
+static_assert(offsetof(MoveArgs, inline_words) == sizeof(SpanHead), "spans follow the head");
+
 
 __device__ __forceinline__ int find_key(const MoveArgs& a, int block) {
   int k = 0;
@@ -240,7 +254,8 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
 // plain contiguous copy of the same bytes and 13.8 us for the flat
 // one-tile-per-workgroup mover above.
 template <bool kGather, int U, int NT>
-__device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const SpanHead& h) {
+__device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const StagedSpans& staged) {
+  const SpanHead& h = staged.head;
   const uint32_t tile = blockDim.x * U;
   const uint32_t L = static_cast<uint32_t>(h.seq_len);
   const uint32_t ntiles = h.ntiles;
@@ -258,8 +273,16 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const SpanHea
     const uint32_t local = ti - h.tile0[k];
     const uint32_t seq = local / tps, piece = local - seq * tps;
     const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
-    const uint32_t row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
-    const uint32_t row1 = a.inline_words[3 * seq + 2];
+    // The first kStagedSeqs spans came with the head (LDS); later ones are read
+    // from the argument block.
+    // (No pointer into `a` here: a by-value argument block whose address
+    // escapes is copied to scratch, 3.7 KB per lane.)
+    uint32_t row0, n0, row1;
+    if (seq < kStagedSeqs) {
+      row0 = staged.spans[3 * seq], n0 = staged.spans[3 * seq + 1], row1 = staged.spans[3 * seq + 2];
+    } else {
+      row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1], row1 = a.inline_words[3 * seq + 2];
+    }
     Where w;
     w.split = n0 * upr;
     w.total = L * upr;
@@ -466,33 +489,38 @@ __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* 
 // The 160-byte head goes from the argument block to LDS with one 16-byte load
 // per lane of the first ten lanes — a single memory latency however the
 // compiler would have scheduled the individual field reads.
-__device__ __forceinline__ void stage_head(const MoveArgs* a, SpanHead* dst) {
-  if (threadIdx.x < sizeof(SpanHead) / 16)
-    reinterpret_cast<u32x4*>(dst)[threadIdx.x] =
-        reinterpret_cast<const u32x4*>(&a->head)[threadIdx.x];
+// `bytes`: the argument block as raw 16-byte units — the device copy for the
+// indirect kernels, the kernel-argument segment itself for the by-value ones
+// (indexing the by-value parameter with a lane id makes the compiler copy the
+// whole 3.7 KB struct into scratch, per lane: 260 us instead of 11).
+__device__ __forceinline__ void stage_head(const u32x4* bytes, StagedSpans* dst) {
+  if (threadIdx.x < sizeof(StagedSpans) / 16)
+    reinterpret_cast<u32x4*>(dst)[threadIdx.x] = bytes[threadIdx.x];
   __syncthreads();
 }
 
 template <bool kGather, int U, int NT>
-__device__ __forceinline__ void span_move_body(const MoveArgs& a) {
-  __shared__ SpanHead head;
-  stage_head(&a, &head);
-  if (static_cast<int>(blockIdx.x) < head.wide_workers) {
-    move_wide_spans<kGather, U, NT>(a, head);
+__device__ __forceinline__ void span_move_body(const MoveArgs& a, const u32x4* bytes) {
+  __shared__ StagedSpans staged;
+  stage_head(bytes, &staged);
+  if (static_cast<int>(blockIdx.x) < staged.head.wide_workers) {
+    move_wide_spans<kGather, U, NT>(a, staged);
     return;
   }
-  const int block = static_cast<int>(blockIdx.x) - head.wide_workers;
+  const int block = static_cast<int>(blockIdx.x) - staged.head.wide_workers;
   if (kGather) gather_block<2, NT>(a, block);
   else scatter_block<2, NT>(a, block);
 }
 
 template <bool kGather, int U, int NT>
 __global__ __launch_bounds__(1024) void span_move_kernel(const MoveArgs a) {
-  span_move_body<kGather, U, NT>(a);
+  // MoveArgs is the only parameter: it starts the kernel-argument segment.
+  span_move_body<kGather, U, NT>(
+      a, (const u32x4*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
 }
 template <bool kGather, int U, int NT>
 __global__ __launch_bounds__(1024) void span_move_kernel_indirect(const MoveArgs* __restrict__ a) {
-  span_move_body<kGather, U, NT>(*a);
+  span_move_body<kGather, U, NT>(*a, reinterpret_cast<const u32x4*>(a));
 }
 
 // Host-resident kernel arguments (HIP_FORCE_DEV_KERNARG=0): one workgroup
