@@ -747,7 +747,15 @@ size_t move_args_bytes() { return sizeof(MoveArgs); }
 hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t stream,
                               hipEvent_t stop) {
   const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
-  hipExtLaunchKernelGGL(args_writer_kernel, dim3(1), dim3(256), 0, stream, nullptr, stop, 0, a,
+  // Eight workgroups, one per XCD (workgroup b runs on XCD b % 8): each writes
+  // the same bytes, so the block is in EVERY XCD's L2 when the mover's
+  // workgroups ask for it (the L2s are per XCD; one writer leaves seven cold).
+  static const int writers = [] {
+    const char* e = std::getenv("EMB_ARGS_WRITERS");
+    const int n = e ? std::atoi(e) : 8;
+    return n >= 1 && n <= 64 ? n : 8;
+  }();
+  hipExtLaunchKernelGGL(args_writer_kernel, dim3(writers), dim3(256), 0, stream, nullptr, stop, 0, a,
                         static_cast<u32x4*>(device_dst));
   return hipGetLastError();
 }

@@ -21,3 +21,18 @@ def test_parity_with_kernel_arguments_in_host_memory():
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
+
+
+def test_parity_with_the_flat_mover_only():
+  """EMB_SPAN_VARIANT=...,0 switches the persistent span mover off (the knob is
+  read once per process): sample, windowing, write-back and the grouped
+  (per-destination-rank) layout must give the same bytes through the flat mover,
+  which is what moves > 40 MB launches with device-resident arguments."""
+  env = dict(os.environ, EMB_SPAN_VARIANT='4,3,512,0')
+  res = subprocess.run(
+      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-m', 'gpu', '-q', '-x',
+       '-k', 'golden or full_size or span_mover or fused_sample or grouped or update_table '
+             'or window or random_schemas'],
+      cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+  assert ' passed' in res.stdout

@@ -884,7 +884,8 @@ def test_save_load_with_prioritized_selector(emb, tmp_path):
 
 
 @pytest.mark.parametrize('chunksize,L,batches', [
-    (16, 7, (1, 3, 16)),        # most windows cross a chunk boundary: two runs per sequence
+    (16, 7, (1, 3, 16, 100)),   # most windows cross a chunk boundary: two runs per sequence;
+                                # 100 > the 72 spans staged with the head (read from the arguments)
     (64, 65, (1, 5)),           # BASELINE length, windows of 1-2 runs
     (8, 9, (2, 40)),            # windows of 2-3 chunks: NOT span-shaped, falls back to row tables
 ])
