@@ -68,6 +68,7 @@ struct MoveLaunch {
   uint32_t blocks = 0;
   uint32_t threads = 0;
   bool span = false;       // persistent span mover (wide keys of a span table)
+  bool stage_tables = false;   // arguments in host memory: by-value flat movers stage their tables in LDS
 };
 hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out);
 size_t move_args_bytes();

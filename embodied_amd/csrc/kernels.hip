@@ -60,11 +60,11 @@ struct alignas(16) SpanHead {
 static_assert(sizeof(SpanHead) == 160, "SpanHead is loaded as 40 dwords");
 
 // Per-launch plan in kernel-argument memory (< 4 KiB).
-struct alignas(16) MoveArgs {
-  SpanHead head;
-  // Row table / span table / step ids carried in the arguments.  Directly behind
-  // the head: the span mover stages head + the first spans with ONE load per lane.
-  uint32_t inline_words[kInlineWords];
+// Everything of a launch plan except the head and the inline words: which key
+// owns which virtual blocks, the keys themselves, how rows are resolved.  One
+// contiguous block so that the by-value movers can bring it into LDS with one
+// load per lane when the arguments live in host memory (see stage_tables).
+struct alignas(16) MoveTables {
   KeyDesc key[kMaxKeys];
   int32_t first_block[kMaxKeys + 1];
   int32_t unit[kMaxKeys];           // 0: 16-byte flat path; else bytes per lane
@@ -78,9 +78,6 @@ struct alignas(16) MoveArgs {
   int8_t mask_dtype[kMaxKeys];
   uint8_t* mask_out[kMaxKeys];
   const uint8_t* mask_flags;
-  // Span mode (rows_mode 2): the wide keys are moved by `head.wide_workers`
-  // persistent workgroups walking `head.ntiles` tiles (see move_wide_spans);
-  // those keys own no virtual blocks.
   // Gather only: the batch side in groups of `group` sequences, `group_stride`
   // bytes apart (0 = one dense (n_rows, rowbytes) array per key).  Sequence s of
   // key k starts at key.batch + (s / group) * group_stride + (s % group) * L *
@@ -88,6 +85,19 @@ struct alignas(16) MoveArgs {
   // (distributed.py, DP-slice exchange).
   int32_t group;
   int64_t group_stride;
+};
+static_assert(sizeof(MoveTables) % 16 == 0 && sizeof(MoveTables) / 16 <= 64,
+              "the tables are staged as one 16-byte load per lane of one wave");
+
+// Per-launch plan in kernel-argument memory (< 4 KiB).  Span mode (rows_mode 2):
+// the wide keys are moved by `head.wide_workers` persistent workgroups walking
+// `head.ntiles` tiles (see move_wide_spans); those keys own no virtual blocks.
+struct alignas(16) MoveArgs {
+  SpanHead head;
+  // Row table / span table / step ids carried in the arguments.  Directly behind
+  // the head: the span mover stages head + the first spans with ONE load per lane.
+  uint32_t inline_words[kInlineWords];
+  MoveTables t;
 };
 static_assert(sizeof(MoveArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
@@ -102,31 +112,31 @@ static_assert(sizeof(StagedSpans) == 64 * 16, "one 16-byte load per lane of one 
 static_assert(offsetof(MoveArgs, inline_words) == sizeof(SpanHead), "spans follow the head");
 
 
-__device__ __forceinline__ int find_key(const MoveArgs& a, int block) {
+__device__ __forceinline__ int find_key(const MoveTables& tb, int block) {
   int k = 0;
-  while (k + 1 < a.n_keys && block >= a.first_block[k + 1]) ++k;
+  while (k + 1 < tb.n_keys && block >= tb.first_block[k + 1]) ++k;
   return k;
 }
 
 // Pool row of batch row r.
-__device__ __forceinline__ int32_t row_of(const MoveArgs& a, uint32_t r) {
-  if (a.rows_mode == 2) {
-    const uint32_t seq = r / static_cast<uint32_t>(a.seq_len);
-    const uint32_t t = r - seq * static_cast<uint32_t>(a.seq_len);
+__device__ __forceinline__ int32_t row_of(const MoveArgs& a, const MoveTables& tb, uint32_t r) {
+  if (tb.rows_mode == 2) {
+    const uint32_t seq = r / static_cast<uint32_t>(tb.seq_len);
+    const uint32_t t = r - seq * static_cast<uint32_t>(tb.seq_len);
     const uint32_t row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
     return static_cast<int32_t>(t < n0 ? row0 + t : a.inline_words[3 * seq + 2] + (t - n0));
   }
-  if (a.rows_mode == 1) return static_cast<int32_t>(a.inline_words[r]);
-  return a.rows[r];
+  if (tb.rows_mode == 1) return static_cast<int32_t>(a.inline_words[r]);
+  return tb.rows[r];
 }
 
 // Byte offset of batch row r of `key` on the batch side (see MoveArgs::group).
-__device__ __forceinline__ int64_t batch_offset(const MoveArgs& a, const KeyDesc& key, uint32_t r) {
-  if (a.group == 0) return static_cast<int64_t>(r) * key.rowbytes;
-  const uint32_t L = static_cast<uint32_t>(a.seq_len), g = static_cast<uint32_t>(a.group);
+__device__ __forceinline__ int64_t batch_offset(const MoveTables& tb, const KeyDesc& key, uint32_t r) {
+  if (tb.group == 0) return static_cast<int64_t>(r) * key.rowbytes;
+  const uint32_t L = static_cast<uint32_t>(tb.seq_len), g = static_cast<uint32_t>(tb.group);
   const uint32_t seq = r / L, t = r - seq * L;
   const uint32_t grp = seq / g, j = seq - grp * g;
-  return static_cast<int64_t>(grp) * a.group_stride + static_cast<int64_t>(j * L + t) * key.rowbytes;
+  return static_cast<int64_t>(grp) * tb.group_stride + static_cast<int64_t>(j * L + t) * key.rowbytes;
 }
 
 template <typename T>
@@ -162,10 +172,10 @@ __device__ __forceinline__ void copy_bytes(const uint8_t* s, uint8_t* d, int uni
 // independent loads in flight before its first store, and no lane waits on a
 // per-workgroup scalar dependency chain.
 template <bool kGather, int U, int NT>
-__device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key, int local,
+__device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& tb, const KeyDesc& key, int local,
                                           int nblocks) {
   const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
-  const uint32_t total = upr * static_cast<uint32_t>(a.n_rows);
+  const uint32_t total = upr * static_cast<uint32_t>(tb.n_rows);
   // Optional (EMB_MOVE_VARIANT's third field = 1; off by default): workgroup b
   // runs on XCD b % 8, so this gives every XCD one contiguous eighth of the
   // batch.  Measured on MI355X it is 0.2-0.3 us SLOWER at batch 16 inside the
@@ -173,27 +183,27 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   // each frame over all XCDs' memory channels, which a streaming copy prefers.
   int vlocal = local;
   const int per_xcd = nblocks >> 3;
-  if (a.xcd_remap && local < (per_xcd << 3)) vlocal = (local & 7) * per_xcd + (local >> 3);
+  if (tb.xcd_remap && local < (per_xcd << 3)) vlocal = (local & 7) * per_xcd + (local >> 3);
   // One division per wave for the workgroup's first unit; lanes step from it
   // with adds and compares (a 32-bit divide costs ~40 VALU instructions).
   const uint32_t base = static_cast<uint32_t>(vlocal) * (blockDim.x * U);
   const uint32_t r0 = base / upr;
   const uint32_t off0 = base - r0 * upr;
-  const uint32_t L = static_cast<uint32_t>(a.seq_len);
+  const uint32_t L = static_cast<uint32_t>(tb.seq_len);
   const uint32_t seq0 = r0 / L, t0 = r0 - seq0 * L;
   // The workgroup's units span at most kRows consecutive batch rows when rows
   // are long (the usual case: one 28 KB frame = 1764 units): resolve those rows
   // ONCE per wave with wave-uniform (scalar) reads of the inline span table and
   // let the lanes select, instead of every lane reading the table.
   constexpr int kRows = 3;
-  const bool few_rows = a.rows_mode == 2 &&
+  const bool few_rows = tb.rows_mode == 2 &&
                         (off0 + blockDim.x * U - 1) / upr < static_cast<uint32_t>(kRows);
   int32_t row_tab[kRows];
   if (few_rows) {
     uint32_t seq = seq0, t = t0;
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
-      if (r0 + i < static_cast<uint32_t>(a.n_rows)) {
+      if (r0 + i < static_cast<uint32_t>(tb.n_rows)) {
         const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
         row_tab[i] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
       } else {
@@ -214,13 +224,13 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
       row[j] = -1;
     } else if (few_rows) {
       row[j] = dr == 0 ? row_tab[0] : dr == 1 ? row_tab[1] : row_tab[2];
-    } else if (a.rows_mode == 2) {
+    } else if (tb.rows_mode == 2) {
       uint32_t seq = seq0, t = t0 + dr;
       while (t >= L) { t -= L; ++seq; }
       const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
       row[j] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
     } else {
-      row[j] = row_of(a, r[j]);
+      row[j] = row_of(a, tb, r[j]);
     }
   }
   u32x4 buf[U];
@@ -228,7 +238,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   for (int j = 0; j < U; ++j) {
     if (row[j] < 0) continue;
     const uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
-    const uint8_t* batch = key.batch + batch_offset(a, key, r[j]);
+    const uint8_t* batch = key.batch + batch_offset(tb, key, r[j]);
     const u32x4* src = reinterpret_cast<const u32x4*>(kGather ? pool : batch) + off[j];
     buf[j] = load16<(NT & 1) != 0>(src);
   }
@@ -236,7 +246,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const KeyDesc& key,
   for (int j = 0; j < U; ++j) {
     if (row[j] < 0) continue;
     uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
-    uint8_t* batch = key.batch + batch_offset(a, key, r[j]);
+    uint8_t* batch = key.batch + batch_offset(tb, key, r[j]);
     u32x4* dst = reinterpret_cast<u32x4*>(kGather ? batch : pool) + off[j];
     store16<(NT & 2) != 0>(dst, buf[j]);
   }
@@ -342,31 +352,31 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const StagedS
 // pool[rows[r]] -> batch[r] for every key of the replay in ONE launch, with
 // the is_first / is_last annotation of replay.py:277-292 applied in flight.
 template <int U, int NT>
-__device__ __forceinline__ void gather_block(const MoveArgs& a, int block) {
-  const int k = find_key(a, block);
-  const KeyDesc key = a.key[k];
-  const int local = block - a.first_block[k];
-  const int unit = a.unit[k];
+__device__ __forceinline__ void gather_block(const MoveArgs& a, const MoveTables& tb, int block) {
+  const int k = find_key(tb, block);
+  const KeyDesc key = tb.key[k];
+  const int local = block - tb.first_block[k];
+  const int unit = tb.unit[k];
   if (unit == 0) {
-    move_wide<true, U, NT>(a, key, local, a.first_block[k + 1] - a.first_block[k]);
+    move_wide<true, U, NT>(a, tb, key, local, tb.first_block[k + 1] - tb.first_block[k]);
     return;
   }
   const int64_t upr = key.rowbytes / unit;
   const int64_t u = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
-  if (u >= upr * a.n_rows) return;
+  if (u >= upr * tb.n_rows) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
-  const int64_t row = row_of(a, static_cast<uint32_t>(r));
+  const int64_t row = row_of(a, tb, static_cast<uint32_t>(r));
   if (row < 0) return;   // not this rank's sequence (sharded pools): leave as is
   const uint8_t* src = key.pool + row * key.rowbytes + off;
-  uint8_t* dst = key.batch + batch_offset(a, key, static_cast<uint32_t>(r)) + off;
-  if (key.rowbytes == 1 && (k == a.key_is_first || k == a.key_is_last)) {
-    const int t = static_cast<int>(r % a.seq_len);
+  uint8_t* dst = key.batch + batch_offset(tb, key, static_cast<uint32_t>(r)) + off;
+  if (key.rowbytes == 1 && (k == tb.key_is_first || k == tb.key_is_last)) {
+    const int t = static_cast<int>(r % tb.seq_len);
     uint8_t v = gload<uint8_t>(src);
-    if (k == a.key_is_first) {
+    if (k == tb.key_is_first) {
       if (t == 0) v = 1;
-    } else if (a.is_first_pool && t + 1 < a.seq_len) {
-      v |= gload<uint8_t>(a.is_first_pool + row_of(a, static_cast<uint32_t>(r + 1)));
+    } else if (tb.is_first_pool && t + 1 < tb.seq_len) {
+      v |= gload<uint8_t>(tb.is_first_pool + row_of(a, tb, static_cast<uint32_t>(r + 1)));
     }
     gstore<uint8_t>(dst, v);
     return;
@@ -393,19 +403,19 @@ __device__ __forceinline__ void put_masked_bf16(const uint8_t* src, uint8_t* poo
   if (out) gstore<uint16_t>(out, v);
 }
 
-__device__ __forceinline__ void scatter_masked(const MoveArgs& a, int k, const KeyDesc& key, int local) {
-  const int es = a.unit[k];                       // element size of the key's dtype
+__device__ __forceinline__ void scatter_masked(const MoveArgs& a, const MoveTables& tb, int k, const KeyDesc& key, int local) {
+  const int es = tb.unit[k];                       // element size of the key's dtype
   const int64_t epr = key.rowbytes / es;
   const int64_t e = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
-  if (e >= epr * a.n_rows) return;
+  if (e >= epr * tb.n_rows) return;
   const int64_t r = e / epr;
   const int64_t off = (e - r * epr) * es;
-  const int64_t row = row_of(a, static_cast<uint32_t>(r));
-  const bool keep = gload<uint8_t>(a.mask_flags + r) == 0;
+  const int64_t row = row_of(a, tb, static_cast<uint32_t>(r));
+  const bool keep = gload<uint8_t>(tb.mask_flags + r) == 0;
   const uint8_t* src = key.batch + r * key.rowbytes + off;
   uint8_t* pool = row >= 0 ? key.pool + row * key.rowbytes + off : nullptr;
-  uint8_t* out = a.mask_out[k] ? a.mask_out[k] + r * key.rowbytes + off : nullptr;
-  switch (a.mask_dtype[k]) {
+  uint8_t* out = tb.mask_out[k] ? tb.mask_out[k] + r * key.rowbytes + off : nullptr;
+  switch (tb.mask_dtype[k]) {
     case kU8: case kBool: put_masked<uint8_t>(src, pool, out, keep); break;
     case kI8: put_masked<int8_t>(src, pool, out, keep); break;
     case kI16: put_masked<int16_t>(src, pool, out, keep); break;
@@ -420,28 +430,28 @@ __device__ __forceinline__ void scatter_masked(const MoveArgs& a, int k, const K
 
 // batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
 template <int U, int NT>
-__device__ __forceinline__ void scatter_block(const MoveArgs& a, int block) {
-  const int k = find_key(a, block);
-  const KeyDesc key = a.key[k];
-  const int local = block - a.first_block[k];
-  const int unit = a.unit[k];
-  if ((a.mask_bits >> k) & 1u) {
-    scatter_masked(a, k, key, local);
+__device__ __forceinline__ void scatter_block(const MoveArgs& a, const MoveTables& tb, int block) {
+  const int k = find_key(tb, block);
+  const KeyDesc key = tb.key[k];
+  const int local = block - tb.first_block[k];
+  const int unit = tb.unit[k];
+  if ((tb.mask_bits >> k) & 1u) {
+    scatter_masked(a, tb, k, key, local);
     return;
   }
   if (unit == 0) {
-    move_wide<false, U, NT>(a, key, local, a.first_block[k + 1] - a.first_block[k]);
+    move_wide<false, U, NT>(a, tb, key, local, tb.first_block[k + 1] - tb.first_block[k]);
     return;
   }
   const int64_t upr = key.rowbytes / unit;
   const int64_t u = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
-  if (u >= upr * a.n_rows) return;
+  if (u >= upr * tb.n_rows) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
-  const int64_t row = row_of(a, static_cast<uint32_t>(r));
+  const int64_t row = row_of(a, tb, static_cast<uint32_t>(r));
   if (row < 0) return;
-  if (k == a.inline_key) {   // batch bytes of this key ride in the kernel arguments
-    const uint32_t w = a.inline_words[a.inline_key_word0 + r * (key.rowbytes >> 2) + (off >> 2)];
+  if (k == tb.inline_key) {   // batch bytes of this key ride in the kernel arguments
+    const uint32_t w = a.inline_words[tb.inline_key_word0 + r * (key.rowbytes >> 2) + (off >> 2)];
     gstore<uint32_t>(key.pool + row * key.rowbytes + off, w);
     return;
   }
@@ -456,32 +466,65 @@ __device__ __forceinline__ void scatter_block(const MoveArgs& a, int block) {
 // workgroup's stores with the next one's loads better than this loop does), so
 // it stays off.
 template <int U, int NT>
-__device__ __forceinline__ void gather_body(const MoveArgs& a) {
-  const int total = a.first_block[a.n_keys];
-  for (int block = blockIdx.x; block < total; block += gridDim.x) gather_block<U, NT>(a, block);
+__device__ __forceinline__ void gather_body(const MoveArgs& a, const MoveTables& tb) {
+  const int total = tb.first_block[tb.n_keys];
+  for (int block = blockIdx.x; block < total; block += gridDim.x) gather_block<U, NT>(a, tb, block);
 }
 template <int U, int NT>
-__device__ __forceinline__ void scatter_body(const MoveArgs& a) {
-  const int total = a.first_block[a.n_keys];
-  for (int block = blockIdx.x; block < total; block += gridDim.x) scatter_block<U, NT>(a, block);
+__device__ __forceinline__ void scatter_body(const MoveArgs& a, const MoveTables& tb) {
+  const int total = tb.first_block[tb.n_keys];
+  for (int block = blockIdx.x; block < total; block += gridDim.x) scatter_block<U, NT>(a, tb, block);
 }
 
-// Each mover exists twice: arguments by value in the kernel-argument segment
-// (default), or read through a pointer to a copy in device memory.  The second
-// form is for processes that keep kernel arguments in host memory
-// (HIP_FORCE_DEV_KERNARG=0: cheaper launches, but every wave's argument reads
-// then cross PCIe, which costs a 58 MB gather a third of its speed).
+// The kernel-argument segment as raw 16-byte units (MoveArgs is the only
+// parameter of every mover, so it starts the segment).  Indexing the by-value
+// parameter itself with a lane id would make the compiler copy the whole
+// 3.7 KB struct into scratch, per lane (260 us instead of 11).
+__device__ __forceinline__ const u32x4* kernarg_units() {
+  return (const u32x4*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+// Host-resident kernel arguments: every scalar read of the plan is a PCIe round
+// trip, and a flat-mover wave makes three or four dependent ones (which key is
+// mine -> its descriptor -> my rows) before its first payload load.  The staged
+// variants bring the tables into LDS with one 16-byte load per lane of the first
+// wave: one round trip, then LDS reads; only the inline row words still come from
+// the argument block.  (Insert scatter of 64 rows: 13.5 -> ~9 us.)
+__device__ __forceinline__ void stage_tables(const u32x4* bytes, MoveTables* dst) {
+  constexpr uint32_t first = offsetof(MoveArgs, t) / 16;
+  if (threadIdx.x < sizeof(MoveTables) / 16)
+    reinterpret_cast<u32x4*>(dst)[threadIdx.x] = bytes[first + threadIdx.x];
+  __syncthreads();
+}
+static_assert(offsetof(MoveArgs, t) % 16 == 0, "the tables are staged in 16-byte units");
+
+// Each mover exists three times: arguments by value in the kernel-argument
+// segment (default), the same with the tables staged through LDS (arguments in
+// host memory, small launches), or read through a pointer to a copy in device
+// memory (arguments in host memory, big launches: abi.cpp run_move).
 template <int U, int NT>
-__global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) { gather_body<U, NT>(a); }
+__global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) { gather_body<U, NT>(a, a.t); }
 template <int U, int NT>
-__global__ __launch_bounds__(1024) void gather_kernel_indirect(const MoveArgs* __restrict__ a) {
-  gather_body<U, NT>(*a);
+__global__ __launch_bounds__(1024) void gather_kernel_staged(const MoveArgs a) {
+  __shared__ MoveTables tables;
+  stage_tables(kernarg_units(), &tables);
+  gather_body<U, NT>(a, tables);
 }
 template <int U, int NT>
-__global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) { scatter_body<U, NT>(a); }
+__global__ __launch_bounds__(1024) void gather_kernel_indirect(const MoveArgs* __restrict__ a) {
+  gather_body<U, NT>(*a, a->t);
+}
+template <int U, int NT>
+__global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) { scatter_body<U, NT>(a, a.t); }
+template <int U, int NT>
+__global__ __launch_bounds__(1024) void scatter_kernel_staged(const MoveArgs a) {
+  __shared__ MoveTables tables;
+  stage_tables(kernarg_units(), &tables);
+  scatter_body<U, NT>(a, tables);
+}
 template <int U, int NT>
 __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* __restrict__ a) {
-  scatter_body<U, NT>(*a);
+  scatter_body<U, NT>(*a, a->t);
 }
 
 // Span-mode launch: the first `wide_workers` workgroups are the persistent wide
@@ -490,9 +533,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* 
 // per lane of the first ten lanes — a single memory latency however the
 // compiler would have scheduled the individual field reads.
 // `bytes`: the argument block as raw 16-byte units — the device copy for the
-// indirect kernels, the kernel-argument segment itself for the by-value ones
-// (indexing the by-value parameter with a lane id makes the compiler copy the
-// whole 3.7 KB struct into scratch, per lane: 260 us instead of 11).
+// indirect kernels, the kernel-argument segment itself for the by-value ones.
 __device__ __forceinline__ void stage_head(const u32x4* bytes, StagedSpans* dst) {
   if (threadIdx.x < sizeof(StagedSpans) / 16)
     reinterpret_cast<u32x4*>(dst)[threadIdx.x] = bytes[threadIdx.x];
@@ -508,15 +549,14 @@ __device__ __forceinline__ void span_move_body(const MoveArgs& a, const u32x4* b
     return;
   }
   const int block = static_cast<int>(blockIdx.x) - staged.head.wide_workers;
-  if (kGather) gather_block<2, NT>(a, block);
-  else scatter_block<2, NT>(a, block);
+  if (kGather) gather_block<2, NT>(a, a.t, block);
+  else scatter_block<2, NT>(a, a.t, block);
 }
 
 template <bool kGather, int U, int NT>
 __global__ __launch_bounds__(1024) void span_move_kernel(const MoveArgs a) {
   // MoveArgs is the only parameter: it starts the kernel-argument segment.
-  span_move_body<kGather, U, NT>(
-      a, (const u32x4*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
+  span_move_body<kGather, U, NT>(a, kernarg_units());
 }
 template <bool kGather, int U, int NT>
 __global__ __launch_bounds__(1024) void span_move_kernel_indirect(const MoveArgs* __restrict__ a) {
@@ -649,67 +689,69 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
   const int unroll = span_path ? sv.unroll : variant.unroll;
   const int threads = span_path ? sv.threads : variant.threads;
   out->span = span_path;
+  out->stage_tables = plan.args_in_host_memory;
   MoveArgs& a = *reinterpret_cast<MoveArgs*>(out->args);
   SpanHead& h = a.head;
+  MoveTables& t = a.t;
   std::memset(&h, 0, sizeof(h));
   for (int j = 0; j < kSpanKeys; ++j) h.tile0[j] = 0xFFFFFFFFu;
-  a.group = plan.group > 0 ? plan.group : 0;
-  a.group_stride = plan.group_stride;
-  h.group = a.group;
-  h.group_stride = a.group_stride;
-  if (a.group && (plan.group_stride % 16 != 0 || plan.mask_bits || plan.inline_key >= 0))
+  t.group = plan.group > 0 ? plan.group : 0;
+  t.group_stride = plan.group_stride;
+  h.group = t.group;
+  h.group_stride = t.group_stride;
+  if (t.group && (plan.group_stride % 16 != 0 || plan.mask_bits || plan.inline_key >= 0))
     return hipErrorInvalidValue;       // gather-side layout only, 16-byte aligned groups
-  a.n_keys = plan.n_keys;
-  a.n_rows = plan.n_rows;
-  a.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;
-  a.key_is_first = plan.key_is_first;
-  a.key_is_last = plan.key_is_last;
-  a.is_first_pool = plan.is_first_pool;
-  if (!a.is_first_pool && plan.key_is_first >= 0) a.is_first_pool = plan.key[plan.key_is_first].pool;
-  a.rows = plan.rows;
-  a.rows_mode = 0;
-  a.inline_key = -1;
-  a.inline_key_word0 = 0;
+  t.n_keys = plan.n_keys;
+  t.n_rows = plan.n_rows;
+  t.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;
+  t.key_is_first = plan.key_is_first;
+  t.key_is_last = plan.key_is_last;
+  t.is_first_pool = plan.is_first_pool;
+  if (!t.is_first_pool && plan.key_is_first >= 0) t.is_first_pool = plan.key[plan.key_is_first].pool;
+  t.rows = plan.rows;
+  t.rows_mode = 0;
+  t.inline_key = -1;
+  t.inline_key_word0 = 0;
   if (use_inline) {
     int words;
     if (plan.spans_host) {
-      a.rows_mode = 2;
+      t.rows_mode = 2;
       words = 3 * plan.n_seq;
       std::memcpy(a.inline_words, plan.spans_host, sizeof(uint32_t) * words);
     } else {
-      a.rows_mode = 1;
+      t.rows_mode = 1;
       words = plan.n_rows;
       std::memcpy(a.inline_words, plan.rows_host, sizeof(uint32_t) * words);
     }
     if (plan.inline_key >= 0) {
-      a.inline_key = plan.inline_key;
-      a.inline_key_word0 = words;
+      t.inline_key = plan.inline_key;
+      t.inline_key_word0 = words;
       std::memcpy(a.inline_words + words, plan.inline_bytes,
                   static_cast<size_t>(plan.n_rows) * plan.key[plan.inline_key].rowbytes);
     }
   } else if (plan.inline_key >= 0) {
     return hipErrorInvalidValue;
   }
-  a.xcd_remap = variant.remap;
-  a.mask_bits = plan.mask_bits;
-  a.mask_flags = plan.mask_flags;
+  t.xcd_remap = variant.remap;
+  t.mask_bits = plan.mask_bits;
+  t.mask_flags = plan.mask_flags;
   if (plan.mask_bits && !plan.mask_flags) return hipErrorInvalidValue;
   int64_t blocks = 0;
   for (int k = 0; k < plan.n_keys; ++k) {
-    a.key[k] = plan.key[k];
-    a.mask_dtype[k] = plan.mask_dtype[k];
-    a.mask_out[k] = plan.mask_out[k];
+    t.key[k] = plan.key[k];
+    t.mask_dtype[k] = plan.mask_dtype[k];
+    t.mask_out[k] = plan.mask_out[k];
     const bool masked = (plan.mask_bits >> k) & 1u;
     if (masked) {
       const int es = dtype_size(plan.mask_dtype[k]);
-      if (es == 0 || plan.key[k].rowbytes % es || k == a.inline_key) return hipErrorInvalidValue;
-      a.unit[k] = es;
+      if (es == 0 || plan.key[k].rowbytes % es || k == t.inline_key) return hipErrorInvalidValue;
+      t.unit[k] = es;
     } else
-    a.unit[k] = (k == a.inline_key) ? 4 : pick_unit(plan.key[k]);
-    a.first_block[k] = static_cast<int32_t>(blocks);
-    if (a.unit[k] == 0 && span_path) {
+    t.unit[k] = (k == t.inline_key) ? 4 : pick_unit(plan.key[k]);
+    t.first_block[k] = static_cast<int32_t>(blocks);
+    if (t.unit[k] == 0 && span_path) {
       // tiles of threads * unroll units per sequence; no virtual blocks
-      const int64_t per_seq = static_cast<int64_t>(a.seq_len) * (plan.key[k].rowbytes >> 4);
+      const int64_t per_seq = static_cast<int64_t>(t.seq_len) * (plan.key[k].rowbytes >> 4);
       const int64_t tps = (per_seq + threads * unroll - 1) / (threads * unroll);
       const int64_t first = h.ntiles;
       if (per_seq > UINT32_MAX / 2 || first + tps * plan.n_seq > UINT32_MAX / 2) return hipErrorInvalidValue;
@@ -718,21 +760,21 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
       h.tile0[h.n_wide] = static_cast<uint32_t>(first);
       h.ntiles = static_cast<uint32_t>(first + tps * plan.n_seq);
       ++h.n_wide;
-    } else if (a.unit[k] == 0) {
+    } else if (t.unit[k] == 0) {
       const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes >> 4);
       if (units > UINT32_MAX / 2) return hipErrorInvalidValue;
       blocks += (units + threads * unroll - 1) / (threads * unroll);
     } else {
-      const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes / a.unit[k]);
+      const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes / t.unit[k]);
       blocks += (units + threads - 1) / threads;
     }
     if (blocks > INT32_MAX) return hipErrorInvalidValue;
   }
-  a.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
+  t.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
   out->blocks = static_cast<uint32_t>(blocks);
   if (span_path) {
     h.wide_workers = static_cast<int32_t>(std::min<int64_t>(h.ntiles, int64_t(kCUs) * sv.per_cu));
-    h.seq_len = a.seq_len;
+    h.seq_len = t.seq_len;
     if (blocks + h.wide_workers > INT32_MAX) return hipErrorInvalidValue;
     out->blocks = static_cast<uint32_t>(blocks + h.wide_workers);
   } else if (variant.persist > 0 && blocks > 256ll * variant.persist) {
@@ -747,13 +789,14 @@ size_t move_args_bytes() { return sizeof(MoveArgs); }
 hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t stream,
                               hipEvent_t stop) {
   const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
-  // Eight workgroups, one per XCD (workgroup b runs on XCD b % 8): each writes
-  // the same bytes, so the block is in EVERY XCD's L2 when the mover's
-  // workgroups ask for it (the L2s are per XCD; one writer leaves seven cold).
+  // EMB_ARGS_WRITERS=8 puts one writer on every XCD (workgroup b runs on XCD
+  // b % 8), so the block is in every XCD's L2 when the mover asks for it:
+  // measured -0.15 us on the gather and +3.2 us on this kernel (eight PCIe
+  // readers), so one writer is the default.
   static const int writers = [] {
     const char* e = std::getenv("EMB_ARGS_WRITERS");
-    const int n = e ? std::atoi(e) : 8;
-    return n >= 1 && n <= 64 ? n : 8;
+    const int n = e ? std::atoi(e) : 1;
+    return n >= 1 && n <= 64 ? n : 1;
   }();
   hipExtLaunchKernelGGL(args_writer_kernel, dim3(writers), dim3(256), 0, stream, nullptr, stop, 0, a,
                         static_cast<u32x4*>(device_dst));
@@ -790,8 +833,10 @@ hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device
 #define EMB_MOVE(U_, NT_)                                                                      \
   do {                                                                                         \
     if (gather && ap) hipExtLaunchKernelGGL((gather_kernel_indirect<U_, NT_>), grid, block, 0, stream, start, stop, 0, ap); \
+    else if (gather && launch.stage_tables) hipExtLaunchKernelGGL((gather_kernel_staged<U_, NT_>), grid, block, 0, stream, start, stop, 0, a); \
     else if (gather) hipExtLaunchKernelGGL((gather_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);            \
     else if (ap) hipExtLaunchKernelGGL((scatter_kernel_indirect<U_, NT_>), grid, block, 0, stream, start, stop, 0, ap);     \
+    else if (launch.stage_tables) hipExtLaunchKernelGGL((scatter_kernel_staged<U_, NT_>), grid, block, 0, stream, start, stop, 0, a); \
     else hipExtLaunchKernelGGL((scatter_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);                       \
   } while (0)
 #define EMB_MOVE_NT(U_)                                                          \
