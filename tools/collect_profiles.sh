@@ -31,11 +31,11 @@ for counter in FETCH_SIZE WRITE_SIZE; do
     python "$R/bench.py" --steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context > /dev/null 2>&1
   python "$R/tools/summarize_pmc.py" /tmp/p_$counter/p_counter_collection.csv > "$O/pmc_$counter.csv"
 done
-python "$R/tools/bench_gather.py" --batches 1,4,8,16,32,64,128,256 --tight > "$O/gather_sweep.txt" 2>&1
+HIP_FORCE_DEV_KERNARG=0 python "$R/tools/bench_gather.py" --batches 1,4,8,16,32,64,128,256 --tight > "$O/gather_sweep.txt" 2>&1
 HIP_FORCE_DEV_KERNARG=1 python "$R/tools/bench_gather.py" --batches 1,4,8,16,32,64,128,256 --tight > "$O/gather_sweep_device_kernargs.txt" 2>&1
 "$R/tools/build/gather_lab" 16 200 4 > "$O/gather_lab_B16.txt" 2>&1 || true
-python "$R/tools/profile_step.py" > "$O/profile_step.txt" 2>&1
-python "$R/tools/profile_train.py" 2>&1 | head -8 > "$O/profile_train.txt"
+HIP_FORCE_DEV_KERNARG=0 python "$R/tools/profile_step.py" > "$O/profile_step.txt" 2>&1
+HIP_FORCE_DEV_KERNARG=0 python "$R/tools/profile_train.py" 2>&1 | head -8 > "$O/profile_train.txt"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/km -o km -- \
   python "$R/tools/bench_kernels.py" > /dev/null 2>&1
 cp /tmp/km/km_kernel_trace.csv "$O/kernels_micro_trace.csv" 2>/dev/null || true
