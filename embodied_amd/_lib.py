@@ -253,6 +253,8 @@ class _FastApi:
 
   def __init__(self, module):
     self.module = module
+    # Replay.add_batch's per-key checks in C (None: the Python loop is used).
+    self.columns = getattr(module, 'columns', None)
     for name, shape in self.SHAPES.items():
       if module is None:
         setattr(self, name, getattr(api, name))

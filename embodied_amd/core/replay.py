@@ -356,18 +356,33 @@ class Replay:
       if plan is None or plan[0] != order or plan[1] != n:
         plan = self._add_plan = (order, n, self._plan_columns(order, n))
       keep, index, Tensor = [], device.index, torch.Tensor
-      for value, (i, dtype, shape, name) in zip(steps.values(), plan[2]):
-        if i < 0:
-          continue                                    # 'log/*': not stored
-        # Usual case: a contiguous tensor of the key's dtype and shape on this GPU.
-        if not (type(value) is Tensor and value.dtype is dtype and value.shape == shape
-                and value.is_contiguous() and value.get_device() == index):
-          if not torch.is_tensor(value):
-            value = torch.from_numpy(np.ascontiguousarray(value))
-          if tuple(value.shape) != shape:
-            raise ValueError((name, tuple(value.shape), shape))
-          value = value.to(device, dtype, non_blocking=True).contiguous()
-          keep.append(value)
+      columns = plan[2]
+      if fast.columns is not None:
+        # The usual case (contiguous tensors of the key's dtype and shape on this
+        # GPU) is checked and its addresses taken in C; what is left comes back
+        # as a list of positions.
+        todo = fast.columns(steps, columns, ptrs, Tensor, index)
+        if todo:
+          values = list(steps.values())
+          todo = [(values[at], columns[at]) for at in todo]
+      else:
+        todo = []
+        for value, column in zip(steps.values(), columns):
+          i, dtype, shape, name = column
+          if i < 0:
+            continue                                    # 'log/*': not stored
+          if (type(value) is Tensor and value.dtype is dtype and value.shape == shape
+              and value.is_contiguous() and value.get_device() == index):
+            ptrs[i] = value.data_ptr()
+          else:
+            todo.append((value, column))
+      for value, (i, dtype, shape, name) in todo or ():
+        if not torch.is_tensor(value):
+          value = torch.from_numpy(np.ascontiguousarray(value))
+        if tuple(value.shape) != shape:
+          raise ValueError((name, tuple(value.shape), shape))
+        value = value.to(device, dtype, non_blocking=True).contiguous()
+        keep.append(value)
         ptrs[i] = value.data_ptr()
       masked = None
       if mask is not None:
@@ -417,7 +432,7 @@ class Replay:
       seen += 1
     if seen + 1 != len(self._keys):
       raise KeyError(f'replay step keys {sorted(order)} differ from the first step')
-    return columns
+    return tuple(columns)
 
   # ----------------------------------------------------------------- sample --
 

@@ -161,6 +161,102 @@ static PyObject* call_scan(PyObject* self, PyObject* const* args, Py_ssize_t nar
   return PyLong_FromLong(status);
 }
 
+/* columns(steps: dict, plan: tuple, out: writable buffer of void*, tensor_type,
+ *         device_index) -> None | list of positions
+ *
+ * Replay.add_batch's per-key loop: for every (name, value) of `steps`, in order,
+ * with plan[i] = (column, dtype, shape, name): if `value` is exactly a
+ * `tensor_type` of that dtype and shape, contiguous, on GPU `device_index`, its
+ * data_ptr() goes to out[column]; otherwise the position is reported back and
+ * the caller converts that value the slow way.  column < 0 = not stored.
+ * The same checks as the Python loop, minus the interpreter between them. */
+static PyObject *s_dtype, *s_shape, *s_is_contiguous, *s_get_device, *s_data_ptr;
+
+static PyObject* call_columns(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 5 || !PyDict_Check(args[0]) || !PyTuple_Check(args[1])) {
+    PyErr_SetString(PyExc_TypeError, "fastcall.columns(dict, plan tuple, buffer, type, device)");
+    return NULL;
+  }
+  PyObject* steps = args[0];
+  PyObject* plan = args[1];
+  PyTypeObject* tensor_type = (PyTypeObject*)args[3];
+  const long device = PyLong_AsLong(args[4]);
+  if (device == -1 && PyErr_Occurred()) return NULL;
+  if (PyDict_GET_SIZE(steps) != PyTuple_GET_SIZE(plan)) {
+    PyErr_SetString(PyExc_ValueError, "fastcall.columns: plan does not match the dict");
+    return NULL;
+  }
+  Py_buffer view;
+  if (PyObject_GetBuffer(args[2], &view, PyBUF_WRITABLE) < 0) return NULL;
+  u64* out = (u64*)view.buf;
+  const Py_ssize_t slots = view.len / (Py_ssize_t)sizeof(u64);
+  PyObject* slow = NULL;
+  PyObject *name, *value;
+  Py_ssize_t pos = 0, i = 0;
+  int failed = 0;
+  while (!failed && PyDict_Next(steps, &pos, &name, &value)) {
+    PyObject* item = PyTuple_GET_ITEM(plan, i);
+    const long column = PyLong_AsLong(PyTuple_GET_ITEM(item, 0));
+    if (column < 0 || column >= slots) {
+      if (column >= slots) { PyErr_SetString(PyExc_IndexError, "fastcall.columns: column"); failed = 1; }
+      ++i;
+      continue;
+    }
+    int ok = Py_TYPE(value) == tensor_type;
+    PyObject* r;
+    if (ok) {
+      r = PyObject_GetAttr(value, s_dtype);
+      if (!r) { failed = 1; break; }
+      ok = r == PyTuple_GET_ITEM(item, 1);
+      Py_DECREF(r);
+    }
+    if (ok) {
+      r = PyObject_GetAttr(value, s_shape);
+      if (!r) { failed = 1; break; }
+      const int eq = PyObject_RichCompareBool(r, PyTuple_GET_ITEM(item, 2), Py_EQ);
+      Py_DECREF(r);
+      if (eq < 0) { failed = 1; break; }
+      ok = eq;
+    }
+    if (ok) {
+      r = PyObject_CallMethodNoArgs(value, s_is_contiguous);
+      if (!r) { failed = 1; break; }
+      ok = r == Py_True;
+      Py_DECREF(r);
+    }
+    if (ok) {
+      r = PyObject_CallMethodNoArgs(value, s_get_device);
+      if (!r) { failed = 1; break; }
+      const long where = PyLong_AsLong(r);
+      Py_DECREF(r);
+      if (where == -1 && PyErr_Occurred()) { failed = 1; break; }
+      ok = where == device;
+    }
+    if (ok) {
+      r = PyObject_CallMethodNoArgs(value, s_data_ptr);
+      if (!r) { failed = 1; break; }
+      u64 address = 0;
+      const int bad = as_u64(r, &address);
+      Py_DECREF(r);
+      if (bad < 0) { failed = 1; break; }
+      out[column] = address;
+    } else {
+      if (!slow && !(slow = PyList_New(0))) { failed = 1; break; }
+      PyObject* index = PyLong_FromSsize_t(i);
+      if (!index || PyList_Append(slow, index) < 0) { Py_XDECREF(index); failed = 1; break; }
+      Py_DECREF(index);
+    }
+    ++i;
+  }
+  PyBuffer_Release(&view);
+  if (failed) {
+    Py_XDECREF(slow);
+    return NULL;
+  }
+  if (slow) return slow;
+  Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     {"ints", (PyCFunction)(void (*)(void))call_ints, METH_FASTCALL,
      "ints(addr, *args) -> status: call an int32 f(pointers/integers...)"},
@@ -168,6 +264,8 @@ static PyMethodDef methods[] = {
      "obs_stack(addr, *11 args) -> status"},
     {"scan", (PyCFunction)(void (*)(void))call_scan, METH_FASTCALL,
      "scan(addr, *10 or 11 args) -> status"},
+    {"columns", (PyCFunction)(void (*)(void))call_columns, METH_FASTCALL,
+     "columns(steps, plan, out, tensor_type, device) -> None | positions for the slow path"},
     {NULL, NULL, 0, NULL},
 };
 
@@ -176,4 +274,12 @@ static struct PyModuleDef module = {
     "Low-overhead calls into libembodied_hip.so by function address.", -1, methods,
 };
 
-PyMODINIT_FUNC PyInit__emb_fastcall(void) { return PyModule_Create(&module); }
+PyMODINIT_FUNC PyInit__emb_fastcall(void) {
+  s_dtype = PyUnicode_InternFromString("dtype");
+  s_shape = PyUnicode_InternFromString("shape");
+  s_is_contiguous = PyUnicode_InternFromString("is_contiguous");
+  s_get_device = PyUnicode_InternFromString("get_device");
+  s_data_ptr = PyUnicode_InternFromString("data_ptr");
+  if (!s_dtype || !s_shape || !s_is_contiguous || !s_get_device || !s_data_ptr) return NULL;
+  return PyModule_Create(&module);
+}
