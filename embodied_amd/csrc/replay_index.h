@@ -420,14 +420,17 @@ class ReplayIndex {
     const uint64_t uid = items_.front().first;
     items_.pop_front();
     ++first_item_;
-    // Consecutive evictions usually hit the same chunk: remember the node.
-    if (!evict_hint_ || evict_hint_->uid != uid) evict_hint_ = &chunks_.at(uid);
-    Chunk& chunk = *evict_hint_;
+    // With N workers consecutive evictions cycle through N chunks: a small
+    // direct-mapped table of nodes (stable addresses) instead of a hash lookup
+    // per eviction.
+    Chunk*& hint = evict_hint_[uid & (kHints - 1)];
+    if (!hint || hint->uid != uid) hint = &chunks_.at(uid);
+    Chunk& chunk = *hint;
     chunk.refs -= 1;
     if (chunk.refs < 1) {
       const uint64_t succ = chunk.succ;
       free_[chunk.slot / (cfg_.n_slots / cfg_.owners)].push_back(chunk.slot);
-      evict_hint_ = nullptr;
+      hint = nullptr;
       chunks_.erase(uid);
       auto nx = chunks_.find(succ);
       if (nx != chunks_.end()) nx->second.refs -= 1;
@@ -446,7 +449,8 @@ class ReplayIndex {
   std::unordered_map<int64_t, std::unique_ptr<Worker>> workers_;
   std::vector<Worker*> dense_;
   std::deque<Pos> fresh_;
-  Chunk* evict_hint_ = nullptr;
+  static constexpr uint64_t kHints = 256;
+  Chunk* evict_hint_[kHints] = {};
   int64_t metrics_[3] = {0, 0, 0};
   mutable std::vector<Span> scratch_;
   std::vector<StepId> ids_;
