@@ -72,6 +72,10 @@ struct MoveLaunch {
 };
 hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out);
 size_t move_args_bytes();
+// An empty one-wave kernel whose completion is stamped with `stop`: put in front
+// of a timed launch it takes the previous (unstamped) kernel's end-of-kernel
+// release into ITS window instead of the timed one's.
+hipError_t launch_marker(hipStream_t stream, hipEvent_t stop);
 // Copies launch.args into device memory with a one-workgroup kernel (its own
 // arguments may live in host memory); `stop` (optional) stamps its completion.
 hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t stream,

@@ -786,6 +786,15 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
 
 size_t move_args_bytes() { return sizeof(MoveArgs); }
 
+namespace {
+__global__ void marker_kernel() {}
+}  // namespace
+
+hipError_t launch_marker(hipStream_t stream, hipEvent_t stop) {
+  hipExtLaunchKernelGGL(marker_kernel, dim3(1), dim3(64), 0, stream, nullptr, stop, 0);
+  return hipGetLastError();
+}
+
 hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t stream,
                               hipEvent_t stop) {
   const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
