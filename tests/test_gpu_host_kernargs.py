@@ -36,3 +36,16 @@ def test_parity_with_the_flat_mover_only():
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
+
+
+def test_parity_with_the_argument_writer_kernel():
+  """Host-resident kernel arguments on a system WITHOUT a large BAR: the movers'
+  argument blocks reach device memory through the one-workgroup writer kernel
+  (EMB_ARGS_BAR=0 forces that route here)."""
+  env = dict(os.environ, HIP_FORCE_DEV_KERNARG='0', EMB_ARGS_BAR='0')
+  res = subprocess.run(
+      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-m', 'gpu', '-q', '-x',
+       '-k', 'full_size or update_roundtrip or very_large_rows or fused_sample'],
+      cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+  assert ' passed' in res.stdout
