@@ -24,12 +24,9 @@ import time
 # setting, read when HIP starts): every launch is ~1.6 us cheaper for the host
 # (4.6 -> 3.0 us on MI355X), and the PPO step is launch-bound.  Waves then read
 # their arguments across PCIe, which is why the big movers get a device copy
-# of their argument block (abi.cpp run_move).  The Dreamer workload is bound by
-# its 144 MB gathers and 84 MB write-backs, not by launches, and keeps the
-# runtime's default.  HIP_FORCE_DEV_KERNARG=1/0 in the environment overrides;
-# DESIGN.md 4 has both sets of numbers.
-if not any('dreamer' in arg for arg in sys.argv[1:]):
-  os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
+# of their argument block (abi.cpp run_move).  HIP_FORCE_DEV_KERNARG=1/0 in the
+# environment overrides; DESIGN.md 4 has both sets of numbers.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
 
 import numpy as np
 import torch
@@ -414,7 +411,7 @@ def main():
     achieved = algo_bytes / avg_s / 1e9
     roofline = {
         'bound': 'hbm',
-        'kernel': ('span_move_kernel<gather> (Replay.sample)' if algo_bytes // 2 <= 40_000_000
+        'kernel': ('span_move_kernel<gather> (Replay.sample)' if algo_bytes // 2 <= 160_000_000
                    or os.environ.get('HIP_FORCE_DEV_KERNARG') == '0'
                    else 'gather_kernel (Replay.sample)'),
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -751,7 +751,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     plan.rows = reinterpret_cast<const int32_t*>(lease.device);
   }
   emb::MoveLaunch launch;
-  HIP_OK(emb::prepare_move(plan, &launch));
+  HIP_OK(emb::prepare_move(plan, &launch, gather));
   // Processes that keep kernel arguments in host memory (HIP_FORCE_DEV_KERNARG=0,
   // cheaper launches) pay PCIe latency on every wave's argument reads: for big
   // moves hand the kernel a device copy of its arguments instead.

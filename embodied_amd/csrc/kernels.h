@@ -70,7 +70,7 @@ struct MoveLaunch {
   bool span = false;       // persistent span mover (wide keys of a span table)
   bool stage_tables = false;   // arguments in host memory: by-value flat movers stage their tables in LDS
 };
-hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out);
+hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather = true);
 size_t move_args_bytes();
 // An empty one-wave kernel whose completion is stamped with `stop`: put in front
 // of a timed launch it takes the previous (unstamped) kernel's end-of-kernel

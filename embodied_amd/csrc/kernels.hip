@@ -512,7 +512,9 @@ __global__ __launch_bounds__(1024) void gather_kernel_staged(const MoveArgs a) {
 }
 template <int U, int NT>
 __global__ __launch_bounds__(1024) void gather_kernel_indirect(const MoveArgs* __restrict__ a) {
-  gather_body<U, NT>(*a, a->t);
+  __shared__ MoveTables tables;     // one load latency instead of a chain of scalar loads
+  stage_tables(reinterpret_cast<const u32x4*>(a), &tables);
+  gather_body<U, NT>(*a, tables);
 }
 template <int U, int NT>
 __global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) { scatter_body<U, NT>(a, a.t); }
@@ -524,7 +526,9 @@ __global__ __launch_bounds__(1024) void scatter_kernel_staged(const MoveArgs a) 
 }
 template <int U, int NT>
 __global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* __restrict__ a) {
-  scatter_body<U, NT>(*a, a->t);
+  __shared__ MoveTables tables;
+  stage_tables(reinterpret_cast<const u32x4*>(a), &tables);
+  scatter_body<U, NT>(*a, tables);
 }
 
 // Span-mode launch: the first `wide_workers` workgroups are the persistent wide
@@ -602,15 +606,16 @@ const MoveVariant& move_variant() {
 // and persistent workgroups per CU; W=0 turns the path off (flat mover for
 // everything).  Defaults from tools/gather_lab.hip on MI355X.
 //
-// The persistent mover wins while the launch is ramp-dominated and loses to
-// the flat mover's many short-lived workgroups once every worker has more than
-// a few tiles (MI355X, S0 rows, kernel us persistent / flat: B=8 7.2 / 8.7,
-// B=16 11.0 / 13.4, B=32 23.1 / 22.5, B=64 44.0 / 40.5, B=128 85.8 / 77.0), so
-// it is used up to `max_mb` MB of wide payload per launch (fifth field).
+// The persistent mover wins clearly while the launch is ramp-dominated and stays
+// level with the flat mover's many short-lived workgroups far beyond that
+// (MI355X, S0 rows, kernel us persistent / flat: B=8 6.8 / 8.7, B=16 10.7 / 13.4,
+// B=32 22.5 / 23.5, B=64 41.7 / 42.1, B=128 81.6 / 79.4; Dreamer keys, 144 MB:
+// 26.8 / 28.7), so it is used up to `max_mb` MB of wide payload per launch
+// (fifth field).
 struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; };
 const SpanVariant& span_variant() {
   static const SpanVariant variant = [] {
-    SpanVariant v{4, 3, 512, 2, 40};
+    SpanVariant v{4, 3, 512, 2, 160};
     if (const char* s = std::getenv("EMB_SPAN_VARIANT"))
       std::sscanf(s, "%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb);
     if (v.unroll != 2 && v.unroll != 4) v.unroll = 4;
@@ -659,7 +664,7 @@ static_assert(sizeof(MoveArgs) <= kMoveArgsBytes, "MoveLaunch::args too small");
 
 }  // namespace
 
-hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
+hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   out->blocks = 0;
   const int inline_need = inline_words_needed(plan);
   const bool use_inline = inline_need > 0 && (plan.spans_host || plan.rows_host);
@@ -679,12 +684,17 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out) {
         wide_bytes += plan.key[k].rowbytes * static_cast<int64_t>(plan.n_rows);
         ++wide_keys;
       }
-    // With kernel arguments in host memory the flat mover's thousands of
-    // workgroups each fetch their plan through a pointer (Dreamer-sized sample,
-    // 3 wide keys, 144 MB: 37 us flat-indirect against 29 us through the span
-    // mover's 512 workgroups), so there the span mover takes every size.
+    // Gathers up to max_mb MB of wide payload; scatters (write-back) up to 40 MB:
+    // the flat scatter streams 84 MB of Dreamer latents at 6.4-6.8 TB/s (13 us),
+    // the persistent one takes 17.6 us for the same bytes.
+    // With host-resident kernel arguments the big movers read their plan from a
+    // ring in fine-grained (uncached) device memory: the span mover touches it
+    // once per workgroup (the staged head), the flat mover's waves walk it with
+    // dependent reads (84 MB write-back: 20.3 us flat-indirect, 17.6 us span) —
+    // there the span mover takes every size.
+    const int64_t limit_mb = gather ? sv.max_mb : (sv.max_mb < 40 ? sv.max_mb : 40);
     span_path = wide_bytes > 0 && wide_keys <= kSpanKeys &&
-                (plan.args_in_host_memory || wide_bytes <= static_cast<int64_t>(sv.max_mb) * 1000000);
+                (plan.args_in_host_memory || wide_bytes <= limit_mb * 1000000);
   }
   const int unroll = span_path ? sv.unroll : variant.unroll;
   const int threads = span_path ? sv.threads : variant.threads;
@@ -1268,7 +1278,7 @@ __global__ __launch_bounds__(kThreads) void synth_env_kernel(
 hipError_t launch_gather(const MovePlan& plan, hipStream_t stream, hipEvent_t start,
                          hipEvent_t stop) {
   MoveLaunch launch;
-  const hipError_t e = prepare_move(plan, &launch);
+  const hipError_t e = prepare_move(plan, &launch, true);
   return e != hipSuccess ? e : launch_move(launch, true, nullptr, stream, start, stop);
 }
 
@@ -1276,7 +1286,7 @@ bool plan_fits_inline(const MovePlan& plan) { return inline_words_needed(plan) >
 
 hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream) {
   MoveLaunch launch;
-  const hipError_t e = prepare_move(plan, &launch);
+  const hipError_t e = prepare_move(plan, &launch, false);
   return e != hipSuccess ? e : launch_move(launch, false, nullptr, stream, nullptr, nullptr);
 }
 
