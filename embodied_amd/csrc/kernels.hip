@@ -783,7 +783,19 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   t.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
   out->blocks = static_cast<uint32_t>(blocks);
   if (span_path) {
-    h.wide_workers = static_cast<int32_t>(std::min<int64_t>(h.ntiles, int64_t(kCUs) * sv.per_cu));
+    // As many workers as the chip takes at once, trimmed so that every worker
+    // walks the same number of tiles (896 tiles: 448 workers x 2 rounds instead
+    // of 512 x 1.75); EMB_SPAN_BALANCE=0 keeps the untrimmed count.
+    static const bool balance = [] {
+      const char* e = std::getenv("EMB_SPAN_BALANCE");
+      return !(e && e[0] == '0');
+    }();
+    int64_t workers = std::min<int64_t>(h.ntiles, int64_t(kCUs) * sv.per_cu);
+    if (balance && workers > 0) {
+      const int64_t rounds = (h.ntiles + workers - 1) / workers;
+      workers = (h.ntiles + rounds - 1) / rounds;
+    }
+    h.wide_workers = static_cast<int32_t>(workers);
     h.seq_len = t.seq_len;
     if (blocks + h.wide_workers > INT32_MAX) return hipErrorInvalidValue;
     out->blocks = static_cast<uint32_t>(blocks + h.wide_workers);
