@@ -348,11 +348,20 @@ def main():
     torch.cuda.synchronize(device)
 
   fence()
+  trace = os.environ.get('EMB_BENCH_TRACE_STEPS') == '1'     # per-step host times of a short region
+  stamps = []
   start = time.perf_counter()
   for _ in range(args.steps):
     one_step()
+    if trace:
+      stamps.append(time.perf_counter())
+  before_fence = time.perf_counter()
   fence()
   elapsed = time.perf_counter() - start
+  if trace and rank == 0:
+    steps_us = [round((b - a) * 1e6) for a, b in zip([start] + stamps, stamps)]
+    print('per-step us:', steps_us[:40], 'final fence us:',
+          round((start + elapsed - before_fence) * 1e6), file=sys.stderr)
   if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
