@@ -160,10 +160,10 @@ class ArgRing {
           hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && large &&
           hipExtMallocWithFlags(reinterpret_cast<void**>(&dev_), kSlots * kSlotBytes,
                                 hipDeviceMallocFinegrained) == hipSuccess) {
-        events_.resize(kSlots);
+        events_.resize(kSlots / kGroup);
         bool ok = true;
         for (auto& e : events_) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        busy_.assign(kSlots, false);
+        busy_.assign(kSlots / kGroup, false);
         if (ok) state_ = 1;
       }
       (void)hipGetLastError();
@@ -171,27 +171,45 @@ class ArgRing {
     return state_ == 1;
   }
   // Copies `bytes` (<= 4 KiB) of arguments into the next slot; returns its
-  // device address.  Call retire() after the launch that reads it.
-  void* put(const void* args, size_t bytes) {
+  // device address.  Call retire() after the launch that reads it.  Slots are
+  // guarded in groups of kGroup with one event per group (an event record costs
+  // the host ~3.7 us: once per eight launches, not once per launch): a group is
+  // entered again only after the event recorded behind its last launch is done.
+  void* put(const void* args, size_t bytes, hipStream_t stream) {
+    if (next_ % kGroup != 0 && stream != group_stream_) {
+      // Another stream takes over in the middle of a group (actor / learner):
+      // close the group on the stream that filled it so far, start a new one.
+      HIP_OK(hipEventRecord(events_[next_ / kGroup], group_stream_));
+      busy_[next_ / kGroup] = true;
+      next_ = (next_ / kGroup + 1) * kGroup % kSlots;
+    }
     slot_ = next_;
     next_ = (next_ + 1) % kSlots;
-    if (busy_[slot_]) {
-      HIP_OK(hipEventSynchronize(events_[slot_]));
-      busy_[slot_] = false;
+    const int group = slot_ / kGroup;
+    if (slot_ % kGroup == 0) {
+      if (busy_[group]) {
+        HIP_OK(hipEventSynchronize(events_[group]));
+        busy_[group] = false;
+      }
+      group_stream_ = stream;
     }
     uint8_t* dst = dev_ + static_cast<size_t>(slot_) * kSlotBytes;
     std::memcpy(dst, args, bytes);
     __builtin_ia32_sfence();
     return dst;
   }
+  // After the launch that reads the slot `put` returned (same stream).
   void retire(hipStream_t stream) {
-    HIP_OK(hipEventRecord(events_[slot_], stream));
-    busy_[slot_] = true;
+    if (slot_ % kGroup == kGroup - 1) {
+      HIP_OK(hipEventRecord(events_[slot_ / kGroup], stream));
+      busy_[slot_ / kGroup] = true;
+    }
   }
 
  private:
-  static constexpr int kSlots = 64;
+  static constexpr int kSlots = 64, kGroup = 8;
   static constexpr size_t kSlotBytes = 4096;
+  hipStream_t group_stream_ = nullptr;
   int state_ = 0;          // 0 unknown, 1 usable, -1 not
   uint8_t* dev_ = nullptr;
   std::vector<hipEvent_t> events_;
@@ -770,7 +788,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
       }
       if (rep->arg_ring.usable()) {
         // The CPU writes the block into device memory through the BAR.
-        device_args = rep->arg_ring.put(launch.args, emb::move_args_bytes());
+        device_args = rep->arg_ring.put(launch.args, emb::move_args_bytes(), stream);
         args_in_bar = true;
         // A timed gather wants a predecessor that carries a completion stamp
         // (see stamp_predecessors): a one-lane marker kernel, only then.
