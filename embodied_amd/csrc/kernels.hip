@@ -693,8 +693,12 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
     // dependent reads (84 MB write-back: 20.3 us flat-indirect, 17.6 us span) —
     // there the span mover takes every size.
     const int64_t limit_mb = gather ? sv.max_mb : (sv.max_mb < 40 ? sv.max_mb : 40);
+    static const bool host_all = [] {       // EMB_SPAN_HOST_ALL=0: size limits in host mode too (A/B)
+      const char* e = std::getenv("EMB_SPAN_HOST_ALL");
+      return !(e && e[0] == '0');
+    }();
     span_path = wide_bytes > 0 && wide_keys <= kSpanKeys &&
-                (plan.args_in_host_memory || wide_bytes <= limit_mb * 1000000);
+                ((plan.args_in_host_memory && host_all) || wide_bytes <= limit_mb * 1000000);
   }
   const int unroll = span_path ? sv.unroll : variant.unroll;
   const int threads = span_path ? sv.threads : variant.threads;
