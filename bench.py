@@ -238,21 +238,28 @@ def main():
       issue = D.Done
 
   def train_step():
-    if not use_dist and args.workload == 'dreamer':
+    if args.workload == 'dreamer':
       # sample -> lambda-returns (replay (B,T) and imagination (B*K,H+1)) ->
       # write the new latents back over the sampled steps (agent.py:144-150).
+      # With ranks (configs[3]): every rank's Replay is its own, the one
+      # collective per train step is the gradient all-reduce, waited for one
+      # train step later.
       batch = next(stream)
       adv = emb.scans.lambda_return(
           batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95)
       emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
       replay.update({'stepid': batch['stepid'], 'dyn/deter': batch['dyn/deter'],
                      'dyn/stoch': batch['dyn/stoch']})
+      if use_dist and args.grad_numel:
+        for future in pending:
+          future.result().wait()
+        pending.clear()
+        pending.append(issue(lambda: D.async_all_reduce(grads)))
     elif not use_dist:
       batch = next(stream)
       adv, tar = emb.scans.gae(
           batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
     else:
-      from embodied_amd import distributed as D
       # Sample straight into one packed buffer so the trajectory exchange is a
       # single RCCL all-gather; both collectives run async on RCCL's stream and
       # are waited for one train step later (the reference returns train outs
@@ -495,7 +502,9 @@ def main():
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
             'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
-            'parallelism': (f'env-sharded x{world}, trajectory exchange {args.exchange} + '
+            'parallelism': (f'env-sharded x{world}, '
+                            + ('per-rank Replay, ' if args.workload == 'dreamer'
+                               else f'trajectory exchange {args.exchange} + ') +
                             f'{args.grad_numel * (2 if args.grad_dtype == "bf16" else 4) >> 20} MiB '
                             f'{args.grad_dtype} grad all-reduce per train step (RCCL)')
                            if use_dist else 'single',

@@ -37,6 +37,18 @@ def test_bench_gpus_2_spawns_two_ranks():
   assert rec['roofline']['launches'] >= 1          # rank 0's gathers inside the timed region
 
 
+def test_bench_dreamer_workload_with_ranks():
+  """configs[3]'s shape of parallelism: per-rank Replay (sample, lambda-return,
+  latent write-back) and one gradient all-reduce per train step."""
+  rec = run_bench('--gpus', '2', '--workload', 'dreamer', '--capacity', '20000', '--steps', '40',
+                  '--warmup', '5', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
+                  env={'EMB_BENCH_BACKEND': 'gloo'})
+  assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2
+  assert 'per-rank Replay' in rec['config']['parallelism']
+  assert 'lambda-return' in rec['config']['workload']
+  assert rec['train_steps_per_s'] > 0 and rec['roofline']['launches'] >= 1
+
+
 def test_bench_short_run_keeps_its_shape():
   """The driver's short form on one GPU: the line carries roofline, the
   sustained window and the CPU baseline; the headline region is exactly --steps."""
