@@ -473,6 +473,13 @@ def main():
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ppo' and not args.host_envs:
     cpu = cpu_baseline(args)
 
+  native, native_stuck = None, False
+  if use_dist and dist.get_backend() == 'nccl' and os.environ.get('EMB_BENCH_NATIVE_COMM') != '0':
+    fence()
+    native, native_stuck = native_comm_check(
+        rank, world, device, args.grad_numel, grad_dtype,
+        B * args.prefetch * L * S // max(world, 1))
+
   if rank == 0:
     # Libraries that wrote to C stdio (RCCL's version banner) come out first, so
     # that the JSON line is the last line on stdout.
@@ -511,11 +518,100 @@ def main():
         },
         'sustained': sustained,
         'roofline': roofline, 'cpu_baseline': cpu,
+        **({'native_comm': native} if native is not None else {}),
     }), flush=True)
+  if native_stuck:       # a collective of the check never returned: leave without the teardown
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
   if use_dist:
     if comm is not None:
       comm.close()
     dist.destroy_process_group()
+
+
+def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, seconds=120.0):
+  """Ranks only, after the timed regions (no part of `value`): the library's own
+  RCCL entry points (`emb_comm_*`, include/embodied_hip.h) on the GPUs of this
+  job, checked against torch.distributed on the same bytes -- all-gather, the
+  DP-slice all-to-all, f32 and bf16 gradient all-reduce -- with the host cost
+  per call of both routes.  Runs under a watchdog: whatever happens in here, the
+  JSON line is printed."""
+  import threading
+  import torch.distributed as dist
+  from embodied_amd import distributed as D
+  result = {'status': 'timeout'}
+
+  def body():
+    torch.cuda.set_device(device)
+    comm = D.NativeComm(rank, world, device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(977 + rank)
+    block = max(16, slice_bytes // 16 * 16)
+    flat = torch.randint(0, 256, (world * block,), dtype=torch.uint8, device=device, generator=gen)
+    checks = {}
+    mine, ref = comm.all_gather(flat[:block].contiguous()), torch.empty_like(flat)
+    dist.all_gather_into_tensor(ref, flat[:block].contiguous())
+    checks['all_gather'] = bool(torch.equal(mine, ref))
+    mine, ref = comm.all_to_all(flat), torch.empty_like(flat)
+    dist.all_to_all_single(ref, flat)
+    checks['all_to_all'] = bool(torch.equal(mine, ref))
+    # Small integers: sums over ranks are exact in f32 and bf16, so the two
+    # routes must agree to the bit whatever order the links add in.
+    for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+      whole = torch.randint(-8, 9, (1 << 20,), device=device, generator=gen).to(dtype)
+      a, b = whole.clone(), whole.clone()
+      comm.all_reduce(a, mean=False)
+      dist.all_reduce(b)
+      checks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, b))
+      a, b = torch.randn(1 << 20, device=device, generator=gen).to(dtype), None
+      b = a.clone()
+      comm.all_reduce(a, mean=True)
+      dist.all_reduce(b, op=dist.ReduceOp.AVG)
+      tol = 1e-5 if dtype == torch.float32 else 2e-2
+      checks[f'all_reduce_mean_{name}'] = bool(torch.allclose(a.float(), b.float(), rtol=tol, atol=tol))
+    # Host and end-to-end cost per call at the job's own sizes.
+    grads = torch.zeros(max(grad_numel, 1), dtype=grad_dtype, device=device)
+    recv = torch.empty_like(flat)
+    routes = {
+        'native_all_reduce': lambda: comm.all_reduce(grads, mean=True),
+        'c10d_all_reduce': lambda: D.async_all_reduce(grads),
+        'native_all_to_all': lambda: comm.all_to_all(flat, recv),
+        'c10d_all_to_all': lambda: D.async_all_to_all(recv, flat),
+    }
+    costs = {}
+    for name, call in routes.items():
+      for _ in range(10):
+        call()
+      torch.cuda.synchronize(device)
+      dist.barrier()
+      t0 = time.perf_counter()
+      for _ in range(100):
+        call()
+      t1 = time.perf_counter()
+      torch.cuda.synchronize(device)
+      t2 = time.perf_counter()
+      costs[name] = {'host_us': round((t1 - t0) * 1e4, 2), 'total_us': round((t2 - t0) * 1e4, 2)}
+    agree = torch.tensor([float(all(checks.values()))], device=device)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    comm.close()
+    result.clear()
+    result.update({
+        'status': 'ok' if agree.item() == 1.0 else 'mismatch', 'ranks': world, 'checks': checks,
+        'all_reduce_bytes': grads.numel() * grads.element_size(), 'all_to_all_bytes': flat.numel(),
+        'per_call': costs})
+
+  def guarded():
+    try:
+      body()
+    except Exception as e:
+      result.clear()
+      result.update({'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]})
+
+  worker = threading.Thread(target=guarded, name='native_comm_check', daemon=True)
+  worker.start()
+  worker.join(seconds)
+  return dict(result), worker.is_alive()
 
 
 def plain_copy_reference(replay, rows, device, iters=200):

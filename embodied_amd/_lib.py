@@ -165,6 +165,8 @@ SIGNATURES = {
     'emb_comm_init': [p, i32, i32, pp],
     'emb_comm_allgather_traj': [p, p, p, i64, p],
     'emb_comm_allreduce_grads': [p, p, i64, i32, p],
+    'emb_comm_allreduce_grads_as': [p, p, i64, i32, i32, p],
+    'emb_comm_alltoall_slices': [p, p, p, i64, p],
     'emb_comm_destroy': [p],
 }
 

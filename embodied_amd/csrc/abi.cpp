@@ -1335,6 +1335,10 @@ struct Rccl {
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
 };
 
@@ -1359,6 +1363,10 @@ const Rccl& rccl() {
     t.comm_destroy = reinterpret_cast<decltype(t.comm_destroy)>(sym("ncclCommDestroy"));
     t.all_gather = reinterpret_cast<decltype(t.all_gather)>(sym("ncclAllGather"));
     t.all_reduce = reinterpret_cast<decltype(t.all_reduce)>(sym("ncclAllReduce"));
+    t.send = reinterpret_cast<decltype(t.send)>(sym("ncclSend"));
+    t.recv = reinterpret_cast<decltype(t.recv)>(sym("ncclRecv"));
+    t.group_start = reinterpret_cast<decltype(t.group_start)>(sym("ncclGroupStart"));
+    t.group_end = reinterpret_cast<decltype(t.group_end)>(sym("ncclGroupEnd"));
     t.error_string = reinterpret_cast<decltype(t.error_string)>(sym("ncclGetErrorString"));
     return t;
   }();
@@ -1413,15 +1421,56 @@ int32_t emb_comm_allgather_traj(emb_comm_t* comm, const void* send, void* recv,
   });
 }
 
-int32_t emb_comm_allreduce_grads(emb_comm_t* comm, void* buf, int64_t count, int32_t mean,
-                                 void* stream) {
+int32_t emb_comm_alltoall_slices(emb_comm_t* comm, const void* send, void* recv,
+                                 int64_t bytes_per_rank, void* stream) {
+  return guarded([&] {
+    need(comm && send && recv && bytes_per_rank >= 0, "comm_alltoall_slices: bad arguments");
+    if (bytes_per_rank == 0) return;
+    const auto* from = static_cast<const uint8_t*>(send);
+    auto* to = static_cast<uint8_t*>(recv);
+    const size_t n = static_cast<size_t>(bytes_per_rank);
+    auto s = static_cast<hipStream_t>(stream);
+    // One fused group of point-to-point transfers: on xGMI every pair of GPUs
+    // has its own link, so the n-1 blocks leave on n-1 links at once.
+    rccl_ok(rccl().group_start(), "ncclGroupStart");
+    ncclResult_t first = ncclSuccess;
+    for (int32_t peer = 0; peer < comm->world && first == ncclSuccess; ++peer) {
+      first = rccl().send(from + peer * n, n, ncclUint8, peer, comm->comm, s);
+      if (first == ncclSuccess) first = rccl().recv(to + peer * n, n, ncclUint8, peer, comm->comm, s);
+    }
+    const ncclResult_t closed = rccl().group_end();
+    rccl_ok(first, "ncclSend/ncclRecv");
+    rccl_ok(closed, "ncclGroupEnd");
+  });
+}
+
+static int32_t allreduce_typed(emb_comm_t* comm, void* buf, int64_t count, int32_t dtype,
+                               int32_t mean, void* stream) {
   return guarded([&] {
     need(comm && buf && count >= 0, "comm_allreduce_grads: bad arguments");
+    ncclDataType_t type = ncclFloat32;
+    switch (dtype) {
+      case EMB_F32: type = ncclFloat32; break;
+      case EMB_BF16: type = ncclBfloat16; break;
+      case EMB_F16: type = ncclFloat16; break;
+      case EMB_F64: type = ncclFloat64; break;
+      default: need(false, "comm_allreduce_grads: dtype must be f16, bf16, f32 or f64");
+    }
     if (count == 0) return;
-    rccl_ok(rccl().all_reduce(buf, buf, static_cast<size_t>(count), ncclFloat32,
+    rccl_ok(rccl().all_reduce(buf, buf, static_cast<size_t>(count), type,
                               mean ? ncclAvg : ncclSum, comm->comm, static_cast<hipStream_t>(stream)),
             "ncclAllReduce");
   });
+}
+
+int32_t emb_comm_allreduce_grads(emb_comm_t* comm, void* buf, int64_t count, int32_t mean,
+                                 void* stream) {
+  return allreduce_typed(comm, buf, count, EMB_F32, mean, stream);
+}
+
+int32_t emb_comm_allreduce_grads_as(emb_comm_t* comm, void* buf, int64_t count, int32_t dtype,
+                                    int32_t mean, void* stream) {
+  return allreduce_typed(comm, buf, count, dtype, mean, stream);
 }
 
 int32_t emb_comm_destroy(emb_comm_t* comm) {

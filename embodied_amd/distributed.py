@@ -517,12 +517,26 @@ class NativeComm:
     return out
 
   def all_reduce(self, grads, mean=True):
-    """In-place sum or mean over ranks of a flat float32 buffer."""
-    assert grads.dtype == torch.float32 and grads.is_contiguous() and grads.is_cuda
-    self._api.emb_comm_allreduce_grads(
-        self._handle, grads.data_ptr(), grads.numel(), int(bool(mean)),
+    """In-place sum or mean over ranks of a flat f16 / bf16 / f32 / f64 buffer."""
+    code = {torch.float16: self._lib.F16, torch.bfloat16: self._lib.BF16,
+            torch.float32: self._lib.F32, torch.float64: self._lib.F64}.get(grads.dtype)
+    assert code is not None and grads.is_contiguous() and grads.is_cuda, grads.dtype
+    self._api.emb_comm_allreduce_grads_as(
+        self._handle, grads.data_ptr(), grads.numel(), code, int(bool(mean)),
         self._lib.raw_stream(grads.device))
     return grads
+
+  def all_to_all(self, flat, out=None):
+    """(world * nbytes,) uint8: block r goes to rank r; block r of the result
+    came from rank r (the DP-slice exchange of `exchange_dp_slices`)."""
+    assert flat.dtype == torch.uint8 and flat.is_contiguous() and flat.is_cuda
+    assert flat.numel() % self.world == 0, (flat.numel(), self.world)
+    if out is None:
+      out = torch.empty_like(flat)
+    self._api.emb_comm_alltoall_slices(
+        self._handle, flat.data_ptr(), out.data_ptr(), flat.numel() // self.world,
+        self._lib.raw_stream(flat.device))
+    return out
 
   def close(self):
     handle, self._handle = self._handle, None

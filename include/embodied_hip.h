@@ -318,7 +318,8 @@ int32_t emb_abstract_traj(const void* reward, const void* cont, int64_t T, int64
  * The two exchange steps of the sharded path on RCCL directly (xGMI inside one
  * node), for hosts that do not go through torch.distributed:
  *   trajectories  -> one all-gather of the packed (B, L, S) byte block per rank
- *   gradients     -> all-reduce (sum or mean) of one flat f32 buffer
+ *                    (or all-to-all of its per-rank blocks: the DP slice)
+ *   gradients     -> all-reduce (sum or mean) of one flat buffer
  *                    (embodied/jax/opt.py:52-54's pmean)
  * RCCL is opened with dlopen at the first call (the library itself does not
  * link against it).  Rank 0 makes the 128-byte id, the caller hands it to the
@@ -333,6 +334,16 @@ int32_t emb_comm_allgather_traj(emb_comm_t* comm, const void* send, void* recv,
                                 int64_t bytes_per_rank, void* stream);
 int32_t emb_comm_allreduce_grads(emb_comm_t* comm, void* buf, int64_t count, int32_t mean,
                                  void* stream);
+/* The same with the element type named (EMB_F16 / EMB_BF16 / EMB_F32 / EMB_F64):
+ * bf16 gradients halve the bytes on the links.                  */
+int32_t emb_comm_allreduce_grads_as(emb_comm_t* comm, void* buf, int64_t count, int32_t dtype,
+                                    int32_t mean, void* stream);
+/* DP-slice exchange (SURVEY.md 8e "only its DP slice via all-to-all"): `send`
+ * and `recv` hold `world` blocks of bytes_per_rank bytes; block r of `send`
+ * goes to rank r, block r of `recv` arrives from rank r (block `rank` is a
+ * local copy).  One fused group of RCCL point-to-point transfers.            */
+int32_t emb_comm_alltoall_slices(emb_comm_t* comm, const void* send, void* recv,
+                                 int64_t bytes_per_rank, void* stream);
 int32_t emb_comm_destroy(emb_comm_t* comm);
 
 /* ---- synthetic vector env (benchmark / test input) ---------- */

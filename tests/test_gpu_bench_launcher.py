@@ -49,6 +49,20 @@ def test_bench_dreamer_workload_with_ranks():
   assert rec['train_steps_per_s'] > 0 and rec['roofline']['launches'] >= 1
 
 
+def test_bench_checks_the_native_collectives_when_it_runs_on_rccl():
+  """With RCCL as the transport the line carries `native_comm`: the emb_comm_*
+  entry points against torch.distributed on the same GPUs (one rank here)."""
+  rec = run_bench('--steps', '200', '--warmup', '50', '--sustained-seconds', '0', '--no-cpu-baseline',
+                  '--no-context', env={'EMB_BENCH_FORCE_DIST': '1'})
+  assert rec['backend'] == 'nccl' and rec['rccl_ranks'] == 1
+  native = rec['native_comm']
+  assert native['status'] == 'ok' and all(native['checks'].values()), native
+  assert set(native['checks']) == {
+      'all_gather', 'all_to_all', 'all_reduce_sum_f32', 'all_reduce_mean_f32',
+      'all_reduce_sum_bf16', 'all_reduce_mean_bf16'}
+  assert native['per_call']['native_all_reduce']['host_us'] > 0
+
+
 def test_bench_short_run_keeps_its_shape():
   """The driver's short form on one GPU: the line carries roofline, the
   sustained window and the CPU baseline; the headline region is exactly --steps."""

@@ -705,8 +705,16 @@ def test_native_rccl_collectives_world1(emb):
   want = grads.clone()
   comm.all_reduce(grads, mean=True)
   comm.all_reduce(grads, mean=False)
+  half = torch.randn(1 << 20, device='cuda').to(torch.bfloat16)
+  half_want = half.clone()
+  comm.all_reduce(half, mean=True)                 # typed form: bf16 gradients
+  swapped = comm.all_to_all(flat)                  # one block per rank: a copy at world 1
   torch.cuda.synchronize()
   assert torch.equal(out, flat) and torch.equal(grads, want)
+  assert torch.equal(half, half_want) and torch.equal(swapped, flat)
+  with pytest.raises(Exception, match='dtype'):
+    comm._api.emb_comm_allreduce_grads_as(
+        comm._handle, flat.data_ptr(), 16, comm._lib.U8, 0, comm._lib.raw_stream(flat.device))
   comm.close()
 
 
