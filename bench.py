@@ -54,6 +54,12 @@ def parse():
                       'all ranks\' envs ((n-1)/n * B*L*S bytes each way per exchanged batch).  '
                       'online = all-gather of those batches ((n-1) * B*L*S received); trajectories '
                       '= all-gather of every batch; returns = all-gather of the GAE outputs only')
+  p.add_argument('--comm', default='auto', choices=['auto', 'native', 'c10d'],
+                 help='N>1: who issues the collectives of the timed path.  c10d = torch.distributed '
+                      '(ProcessGroupNCCL).  native = the library\'s own RCCL entry points '
+                      '(emb_comm_exchange: one call per train step, ~1/3 of the host time).  auto '
+                      '(default) = native if the self-check against torch.distributed passes on '
+                      'every rank before the timed regions, else c10d')
   p.add_argument('--grad-dtype', default='bf16', choices=['bf16', 'f32'],
                  help='N>1: dtype of the flat gradient buffer that is all-reduced every train '
                       'step (the reference all-reduces f32 leaves, embodied/jax/opt.py:52-54; '
@@ -229,6 +235,7 @@ def main():
   counters = {'env_steps': 0, 'train_steps': 0}
   pending, marks = [], []
   comm = None
+  native, native_stuck, native_comm = None, False, None
   if use_dist:
     from embodied_amd import distributed as D
     if os.environ.get('EMB_BENCH_COMM') == 'thread':
@@ -236,6 +243,7 @@ def main():
       issue = comm.submit
     else:
       issue = D.Done
+  use_native = False
 
   def train_step():
     if args.workload == 'dreamer':
@@ -250,7 +258,10 @@ def main():
       emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
       replay.update({'stepid': batch['stepid'], 'dyn/deter': batch['dyn/deter'],
                      'dyn/stoch': batch['dyn/stoch']})
-      if use_dist and args.grad_numel:
+      if use_native and grads is not None:
+        native_comm.wait()
+        native_comm.exchange(grads=grads)
+      elif use_dist and args.grad_numel:
         for future in pending:
           future.result().wait()
         pending.clear()
@@ -275,13 +286,19 @@ def main():
       for future in pending:
         future.result().wait()
       pending.clear()
+      if use_native:
+        native_comm.wait()
       send = None
       if sliced:
         # This rank's slice of the global batch = block `rank` of every rank's
         # batch; it is complete one train step later (the wait above) and is
         # what the learner then computes returns on.
-        work, received, views = D.exchange_dp_slices(flat, layout)
-        pending.append(D.Done(lambda w=work: w))
+        if use_native:     # slices and gradients in ONE library call, on its own stream
+          received = torch.empty_like(flat)
+          native_comm.exchange(flat, received, grads)
+        else:
+          work, received, views = D.exchange_dp_slices(flat, layout)
+          pending.append(D.Done(lambda w=work: w))
         state_keep[:] = [flat, received]
         late, slice_state['recv'] = slice_state.get('recv'), (received, layout)
         source, source_info = late if late is not None else (flat, layout)
@@ -300,7 +317,10 @@ def main():
         gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
         pending.append(issue(lambda g=gathered, s=send: D.async_all_gather(g, s)))
         state_keep[:] = [gathered, send]
-      if args.grad_numel:
+      if use_native:
+        if not sliced and grads is not None:
+          native_comm.exchange(grads=grads)
+      elif args.grad_numel:
         pending.append(issue(lambda: D.async_all_reduce(grads)))
       # When the links are the bottleneck the host could queue train steps far
       # ahead of the GPU (one gathered buffer each): stay within 8 train steps.
@@ -328,6 +348,15 @@ def main():
   for _ in range(fill):
     driver(policy, steps=args.envs)
   counters['env_steps'] = fill * args.envs
+  if use_dist and dist.get_backend() == 'nccl' and args.comm != 'c10d':
+    native, native_stuck, native_comm = native_comm_check(
+        rank, world, device, args.grad_numel, grad_dtype,
+        B * args.prefetch * L * sum(k.rowbytes for k in replay._keys) // world)
+    if args.comm == 'native' and native_comm is None:
+      raise SystemExit(f'--comm native: the self-check did not pass: {native}')
+    # (all-gather forms of the exchange stay on torch.distributed.)
+    use_native = native_comm is not None and args.exchange in ('dp_slice', 'none')
+    native['timed_path'] = 'native' if use_native else 'c10d'
   # EMB_BENCH_NO_TIMER=1: no dispatch stamps (roofline is then null) -- for a
   # rocprofv3 run that sees the gather without the timed-dispatch perturbation.
   # Switched on before the warm-up so that the stamps' events exist by then.
@@ -349,6 +378,8 @@ def main():
     for future in pending:
       future.result().wait()
     pending.clear()
+    if use_native:
+      native_comm.wait()
     torch.cuda.synchronize(device)
     if use_dist:
       dist.barrier()
@@ -473,13 +504,6 @@ def main():
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ppo' and not args.host_envs:
     cpu = cpu_baseline(args)
 
-  native, native_stuck = None, False
-  if use_dist and dist.get_backend() == 'nccl' and os.environ.get('EMB_BENCH_NATIVE_COMM') != '0':
-    fence()
-    native, native_stuck = native_comm_check(
-        rank, world, device, args.grad_numel, grad_dtype,
-        B * args.prefetch * L * S // max(world, 1))
-
   if rank == 0:
     # Libraries that wrote to C stdio (RCCL's version banner) come out first, so
     # that the JSON line is the last line on stdout.
@@ -513,7 +537,8 @@ def main():
                             + ('per-rank Replay, ' if args.workload == 'dreamer'
                                else f'trajectory exchange {args.exchange} + ') +
                             f'{args.grad_numel * (2 if args.grad_dtype == "bf16" else 4) >> 20} MiB '
-                            f'{args.grad_dtype} grad all-reduce per train step (RCCL)')
+                            f'{args.grad_dtype} grad all-reduce per train step (RCCL, issued by '
+                            f'{"emb_comm_exchange" if use_native else "torch.distributed"})')
                            if use_dist else 'single',
         },
         'sustained': sustained,
@@ -527,24 +552,28 @@ def main():
   if use_dist:
     if comm is not None:
       comm.close()
+    if native_comm is not None:
+      native_comm.close()
     dist.destroy_process_group()
 
 
-def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, seconds=120.0):
-  """Ranks only, after the timed regions (no part of `value`): the library's own
+def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, seconds=90.0):
+  """Ranks only, before the timed regions (no part of `value`): the library's own
   RCCL entry points (`emb_comm_*`, include/embodied_hip.h) on the GPUs of this
   job, checked against torch.distributed on the same bytes -- all-gather, the
   DP-slice all-to-all, f32 and bf16 gradient all-reduce -- with the host cost
-  per call of both routes.  Runs under a watchdog: whatever happens in here, the
-  JSON line is printed."""
+  per call of both routes.  Returns (report, stuck, communicator or None): the
+  communicator only if every rank passed.  Runs under a watchdog: if a
+  collective never returns the job goes on with torch.distributed."""
   import threading
   import torch.distributed as dist
   from embodied_amd import distributed as D
   result = {'status': 'timeout'}
+  kept = []
 
   def body():
-    torch.cuda.set_device(device)
     comm = D.NativeComm(rank, world, device)
+    kept.append(comm)
     gen = torch.Generator(device=device)
     gen.manual_seed(977 + rank)
     block = max(16, slice_bytes // 16 * 16)
@@ -578,6 +607,10 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
         'c10d_all_reduce': lambda: D.async_all_reduce(grads),
         'native_all_to_all': lambda: comm.all_to_all(flat, recv),
         'c10d_all_to_all': lambda: D.async_all_to_all(recv, flat),
+        # one train step's worth, own stream, with the wait of the previous one
+        'native_exchange_step': lambda: (comm.wait(), comm.exchange(flat, recv, grads)),
+        'c10d_exchange_step': lambda: (D.async_all_to_all(recv, flat).wait(),
+                                       D.async_all_reduce(grads).wait()),
     }
     costs = {}
     for name, call in routes.items():
@@ -592,26 +625,34 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
       torch.cuda.synchronize(device)
       t2 = time.perf_counter()
       costs[name] = {'host_us': round((t1 - t0) * 1e4, 2), 'total_us': round((t2 - t0) * 1e4, 2)}
-    agree = torch.tensor([float(all(checks.values()))], device=device)
-    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-    comm.close()
-    result.clear()
-    result.update({
-        'status': 'ok' if agree.item() == 1.0 else 'mismatch', 'ranks': world, 'checks': checks,
-        'all_reduce_bytes': grads.numel() * grads.element_size(), 'all_to_all_bytes': flat.numel(),
-        'per_call': costs})
+    return {'status': 'ok' if all(checks.values()) else 'mismatch', 'ranks': world,
+            'checks': checks, 'all_reduce_bytes': grads.numel() * grads.element_size(),
+            'all_to_all_bytes': flat.numel(), 'per_call': costs}
 
   def guarded():
+    torch.cuda.set_device(device)
     try:
-      body()
+      local = body()
     except Exception as e:
-      result.clear()
-      result.update({'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]})
+      local = {'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]}
+    # Every rank reaches this reduce whatever happened above, so that all ranks
+    # take the same decision about the timed path.
+    agree = torch.tensor([1.0 if local['status'] == 'ok' else 0.0], device=device)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    torch.cuda.synchronize(device)
+    if agree.item() != 1.0 and local['status'] == 'ok':
+      local['status'] = 'failed on another rank'
+    result.clear()
+    result.update(local)
 
   worker = threading.Thread(target=guarded, name='native_comm_check', daemon=True)
   worker.start()
   worker.join(seconds)
-  return dict(result), worker.is_alive()
+  stuck = worker.is_alive()
+  usable = kept[0] if (kept and not stuck and result.get('status') == 'ok') else None
+  if kept and usable is None and not stuck:
+    kept[0].close()
+  return dict(result), stuck, usable
 
 
 def plain_copy_reference(replay, rows, device, iters=200):

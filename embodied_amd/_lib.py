@@ -167,6 +167,8 @@ SIGNATURES = {
     'emb_comm_allreduce_grads': [p, p, i64, i32, p],
     'emb_comm_allreduce_grads_as': [p, p, i64, i32, i32, p],
     'emb_comm_alltoall_slices': [p, p, p, i64, p],
+    'emb_comm_exchange': [p, p, p, p, i64, p, i64, i32, i32],
+    'emb_comm_wait': [p, p],
     'emb_comm_destroy': [p],
 }
 
@@ -251,6 +253,7 @@ class _FastApi:
       'emb_replay_gather_rows': 'ints', 'emb_replay_scatter_rows': 'ints',
       'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',
       'emb_scan_gae_grouped': 'scan',
+      'emb_comm_exchange': 'ints', 'emb_comm_wait': 'ints',
   }
 
   def __init__(self, module):

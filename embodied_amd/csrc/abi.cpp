@@ -1383,7 +1383,41 @@ void rccl_ok(ncclResult_t r, const char* what) {
 struct emb_comm {
   ncclComm_t comm = nullptr;
   int32_t rank = 0, world = 1;
+  // emb_comm_exchange: the communicator's own stream, so that a train step's
+  // collectives overlap whatever the caller's stream does next.
+  hipStream_t side = nullptr;
+  hipEvent_t forked = nullptr, done = nullptr;
+  bool in_flight = false;
 };
+
+static void alltoall_on(emb_comm* comm, const void* send, void* recv, int64_t bytes_per_rank,
+                        hipStream_t s) {
+  const auto* from = static_cast<const uint8_t*>(send);
+  auto* to = static_cast<uint8_t*>(recv);
+  const size_t n = static_cast<size_t>(bytes_per_rank);
+  // One fused group of point-to-point transfers: on xGMI every pair of GPUs
+  // has its own link, so the n-1 blocks leave on n-1 links at once.
+  rccl_ok(rccl().group_start(), "ncclGroupStart");
+  ncclResult_t first = ncclSuccess;
+  for (int32_t peer = 0; peer < comm->world && first == ncclSuccess; ++peer) {
+    first = rccl().send(from + peer * n, n, ncclUint8, peer, comm->comm, s);
+    if (first == ncclSuccess) first = rccl().recv(to + peer * n, n, ncclUint8, peer, comm->comm, s);
+  }
+  const ncclResult_t closed = rccl().group_end();
+  rccl_ok(first, "ncclSend/ncclRecv");
+  rccl_ok(closed, "ncclGroupEnd");
+}
+
+static ncclDataType_t grad_type(int32_t dtype) {
+  switch (dtype) {
+    case EMB_F32: return ncclFloat32;
+    case EMB_BF16: return ncclBfloat16;
+    case EMB_F16: return ncclFloat16;
+    case EMB_F64: return ncclFloat64;
+    default: need(false, "comm_allreduce_grads: dtype must be f16, bf16, f32 or f64");
+  }
+  return ncclFloat32;
+}
 
 extern "C" {
 
@@ -1406,6 +1440,9 @@ int32_t emb_comm_init(const uint8_t* id, int32_t rank, int32_t world, emb_comm_t
     comm->rank = rank;
     comm->world = world;
     rccl_ok(rccl().comm_init_rank(&comm->comm, world, uid, rank), "ncclCommInitRank");
+    HIP_OK(hipStreamCreateWithFlags(&comm->side, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&comm->forked, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&comm->done, hipEventDisableTiming));
     *out = comm.release();
   });
 }
@@ -1426,21 +1463,7 @@ int32_t emb_comm_alltoall_slices(emb_comm_t* comm, const void* send, void* recv,
   return guarded([&] {
     need(comm && send && recv && bytes_per_rank >= 0, "comm_alltoall_slices: bad arguments");
     if (bytes_per_rank == 0) return;
-    const auto* from = static_cast<const uint8_t*>(send);
-    auto* to = static_cast<uint8_t*>(recv);
-    const size_t n = static_cast<size_t>(bytes_per_rank);
-    auto s = static_cast<hipStream_t>(stream);
-    // One fused group of point-to-point transfers: on xGMI every pair of GPUs
-    // has its own link, so the n-1 blocks leave on n-1 links at once.
-    rccl_ok(rccl().group_start(), "ncclGroupStart");
-    ncclResult_t first = ncclSuccess;
-    for (int32_t peer = 0; peer < comm->world && first == ncclSuccess; ++peer) {
-      first = rccl().send(from + peer * n, n, ncclUint8, peer, comm->comm, s);
-      if (first == ncclSuccess) first = rccl().recv(to + peer * n, n, ncclUint8, peer, comm->comm, s);
-    }
-    const ncclResult_t closed = rccl().group_end();
-    rccl_ok(first, "ncclSend/ncclRecv");
-    rccl_ok(closed, "ncclGroupEnd");
+    alltoall_on(comm, send, recv, bytes_per_rank, static_cast<hipStream_t>(stream));
   });
 }
 
@@ -1448,14 +1471,7 @@ static int32_t allreduce_typed(emb_comm_t* comm, void* buf, int64_t count, int32
                                int32_t mean, void* stream) {
   return guarded([&] {
     need(comm && buf && count >= 0, "comm_allreduce_grads: bad arguments");
-    ncclDataType_t type = ncclFloat32;
-    switch (dtype) {
-      case EMB_F32: type = ncclFloat32; break;
-      case EMB_BF16: type = ncclBfloat16; break;
-      case EMB_F16: type = ncclFloat16; break;
-      case EMB_F64: type = ncclFloat64; break;
-      default: need(false, "comm_allreduce_grads: dtype must be f16, bf16, f32 or f64");
-    }
+    const ncclDataType_t type = grad_type(dtype);
     if (count == 0) return;
     rccl_ok(rccl().all_reduce(buf, buf, static_cast<size_t>(count), type,
                               mean ? ncclAvg : ncclSum, comm->comm, static_cast<hipStream_t>(stream)),
@@ -1473,9 +1489,45 @@ int32_t emb_comm_allreduce_grads_as(emb_comm_t* comm, void* buf, int64_t count, 
   return allreduce_typed(comm, buf, count, dtype, mean, stream);
 }
 
+int32_t emb_comm_exchange(emb_comm_t* comm, void* after_stream, const void* slices_send,
+                          void* slices_recv, int64_t bytes_per_rank, void* grads, int64_t count,
+                          int32_t dtype, int32_t mean) {
+  return guarded([&] {
+    need(comm && bytes_per_rank >= 0 && count >= 0, "comm_exchange: bad arguments");
+    need(bytes_per_rank == 0 || (slices_send && slices_recv), "comm_exchange: null slice buffers");
+    need(count == 0 || grads, "comm_exchange: null gradient buffer");
+    const ncclDataType_t type = grad_type(count ? dtype : EMB_F32);
+    if (bytes_per_rank == 0 && count == 0) return;
+    HIP_OK(hipEventRecord(comm->forked, static_cast<hipStream_t>(after_stream)));
+    HIP_OK(hipStreamWaitEvent(comm->side, comm->forked, 0));
+    if (bytes_per_rank) alltoall_on(comm, slices_send, slices_recv, bytes_per_rank, comm->side);
+    if (count)
+      rccl_ok(rccl().all_reduce(grads, grads, static_cast<size_t>(count), type,
+                                mean ? ncclAvg : ncclSum, comm->comm, comm->side),
+              "ncclAllReduce");
+    HIP_OK(hipEventRecord(comm->done, comm->side));
+    comm->in_flight = true;
+  });
+}
+
+int32_t emb_comm_wait(emb_comm_t* comm, void* stream) {
+  return guarded([&] {
+    need(comm, "comm_wait: null communicator");
+    if (!comm->in_flight) return;
+    HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), comm->done, 0));
+    comm->in_flight = false;
+  });
+}
+
 int32_t emb_comm_destroy(emb_comm_t* comm) {
   return guarded([&] {
     if (!comm) return;
+    if (comm->side) {
+      (void)hipStreamSynchronize(comm->side);
+      (void)hipEventDestroy(comm->forked);
+      (void)hipEventDestroy(comm->done);
+      (void)hipStreamDestroy(comm->side);
+    }
     if (comm->comm) rccl_ok(rccl().comm_destroy(comm->comm), "ncclCommDestroy");
     delete comm;
   });

@@ -538,6 +538,31 @@ class NativeComm:
         self._lib.raw_stream(flat.device))
     return out
 
+  def exchange(self, slices=None, received=None, grads=None, mean=True):
+    """One train step's collectives on the communicator's own stream, after
+    what the current stream holds so far: the DP-slice all-to-all of `slices`
+    into `received` (both (world * nbytes,) uint8) and / or the in-place
+    all-reduce of `grads`.  `wait()` orders the current stream after them; the
+    caller keeps the buffers until then."""
+    device = (grads if grads is not None else slices).device
+    code, count = self._lib.F32, 0
+    if grads is not None:
+      code = {torch.float16: self._lib.F16, torch.bfloat16: self._lib.BF16,
+              torch.float32: self._lib.F32, torch.float64: self._lib.F64}[grads.dtype]
+      count = grads.numel()
+    per_rank = 0
+    if slices is not None:
+      assert slices.dtype == torch.uint8 and slices.numel() % self.world == 0
+      assert received is not None and received.numel() == slices.numel()
+      per_rank = slices.numel() // self.world
+    self._lib.fast.emb_comm_exchange(
+        self._handle.value, self._lib.raw_stream(device),
+        slices.data_ptr() if per_rank else None, received.data_ptr() if per_rank else None, per_rank,
+        grads.data_ptr() if count else None, count, code, int(bool(mean)))
+
+  def wait(self, device=None):
+    self._lib.fast.emb_comm_wait(self._handle.value, self._lib.raw_stream(device or self.device))
+
   def close(self):
     handle, self._handle = self._handle, None
     if handle:

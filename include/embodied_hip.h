@@ -344,6 +344,18 @@ int32_t emb_comm_allreduce_grads_as(emb_comm_t* comm, void* buf, int64_t count, 
  * local copy).  One fused group of RCCL point-to-point transfers.            */
 int32_t emb_comm_alltoall_slices(emb_comm_t* comm, const void* send, void* recv,
                                  int64_t bytes_per_rank, void* stream);
+/* One train step's exchange, asynchronous on the communicator's OWN stream so
+ * that it overlaps what the caller queues next (the reference hands train
+ * outputs out one step late for the same reason, embodied/jax/agent.py:286-294):
+ * the collectives start after everything queued on `after_stream` so far --
+ * first the slices (bytes_per_rank > 0), then the gradients (count > 0).
+ * emb_comm_wait makes `stream` wait for the exchange issued last; buffers stay
+ * the caller's and must live until then.  Host cost: two event records and two
+ * stream waits per train step, whatever the number of collectives.            */
+int32_t emb_comm_exchange(emb_comm_t* comm, void* after_stream, const void* slices_send,
+                          void* slices_recv, int64_t bytes_per_rank, void* grads, int64_t count,
+                          int32_t dtype, int32_t mean);
+int32_t emb_comm_wait(emb_comm_t* comm, void* stream);
 int32_t emb_comm_destroy(emb_comm_t* comm);
 
 /* ---- synthetic vector env (benchmark / test input) ---------- */

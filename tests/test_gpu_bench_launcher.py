@@ -61,6 +61,19 @@ def test_bench_checks_the_native_collectives_when_it_runs_on_rccl():
       'all_gather', 'all_to_all', 'all_reduce_sum_f32', 'all_reduce_mean_f32',
       'all_reduce_sum_bf16', 'all_reduce_mean_bf16'}
   assert native['per_call']['native_all_reduce']['host_us'] > 0
+  # ... and, having passed, they carry the timed path (one emb_comm_exchange per train step).
+  assert native['timed_path'] == 'native' and 'emb_comm_exchange' in rec['config']['parallelism']
+  assert rec['train_steps_per_s'] > 0 and rec['roofline']['launches'] >= 1
+
+
+def test_bench_comm_c10d_keeps_torch_distributed_in_the_timed_path():
+  rec = run_bench('--steps', '200', '--warmup', '50', '--sustained-seconds', '0', '--no-cpu-baseline',
+                  '--no-context', '--comm', 'c10d', env={'EMB_BENCH_FORCE_DIST': '1'})
+  assert 'native_comm' not in rec and 'torch.distributed' in rec['config']['parallelism']
+  rec = run_bench('--steps', '200', '--warmup', '50', '--sustained-seconds', '0', '--no-cpu-baseline',
+                  '--no-context', '--workload', 'dreamer', '--capacity', '20000',
+                  env={'EMB_BENCH_FORCE_DIST': '1'})
+  assert rec['native_comm']['timed_path'] == 'native' and rec['train_steps_per_s'] > 0
 
 
 def test_bench_short_run_keeps_its_shape():

@@ -712,6 +712,21 @@ def test_native_rccl_collectives_world1(emb):
   torch.cuda.synchronize()
   assert torch.equal(out, flat) and torch.equal(grads, want)
   assert torch.equal(half, half_want) and torch.equal(swapped, flat)
+  # One train step's exchange on the communicator's own stream: it starts after
+  # what the current stream has queued (the fill below) and `wait` orders the
+  # reader after it.
+  for round_ in range(20):
+    source = torch.empty(8 << 20, dtype=torch.uint8, device='cuda')
+    source.fill_(round_ + 1)
+    received = torch.zeros_like(source)
+    comm.exchange(source, received, half)
+    comm.wait()
+    assert int(received.min()) == round_ + 1 and int(received.max()) == round_ + 1
+  comm.exchange(grads=grads, mean=False)
+  comm.wait()
+  comm.wait()                                      # nothing in flight: a no-op
+  torch.cuda.synchronize()
+  assert torch.equal(half, half_want) and torch.equal(grads, want)
   with pytest.raises(Exception, match='dtype'):
     comm._api.emb_comm_allreduce_grads_as(
         comm._handle, flat.data_ptr(), 16, comm._lib.U8, 0, comm._lib.raw_stream(flat.device))
