@@ -570,9 +570,19 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
   from embodied_amd import distributed as D
   result = {'status': 'timeout'}
   kept = []
+  # The torch.distributed side of the check has a process group of its own: if
+  # the check derails on some rank (its collectives no longer pair up), the
+  # job's default group has seen none of it.
+  group = dist.new_group(backend='nccl')
+  pg = group
+
+  def share(data):
+    box = [data]
+    dist.broadcast_object_list(box, src=0, group=group, device=device)
+    return box[0]
 
   def body():
-    comm = D.NativeComm(rank, world, device)
+    comm = D.NativeComm(rank, world, device, share=share)
     kept.append(comm)
     gen = torch.Generator(device=device)
     gen.manual_seed(977 + rank)
@@ -580,10 +590,10 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
     flat = torch.randint(0, 256, (world * block,), dtype=torch.uint8, device=device, generator=gen)
     checks = {}
     mine, ref = comm.all_gather(flat[:block].contiguous()), torch.empty_like(flat)
-    dist.all_gather_into_tensor(ref, flat[:block].contiguous())
+    dist.all_gather_into_tensor(ref, flat[:block].contiguous(), group=group)
     checks['all_gather'] = bool(torch.equal(mine, ref))
     mine, ref = comm.all_to_all(flat), torch.empty_like(flat)
-    dist.all_to_all_single(ref, flat)
+    dist.all_to_all_single(ref, flat, group=group)
     checks['all_to_all'] = bool(torch.equal(mine, ref))
     # Small integers: sums over ranks are exact in f32 and bf16, so the two
     # routes must agree to the bit whatever order the links add in.
@@ -591,12 +601,12 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
       whole = torch.randint(-8, 9, (1 << 20,), device=device, generator=gen).to(dtype)
       a, b = whole.clone(), whole.clone()
       comm.all_reduce(a, mean=False)
-      dist.all_reduce(b)
+      dist.all_reduce(b, group=group)
       checks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, b))
       a, b = torch.randn(1 << 20, device=device, generator=gen).to(dtype), None
       b = a.clone()
       comm.all_reduce(a, mean=True)
-      dist.all_reduce(b, op=dist.ReduceOp.AVG)
+      dist.all_reduce(b, op=dist.ReduceOp.AVG, group=group)
       tol = 1e-5 if dtype == torch.float32 else 2e-2
       checks[f'all_reduce_mean_{name}'] = bool(torch.allclose(a.float(), b.float(), rtol=tol, atol=tol))
     # Host and end-to-end cost per call at the job's own sizes.
@@ -604,20 +614,20 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
     recv = torch.empty_like(flat)
     routes = {
         'native_all_reduce': lambda: comm.all_reduce(grads, mean=True),
-        'c10d_all_reduce': lambda: D.async_all_reduce(grads),
+        'c10d_all_reduce': lambda: pg.allreduce([grads]),
         'native_all_to_all': lambda: comm.all_to_all(flat, recv),
-        'c10d_all_to_all': lambda: D.async_all_to_all(recv, flat),
+        'c10d_all_to_all': lambda: pg.alltoall_base(recv, flat, [], []),
         # one train step's worth, own stream, with the wait of the previous one
         'native_exchange_step': lambda: (comm.wait(), comm.exchange(flat, recv, grads)),
-        'c10d_exchange_step': lambda: (D.async_all_to_all(recv, flat).wait(),
-                                       D.async_all_reduce(grads).wait()),
+        'c10d_exchange_step': lambda: (pg.alltoall_base(recv, flat, [], []).wait(),
+                                       pg.allreduce([grads]).wait()),
     }
     costs = {}
     for name, call in routes.items():
       for _ in range(10):
         call()
       torch.cuda.synchronize(device)
-      dist.barrier()
+      dist.barrier(group=group)
       t0 = time.perf_counter()
       for _ in range(100):
         call()
@@ -638,7 +648,7 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
     # Every rank reaches this reduce whatever happened above, so that all ranks
     # take the same decision about the timed path.
     agree = torch.tensor([1.0 if local['status'] == 'ok' else 0.0], device=device)
-    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
     torch.cuda.synchronize(device)
     if agree.item() != 1.0 and local['status'] == 'ok':
       local['status'] = 'failed on another rank'
