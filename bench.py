@@ -165,6 +165,10 @@ def build_path(args, rank, device):
   return emb, env, replay, driver, policy
 
 
+def train_steps_local(counters, base, headline):
+  return headline['train_steps'] - base['train_steps']
+
+
 def launch_ranks(args):
   """`python bench.py --gpus N` without a launcher: start N local ranks, one per
   GPU, under torch.distributed.run and become that process (rank 0 prints the
@@ -244,6 +248,7 @@ def main():
     else:
       issue = D.Done
   use_native = False
+  collectives = {'on': True, 'sliced': 0}
 
   def train_step():
     if args.workload == 'dreamer':
@@ -258,15 +263,15 @@ def main():
       emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
       replay.update({'stepid': batch['stepid'], 'dyn/deter': batch['dyn/deter'],
                      'dyn/stoch': batch['dyn/stoch']})
-      if use_native and grads is not None:
+      if use_native and grads is not None and collectives['on']:
         native_comm.wait()
         native_comm.exchange(grads=grads)
-      elif use_dist and args.grad_numel:
+      elif use_dist and args.grad_numel and collectives['on']:
         for future in pending:
           future.result().wait()
         pending.clear()
         pending.append(issue(lambda: D.async_all_reduce(grads)))
-    elif not use_dist:
+    elif not use_dist or not collectives['on']:
       batch = next(stream)
       adv, tar = emb.scans.gae(
           batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
@@ -280,6 +285,7 @@ def main():
                 and replay.online_pending() > 0)
       if sliced:
         # Fresh on-policy windows: cut the batch into one block per rank.
+        collectives['sliced'] += 1
         flat, batch, layout = D.sample_packed(replay, rows, groups=world)
       else:
         flat, batch, layout = D.sample_packed(replay, rows)
@@ -442,6 +448,44 @@ def main():
         'gather_avg_us': round(s_ms / s_launches * 1e3, 2) if s_launches else None,
         'gather_launches': s_launches,
     }
+  # Ranks only, context: the same loop with the collectives switched off (N
+  # independent replicas: no exchange, no gradient all-reduce) -- what the path
+  # itself does on N GPUs, next to what the links allow with them.
+  replicas_only = None
+  sliced_share = min(1.0, collectives['sliced'] / max(1, counters['train_steps']))
+  if use_dist and args.sustained_seconds > 0:
+    fence()
+    collectives['on'] = False
+    r_steps = max(256, int(2.0 / max(elapsed / args.steps, 1e-6)) // 256 * 256)   # same on every rank
+    r_before = counters['train_steps']
+    r_start = time.perf_counter()
+    for _ in range(r_steps):
+      one_step()
+    fence()
+    r_elapsed = time.perf_counter() - r_start
+    t = torch.tensor([r_elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    r_elapsed = float(t.item())
+    collectives['on'] = True
+    replay.profile_read(reset=True)
+    replicas_only = {
+        'seconds': round(r_elapsed, 3), 'steps': r_steps,
+        'env_steps_per_s': round(r_steps * args.envs * world / r_elapsed, 1),
+        'train_steps_per_s': round((counters['train_steps'] - r_before) * world / r_elapsed, 2),
+        'what': 'same loop, collectives off: N independent replicas',
+    }
+  if native is not None and 'per_call' in native and train_steps_local(counters, base, headline) > 0:
+    # RCCL's own time for one train step's collectives at this world size
+    # against the period at which the timed region issued train steps.
+    calls = native['per_call']
+    done = train_steps_local(counters, base, headline)
+    share = sliced_share
+    native['per_train_step'] = {
+        'collectives_us': round(calls['native_all_reduce']['total_us']
+                                + share * calls['native_all_to_all']['total_us'], 1),
+        'issue_period_us': round(elapsed / done * 1e6, 1),
+        'sliced_share': round(share, 3),
+    }
   counters.update(headline)
   env_steps = (counters['env_steps'] - base['env_steps']) * world
   train_steps = (counters['train_steps'] - base['train_steps']) * world
@@ -544,6 +588,7 @@ def main():
         'sustained': sustained,
         'roofline': roofline, 'cpu_baseline': cpu,
         **({'native_comm': native} if native is not None else {}),
+        **({'replicas_only': replicas_only} if replicas_only is not None else {}),
     }), flush=True)
   if native_stuck:       # a collective of the check never returned: leave without the teardown
     sys.stdout.flush()

@@ -35,6 +35,8 @@ def test_bench_gpus_2_spawns_two_ranks():
   assert rec['scaling'] == 'weak' and rec['value'] > 0
   assert rec['sustained']['seconds'] >= 2.0
   assert rec['roofline']['launches'] >= 1          # rank 0's gathers inside the timed region
+  # context for reading a scaling curve: the same loop as N independent replicas
+  assert rec['replicas_only']['env_steps_per_s'] > 0 and rec['replicas_only']['steps'] % 256 == 0
 
 
 def test_bench_dreamer_workload_with_ranks():
@@ -63,6 +65,7 @@ def test_bench_checks_the_native_collectives_when_it_runs_on_rccl():
   assert native['per_call']['native_all_reduce']['host_us'] > 0
   # ... and, having passed, they carry the timed path (one emb_comm_exchange per train step).
   assert native['timed_path'] == 'native' and 'emb_comm_exchange' in rec['config']['parallelism']
+  assert native['per_train_step']['collectives_us'] > 0 and native['per_train_step']['issue_period_us'] > 0
   assert rec['train_steps_per_s'] > 0 and rec['roofline']['launches'] >= 1
 
 
