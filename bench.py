@@ -514,7 +514,7 @@ def main():
     }
 
   # Outside the timed region, measured context (no credit): SURVEY 8d's
-  # batches-per-launch sweep 1 / 8 / 64 (the reference's prefetch depth is 1, so
+  # batches-per-launch sweep 1 / 4 / 8 / 16 / 64 (the reference's prefetch depth is 1, so
   # one batch of B=16 per launch is the faithful headline), and a plain
   # device-to-device copy of one batch's bytes out of the same pool — what a
   # kernel with no gather structure at all achieves on this box, read cold.
@@ -523,7 +523,7 @@ def main():
     try:
       replay.profile(True, every=1)
       sweep = {}
-      for per_launch in (1, 8, 64):
+      for per_launch in (1, 4, 8, 16, 64):       # B = 16, 64, 128, 256, 1024 sequences
         big = B * per_launch
         for _ in range(3):
           replay.sample(big, 'report')

@@ -87,7 +87,7 @@ def test_bench_short_run_keeps_its_shape():
   roof = rec['roofline']
   assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and 0 < roof['frac'] < 1
   assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
-  assert set(roof['batches_per_launch_sweep']) == {'1', '8', '64'}
+  assert set(roof['batches_per_launch_sweep']) == {'1', '4', '8', '16', '64'}
   assert rec['sustained']['seconds'] >= 2.0 and rec['sustained']['gather_launches'] > 100
   assert rec['cpu_baseline']['kind'] == 'port' and rec['cpu_baseline']['cores'] == 1
 
