@@ -367,9 +367,15 @@ def main():
   # rocprofv3 run that sees the gather without the timed-dispatch perturbation.
   # Switched on before the warm-up so that the stamps' events exist by then.
   # One gather in --stamp-every carries stamps, unless the timed region is too
-  # short for that to leave a usable sample (the driver's --steps 20 has four).
+  # short for that to leave a usable sample (the driver's --steps 20 has three
+  # or four gathers: every second one then).
   expected = args.steps * args.envs * args.train_ratio / (B * T)
-  stamp_every = args.stamp_every if (expected >= 256 and args.consec == 1) else 1
+  if args.consec != 1:
+    stamp_every = 1
+  elif expected >= 256:
+    stamp_every = args.stamp_every
+  else:                       # three or four gathers in the region: at least one is stamped
+    stamp_every = 2 if expected >= 3 else 1
   replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1', every=stamp_every)
   # The fill runs no train step: warm the train path (allocator, online queue,
   # caches) whatever --warmup says, then the caller's warmup steps.
