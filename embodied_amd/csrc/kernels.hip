@@ -612,14 +612,24 @@ const MoveVariant& move_variant() {
 // B=32 22.5 / 23.5, B=64 41.7 / 42.1, B=128 81.6 / 79.4; Dreamer keys, 144 MB:
 // 26.8 / 28.7), so it is used up to `max_mb` MB of wide payload per launch
 // (fifth field).
-struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; };
+//
+// Non-temporal hints (bit 0 loads, bit 1 stores) are per direction: the sample
+// gather is fastest with both (B=16: 10.7 us against 11.2 / 10.9 / 12.2 for
+// loads-only / stores-only / none), the write-back with NONE (sixth field,
+// rocprofv3 medians: Dreamer's 84 MB of latents 12.5 us against 17.4 with both,
+// 17.2 stores-only, 13.2 loads-only; 59 MB of image rows 11.9 against 13.9 /
+// 14.8 / 13.5): non-temporal stores into pool rows scattered over HBM lose the
+// L2's write combining, and the source batch was just written by the learner.
+struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; int nt_scatter; };
 const SpanVariant& span_variant() {
   static const SpanVariant variant = [] {
-    SpanVariant v{4, 3, 512, 2, 160};
+    SpanVariant v{4, 3, 512, 2, 160, 0};
     if (const char* s = std::getenv("EMB_SPAN_VARIANT"))
-      std::sscanf(s, "%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb);
+      std::sscanf(s, "%d,%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb,
+                  &v.nt_scatter);
     if (v.unroll != 2 && v.unroll != 4) v.unroll = 4;
     if (v.nt < 0 || v.nt > 3) v.nt = 3;
+    if (v.nt_scatter < 0 || v.nt_scatter > 3) v.nt_scatter = 0;
     if (v.threads != 256 && v.threads != 512 && v.threads != 1024) v.threads = 512;
     if (v.per_cu < 0 || v.per_cu > 16) v.per_cu = 2;
     return v;
@@ -853,7 +863,7 @@ hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device
     else hipExtLaunchKernelGGL((span_move_kernel<G_, U_, NT_>), grid, block, 0, stream, start, stop, 0, a);             \
   } while (0)
 #define EMB_SPAN_NT(G_, U_)                                                      \
-  switch (sv.nt) {                                                               \
+  switch (G_ ? sv.nt : sv.nt_scatter) {                                          \
     case 0: EMB_SPAN(G_, U_, 0); break;                                          \
     case 1: EMB_SPAN(G_, U_, 1); break;                                          \
     case 2: EMB_SPAN(G_, U_, 2); break;                                          \
