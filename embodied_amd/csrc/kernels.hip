@@ -702,7 +702,11 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
     // once per workgroup (the staged head), the flat mover's waves walk it with
     // dependent reads (84 MB write-back: 20.3 us flat-indirect, 17.6 us span) —
     // there the span mover takes every size.
-    const int64_t limit_mb = gather ? sv.max_mb : (sv.max_mb < 40 ? sv.max_mb : 40);
+    static const int64_t scatter_mb = [] {    // EMB_SPAN_SCATTER_MB: size limit of span write-backs
+      const char* e = std::getenv("EMB_SPAN_SCATTER_MB");
+      return e ? std::atoll(e) : 40;
+    }();
+    const int64_t limit_mb = gather ? sv.max_mb : (sv.max_mb < scatter_mb ? sv.max_mb : scatter_mb);
     static const bool host_all = [] {       // EMB_SPAN_HOST_ALL=0: size limits in host mode too (A/B)
       const char* e = std::getenv("EMB_SPAN_HOST_ALL");
       return !(e && e[0] == '0');
