@@ -1107,6 +1107,47 @@ __device__ __forceinline__ void affine_suffix(float& a, float& b, int sl) {
   }
 }
 
+// Four consecutive elements of a row at once.  Rows start wherever b*T puts
+// them, so the vector types promise dword (floats) resp. byte (flags)
+// alignment only; gfx950 serves such global loads in one instruction.
+typedef float F4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint8_t B4 __attribute__((ext_vector_type(4), aligned(1)));
+// (A branch-free form -- the short lane reads the four elements that END at
+// its last one and shifts them down -- measured slower: 15.6 us against 13.4 at
+// (65 536, 64), no gain at small sizes.)
+__device__ __forceinline__ void load4(const float* p, int valid, float* out) {
+  if (valid >= 4) {
+    const F4 x = gload<F4>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = x[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = k < valid ? gload<float>(p + k) : 0.f;
+  }
+}
+__device__ __forceinline__ void load4(const uint8_t* p, int valid, uint8_t* out) {
+  if (valid >= 4) {
+    const B4 x = gload<B4>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = x[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = k < valid ? gload<uint8_t>(p + k) : uint8_t{0};
+  }
+}
+__device__ __forceinline__ void store4(float* p, int valid, const float* y) {
+  if (valid >= 4) {
+    F4 x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = y[k];
+    gstore<F4>(p, x);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < valid) gstore<float>(p + k, y[k]);
+  }
+}
+
 // What differs between the scans: how (a_t, b_t) are formed from the inputs,
 // the seed y_n, and what is stored.
 struct GaeOp {   // ppo/agent.py:188-201
@@ -1137,6 +1178,44 @@ struct GaeOp {   // ppo/agent.py:188-201
     adv[b * (T - 1) + t] = y;
     tar[b * (T - 1) + t] = y + keep;
   }
+  // Elements t0 .. t0+3 of row b (`valid` of them exist): same arithmetic as
+  // coef/store, the row's index math done once.
+  __device__ void coef4(int64_t b, int t0, int valid, float* a, float* bc, float* keep) const {
+    const int64_t i = b * T + t0;
+    int64_t ir = i, il = i;
+    if (group) {
+      const int64_t g = b / group, j = b - g * group;
+      ir = g * gs_rew + j * T + t0;
+      il = g * gs_flag + j * T + t0;
+    }
+    // val[t0 .. t0+valid]: one more than the elements, the last one's successor
+    // (it exists: t0 + valid <= T - 1).
+    float v[5], r[4];
+    uint8_t tm[4], ls[4];
+    load4(val + i, valid, v);
+    const float after = gload<float>(val + i + valid);
+    load4(rew + ir + 1, valid, r);
+    load4(term + il + 1, valid, tm);
+    load4(last + il + 1, valid, ls);
+    v[4] = after;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float next = k + 1 == valid ? after : v[k + 1];
+      const bool t_ = tm[k] != 0;
+      const float live = t_ ? 0.f : live_scale;
+      const float cont = (t_ || ls[k] != 0) ? 0.f : lam;
+      keep[k] = v[k];
+      a[k] = r[k] + live * next - v[k];
+      bc[k] = live * cont;
+    }
+  }
+  __device__ void store4(int64_t b, int t0, int valid, const float* y, const float* keep) const {
+    float z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = y[k] + keep[k];
+    emb::store4(adv + b * (T - 1) + t0, valid, y);
+    emb::store4(tar + b * (T - 1) + t0, valid, z);
+  }
 };
 
 struct LambdaOp {   // dreamerv3/agent.py:482-490
@@ -1152,10 +1231,31 @@ struct LambdaOp {   // dreamerv3/agent.py:482-490
     bc = live * cont;
   }
   __device__ void store(int64_t b, int64_t t, float y, float) const { ret[b * (T - 1) + t] = y; }
+  __device__ void coef4(int64_t b, int t0, int valid, float* a, float* bc, float* keep) const {
+    const int64_t i = b * T + t0 + 1;
+    float r[4], bt[4];
+    uint8_t tm[4], ls[4];
+    load4(rew + i, valid, r);
+    load4(boot + i, valid, bt);
+    load4(term + i, valid, tm);
+    load4(last + i, valid, ls);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float live = (1.f - static_cast<float>(tm[k] != 0)) * disc;
+      const float cont = (1.f - static_cast<float>(ls[k] != 0)) * lam;
+      keep[k] = 0.f;
+      a[k] = r[k] + (1.f - cont) * live * bt[k];
+      bc[k] = live * cont;
+    }
+  }
+  __device__ void store4(int64_t b, int t0, int valid, const float* y, const float*) const {
+    emb::store4(ret + b * (T - 1) + t0, valid, y);
+  }
 };
 
 // Short rows: a W-lane segment per row, rows longer than W walked right to
 // left with the running value in a register.
+
 template <int W, typename Op>
 __global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op, int64_t B, int64_t n) {
   const int sl = threadIdx.x % W;
@@ -1172,6 +1272,47 @@ __global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op, int64_
     if (ok) op.store(b, t, y, keep);
     carry = __shfl(y, 0, W);
   }
+}
+//
+// FOUR elements per lane: at large B the one-element-per-lane form above is
+// bound by its instruction count, not by HBM ((65 536, 64): ~220 VALU
+// instructions per wave and row, most of them 64-bit index arithmetic and
+// shuffle addressing, 19.3 us = 50 % of peak): here the row's index math is done
+// once per four elements, the loads are 16-byte / 4-byte vectors, the four
+// elements of a lane are folded sequentially (3 fma pairs) and the Kogge-Stone
+// runs over W = rowlen/4 lanes (4 rounds for T = 64 instead of 6).
+template <int W, typename Op>
+__global__ __launch_bounds__(kThreads) void scan_rows4_kernel(const Op op, int64_t B, int n) {
+  const int sl = threadIdx.x % W;
+  const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
+  const int t0 = 4 * sl;
+  const bool row_ok = b < B;
+  const int valid = row_ok ? (n - t0 >= 4 ? 4 : (n - t0 > 0 ? n - t0 : 0)) : 0;
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, bc[4] = {1.f, 1.f, 1.f, 1.f}, keep[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid > 0) op.coef4(b, t0, valid, a, bc, keep);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k >= valid) {            // (0, 1) = identity map right of the row's end
+      a[k] = 0.f;
+      bc[k] = 1.f;
+    }
+  // this lane's four elements as one map, then the maps of the lanes to the right
+  float A = a[3], Bm = bc[3];
+#pragma unroll
+  for (int k = 2; k >= 0; --k) {
+    A = fmaf(bc[k], A, a[k]);
+    Bm = bc[k] * Bm;
+  }
+  affine_suffix<W>(A, Bm, sl);
+  const float seed = row_ok ? op.seed(b) : 0.f;
+  const float first = fmaf(Bm, seed, A);               // y at t0
+  float carry = __shfl_down(first, 1, W);              // y at t0 + 4 = the next lane's first
+  if (sl == W - 1) carry = seed;
+  float y[4];
+  y[3] = fmaf(bc[3], carry, a[3]);
+#pragma unroll
+  for (int k = 2; k >= 0; --k) y[k] = fmaf(bc[k], y[k + 1], a[k]);
+  if (valid > 0) op.store4(b, t0, valid, y, keep);
 }
 
 // Long rows: one workgroup of `waves` wavefronts per row.  Each wave reduces its
@@ -1215,12 +1356,36 @@ hipError_t launch_scan(const Op& op, int64_t B, int64_t n, hipStream_t stream) {
                        0, stream, op, n);
     return hipGetLastError();
   }
-  const int W = n <= 16 ? 16 : n <= 32 ? 32 : 64;
+  // EMB_SCAN_FORM=1: the one-element-per-lane kernel (A/B against rows4).
+  static const bool one_per_lane = [] {
+    const char* e = std::getenv("EMB_SCAN_FORM");
+    return e && e[0] == '1';
+  }();
+  // Short rows in small batches (Dreamer's imagined returns, (1024, 16)) stay
+  // with one element per lane: 64 workgroups instead of 16, 3.4 us against 3.7.
+  if (one_per_lane || (n <= 16 && B <= 8192)) {
+    const int W = n <= 16 ? 16 : n <= 32 ? 32 : 64;
+    const int64_t rows_per_block = kThreads / W;
+    const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
+    if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+    else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+    else hipLaunchKernelGGL((scan_rows_kernel<64, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+    return hipGetLastError();
+  }
+  const int W = n <= 16 ? 4 : n <= 32 ? 8 : n <= 64 ? 16 : n <= 128 ? 32 : 64;
   const int64_t rows_per_block = kThreads / W;
   const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
-  if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
-  else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
-  else hipLaunchKernelGGL((scan_rows_kernel<64, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+  const int len = static_cast<int>(n);
+#define EMB_SCAN4(W_) \
+  hipLaunchKernelGGL((scan_rows4_kernel<W_, Op>), grid, dim3(kThreads), 0, stream, op, B, len)
+  switch (W) {
+    case 4: EMB_SCAN4(4); break;
+    case 8: EMB_SCAN4(8); break;
+    case 16: EMB_SCAN4(16); break;
+    case 32: EMB_SCAN4(32); break;
+    default: EMB_SCAN4(64); break;
+  }
+#undef EMB_SCAN4
   return hipGetLastError();
 }
 

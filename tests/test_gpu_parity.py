@@ -183,6 +183,30 @@ def test_scans_match_oracle(emb, shape, seed):
   close(ret.cpu().numpy(), want, axis=0)
 
 
+@pytest.mark.parametrize('rows', [1, 3, 70])
+def test_scans_at_every_row_length(emb, rows):
+  """Every T from 2 to 70 and around the 128 / 256 / 257 boundaries: the
+  four-elements-per-lane kernel with 1, 2, 3 and 4 valid elements in its last
+  lane, every segment width (4 .. 64 lanes) and the hand-over to the long-row
+  kernel; rows that do not fill the last wave.  Unaligned row starts (T odd)
+  exercise the dword / byte aligned vector loads."""
+  gen = np.random.default_rng(1000 + rows)
+  dev = lambda x: torch.as_tensor(x).cuda()
+  for T in [*range(2, 71), 126, 127, 128, 129, 130, 131, 254, 255, 256, 257, 258, 259, 300]:
+    rew = gen.standard_normal((rows, T)).astype(np.float32)
+    val = gen.standard_normal((rows, T)).astype(np.float32)
+    boot = gen.standard_normal((rows, T)).astype(np.float32)
+    last = gen.random((rows, T)) < 0.05
+    term = last & (gen.random((rows, T)) < 0.5)
+    adv, tar = emb.scans.gae(dev(rew), dev(val), dev(last), dev(term), hor=200, lam=0.8)
+    wadv, wtar = np_oracle.gae(rew, val, last, term, hor=200, lam=0.8)
+    np.testing.assert_allclose(adv.cpu().numpy(), wadv, rtol=1e-5, atol=1e-5, err_msg=f'T={T}')
+    np.testing.assert_allclose(tar.cpu().numpy(), wtar, rtol=1e-5, atol=1e-5, err_msg=f'T={T}')
+    ret = emb.scans.lambda_return(dev(last), dev(term), dev(rew), dev(val), dev(boot), 0.997, 0.95)
+    want = np_oracle.lambda_return(last, term, rew, boot, 0.997, 0.95)
+    np.testing.assert_allclose(ret.cpu().numpy(), want, rtol=1e-5, atol=1e-5, err_msg=f'T={T}')
+
+
 def test_scan_adversarial_long_horizon(emb):
   """b_t close to 1 over T=64: the parallel scan must stay within 1e-5
   relative of the sequential float32 recurrence and of the float64 closed form."""
