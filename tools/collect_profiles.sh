@@ -38,7 +38,23 @@ HIP_FORCE_DEV_KERNARG=0 python "$R/tools/profile_step.py" > "$O/profile_step.txt
 HIP_FORCE_DEV_KERNARG=0 python "$R/tools/profile_train.py" 2>&1 | head -8 > "$O/profile_train.txt"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/km -o km -- \
   python "$R/tools/bench_kernels.py" > /dev/null 2>&1
-cp /tmp/km/km_kernel_trace.csv "$O/kernels_micro_trace.csv" 2>/dev/null || true
+python "$R/tools/summarize_trace.py" /tmp/km/km_kernel_trace.csv 3 > "$O/kernels_micro.csv" 2>/dev/null || true
+# return scans at SURVEY 8d's large synthetic size, both kernel forms
+for form in 4 1; do
+  EMB_SCAN_FORM=$form rocprofv3 --kernel-trace --output-format csv -d /tmp/sc$form -o sc -- \
+    python "$R/tools/bench_scans.py" > /dev/null 2>&1
+  python "$R/tools/summarize_trace.py" /tmp/sc$form/sc_kernel_trace.csv 20 | grep -i "kernel\|scan_rows" \
+    > "$O/scans_large_form$form.csv" || true
+done
+# write-back of image rows through the span mover
+HIP_FORCE_DEV_KERNARG=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/up -o up -- \
+  python "$R/tools/bench_update.py" 16 > /dev/null 2>&1
+python "$R/tools/summarize_trace.py" /tmp/up/up_kernel_trace.csv 100 > "$O/update_image_rows.csv" 2>/dev/null || true
+# the multi-rank code path with RCCL as the transport, one rank (what a 1-GPU box can run)
+EMB_BENCH_FORCE_DIST=1 python "$R/bench.py" --no-cpu-baseline --no-context --sustained-seconds 5 2>/dev/null \
+  | grep '^{' > "$O/bench_world1_rccl.json" || true
+EMB_BENCH_FORCE_DIST=1 python "$R/bench.py" --comm c10d --no-cpu-baseline --no-context --sustained-seconds 5 2>/dev/null \
+  | grep '^{' > "$O/bench_world1_rccl_c10d.json" || true
 python - "$O" <<'PY'
 import csv, json, sys
 out = sys.argv[1]
