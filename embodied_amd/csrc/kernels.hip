@@ -613,23 +613,27 @@ const MoveVariant& move_variant() {
 // 26.8 / 28.7), so it is used up to `max_mb` MB of wide payload per launch
 // (fifth field).
 //
-// Non-temporal hints (bit 0 loads, bit 1 stores) are per direction: the sample
-// gather is fastest with both (B=16: 10.7 us against 11.2 / 10.9 / 12.2 for
-// loads-only / stores-only / none), the write-back with NONE (sixth field,
-// rocprofv3 medians: Dreamer's 84 MB of latents 12.5 us against 17.4 with both,
-// 17.2 stores-only, 13.2 loads-only; 59 MB of image rows 11.9 against 13.9 /
-// 14.8 / 13.5): non-temporal stores into pool rows scattered over HBM lose the
-// L2's write combining, and the source batch was just written by the learner.
+// Non-temporal hints (bit 0 loads, bit 1 stores; second field for gathers,
+// sixth for write-backs).  The sample gather is fastest with both (B=16: 10.7 us
+// against 11.2 / 10.9 / 12.2 for loads-only / stores-only / none).  What they
+// cost is paid by the NEXT reader of the batch: `nt` stores leave nothing of it
+// in L2 / Infinity Cache.  Measured with the write-back of the same tensors as
+// that reader (Dreamer workload, 84 MB, rocprofv3 medians over five GPUs):
+// 13.0-13.4 us behind a gather with plain stores, 16.6-18.3 us behind one with
+// `nt` stores -- whatever the write-back's own hints are (they move it by
+// +-0.3-1 us).  The default keeps the gather kernel itself fastest;
+// EMB_SPAN_VARIANT=4,1 is the setting for a learner that reads the whole batch
+// right after sampling.
 struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; int nt_scatter; };
 const SpanVariant& span_variant() {
   static const SpanVariant variant = [] {
-    SpanVariant v{4, 3, 512, 2, 160, 0};
+    SpanVariant v{4, 3, 512, 2, 160, 3};
     if (const char* s = std::getenv("EMB_SPAN_VARIANT"))
       std::sscanf(s, "%d,%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb,
                   &v.nt_scatter);
     if (v.unroll != 2 && v.unroll != 4) v.unroll = 4;
     if (v.nt < 0 || v.nt > 3) v.nt = 3;
-    if (v.nt_scatter < 0 || v.nt_scatter > 3) v.nt_scatter = 0;
+    if (v.nt_scatter < 0 || v.nt_scatter > 3) v.nt_scatter = 3;
     if (v.threads != 256 && v.threads != 512 && v.threads != 1024) v.threads = 512;
     if (v.per_cu < 0 || v.per_cu > 16) v.per_cu = 2;
     return v;
