@@ -477,6 +477,61 @@ class ShardedReplay:
     return views
 
 
+class GlobalClock:
+  """Wall-clock decisions every replica takes alike (clock.py:77-94: log / save
+  / report in lockstep).  The reference asks an RPC server that runs replica
+  0's clock behind two barriers; here the k-th call on every rank is ONE MAX
+  all-reduce of two flags -- "somebody asked to skip" and "rank 0's clock is
+  due" -- over the process group (host tensors with gloo, device tensors with
+  RCCL).  Same rules as the server's `should` (clock.py:44-67): 0 = never,
+  negative = always, rank 0's clock restarts when due even if the decision is
+  then vetoed by a skip; the first call is skipped unless `first`
+  (clock.py:81-82,87-89).  Without a process group (or with one rank) it is a
+  LocalClock."""
+
+  def __init__(self, every, first=False, group=None, device=None):
+    from .utils import LocalClock
+    self.every = float(every)
+    self.group = group
+    self.multihost = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not self.multihost:
+      self.clock = LocalClock(every, first)
+      return
+    if dist.get_backend(group) == 'nccl':
+      device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+    else:
+      device = torch.device('cpu')
+    self.device = device
+    self.rank = dist.get_rank(group)
+    # every replica must have built the clock with the same period (clock.py:38-39)
+    periods = torch.tensor([self.every, -self.every], dtype=torch.float64, device=device)
+    dist.all_reduce(periods, op=dist.ReduceOp.MAX, group=group)
+    assert periods[0].item() == -periods[1].item() == self.every, 'GlobalClock: periods differ'
+    import time
+    self.prev = time.time()
+    self.skip_next = not first
+
+  def __call__(self, step=None, skip=None):
+    if not self.multihost:
+      return self.clock(step, skip)
+    import time
+    if self.skip_next:
+      self.skip_next = False
+      skip = True
+    due = False
+    if self.rank == 0:
+      now = time.time()
+      if self.every < 0:
+        due = True
+      elif self.every > 0 and now >= self.prev + self.every:
+        self.prev = now
+        due = True
+    flags = torch.tensor([1.0 if skip else 0.0, 1.0 if due else 0.0], device=self.device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+    skipped, due = flags.tolist()
+    return bool(due) and not bool(skipped)
+
+
 class NativeComm:
   """The two collectives on RCCL through the library's own C ABI
   (`emb_comm_*`, include/embodied_hip.h) instead of torch.distributed: for hosts

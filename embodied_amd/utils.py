@@ -88,7 +88,9 @@ class LocalClock:
     self.prev = None
     self.first = first
 
-  def __call__(self, step=None):
+  def __call__(self, step=None, skip=None):
+    if skip:
+      return False
     if self.every == 0:
       return False
     if self.every < 0:

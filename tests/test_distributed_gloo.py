@@ -197,3 +197,38 @@ def test_dp_slice_exchange_world2_and_world4():
           assert (got['image'][src, j] == tag).all()
           assert (got['reward'][src, j] == tag + 0.5).all()
           assert (got['stepid'][src, j] == tag).all()
+
+
+def _clock_job(rank, world, D):
+  """Three ranks whose own wall clocks are skewed (rank r sleeps r * 30 ms more
+  per call): every decision must still come out the same on all of them."""
+  import time
+  always, never = D.GlobalClock(-1), D.GlobalClock(0)
+  timed, far = D.GlobalClock(0.15), D.GlobalClock(1000)
+  first = D.GlobalClock(0.15, first=True)
+  decisions = []
+  for call in range(12):
+    time.sleep(0.02 + 0.03 * rank)
+    decisions.append((
+        always(call), never(call), timed(call), first(call), far(call),
+        # rank 1 vetoes call 5 of the always-clock: nobody may act on it
+        always(call, skip=(rank == 1 and call == 5))))
+  return decisions
+
+
+def test_global_clock_decides_alike_on_every_rank_world3():
+  out = run_world(_clock_job, 3)
+  assert out[0] == out[1] == out[2]
+  always, never, timed, first, far, vetoed = zip(*out[0])
+  assert always == (False,) + (True,) * 11           # the first call is skipped (clock.py:81-89)
+  assert not any(never)
+  assert not any(never) and not any(far)
+  assert not timed[0] and any(timed) and any(first)   # rank 0's clock: due every 0.15 s
+  assert vetoed[5] is False and all(vetoed[6:])
+
+
+def test_global_clock_without_a_group_is_a_local_clock():
+  from embodied_amd import distributed as D
+  clock = D.GlobalClock(-1)
+  assert not clock.multihost and clock(0) is True and clock(1, skip=True) is False
+  assert D.GlobalClock(0)(0) is False
