@@ -433,6 +433,8 @@ def main():
       s_steps += 256
       go_on = time.perf_counter() - s_start < args.sustained_seconds
       if use_dist:          # every rank must leave the loop after the same step
+        if use_native:      # the process group's collective queues up behind the library's
+          native_comm.wait()
         flag = torch.tensor([1.0 if go_on else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         go_on = bool(flag.item())
