@@ -585,6 +585,9 @@ def main():
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
             'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
+            # the per-step Python of Driver / Replay / streams: Cython-compiled copies of the
+            # same sources (embodied_amd/_compiled_finder.py) or the plain modules
+            'host_modules': 'compiled' if 'embodied_amd.core.driver' in emb.compiled.loaded else 'python',
             'parallelism': (f'env-sharded x{world}, '
                             + ('per-rank Replay, ' if args.workload == 'dreamer'
                                else f'trajectory exchange {args.exchange} + ') +

@@ -2,6 +2,9 @@
 the reference's Python interfaces."""
 __version__ = '0.1.0'
 
+from . import _compiled_finder
+compiled = _compiled_finder.install()   # compiled copies of the hot host modules, if built and fresh
+
 from . import _lib  # raises if libembodied_hip.so is missing: no CPU fallback
 
 from .space import Space

@@ -25,6 +25,16 @@ ARCH = 'gfx950'
 FASTCALL = HERE / ('_emb_fastcall' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
 
 
+# Hot host modules compiled with Cython from their unchanged .py sources
+# (_compiled_finder.py): the per-step Python of the vectorised loop.
+COMPILED = [
+    'embodied_amd.core.driver', 'embodied_amd.core.replay', 'embodied_amd.core.streams',
+    'embodied_amd.ops', 'embodied_amd.scans', 'embodied_amd.distributed',
+    'embodied_amd.envs.synthetic',
+]
+COMPILED_DIR = HERE / '_compiled'
+
+
 def hipcc():
   for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
     if cand and pathlib.Path(cand).exists():
@@ -133,5 +143,83 @@ def build_fastcall(verbose=True):
   return FASTCALL
 
 
+def compiled_stale():
+  import hashlib
+  import json
+  try:
+    manifest = json.loads((COMPILED_DIR / 'manifest.json').read_text())
+  except (OSError, ValueError):
+    return True
+  for name in COMPILED:
+    entry = manifest.get(name)
+    source = HERE.parent / (name.replace('.', '/') + '.py')
+    if (not entry or not (COMPILED_DIR / entry['file']).exists()
+        or hashlib.sha256(source.read_bytes()).hexdigest() != entry['sha256']):
+      return True
+  return False
+
+
+def build_compiled(force=False, verbose=True):
+  """Cython -> C -> gcc -shared for every module in COMPILED; the manifest with
+  the sources' digests is written last.  Any failure leaves the package on its
+  plain .py modules (and says so): this is an accelerator, not a dependency."""
+  import hashlib
+  import json
+  if not force and not compiled_stale():
+    return COMPILED_DIR
+  gcc = shutil.which('gcc') or shutil.which('cc')
+  include = sysconfig.get_paths().get('include')
+  try:
+    from Cython.Compiler import Options
+    from Cython.Compiler.Main import compile as cython_compile
+  except Exception as e:      # no Cython: plain modules
+    if verbose:
+      print(f'Cython not importable ({e}): host modules stay plain Python', file=sys.stderr)
+    return None
+  if not gcc or not include or not (pathlib.Path(include) / 'Python.h').exists():
+    if verbose:
+      print('no C compiler / Python.h: host modules stay plain Python', file=sys.stderr)
+    return None
+  COMPILED_DIR.mkdir(exist_ok=True)
+  work = OBJ / 'cython'
+  work.mkdir(parents=True, exist_ok=True)
+  suffix = sysconfig.get_config_var('EXT_SUFFIX') or '.so'
+
+  def one(name):
+    source = HERE.parent / (name.replace('.', '/') + '.py')
+    text = source.read_bytes()
+    c_file = work / (name + '.c')
+    options = Options.CompilationOptions(
+        Options.default_options, output_file=str(c_file), language_level=3,
+        compiler_directives={'binding': True, 'language_level': 3})
+    result = cython_compile(str(source), options, full_module_name=name)
+    if result.num_errors:
+      raise RuntimeError(f'cython failed on {source}')
+    binary = COMPILED_DIR / (name + suffix)
+    tmp = binary.with_name(binary.name + '.tmp')
+    cmd = [gcc, '-O2', '-shared', '-fPIC', '-fwrapv', '-w', f'-I{include}', str(c_file), '-o', str(tmp)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode:
+      raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
+    os.replace(tmp, binary)
+    return name, {'file': binary.name, 'source': name.replace('.', '/') + '.py',
+                  'sha256': hashlib.sha256(text).hexdigest()}
+
+  manifest_path = COMPILED_DIR / 'manifest.json'
+  if manifest_path.exists():
+    manifest_path.unlink()          # nothing is trusted while binaries are being replaced
+  try:
+    manifest = dict(one(name) for name in COMPILED)     # Cython's compiler is not thread-safe
+  except Exception as e:
+    if verbose:
+      print(f'compiling the host modules failed, they stay plain Python: {e}', file=sys.stderr)
+    return None
+  manifest_path.write_text(json.dumps(manifest, indent=1))
+  if verbose:
+    print(f'built {len(manifest)} host modules in {COMPILED_DIR}')
+  return COMPILED_DIR
+
+
 if __name__ == '__main__':
   build(force='--force' in sys.argv)
+  build_compiled(force='--force' in sys.argv)

@@ -5,6 +5,7 @@ import pstats
 import sys
 
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
+os.environ.setdefault('EMB_PURE_PYTHON', '1')     # the profiler sees Python frames only
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
