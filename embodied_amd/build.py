@@ -30,8 +30,8 @@ FASTCALL = HERE / ('_emb_fastcall' + (sysconfig.get_config_var('EXT_SUFFIX') or 
 COMPILED = [
     'embodied_amd.core.driver', 'embodied_amd.core.replay', 'embodied_amd.core.streams',
     'embodied_amd.ops', 'embodied_amd.scans', 'embodied_amd.distributed',
-    'embodied_amd.envs.synthetic',
-]
+    'embodied_amd.envs.synthetic', 'embodied_amd.core.limiters',
+]   # (modules that locate files through __file__, like _lib, stay plain)
 COMPILED_DIR = HERE / '_compiled'
 
 
@@ -214,6 +214,10 @@ def build_compiled(force=False, verbose=True):
     if verbose:
       print(f'compiling the host modules failed, they stay plain Python: {e}', file=sys.stderr)
     return None
+  keep = {entry['file'] for entry in manifest.values()}
+  for leftover in COMPILED_DIR.glob('*' + suffix):      # modules no longer in the table
+    if leftover.name not in keep:
+      leftover.unlink()
   manifest_path.write_text(json.dumps(manifest, indent=1))
   if verbose:
     print(f'built {len(manifest)} host modules in {COMPILED_DIR}')
