@@ -780,7 +780,12 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   if (host_kernargs()) {
     int64_t bytes = 0;
     for (int k = 0; k < plan.n_keys; ++k) bytes += plan.key[k].rowbytes * n_rows;
-    if (bytes >= (4 << 20)) {
+    // EMB_ARGS_DEVICE_MIN: smallest move (bytes) that gets a device copy of its arguments.
+    static const int64_t device_min = [] {
+      const char* e = std::getenv("EMB_ARGS_DEVICE_MIN");
+      return e ? std::atoll(e) : int64_t{4} << 20;
+    }();
+    if (bytes >= device_min) {
       hipEvent_t none = nullptr, done = nullptr;
       if (stamp_this && stamp_predecessors()) {
         rep->timer_other.enabled = rep->timer_other.discard = true;
