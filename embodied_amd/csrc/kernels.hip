@@ -1436,10 +1436,14 @@ __global__ __launch_bounds__(kThreads) void abstract_traj_kernel(
 
 // Device-resident stand-in for N simulators: the episode logic
 // of envs/dummy.py:38-48 with counter-hash frames, so gathers are verifiable.
+// (Argument order: what the first instructions need -- the state, the reset
+// flags, the frame pointer and sizes -- sits in the first 64 bytes, which the
+// kernel-argument preload delivers in SGPRs; with host-resident arguments
+// everything behind them costs a PCIe read before the kernel can do anything.)
 __global__ __launch_bounds__(kThreads) void synth_env_kernel(
-    uint8_t* image, float* reward, uint8_t* is_first, uint8_t* is_last,
-    uint8_t* is_terminal, int64_t frame_bytes, int64_t env0, int64_t episode_len,
-    const uint8_t* reset, int32_t* counters) {
+    int32_t* counters, const uint8_t* reset, uint8_t* image, int64_t frame_bytes, int64_t env0,
+    int64_t episode_len, float* reward, uint8_t* is_first, uint8_t* is_last,
+    uint8_t* is_terminal) {
   const int64_t e = blockIdx.y;
   __shared__ int32_t s_count;
   if (threadIdx.x == 0) s_count = counters[2 * e];
@@ -1581,8 +1585,8 @@ hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, ui
   if (n <= 0) return hipSuccess;
   if (frame_bytes % 16 != 0 || reinterpret_cast<uint64_t>(image) % 16 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(synth_env_kernel, dim3(1, static_cast<uint32_t>(n)), dim3(kThreads), 0, stream,
-                     image, reward, is_first, is_last, is_terminal, frame_bytes, env0,
-                     episode_len, reset, counters);
+                     counters, reset, image, frame_bytes, env0, episode_len, reward, is_first,
+                     is_last, is_terminal);
   return hipGetLastError();
 }
 
