@@ -13,6 +13,8 @@ import pathlib
 import torch  # noqa: F401
 
 HERE = pathlib.Path(__file__).resolve().parent
+if HERE.name == '_compiled':      # the Cython copy of this module lives one level down
+  HERE = HERE.parent
 PATH = pathlib.Path(os.environ.get('EMB_LIB_PATH') or HERE / 'libembodied_hip.so')
 
 OK, ERR_INVALID, ERR_HIP, ERR_EMPTY, ERR_POOL_FULL, ERR_NOT_FOUND, ERR_INTERNAL = (

@@ -30,8 +30,8 @@ FASTCALL = HERE / ('_emb_fastcall' + (sysconfig.get_config_var('EXT_SUFFIX') or 
 COMPILED = [
     'embodied_amd.core.driver', 'embodied_amd.core.replay', 'embodied_amd.core.streams',
     'embodied_amd.ops', 'embodied_amd.scans', 'embodied_amd.distributed',
-    'embodied_amd.envs.synthetic', 'embodied_amd.core.limiters',
-]   # (modules that locate files through __file__, like _lib, stay plain)
+    'embodied_amd.envs.synthetic', 'embodied_amd.core.limiters', 'embodied_amd._lib',
+]   # (a compiled module's __file__ points into _compiled/: _lib allows for that)
 COMPILED_DIR = HERE / '_compiled'
 
 
