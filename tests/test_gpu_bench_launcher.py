@@ -90,6 +90,8 @@ def test_bench_short_run_keeps_its_shape():
   assert set(roof['batches_per_launch_sweep']) == {'1', '4', '8', '16', '64'}
   assert rec['sustained']['seconds'] >= 2.0 and rec['sustained']['gather_launches'] > 100
   assert rec['cpu_baseline']['kind'] == 'port' and rec['cpu_baseline']['cores'] == 1
+  assert rec['config']['kernargs'] in ('host', 'device')
+  assert rec['config']['host_modules'] in ('compiled', 'python')
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():
