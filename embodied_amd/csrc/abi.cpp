@@ -839,6 +839,11 @@ struct KeyList {
   std::vector<int8_t> mask_dtype;
   std::vector<uint8_t*> mask_out;
   const uint8_t* mask_flags = nullptr;
+  KeyList() {           // one allocation each instead of a doubling series per call
+    key.reserve(16);
+    mask_dtype.reserve(16);
+    mask_out.reserve(16);
+  }
   void push(uint8_t* pool, const void* batch, int64_t rowbytes) {
     key.push_back({pool, const_cast<uint8_t*>(static_cast<const uint8_t*>(batch)), rowbytes});
     mask_dtype.push_back(-1);
