@@ -92,6 +92,8 @@ def test_bench_short_run_keeps_its_shape():
   assert rec['cpu_baseline']['kind'] == 'port' and rec['cpu_baseline']['cores'] == 1
   assert rec['config']['kernargs'] in ('host', 'device')
   assert rec['config']['host_modules'] in ('compiled', 'python')
+  cpus = rec['config']['cpus']                    # pinned to a few idle CPUs on a big shared host
+  assert cpus is None or (len(cpus) == 4 and cpus == sorted(cpus))
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():
