@@ -67,7 +67,9 @@ def pin_cpus(width=4):
       for i in range(0, len(allowed) - width + 1, width):
         cpus = allowed[i:i + width]
         if cpus[-1] - cpus[0] == width - 1 and all(c in load for c in cpus):
-          windows.append((round(sum(load[c] for c in cpus), 2), i, cpus))
+          # (coarse: idle windows tie and fall back to their order, so that ranks
+          # measuring at slightly different moments still rank them alike)
+          windows.append((round(sum(load[c] for c in cpus), 1), i, cpus))
       if not windows:
         return None
       windows.sort()
@@ -94,7 +96,9 @@ def _is_launcher():
   return False
 
 
-PINNED = pin_cpus() if __name__ == '__main__' and not _is_launcher() else None
+# (Env worker processes would inherit the mask: the host-env workloads stay unpinned.)
+PINNED = (pin_cpus() if __name__ == '__main__' and not _is_launcher()
+          and not {'--parallel-envs', '--host-envs'} & set(sys.argv) else None)
 
 import numpy as np
 import torch
