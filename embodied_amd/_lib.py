@@ -53,6 +53,13 @@ PRIORITIZE_FN = C.CFUNCTYPE(
     None, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.c_int64)
 
 
+class ObsSpec(C.Structure):
+  """emb_obs_spec_t: how emb_replay_obs_stack_insert lays out the policy batch."""
+  _fields_ = [
+      ('pixels', C.c_int64), ('channels', C.c_int64), ('layout', C.c_int32),
+      ('out_dtype', C.c_int32), ('scale', C.c_float), ('offset', C.c_float)]
+
+
 class SelectorCallbacks(C.Structure):
   _fields_ = [
       ('user', C.c_void_p), ('sample', SAMPLE_FN), ('size', SIZE_FN),
@@ -137,6 +144,8 @@ SIGNATURES = {
     'emb_replay_stats': [p, p, i32],
     'emb_replay_add': [p, i64, p, p, p],
     'emb_replay_add_masked': [p, i64, p, p, i32, p, p, p, p, p],
+    'emb_replay_obs_stack_insert': [p, i64, p, i32, p, p, p, p, p, p],
+    'emb_replay_publish': [p, i64, p, p, i32, p, p, p, p, u64, p],
     'emb_replay_sample': [p, i64, i32, p, p, p, p],
     'emb_replay_sample_grouped': [p, i64, i32, p, i32, i64, p, p, p],
     'emb_replay_update': [p, i64, i64, p, i32, p, p, p],
@@ -162,7 +171,7 @@ SIGNATURES = {
     'emb_scan_lambda': [p, p, p, p, i64, i64, f32, f32, p, p],
     'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],
     'emb_abstract_traj': [p, p, i64, i64, i32, p, p, p],
-    'emb_synth_env_step': [p, p, p, p, p, i64, i64, i64, i64, p, p, p],
+    'emb_synth_env_step': [p, p, p, p, p, i64, i64, i64, i64, p, p, i32, p],
     'emb_comm_unique_id': [p],
     'emb_comm_init': [p, i32, i32, pp],
     'emb_comm_allgather_traj': [p, p, p, i64, p],
@@ -251,6 +260,7 @@ class _FastApi:
   SHAPES = {
       'emb_synth_env_step': 'ints', 'emb_mask_actions': 'ints',
       'emb_replay_add': 'ints', 'emb_replay_add_masked': 'ints',
+      'emb_replay_obs_stack_insert': 'ints', 'emb_replay_publish': 'ints',
       'emb_replay_sample': 'ints', 'emb_replay_sample_grouped': 'ints', 'emb_replay_update': 'ints',
       'emb_replay_gather_rows': 'ints', 'emb_replay_scatter_rows': 'ints',
       'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',

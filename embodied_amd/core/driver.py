@@ -18,6 +18,7 @@ Callbacks registered with `on_step(fn)` keep the reference contract
 stacked transition once per step.
 """
 import multiprocessing as mp
+import os
 from multiprocessing import shared_memory
 import time
 
@@ -28,6 +29,10 @@ import torch
 from .. import _lib
 from .._lib import api, fast
 from . import replay as replaylib
+
+# EMB_EARLY_INSERT=0: the Driver does not offer observations to its Replay ahead
+# of the policy (every key then goes in with the post-policy insert; the A/B).
+_EARLY_INSERT = os.environ.get('EMB_EARLY_INSERT', '1') != '0'
 
 _DTYPE_CODE = {
     torch.uint8: _lib.U8, torch.int8: _lib.I8, torch.int16: _lib.I16,
@@ -100,6 +105,7 @@ class Driver:
     self._slab = {}
     self._obs_names, self._obs_has_logs = None, False
     self._uploaded, self._upload_pending = None, False
+    self._mask_ring = None
     self._workers = np.arange(self.length, dtype=np.int64)
     self._workers.setflags(write=False)     # lets Replay.add_batch keep its converted copy
     self.reset()
@@ -275,16 +281,29 @@ class Driver:
     if self._obs_has_logs:
       logs = {k: v for k, v in obs.items() if k.startswith('log/')}
       obs = {k: v for k, v in obs.items() if not k.startswith('log/')}
+    # The only consumer of the step is one Replay: it is told about the step's
+    # observations before the policy runs (an agent that builds its policy
+    # batch with ops.obs_stack then writes them to their pool rows in the same
+    # launch), and the action mask rides in its insert launch (the pool rows and
+    # the next step's actions both receive value * ~is_last) instead of taking a
+    # launch of its own.
+    sink = self._sinks[0] if len(self._sinks) == 1 and not logs else None
+    if sink is not None and _EARLY_INSERT:
+      sink.offer(obs, self._workers)
     self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
     assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
     is_last = obs['is_last']
     acts = {k: self._to_device(v) for k, v in acts.items()}
-    if len(self._sinks) == 1 and self._sinks[0] is not None and not logs:
-      # The only consumer of the step is one Replay: the mask rides in its
-      # insert launch (the pool rows and the next step's actions both receive
-      # value * ~is_last) instead of taking a launch of its own.
-      acts = self._sinks[0].add_batch(
-          {**obs, **acts, **outs}, self._workers, mask=(tuple(acts), is_last))
+    if sink is not None:
+      # (The masked actions rotate through four sets of buffers, like a vector
+      # env's own outputs: a set is overwritten four steps later.)
+      names = tuple(acts)
+      ring = self._mask_ring
+      if ring is None or ring[0] != names:
+        ring = self._mask_ring = (names, [{} for _ in range(4)], [0])
+      ring[2][0] = turn = (ring[2][0] + 1) & 3
+      acts = sink.add_batch(
+          {**obs, **acts, **outs}, self._workers, mask=(names, is_last, ring[1][turn]))
       self.acts = {**acts, 'reset': is_last}
     else:
       acts = {k: mask_actions(v, is_last) for k, v in acts.items()}

@@ -16,8 +16,10 @@ import concurrent.futures
 import ctypes as C
 import io
 import pathlib
+import sys
 import threading
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -41,6 +43,11 @@ _DTYPE_CODE = {
     torch.int64: _lib.I64, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16,
     torch.float32: _lib.F32, torch.float64: _lib.F64, torch.bool: _lib.BOOL,
 }
+
+
+# Holders of a tensor's storage (tensors, views, storage handles): lets `sample`
+# prove that nobody can see an output set any more before it is used again.
+_STORAGE_USE_COUNT = getattr(torch._C, '_storage_Use_Count', None)
 
 
 def _itemsize(dtype):
@@ -136,8 +143,21 @@ class Replay:
     self._mask_plans = {}
     self._add_plan = None
     self._stage_busy, self._stage_pending = None, False
-    self._spare = None
     self._rowbytes_total = None
+    self._out_pool = {} if _STORAGE_USE_COUNT is not None else None
+    self._pool_bytes = 0
+    probe = [object()]
+    self._ref_base = sys.getrefcount(probe[0])
+    # Early insert (offer / _early_insert): the Driver's offer of the current
+    # step, the token of the launch that took it up, cached plans.
+    self._offer_tag = weakref.ref(self)
+    self._offer_obs, self._offer_workers = None, None
+    self._offer_names, self._early_plans, self._early_specs = {}, {}, {}
+    self._colspecs = {}
+    self._early_ptrs = None
+    self._pre_token = 0
+    self._token = C.c_uint64()
+    self.early_inserts = 0          # steps whose observation keys went in with the obs stack
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
     if directory and self._owners == 1 and pathlib.Path(directory).is_dir():
       self._reserve_directory_uids(directory)
@@ -330,17 +350,9 @@ class Replay:
 
     `mask=(names, is_last)` fuses the Driver's action mask into the insert
     (driver.py:72-74): the listed keys are stored as `value * ~is_last` in their
-    own dtype and the masked tensors are returned (dict name -> tensor)."""
-    if workers is not self._workers_seen:
-      self._workers_np = np.array(workers, np.int64, ndmin=1)      # private copy
-      self._workers_ptr = _lib.ptr(self._workers_np)
-      # Remember the caller's object only if it cannot change under us (the
-      # Driver's read-only id array, a tuple): a list or writable array that is
-      # mutated in place must be read again on every call.
-      frozen = isinstance(workers, tuple) or (
-          isinstance(workers, np.ndarray) and not workers.flags.writeable)
-      self._workers_seen = workers if frozen else None
-    workers, workers_ptr = self._workers_np, self._workers_ptr
+    own dtype and the masked tensors are returned (dict name -> tensor);
+    `mask=(names, is_last, outs)` writes them into the caller's `outs[name]`."""
+    workers, workers_ptr = self._workers_of(workers)
     n = len(workers)
     with self._lock:
       if self._keys is None:
@@ -357,28 +369,9 @@ class Replay:
       plan = self._add_plan
       if plan is None or plan[0] != order or plan[1] != n:
         plan = self._add_plan = (order, n, self._plan_columns(order, n))
-      keep, index, Tensor = [], device.index, torch.Tensor
-      columns = plan[2]
-      if fast.columns is not None:
-        # The usual case (contiguous tensors of the key's dtype and shape on this
-        # GPU) is checked and its addresses taken in C; what is left comes back
-        # as a list of positions.
-        todo = fast.columns(steps, columns, ptrs, Tensor, index)
-        if todo:
-          values = list(steps.values())
-          todo = [(values[at], columns[at]) for at in todo]
-      else:
-        todo = []
-        for value, column in zip(steps.values(), columns):
-          i, dtype, shape, name = column
-          if i < 0:
-            continue                                    # 'log/*': not stored
-          if (type(value) is Tensor and value.dtype is dtype and value.shape == shape
-              and value.is_contiguous() and value.get_device() == index):
-            ptrs[i] = value.data_ptr()
-          else:
-            todo.append((value, column))
-      for value, (i, dtype, shape, name) in todo or ():
+      keep = []
+      todo = self._collect(steps, plan[2], ptrs)
+      for value, (i, dtype, shape, name, *_) in todo or ():
         if not torch.is_tensor(value):
           value = torch.from_numpy(np.ascontiguousarray(value))
         if tuple(value.shape) != shape:
@@ -388,24 +381,36 @@ class Replay:
         ptrs[i] = value.data_ptr()
       masked = None
       if mask is not None:
-        names, flags = mask
+        names, flags, *given = mask
         plan = self._mask_plans.get(names)
         if plan is None:
           ids = (C.c_int32 * len(names))(*[keyid[name] for name in names])
           codes = (C.c_int32 * len(names))(*[_DTYPE_CODE[keys[keyid[name]].dtype] for name in names])
           plan = self._mask_plans[names] = (ids, codes, (C.c_void_p * len(names))())
         ids, codes, outs = plan
-        masked = {}
+        masked = given[0] if given and given[0] is not None else {}
         for j, name in enumerate(names):
-          key = keys[ids[j]]
-          out = masked[name] = _lib.empty((n, *key.shape), key.dtype, device)
+          out = masked.get(name)
+          if out is None:
+            key = keys[ids[j]]
+            out = masked[name] = _lib.empty((n, *key.shape), key.dtype, device)
           outs[j] = out.data_ptr()
         if flags.device != device or not flags.is_contiguous():
           flags = flags.to(device).contiguous()
         keep.append(flags)
+      # The early insert of this step (offer / _early_insert), if there was one.
+      token, self._pre_token, self._offer_obs = self._pre_token, 0, None
       while True:
         try:
-          if masked is None:
+          if token:
+            if masked is None:
+              fast.emb_replay_publish(
+                  self._h, n, workers_ptr, ptrs, 0, None, None, None, None, token, self._stream())
+            else:
+              fast.emb_replay_publish(
+                  self._h, n, workers_ptr, ptrs, len(ids), ids, codes, outs, flags.data_ptr(),
+                  token, self._stream())
+          elif masked is None:
             fast.emb_replay_add(self._h, n, workers_ptr, ptrs, self._stream())
           else:
             fast.emb_replay_add_masked(
@@ -417,6 +422,141 @@ class Replay:
       self._reraise()
     return masked
 
+  def _workers_of(self, workers):
+    """(private int64 copy, its address) of a worker list."""
+    if workers is not self._workers_seen:
+      self._workers_np = np.array(workers, np.int64, ndmin=1)      # private copy
+      self._workers_ptr = _lib.ptr(self._workers_np)
+      # Remember the caller's object only if it cannot change under us (the
+      # Driver's read-only id array, a tuple): a list or writable array that is
+      # mutated in place must be read again on every call.
+      frozen = isinstance(workers, tuple) or (
+          isinstance(workers, np.ndarray) and not workers.flags.writeable)
+      self._workers_seen = workers if frozen else None
+    return self._workers_np, self._workers_ptr
+
+  # ----------------------------------------------------------- early insert --
+
+  def offer(self, obs, workers):
+    """Driver -> Replay before the policy runs (driver.py:65-69): `obs` holds
+    the (N, ...) device tensors of the step that the next `add_batch(...,
+    workers)` will bring back.  If the agent turns one of its uint8 frame keys
+    into the policy batch with `ops.obs_stack` while the offer stands, that
+    launch also writes the observation keys into the step's pool rows
+    (emb_replay_obs_stack_insert: every frame is read once) and `add_batch` has
+    only the actions left.  Without that call nothing changes."""
+    self._offer_obs = obs
+    self._offer_workers = workers
+    self._pre_token = 0
+    order = tuple(obs)
+    names = self._offer_names.get(order)
+    if names is None:
+      names = self._offer_names[order] = tuple(
+          k for k, v in obs.items()
+          if torch.is_tensor(v) and v.dtype is torch.uint8 and v.ndim == 4 and v.is_cuda)
+    tag = self._offer_tag
+    for name in names:
+      frames = obs[name]
+      if getattr(frames, '_emb_offer', None) is not tag:
+        frames._emb_offer = tag
+
+  def _early_insert(self, frames, pixels, channels, first, dtype, scale, offset, out):
+    """ops.obs_stack on an offered frame tensor.  True: the policy batch has
+    been written (with or without the early insert); False: not handled."""
+    obs = self._offer_obs
+    if obs is None or self._pre_token or self._keys is None:
+      return False
+    with self._lock:
+      if self._staged:
+        self._flush()
+      order = tuple(obs)
+      frame_name = None
+      for name in self._offer_names.get(order, ()):
+        if obs[name] is frames:
+          frame_name = name
+          break
+      if frame_name is None or frame_name not in self._keyid:
+        return False
+      n = frames.shape[0]
+      plan = self._early_plans.get((order, frame_name, n))
+      if plan is None:
+        # Per position of the obs dict: (pool column or -1, dtype, (n, *shape),
+        # name).  The frame key and the narrow keys (<= 256 bytes per step)
+        # take part; everything else waits for add_batch.
+        columns = []
+        for name in order:
+          i = self._keyid.get(name, -1)
+          if i >= 0 and name != frame_name and self._keys[i].rowbytes > 256:
+            i = -1
+          columns.append(self._column(i, n, name))
+        plan = self._early_plans[(order, frame_name, n)] = (
+            tuple(columns), self._keyid[frame_name])
+      columns, frame_key = plan
+      if self._early_ptrs is None:
+        self._early_ptrs = (C.c_void_p * len(self._keys))()
+      if self._collect(obs, columns, self._early_ptrs):
+        return False                     # some key is not a ready device tensor
+      spec_key = (pixels, channels, first, dtype, scale, offset)
+      spec = self._early_specs.get(spec_key)
+      if spec is None:
+        code = _DTYPE_CODE.get(dtype)
+        if code not in (_lib.U8, _lib.F16, _lib.BF16, _lib.F32):
+          return False
+        struct = _lib.ObsSpec(
+            pixels, channels, _lib.LAYOUT_CHANNELS_FIRST if first else _lib.LAYOUT_SAME,
+            code, scale, offset)
+        spec = self._early_specs[spec_key] = (struct, C.addressof(struct))
+      _, workers_ptr = self._workers_of(self._offer_workers)
+      if len(self._workers_np) != n:
+        return False
+      fast.emb_replay_obs_stack_insert(
+          self._h, n, workers_ptr, frame_key, frames.data_ptr(), spec[1], out.data_ptr(),
+          self._early_ptrs, self._stream(), self._token)
+      self._pre_token = self._token.value
+      if self._pre_token:
+        self.early_inserts += 1
+    return True
+
+  def _collect(self, values, columns, ptrs):
+    """data_ptr() of every ready value (a contiguous tensor of the column's dtype
+    and shape on this GPU) into ptrs[column]; returns the (value, column) pairs
+    that are not ready, or None.  A tensor object that passed is marked
+    (`_emb_ok` = its column entry): vector envs hand out the same few tensor
+    objects step after step, and the next call takes the data_ptr() of a marked
+    one after a single identity comparison."""
+    if fast.columns is not None:
+      todo = fast.columns(values, columns, ptrs, torch.Tensor, self.device.index)
+      if todo:
+        listed = list(values.values())
+        todo = [(listed[at], columns[at]) for at in todo]
+      return todo
+    todo, index, Tensor = [], self.device.index, torch.Tensor
+    for value, column in zip(values.values(), columns):
+      i, dtype, shape, name = column[:4]
+      if i < 0:
+        continue                                    # not stored / not part of this pass
+      if type(value) is Tensor and getattr(value, '_emb_ok', None) is column:
+        ptrs[i] = value.data_ptr()                  # this tensor object passed the checks before
+      elif (type(value) is Tensor and value.dtype is dtype and value.shape == shape
+            and value.is_contiguous() and value.get_device() == index):
+        value._emb_ok = column
+        ptrs[i] = value.data_ptr()
+      else:
+        todo.append((value, column))
+    return todo
+
+  def _column(self, i, n, name):
+    """(pool column or -1, dtype, (n, *shape), name): ONE object per (column, n),
+    shared by every plan, because `_collect` marks a tensor that passed the checks
+    with the column entry it passed them against."""
+    if i < 0:
+      return (-1, None, None, name)
+    spec = self._colspecs.get((i, n))
+    if spec is None:
+      key = self._keys[i]
+      spec = self._colspecs[(i, n)] = (i, key.dtype, (n, *key.shape), name, self.device.index)
+    return spec
+
   def _plan_columns(self, order, n):
     """For every position of a step dict with keys `order`: (pool column or -1,
     dtype, (n, *shape), name).  Raises like the per-step checks did when the key
@@ -426,11 +566,10 @@ class Replay:
       i = self._keyid.get(name)
       if i is None:
         if name.startswith('log/'):
-          columns.append((-1, None, None, name))
+          columns.append(self._column(-1, n, name))
           continue
         raise KeyError(f'replay step key {name!r} was not in the first step')
-      key = self._keys[i]
-      columns.append((i, key.dtype, (n, *key.shape), name))
+      columns.append(self._column(i, n, name))
       seen += 1
     if seen + 1 != len(self._keys):
       raise KeyError(f'replay step keys {sorted(order)} differ from the first step')
@@ -446,46 +585,70 @@ class Replay:
         lambda: len(self._native), f'Replay buffer {self.name} is empty')
     with self._lock:
       self._flush()
+      stream = self._stream()
       out, ptrs = self._alloc_batch(batch, self.length)
       first = (C.c_uint8 * (batch * _lib.STEPID_BYTES))()
       fast.emb_replay_sample(
-          self._h, batch, _lib.MODES[mode], ptrs, None, first, self._stream())
+          self._h, batch, _lib.MODES[mode], ptrs, None, first, stream)
       self._reraise()
       # Host copy of stepid[:, 0] rides on the tensor object so `update` with
       # the same tensor needs no device read-back (a sync).
       out['stepid']._emb_first = first
-      self._alloc_ahead(batch, self.length)
     return self._finish(out)
 
   def _alloc_batch(self, batch, length):
-    # Fresh output tensors, but allocated one sample AHEAD: `sample` takes the
-    # set made right after the previous launch (while the GPU was busy with that
-    # gather) and makes the next one after its own launch — the ~9 us of
-    # allocations no longer sit between the index draw and the launch, where
-    # the GPU waits for them.
-    spare = self._spare
-    if spare is not None and spare[0] == (batch, length):
-      self._spare = None
-      return spare[1]
-    return self._alloc_batch_now(batch, length)
-
-  def _alloc_ahead(self, batch, length):
+    """Output tensors for one sampled batch: (dict name -> tensor, ctypes array
+    of their addresses).  `sample` returns tensors the caller owns, like the
+    reference's fresh arrays (replay.py:255-275) -- but seven `torch.empty` per
+    batch are ~9 us of host time, so sets whose tensors NOBODY references any
+    more are used again: a set goes back into rotation only when every tensor's
+    Python reference count and every storage's use count say that this pool is
+    the only holder (a view, a detach(), a tensor kept in a list all keep the
+    set out), which no caller can tell from a fresh allocation.  Work queued on
+    the same stream is ordered before the next gather as it would be with the
+    caching allocator handing the block out again; sets are never shared across
+    streams."""
     if self._reuse:
-      return
+      return self._alloc_batch_now(batch, length)
+    pool = self._out_pool
+    if pool is None or self._multistream:
+      return self._new_batch(batch, length)
+    stream = self._last_stream
+    sets = pool.get((batch, length))
+    if sets is None:
+      sets = pool[(batch, length)] = []
+    refs, uses, held = sys.getrefcount, _STORAGE_USE_COUNT, self._ref_base
+    for tensors, cdata, ptrs, owner, _ in sets:
+      if owner != stream:
+        continue
+      for i in range(len(tensors)):
+        # `held` = what getrefcount reports for an object only a list holds;
+        # 2 = the tensor and the storage handle this pool keeps.
+        if refs(tensors[i]) != held or uses(cdata[i]) != 2:
+          break
+      else:
+        return dict(zip(self._key_names, tensors)), ptrs
+    out, ptrs = self._new_batch(batch, length)
     if self._rowbytes_total is None:
       self._rowbytes_total = sum(k.rowbytes for k in self._keys)
-    if batch * length * self._rowbytes_total <= 256 << 20:       # a spare set stays allocated
-      self._spare = ((batch, length), self._new_batch(batch, length))
+      self._key_names = [k.name for k in self._keys]
+    nbytes = batch * length * self._rowbytes_total
+    if len(sets) < 4 and self._pool_bytes + nbytes <= 2 << 30:
+      tensors = list(out.values())
+      stores = [t.untyped_storage() for t in tensors]
+      cdata = [s._cdata for s in stores]
+      if all(uses(c) == 2 for c in cdata):
+        self._pool_bytes += nbytes
+        sets.append((tensors, cdata, ptrs, stream, stores))
+    return out, ptrs
 
   def _alloc_batch_now(self, batch, length):
-    if self._reuse:
-      ring = self._out_ring.setdefault((batch, length), [[], 0])
-      if len(ring[0]) < self._reuse:
-        ring[0].append(self._new_batch(batch, length))
-      out, ptrs = ring[0][ring[1] % len(ring[0])]
-      ring[1] += 1
-      return dict(out), ptrs
-    return self._new_batch(batch, length)
+    ring = self._out_ring.setdefault((batch, length), [[], 0])
+    if len(ring[0]) < self._reuse:
+      ring[0].append(self._new_batch(batch, length))
+    out, ptrs = ring[0][ring[1] % len(ring[0])]
+    ring[1] += 1
+    return dict(out), ptrs
 
   def _new_batch(self, batch, length):
     # torch.empty_like on a zero-stride, one-element template is about twice as
@@ -525,9 +688,10 @@ class Replay:
     batch, length = rows.shape
     with self._lock:
       self._flush()
+      stream = self._stream()
       out, ptrs = self._alloc_batch(batch, length)
       api.emb_replay_gather_rows(
-          self._handle, _lib.ptr(rows), rows.size, length, ptrs, self._stream())
+          self._handle, _lib.ptr(rows), rows.size, length, ptrs, stream)
     return self._finish(out)
 
   def sample_windows(self, batch, length, consec, prefix=0, mode='train'):

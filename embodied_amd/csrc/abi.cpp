@@ -173,9 +173,18 @@ class ArgRing {
   // Copies `bytes` (<= 4 KiB) of arguments into the next slot; returns its
   // device address.  Call retire() after the launch that reads it.  Slots are
   // guarded in groups of kGroup with one event per group (an event record costs
-  // the host ~3.7 us: once per eight launches, not once per launch): a group is
-  // entered again only after the event recorded behind its last launch is done.
+  // the host ~3.7 us: once per group, not once per launch): a group is entered
+  // again only after the event recorded behind its last launch is done.
   void* put(const void* args, size_t bytes, hipStream_t stream) {
+    uint8_t* dst = take(stream);
+    std::memcpy(dst, args, bytes);
+    __builtin_ia32_sfence();
+    return dst;
+  }
+  // The next slot itself (write-combined device memory: fill it front to back,
+  // never read it), for callers that build their block in place; follow with
+  // publish() before the launch and retire() after it.
+  uint8_t* take(hipStream_t stream) {
     if (next_ % kGroup != 0 && stream != group_stream_) {
       // Another stream takes over in the middle of a group (actor / learner):
       // close the group on the stream that filled it so far, start a new one.
@@ -193,11 +202,10 @@ class ArgRing {
       }
       group_stream_ = stream;
     }
-    uint8_t* dst = dev_ + static_cast<size_t>(slot_) * kSlotBytes;
-    std::memcpy(dst, args, bytes);
-    __builtin_ia32_sfence();
-    return dst;
+    return dev_ + static_cast<size_t>(slot_) * kSlotBytes;
   }
+  static void publish() { __builtin_ia32_sfence(); }
+  static constexpr size_t kSlotBytes = 4096;
   // After the launch that reads the slot `put` returned (same stream).
   void retire(hipStream_t stream) {
     if (slot_ % kGroup == kGroup - 1) {
@@ -207,8 +215,9 @@ class ArgRing {
   }
 
  private:
-  static constexpr int kSlots = 64, kGroup = 8;
-  static constexpr size_t kSlotBytes = 4096;
+  // 512 slots in groups of 64: one event record (~3.7 us of host time) per 64
+  // launches; a group is entered again 448 launches after it was closed.
+  static constexpr int kSlots = 512, kGroup = 64;
   hipStream_t group_stream_ = nullptr;
   int state_ = 0;          // 0 unknown, 1 usable, -1 not
   uint8_t* dev_ = nullptr;
@@ -371,10 +380,23 @@ struct emb_replay {
   hipEvent_t wrote = nullptr, read = nullptr;
   hipStream_t wrote_on = nullptr, read_on = nullptr;
   bool has_wrote = false, has_read = false;
+  // Early insert (emb_replay_obs_stack_insert): the keys of the next add for
+  // `workers` that are already in their pool rows, and where they came from.
+  struct Prewritten {
+    uint64_t token = 0;              // 0 = nothing outstanding
+    std::vector<int64_t> workers;
+    std::vector<int32_t> rows;
+    std::vector<const void*> src;    // per replay key: the buffer it was copied from (null = not written)
+    hipStream_t stream = nullptr;
+  } pre;
+  uint64_t pre_serial = 0, peek_mark = 0;
+  int32_t* dev_rows = nullptr;       // the prewrite launch's rows, for the publish launch
+  size_t dev_rows_cap = 0;
 
   ~emb_replay() {
     if (wrote) (void)hipEventDestroy(wrote);
     if (read) (void)hipEventDestroy(read);
+    if (dev_rows) (void)hipFree(dev_rows);
   }
 
   void order_before(bool gather, hipStream_t stream) {
@@ -879,36 +901,80 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
   }
 }
 
+// A completion stamp for a pool write while gathers are being timed with
+// device-resident kernel arguments (see stamp_predecessors), else null.
+static hipEvent_t write_stamp(emb_replay* rep) {
+  hipEvent_t none = nullptr, stop = nullptr;
+  if (rep->timer.enabled && stamp_predecessors() && !host_kernargs()) {
+    rep->timer_other.enabled = rep->timer_other.discard = true;
+    rep->timer_other.next(&none, &stop);
+  }
+  return stop;
+}
+
 static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const void* const* src,
                        int32_t n_masked, const int32_t* masked_keys, const int32_t* masked_dtypes,
-                       void* const* masked_out, const void* is_last, hipStream_t stream) {
+                       void* const* masked_out, const void* is_last, hipStream_t stream,
+                       uint64_t token = 0) {
   need(n >= 0 && workers && src, "add: bad arguments");
   need(!rep->keys.empty(), "add: call emb_replay_set_keys first");
   need(n_masked == 0 || (masked_keys && masked_dtypes && is_last), "add: bad mask arguments");
   if (n == 0) return;
-  KeyList list;
   for (size_t k = 0; k < rep->keys.size(); ++k) {
     need(rep->keys[k].pool, "add: key has no pool");
+    need(static_cast<int>(k) == rep->key_stepid || src[k], "add: null source buffer");
+  }
+  for (int32_t j = 0; j < n_masked; ++j) {
+    need(masked_keys[j] >= 0 && masked_keys[j] < static_cast<int32_t>(rep->keys.size()) &&
+             masked_keys[j] != rep->key_stepid, "add: masked key id out of range");
+    need(masked_dtypes[j] >= 0 && masked_dtypes[j] <= emb::kBool, "add: bad masked dtype");
+  }
+  if (token != 0 && rep->pre.token == token)
+    for (int32_t j = 0; j < n_masked; ++j)     // a masked key must not have been written unmasked
+      need(!rep->pre.src[masked_keys[j]] || rep->pre.src[masked_keys[j]] != src[masked_keys[j]],
+           "add: a masked key was part of the early insert");
+  rep->rows.resize(n);
+  rep->ids.resize(n);
+  add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());   // PoolFull: nothing changed yet
+  // Keys that emb_replay_obs_stack_insert already wrote: same token, same
+  // workers, same stream, and the rows this add was given are the peeked ones.
+  emb_replay::Prewritten& pre = rep->pre;
+  bool early = token != 0 && pre.token == token && pre.stream == stream &&
+               static_cast<int64_t>(pre.workers.size()) == n &&
+               std::equal(workers, workers + n, pre.workers.begin()) &&
+               std::equal(rep->rows.begin(), rep->rows.end(), pre.rows.begin());
+  pre.token = 0;        // any add consumes an outstanding early insert
+  KeyList list;
+  for (size_t k = 0; k < rep->keys.size(); ++k) {
+    if (early && pre.src[k] && (static_cast<int>(k) == rep->key_stepid || pre.src[k] == src[k]))
+      continue;                                         // already in its pool rows
     if (static_cast<int>(k) == rep->key_stepid) {
       list.key_stepid = static_cast<int>(list.key.size());
       list.push(rep->keys[k].pool, nullptr, rep->keys[k].rowbytes);
       continue;
     }
-    need(src[k], "add: null source buffer");
     list.push(rep->keys[k].pool, src[k], rep->keys[k].rowbytes);
+    for (int32_t j = 0; j < n_masked; ++j) {
+      if (masked_keys[j] != static_cast<int32_t>(k)) continue;
+      list.mask_dtype.back() = static_cast<int8_t>(masked_dtypes[j]);
+      list.mask_out.back() = masked_out ? static_cast<uint8_t*>(masked_out[j]) : nullptr;
+      list.mask_flags = static_cast<const uint8_t*>(is_last);
+    }
   }
-  for (int32_t j = 0; j < n_masked; ++j) {
-    const int32_t k = masked_keys[j];
-    need(k >= 0 && k < static_cast<int32_t>(rep->keys.size()) && k != rep->key_stepid,
-         "add: masked key id out of range");
-    need(masked_dtypes[j] >= 0 && masked_dtypes[j] <= emb::kBool, "add: bad masked dtype");
-    list.mask_dtype[k] = static_cast<int8_t>(masked_dtypes[j]);
-    list.mask_out[k] = masked_out ? static_cast<uint8_t*>(masked_out[j]) : nullptr;
-    list.mask_flags = static_cast<const uint8_t*>(is_last);
+  if (list.key.empty()) return;
+  if (early && list.key.size() == 1 && list.key_stepid < 0 &&
+      list.key[0].rowbytes * n <= (int64_t{1} << 20)) {
+    // All that is left is one small key (the action): the rows are in device
+    // memory since the early insert, the launch needs 56 bytes of arguments.
+    const bool masked = list.mask_flags && list.mask_dtype[0] >= 0;
+    rep->order_before(false, stream);
+    HIP_OK(emb::launch_publish_one(list.key[0].batch, list.key[0].pool, masked ? list.mask_out[0] : nullptr,
+                                   rep->dev_rows, masked ? list.mask_flags : nullptr, n,
+                                   list.key[0].rowbytes, masked ? list.mask_dtype[0] : emb::kU8, stream,
+                                   write_stamp(rep)));
+    rep->order_after(false, stream);
+    return;
   }
-  rep->rows.resize(n);
-  rep->ids.resize(n);
-  add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());
   run_move_all(rep, list, rep->rows.data(), n, list.key_stepid >= 0 ? rep->ids.data() : nullptr,
                false, stream);
 }
@@ -925,6 +991,121 @@ int32_t emb_replay_add_masked(emb_replay_t* rep, int64_t n, const int64_t* worke
                               const void* is_last, void* stream) {
   REP_OP(add_locked(rep, n, workers, src, n_masked, masked_keys, masked_dtypes, masked_out, is_last,
                     static_cast<hipStream_t>(stream)));
+}
+
+int32_t emb_replay_publish(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                           const void* const* src, int32_t n_masked, const int32_t* masked_keys,
+                           const int32_t* masked_dtypes, void* const* masked_out, const void* is_last,
+                           uint64_t token, void* stream) {
+  REP_OP(add_locked(rep, n, workers, src, n_masked, masked_keys, masked_dtypes, masked_out, is_last,
+                    static_cast<hipStream_t>(stream), token));
+}
+
+int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                                    int32_t frame_key, const void* frames, const emb_obs_spec_t* spec,
+                                    void* dst, const void* const* src, void* stream,
+                                    uint64_t* token_out) {
+  REP_OP({
+    need(n >= 0 && workers && frames && spec && dst && src && token_out, "obs_stack_insert: bad arguments");
+    need(spec->pixels > 0 && spec->channels > 0, "obs_stack_insert: bad frame shape");
+    need(spec->layout == EMB_LAYOUT_SAME || spec->layout == EMB_LAYOUT_CHANNELS_FIRST,
+         "obs_stack_insert: bad layout");
+    *token_out = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) return;
+    emb_replay::Prewritten& pre = rep->pre;
+    pre.token = 0;
+    const int n_keys = static_cast<int>(rep->keys.size());
+    emb::PrewritePlan plan;
+    plan.frames = static_cast<const uint8_t*>(frames);
+    plan.dst = dst;
+    plan.pixels = spec->pixels;
+    plan.channels = spec->channels;
+    plan.layout = spec->layout;
+    plan.out_dtype = spec->out_dtype;
+    plan.scale = spec->scale;
+    plan.offset = spec->offset;
+    plan.n = static_cast<int32_t>(n);
+    bool early = frame_key >= 0 && frame_key < n_keys && frame_key != rep->key_stepid &&
+                 rep->keys[frame_key].pool && src[frame_key] == frames &&
+                 rep->keys[frame_key].rowbytes == spec->pixels * spec->channels && n <= INT32_MAX;
+    if (early) {
+      rep->rows.resize(n);
+      rep->ids.resize(n);
+      const uint64_t mark = ++rep->peek_mark;
+      for (int64_t i = 0; i < n && early; ++i) {
+        int64_t row = 0;
+        early = rep->index->peek(workers[i], mark, &row, &rep->ids[i]);
+        rep->rows[i] = static_cast<int32_t>(row);
+      }
+    }
+    if (early) {
+      plan.frame_pool = rep->keys[frame_key].pool;
+      pre.src.assign(n_keys, nullptr);
+      pre.src[frame_key] = frames;
+      for (int k = 0; k < n_keys; ++k) {
+        if (k == frame_key) continue;
+        if (k == rep->key_stepid) {
+          plan.stepid_pool = rep->keys[k].pool;
+          pre.src[k] = rep->keys[k].pool;       // any non-null mark: step ids have no source buffer
+          continue;
+        }
+        // Narrow observation keys the caller listed ride along; wide ones and
+        // everything not listed (actions, agent outputs) wait for the publish.
+        if (!src[k] || !rep->keys[k].pool || rep->keys[k].rowbytes > 256 ||
+            plan.n_narrow >= emb::kPreNarrow)
+          continue;
+        plan.narrow[plan.n_narrow++] = {static_cast<const uint8_t*>(src[k]), rep->keys[k].pool,
+                                        rep->keys[k].rowbytes};
+        pre.src[k] = src[k];
+      }
+      early = emb::prewrite_supported(plan);
+    }
+    if (!early) {
+      HIP_OK(emb::launch_obs_stack(static_cast<const uint8_t*>(frames), nullptr, dst, n, spec->pixels,
+                                   spec->channels, spec->layout, spec->out_dtype, spec->scale,
+                                   spec->offset, s));
+      return;
+    }
+    if (rep->dev_rows_cap < static_cast<size_t>(n)) {
+      if (rep->dev_rows) HIP_OK(hipFree(rep->dev_rows));      // (synchronises: nothing still reads it)
+      rep->dev_rows = nullptr;
+      rep->dev_rows_cap = 0;
+      size_t cap = 256;
+      while (cap < static_cast<size_t>(n)) cap *= 2;
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&rep->dev_rows), cap * sizeof(int32_t)));
+      rep->dev_rows_cap = cap;
+    }
+    plan.rows_out = rep->dev_rows;
+    // The per-env table goes to device memory: written by the CPU through the
+    // BAR when it fits a slot of the argument ring, else staged and copied.
+    const size_t bytes = emb::prewrite_table_bytes(n);
+    const uint8_t* ids = reinterpret_cast<const uint8_t*>(rep->ids.data());
+    TableRing::Lease lease{-1, nullptr, nullptr};
+    bool in_bar = false;
+    if (bytes <= ArgRing::kSlotBytes && rep->arg_ring.usable()) {
+      uint8_t* slot = rep->arg_ring.take(s);
+      emb::prewrite_fill_table(slot, plan, rep->rows.data(), ids);
+      ArgRing::publish();
+      plan.table_dev = slot;
+      in_bar = true;
+    } else {
+      lease = rep->ring.acquire(bytes, s);
+      emb::prewrite_fill_table(lease.host, plan, rep->rows.data(), ids);
+      rep->ring.upload(lease, bytes, s);
+      plan.table_dev = lease.device;
+    }
+    rep->order_before(false, s);
+    HIP_OK(emb::launch_obs_stack_insert(plan, s, write_stamp(rep)));
+    rep->order_after(false, s);
+    if (in_bar) rep->arg_ring.retire(s);
+    if (lease.slot >= 0) rep->ring.retire(lease, s);
+    pre.workers.assign(workers, workers + n);
+    pre.rows = rep->rows;
+    pre.stream = s;
+    pre.token = ++rep->pre_serial;
+    *token_out = pre.token;
+  });
 }
 
 static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* const* dst,
@@ -1321,7 +1502,7 @@ int32_t emb_abstract_traj(const void* reward, const void* cont, int64_t T, int64
 
 int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_last, void* is_terminal,
                            int64_t n, int64_t frame_bytes, int64_t env0, int64_t episode_len,
-                           const void* reset, void* counters, void* stream) {
+                           const void* reset, void* counters, int32_t turn, void* stream) {
   return guarded([&] {
     need(image && reward && is_first && is_last && is_terminal && counters && n >= 0 && episode_len >= 1,
          "synth_env_step: bad arguments");
@@ -1329,7 +1510,7 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
                                  static_cast<uint8_t*>(is_first), static_cast<uint8_t*>(is_last),
                                  static_cast<uint8_t*>(is_terminal), n, frame_bytes, env0, episode_len,
                                  static_cast<const uint8_t*>(reset), static_cast<int32_t*>(counters),
-                                 static_cast<hipStream_t>(stream)));
+                                 turn, static_cast<hipStream_t>(stream)));
   });
 }
 

@@ -165,12 +165,26 @@ static PyObject* call_scan(PyObject* self, PyObject* const* args, Py_ssize_t nar
  *         device_index) -> None | list of positions
  *
  * Replay.add_batch's per-key loop: for every (name, value) of `steps`, in order,
- * with plan[i] = (column, dtype, shape, name): if `value` is exactly a
+ * with plan[i] = (column, dtype, shape, name[, device]): if `value` is exactly a
  * `tensor_type` of that dtype and shape, contiguous, on GPU `device_index`, its
  * data_ptr() goes to out[column]; otherwise the position is reported back and
  * the caller converts that value the slow way.  column < 0 = not stored.
- * The same checks as the Python loop, minus the interpreter between them. */
-static PyObject *s_dtype, *s_shape, *s_is_contiguous, *s_get_device, *s_data_ptr;
+ * The same checks as the Python loop, minus the interpreter between them.
+ *
+ * A tensor OBJECT that passed the checks against plan[i] is marked with that
+ * plan entry (attribute `_emb_ok`): vector envs hand out the same few tensor
+ * objects step after step, and a tensor's dtype, shape, device and strides do
+ * not change behind its back (short of resize_ / set_ / `.data =`, which
+ * nothing does to an observation), so the next call takes its data_ptr() after
+ * one identity comparison instead of four attribute calls. */
+static PyObject *s_dtype, *s_shape, *s_is_contiguous, *s_get_device, *s_data_ptr, *s_emb_ok;
+
+/* value.__dict__.get('_emb_ok'), borrowed, without creating the dict or raising. */
+static PyObject* ready_mark(PyObject* value) {
+  PyObject** dict = _PyObject_GetDictPtr(value);
+  if (!dict || !*dict) return NULL;
+  return PyDict_GetItemWithError(*dict, s_emb_ok);
+}
 
 static PyObject* call_columns(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
   if (nargs != 5 || !PyDict_Check(args[0]) || !PyTuple_Check(args[1])) {
@@ -204,13 +218,19 @@ static PyObject* call_columns(PyObject* self, PyObject* const* args, Py_ssize_t 
     }
     int ok = Py_TYPE(value) == tensor_type;
     PyObject* r;
-    if (ok) {
+    /* Marks are taken and left only for plan entries that name their device
+     * (a fifth element equal to `device`). */
+    const int markable = PyTuple_GET_SIZE(item) >= 5 &&
+                         PyLong_AsLong(PyTuple_GET_ITEM(item, 4)) == device;
+    const int marked = ok && markable && ready_mark(value) == item;
+    if (ok && !marked && PyErr_Occurred()) { failed = 1; break; }
+    if (ok && !marked) {
       r = PyObject_GetAttr(value, s_dtype);
       if (!r) { failed = 1; break; }
       ok = r == PyTuple_GET_ITEM(item, 1);
       Py_DECREF(r);
     }
-    if (ok) {
+    if (ok && !marked) {
       r = PyObject_GetAttr(value, s_shape);
       if (!r) { failed = 1; break; }
       const int eq = PyObject_RichCompareBool(r, PyTuple_GET_ITEM(item, 2), Py_EQ);
@@ -218,19 +238,21 @@ static PyObject* call_columns(PyObject* self, PyObject* const* args, Py_ssize_t 
       if (eq < 0) { failed = 1; break; }
       ok = eq;
     }
-    if (ok) {
+    if (ok && !marked) {
       r = PyObject_CallMethodNoArgs(value, s_is_contiguous);
       if (!r) { failed = 1; break; }
       ok = r == Py_True;
       Py_DECREF(r);
     }
-    if (ok) {
+    if (ok && !marked) {
       r = PyObject_CallMethodNoArgs(value, s_get_device);
       if (!r) { failed = 1; break; }
       const long where = PyLong_AsLong(r);
       Py_DECREF(r);
       if (where == -1 && PyErr_Occurred()) { failed = 1; break; }
       ok = where == device;
+      if (ok && markable && PyObject_SetAttr(value, s_emb_ok, item) < 0)
+        PyErr_Clear();                               /* no __dict__: stay unmarked */
     }
     if (ok) {
       r = PyObject_CallMethodNoArgs(value, s_data_ptr);
@@ -280,6 +302,7 @@ PyMODINIT_FUNC PyInit__emb_fastcall(void) {
   s_is_contiguous = PyUnicode_InternFromString("is_contiguous");
   s_get_device = PyUnicode_InternFromString("get_device");
   s_data_ptr = PyUnicode_InternFromString("data_ptr");
-  if (!s_dtype || !s_shape || !s_is_contiguous || !s_get_device || !s_data_ptr) return NULL;
+  s_emb_ok = PyUnicode_InternFromString("_emb_ok");
+  if (!s_dtype || !s_shape || !s_is_contiguous || !s_get_device || !s_data_ptr || !s_emb_ok) return NULL;
   return PyModule_Create(&module);
 }

@@ -141,10 +141,46 @@ hipError_t launch_abstract_traj(const float* reward, const float* cont, int64_t 
 
 // Synthetic vector env (bench/test input): counter-hash frames written straight
 // into HBM, SURVEY.md 8d.
+// `counters` = int32[2][2n]: generation `turn` is read, the other one written.
 hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first,
                             uint8_t* is_last, uint8_t* is_terminal, int64_t n,
                             int64_t frame_bytes, int64_t env0, int64_t episode_len,
-                            const uint8_t* reset, int32_t* counters,
+                            const uint8_t* reset, int32_t* counters, int turn,
                             hipStream_t stream);
+
+// Obs stack fused with the early part of Replay.add (driver.py:65 +
+// jax/agent.py:230 + chunk.py:41-50): every frame is read once and written to
+// the policy batch AND to the pool row its step will occupy; up to kPreNarrow
+// narrow observation keys, the step ids and a device copy of the row table ride
+// in the same launch.  Rows, step ids and the narrow keys' descriptors reach
+// the kernel through `table_dev`: prewrite_table_bytes(n) bytes of DEVICE
+// memory filled with prewrite_fill_table (directly through the BAR, or a
+// staging buffer + copy).
+constexpr int kPreNarrow = 8;
+constexpr int kStepBytes = 20;
+struct PrewritePlan {
+  const uint8_t* frames = nullptr;   // (n, pixels, channels) u8
+  void* dst = nullptr;               // policy batch
+  uint8_t* frame_pool = nullptr;     // pool of the frame key (rows of pixels * channels bytes)
+  int64_t pixels = 0, channels = 0;
+  int layout = kLayoutSame, out_dtype = kU8;
+  float scale = 1.f, offset = 0.f;
+  int32_t n = 0;
+  int32_t n_narrow = 0;
+  struct { const uint8_t* src; uint8_t* pool; int64_t rowbytes; } narrow[kPreNarrow] = {};
+  uint8_t* stepid_pool = nullptr;
+  const void* table_dev = nullptr;
+  int32_t* rows_out = nullptr;       // device int32[n] for launch_publish_one (optional)
+};
+bool prewrite_supported(const PrewritePlan& plan);
+size_t prewrite_table_bytes(int64_t n);
+void prewrite_fill_table(void* dst, const PrewritePlan& plan, const int32_t* rows, const uint8_t* stepids);
+hipError_t launch_obs_stack_insert(const PrewritePlan& plan, hipStream_t stream, hipEvent_t stop = nullptr);
+// One key of n rows to the pool rows `rows_dev` (device int32[n], -1 = skip):
+// value * !flags[r] in `dtype` when flags is set (and to `out` as well), a plain
+// copy otherwise.
+hipError_t launch_publish_one(const void* src, void* pool, void* out, const int32_t* rows_dev,
+                              const uint8_t* flags, int64_t n, int64_t rowbytes, int dtype,
+                              hipStream_t stream, hipEvent_t stop = nullptr);
 
 }  // namespace emb

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace emb {
 namespace {
@@ -1056,6 +1057,204 @@ hipError_t obs_stack_typed(const uint8_t* src, const int32_t* env_ids, void* dst
   return hipGetLastError();
 }
 
+// ------------------------------------------------- obs stack + early insert --
+//
+// The frames of a vectorised step are needed twice: by the policy (cast /
+// transposed into its batch) and by the replay (copied into the pool rows the
+// step will occupy).  Those rows are known before the policy runs — a worker's
+// next row is its open chunk's cursor (replay_index.h peek) — so ONE launch
+// reads every frame once and writes both: the policy batch exactly as
+// obs_stack_kernel does, and the same 16 bytes per lane into the reserved pool
+// row.  The other observation keys (reward, flags: a few bytes per env) and the
+// step ids ride along in the workgroup that owns the frame's tail.  What is
+// left for after the policy is the action (publish_one_kernel).
+//
+// Arguments: 64 bytes, all of them inside the kernel-argument preload (they
+// arrive in SGPRs with the wave).  Everything per-env — the row table, the step
+// ids, the narrow keys' descriptors — sits in a block in DEVICE memory that the
+// host wrote through the BAR (abi.cpp ArgRing) or uploaded: with host-resident
+// kernel arguments every wave's read of a by-value table would be a PCIe round
+// trip of its own (1 800 waves: measured 11.5 us for this launch instead of 5).
+// The row of a frame is read while the frame's loads are in flight (the
+// policy-batch stores do not depend on it).
+struct PreKey {
+  const uint8_t* src;
+  uint8_t* pool;
+  int64_t rowbytes;
+};
+struct alignas(16) PreTable {
+  uint8_t* stepid_pool;
+  int64_t pad_;
+  PreKey narrow[kPreNarrow];
+  uint32_t words[1];            // rows[n] | step ids, 5 words per row (6 * n words)
+};
+struct PrewriteArgs {
+  const uint8_t* frames;
+  void* dst;
+  uint8_t* frame_pool;
+  int64_t pixels;
+  float scale, offset;
+  int32_t n, n_narrow;
+  const PreTable* table;        // device memory
+  int32_t* rows_out;            // device int32[n]: the rows again, for the publish launch (may be null)
+};
+static_assert(sizeof(PrewriteArgs) == 64, "obs_stack_insert_kernel's arguments are preloaded");
+
+// The narrow keys, the step id and the row for the publish launch of env n: one
+// extra workgroup per env (blockIdx.x == gridDim.x - 1), so that this chain of
+// dependent reads (table -> source bytes -> stores) runs beside the frame
+// workgroups instead of behind one of them.  All loads are issued before the
+// first store: three memory round trips, however many keys.
+__device__ __forceinline__ void prewrite_narrow(const PrewriteArgs& a, int64_t n) {
+  const PreTable& t = *a.table;
+  const uint32_t* tab = t.words;
+  const int64_t row = static_cast<int32_t>(gload<uint32_t>(tab + n));
+  if (row < 0) return;
+  uint32_t sid = 0;
+  if (threadIdx.x < kStepBytes / 4)
+    sid = gload<uint32_t>(tab + a.n + n * (kStepBytes / 4) + threadIdx.x);
+  PreKey key[kPreNarrow];
+#pragma unroll
+  for (int k = 0; k < kPreNarrow; ++k) key[k] = t.narrow[k];      // uniform: scalar loads
+  uint8_t v[kPreNarrow];
+#pragma unroll
+  for (int k = 0; k < kPreNarrow; ++k) {
+    v[k] = 0;
+    if (k < a.n_narrow && static_cast<int64_t>(threadIdx.x) < key[k].rowbytes)
+      v[k] = gload<uint8_t>(key[k].src + n * key[k].rowbytes + threadIdx.x);
+  }
+#pragma unroll
+  for (int k = 0; k < kPreNarrow; ++k)
+    if (k < a.n_narrow && static_cast<int64_t>(threadIdx.x) < key[k].rowbytes)
+      gstore<uint8_t>(key[k].pool + row * key[k].rowbytes + threadIdx.x, v[k]);
+  if (t.stepid_pool && threadIdx.x < kStepBytes / 4)
+    gstore<uint32_t>(t.stepid_pool + row * kStepBytes + threadIdx.x * 4, sid);
+  if (a.rows_out && threadIdx.x == 0) a.rows_out[n] = static_cast<int32_t>(row);
+}
+static_assert(kThreads >= 256, "a narrow key (<= 256 bytes per step) is one byte per lane");
+
+template <typename Out, int C, bool kChannelsFirst>
+__global__ __launch_bounds__(kThreads) void obs_stack_insert_kernel(const PrewriteArgs a) {
+  const int64_t n = blockIdx.y;
+  if (blockIdx.x == gridDim.x - 1) {
+    prewrite_narrow(a, n);
+    return;
+  }
+  const int64_t pixels = a.pixels;
+  const int64_t quads = pixels >> 2;
+  const uint32_t* frame = reinterpret_cast<const uint32_t*>(a.frames + n * pixels * C);
+  Out* out = static_cast<Out*>(a.dst) + n * pixels * C;
+  const int64_t row = static_cast<int32_t>(gload<uint32_t>(a.table->words + n));
+  uint32_t* pool = reinterpret_cast<uint32_t*>(a.frame_pool + row * pixels * C);
+  const int64_t stride = static_cast<int64_t>(gridDim.x - 1) * kThreads;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; q < quads; q += stride) {
+    uint32_t w[C];
+    if constexpr (C == 4) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(frame) + q);
+      w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) w[c] = frame[q * C + c];
+    }
+    auto byte_at = [&w](int idx) {
+      return static_cast<uint8_t>((w[idx >> 2] >> ((idx & 3) * 8)) & 0xFFu);
+    };
+    if (kChannelsFirst) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        Quad<Out> o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o.v[p] = cvt<Out>(byte_at(p * C + c), a.scale, a.offset);
+        store_quad(out + c * pixels + q * 4, o);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        Quad<Out> o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o.v[p] = cvt<Out>(byte_at(j * 4 + p), a.scale, a.offset);
+        store_quad(out + (q * C + j) * 4, o);
+      }
+    }
+    if (row >= 0) {
+      if constexpr (C == 4) {
+        __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4*>(pool) + q);
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) __builtin_nontemporal_store(w[c], pool + q * C + c);
+      }
+    }
+  }
+}
+
+// What is left of an insert after obs_stack_insert_kernel when the only other
+// key is the action: rows[r] comes from the table that launch left in device
+// memory, the value is written as src * !flags[r] (driver.py:72-74; a real
+// multiply in the key's dtype) to its pool row and to `out`, the actions the
+// next env step receives.  56 bytes of arguments: all of them preloaded.
+struct PublishArgs {
+  const uint8_t* src;
+  uint8_t* pool;
+  uint8_t* out;
+  const int32_t* rows;
+  const uint8_t* flags;      // null: plain copy
+  int32_t n, rowbytes, dtype, elem;
+};
+static_assert(sizeof(PublishArgs) <= 64, "publish_one_kernel's arguments are preloaded");
+
+__global__ __launch_bounds__(kThreads) void publish_one_kernel(const PublishArgs a) {
+  const int64_t epr = a.rowbytes / a.elem;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= epr * a.n) return;
+  const int64_t r = e / epr;
+  const int64_t off = (e - r * epr) * a.elem;
+  const int64_t row = a.rows[r];
+  const bool keep = !a.flags || gload<uint8_t>(a.flags + r) == 0;
+  const uint8_t* src = a.src + r * a.rowbytes + off;
+  uint8_t* pool = row >= 0 ? a.pool + row * a.rowbytes + off : nullptr;
+  uint8_t* out = a.out ? a.out + r * a.rowbytes + off : nullptr;
+  switch (a.dtype) {
+    case kU8: case kBool: put_masked<uint8_t>(src, pool, out, keep); break;
+    case kI8: put_masked<int8_t>(src, pool, out, keep); break;
+    case kI16: put_masked<int16_t>(src, pool, out, keep); break;
+    case kI32: put_masked<int32_t>(src, pool, out, keep); break;
+    case kI64: put_masked<int64_t>(src, pool, out, keep); break;
+    case kF16: put_masked<_Float16>(src, pool, out, keep); break;
+    case kBF16: put_masked_bf16(src, pool, out, keep); break;
+    case kF32: put_masked<float>(src, pool, out, keep); break;
+    default: put_masked<double>(src, pool, out, keep); break;
+  }
+}
+
+template <typename Out>
+hipError_t obs_stack_insert_typed(const PrewriteArgs& a, int64_t channels, int layout,
+                                  hipStream_t stream, hipEvent_t stop) {
+  const int64_t quads = a.pixels / 4;
+  // frame workgroups + one workgroup per env for the narrow keys
+  dim3 grid(static_cast<uint32_t>(std::min<int64_t>((quads + kThreads - 1) / kThreads, 32)) + 1,
+            static_cast<uint32_t>(a.n));
+  const bool cf = layout == kLayoutChannelsFirst && channels > 1;
+  // (hipExtLaunchKernelGGL only when a completion stamp is wanted: the plain
+  // launch is the cheaper call.)
+#define EMB_PRE(C)                                                                                \
+  if (cf && stop) hipExtLaunchKernelGGL((obs_stack_insert_kernel<Out, C, true>), grid,            \
+                                        dim3(kThreads), 0, stream, nullptr, stop, 0, a);          \
+  else if (cf) hipLaunchKernelGGL((obs_stack_insert_kernel<Out, C, true>), grid, dim3(kThreads),  \
+                                  0, stream, a);                                                  \
+  else if (stop) hipExtLaunchKernelGGL((obs_stack_insert_kernel<Out, C, false>), grid,            \
+                                       dim3(kThreads), 0, stream, nullptr, stop, 0, a);           \
+  else hipLaunchKernelGGL((obs_stack_insert_kernel<Out, C, false>), grid, dim3(kThreads), 0,      \
+                          stream, a);
+  switch (channels) {
+    case 1: EMB_PRE(1) break;
+    case 2: EMB_PRE(2) break;
+    case 3: EMB_PRE(3) break;
+    default: EMB_PRE(4) break;
+  }
+#undef EMB_PRE
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------- action mask --
 
 template <typename T>
@@ -1154,23 +1353,34 @@ __device__ __forceinline__ void store4(float* p, int valid, const float* y) {
 
 // What differs between the scans: how (a_t, b_t) are formed from the inputs,
 // the seed y_n, and what is stored.
-struct GaeOp {   // ppo/agent.py:188-201
+// (Sizes: GaeOp<false> is exactly 64 bytes and LambdaOp 56, so that a scan's
+// whole argument block arrives through the kernel-argument preload: with
+// host-resident arguments anything beyond 64 bytes is a PCIe read in front of
+// the first instruction of every wave.  B and T ride inside the op for that.)
+struct NoGroups {};
+struct Groups { int64_t group, gs_rew, gs_flag; };
+template <bool kGrouped>
+struct GaeOp : std::conditional_t<kGrouped, Groups, NoGroups> {   // ppo/agent.py:188-201
   const float* rew; const float* val; const uint8_t* last; const uint8_t* term;
-  int64_t T; float live_scale, lam; float* adv; float* tar;
-  // rew / last / term may come straight out of a grouped packed batch
+  float* adv; float* tar;
+  int32_t T, B; float live_scale, lam;
+  // kGrouped: rew / last / term come straight out of a grouped packed batch
   // (distributed.py): row b then starts (b / group) * gs + (b % group) * T
-  // elements into its key (gs_rew in floats, gs_flag in bytes); 0 = dense rows.
+  // elements into its key (gs_rew in floats, gs_flag in bytes).
   // `val` (the critic's output) and the results are always dense.
-  int64_t group, gs_rew, gs_flag;
   __device__ float seed(int64_t) const { return 0.f; }
+  __device__ void where(int64_t b, int64_t t, int64_t& ir, int64_t& il) const {
+    ir = il = b * T + t;
+    if constexpr (kGrouped) {
+      const int64_t g = b / this->group, j = b - g * this->group;
+      ir = g * this->gs_rew + j * T + t;
+      il = g * this->gs_flag + j * T + t;
+    }
+  }
   __device__ void coef(int64_t b, int64_t t, float& a, float& bc, float& keep) const {
     const int64_t i = b * T + t;
-    int64_t ir = i, il = i;
-    if (group) {
-      const int64_t g = b / group, j = b - g * group;
-      ir = g * gs_rew + j * T + t;
-      il = g * gs_flag + j * T + t;
-    }
+    int64_t ir, il;
+    where(b, t, ir, il);
     const bool tm = term[il + 1] != 0;
     const float live = tm ? 0.f : live_scale;
     const float cont = (tm || last[il + 1] != 0) ? 0.f : lam;
@@ -1186,12 +1396,8 @@ struct GaeOp {   // ppo/agent.py:188-201
   // coef/store, the row's index math done once.
   __device__ void coef4(int64_t b, int t0, int valid, float* a, float* bc, float* keep) const {
     const int64_t i = b * T + t0;
-    int64_t ir = i, il = i;
-    if (group) {
-      const int64_t g = b / group, j = b - g * group;
-      ir = g * gs_rew + j * T + t0;
-      il = g * gs_flag + j * T + t0;
-    }
+    int64_t ir, il;
+    where(b, t0, ir, il);
     // val[t0 .. t0+valid]: one more than the elements, the last one's successor
     // (it exists: t0 + valid <= T - 1).
     float v[5], r[4];
@@ -1221,10 +1427,11 @@ struct GaeOp {   // ppo/agent.py:188-201
     emb::store4(tar + b * (T - 1) + t0, valid, z);
   }
 };
+static_assert(sizeof(GaeOp<false>) == 64, "the dense GAE op is covered by the kernel-argument preload");
 
 struct LambdaOp {   // dreamerv3/agent.py:482-490
   const uint8_t* last; const uint8_t* term; const float* rew; const float* boot;
-  int64_t T; float disc, lam; float* ret;
+  float* ret; int32_t T, B; float disc, lam;
   __device__ float seed(int64_t b) const { return boot[b * T + T - 1]; }
   __device__ void coef(int64_t b, int64_t t, float& a, float& bc, float& keep) const {
     const int64_t i = b * T + t;
@@ -1256,12 +1463,14 @@ struct LambdaOp {   // dreamerv3/agent.py:482-490
     emb::store4(ret + b * (T - 1) + t0, valid, y);
   }
 };
+static_assert(sizeof(LambdaOp) <= 64, "covered by the kernel-argument preload");
 
 // Short rows: a W-lane segment per row, rows longer than W walked right to
 // left with the running value in a register.
 
 template <int W, typename Op>
-__global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op, int64_t B, int64_t n) {
+__global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op) {
+  const int64_t B = op.B, n = op.T - 1;
   const int sl = threadIdx.x % W;
   const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
   const bool row_ok = b < B;
@@ -1286,7 +1495,9 @@ __global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op, int64_
 // elements of a lane are folded sequentially (3 fma pairs) and the Kogge-Stone
 // runs over W = rowlen/4 lanes (4 rounds for T = 64 instead of 6).
 template <int W, typename Op>
-__global__ __launch_bounds__(kThreads) void scan_rows4_kernel(const Op op, int64_t B, int n) {
+__global__ __launch_bounds__(kThreads) void scan_rows4_kernel(const Op op) {
+  const int64_t B = op.B;
+  const int n = op.T - 1;
   const int sl = threadIdx.x % W;
   const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
   const int t0 = 4 * sl;
@@ -1325,7 +1536,8 @@ __global__ __launch_bounds__(kThreads) void scan_rows4_kernel(const Op op, int64
 // right to left in pieces of 64 * waves steps with the carry handed on through
 // LDS.
 template <typename Op>
-__global__ __launch_bounds__(1024) void scan_long_rows_kernel(const Op op, int64_t n) {
+__global__ __launch_bounds__(1024) void scan_long_rows_kernel(const Op op) {
+  const int64_t n = op.T - 1;
   __shared__ float s_a[16], s_b[16], s_carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int64_t b = blockIdx.x;
@@ -1353,11 +1565,12 @@ __global__ __launch_bounds__(1024) void scan_long_rows_kernel(const Op op, int64
 }
 
 template <typename Op>
-hipError_t launch_scan(const Op& op, int64_t B, int64_t n, hipStream_t stream) {
+hipError_t launch_scan(const Op& op, hipStream_t stream) {
+  const int64_t B = op.B, n = op.T - 1;
   if (n > 256) {
     const int waves = static_cast<int>(std::min<int64_t>(16, (n + 63) / 64));
     hipLaunchKernelGGL(scan_long_rows_kernel<Op>, dim3(static_cast<uint32_t>(B)), dim3(64 * waves),
-                       0, stream, op, n);
+                       0, stream, op);
     return hipGetLastError();
   }
   // EMB_SCAN_FORM=1: the one-element-per-lane kernel (A/B against rows4).
@@ -1371,17 +1584,16 @@ hipError_t launch_scan(const Op& op, int64_t B, int64_t n, hipStream_t stream) {
     const int W = n <= 16 ? 16 : n <= 32 ? 32 : 64;
     const int64_t rows_per_block = kThreads / W;
     const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
-    if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
-    else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
-    else hipLaunchKernelGGL((scan_rows_kernel<64, Op>), grid, dim3(kThreads), 0, stream, op, B, n);
+    if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op>), grid, dim3(kThreads), 0, stream, op);
+    else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op>), grid, dim3(kThreads), 0, stream, op);
+    else hipLaunchKernelGGL((scan_rows_kernel<64, Op>), grid, dim3(kThreads), 0, stream, op);
     return hipGetLastError();
   }
   const int W = n <= 16 ? 4 : n <= 32 ? 8 : n <= 64 ? 16 : n <= 128 ? 32 : 64;
   const int64_t rows_per_block = kThreads / W;
   const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
-  const int len = static_cast<int>(n);
 #define EMB_SCAN4(W_) \
-  hipLaunchKernelGGL((scan_rows4_kernel<W_, Op>), grid, dim3(kThreads), 0, stream, op, B, len)
+  hipLaunchKernelGGL((scan_rows4_kernel<W_, Op>), grid, dim3(kThreads), 0, stream, op)
   switch (W) {
     case 4: EMB_SCAN4(4); break;
     case 8: EMB_SCAN4(8); break;
@@ -1436,40 +1648,87 @@ __global__ __launch_bounds__(kThreads) void abstract_traj_kernel(
 
 // Device-resident stand-in for N simulators: the episode logic
 // of envs/dummy.py:38-48 with counter-hash frames, so gathers are verifiable.
-// (Argument order: what the first instructions need -- the state, the reset
-// flags, the frame pointer and sizes -- sits in the first 64 bytes, which the
-// kernel-argument preload delivers in SGPRs; with host-resident arguments
-// everything behind them costs a PCIe read before the kernel can do anything.)
-__global__ __launch_bounds__(kThreads) void synth_env_kernel(
-    int32_t* counters, const uint8_t* reset, uint8_t* image, int64_t frame_bytes, int64_t env0,
-    int64_t episode_len, float* reward, uint8_t* is_first, uint8_t* is_last,
-    uint8_t* is_terminal) {
+//
+// 60 bytes of arguments, all inside the kernel-argument preload (with
+// host-resident arguments anything behind the first 64 bytes costs every wave
+// a PCIe read before its first instruction): the three flag outputs travel as
+// 32-bit offsets from the reward pointer (the launcher falls back to the
+// five-pointer form when they do not fit).  The per-env state is read from one
+// half of `counters` and written to the other (`turn`), so that every
+// workgroup of an env may read it while the last one writes: a frame is cut
+// over gridDim.x workgroups instead of one.
+struct SynthArgs {
+  int32_t* counters;          // 2 x int32[2n]: {count, done} per env, two generations
+  const uint8_t* reset;
+  uint8_t* image;
+  float* reward;
+  int32_t off_first, off_last, off_terminal;   // bytes from `reward`
+  int32_t frame_bytes, env0, episode_len, n_turn;   // n << 1 | turn
+};
+static_assert(sizeof(SynthArgs) <= 64, "synth_env_kernel's arguments are preloaded");
+
+__global__ __launch_bounds__(kThreads) void synth_env_kernel(const SynthArgs a) {
   const int64_t e = blockIdx.y;
-  __shared__ int32_t s_count;
-  if (threadIdx.x == 0) s_count = counters[2 * e];
-  __syncthreads();
-  int32_t count = s_count;
-  const bool was_done = counters[2 * e + 1] != 0;
-  const bool restart = (reset && reset[e]) || was_done;
-  const int64_t length = episode_len + ((env0 + e) % 8) * 13;
+  const int32_t n = a.n_turn >> 1, turn = a.n_turn & 1;
+  const int32_t* __restrict__ in = a.counters + turn * 2 * n;
+  int32_t count = in[2 * e];
+  const bool was_done = in[2 * e + 1] != 0;
+  const bool restart = (a.reset && a.reset[e]) || was_done;
+  const int64_t length = a.episode_len + ((a.env0 + e) % 8) * 13;
   count = restart ? 0 : count + 1;
   const bool done = !restart && count >= length;
-  const uint32_t salt = static_cast<uint32_t>((env0 + e) * 131 + static_cast<int64_t>(count) * 7);
+  const uint32_t salt = static_cast<uint32_t>((a.env0 + e) * 131 + static_cast<int64_t>(count) * 7);
   // byte i of the frame = (salt + i) & 0xFF, written 16 bytes per lane.
-  u32x4* out = reinterpret_cast<u32x4*>(image + e * frame_bytes);
-  const int64_t vecs = frame_bytes >> 4;
+  u32x4* out = reinterpret_cast<u32x4*>(a.image + e * a.frame_bytes);
+  const int64_t vecs = a.frame_bytes >> 4;
   auto word = [salt](int64_t byte0) {
     const uint32_t x = salt + static_cast<uint32_t>(byte0);
     return (x & 0xFF) | (((x + 1) & 0xFF) << 8) | (((x + 2) & 0xFF) << 16) | (((x + 3) & 0xFF) << 24);
   };
-  for (int64_t i = threadIdx.x; i < vecs; i += kThreads)
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < vecs;
+       i += static_cast<int64_t>(gridDim.x) * kThreads)
     __builtin_nontemporal_store(
         u32x4{word(i * 16), word(i * 16 + 4), word(i * 16 + 8), word(i * 16 + 12)}, out + i);
-  __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    counters[2 * e] = count;
-    counters[2 * e + 1] = done ? 1 : 0;
-    reward[e] = restart ? 0.f : static_cast<float>(count % 7);
+    int32_t* next = a.counters + (1 - turn) * 2 * n;
+    next[2 * e] = count;
+    next[2 * e + 1] = done ? 1 : 0;
+    uint8_t* flags = reinterpret_cast<uint8_t*>(a.reward);
+    a.reward[e] = restart ? 0.f : static_cast<float>(count % 7);
+    flags[a.off_first + e] = restart ? 1 : 0;
+    flags[a.off_last + e] = done ? 1 : 0;
+    flags[a.off_terminal + e] = done ? 1 : 0;
+  }
+}
+
+// The same step when the flag buffers are too far from `reward` for 32-bit
+// offsets (80 bytes of arguments).
+__global__ __launch_bounds__(kThreads) void synth_env_far_kernel(
+    const SynthArgs a, uint8_t* is_first, uint8_t* is_last, uint8_t* is_terminal) {
+  const int64_t e = blockIdx.y;
+  const int32_t n = a.n_turn >> 1, turn = a.n_turn & 1;
+  const int32_t* __restrict__ in = a.counters + turn * 2 * n;
+  int32_t count = in[2 * e];
+  const bool restart = (a.reset && a.reset[e]) || in[2 * e + 1] != 0;
+  const int64_t length = a.episode_len + ((a.env0 + e) % 8) * 13;
+  count = restart ? 0 : count + 1;
+  const bool done = !restart && count >= length;
+  const uint32_t salt = static_cast<uint32_t>((a.env0 + e) * 131 + static_cast<int64_t>(count) * 7);
+  u32x4* out = reinterpret_cast<u32x4*>(a.image + e * a.frame_bytes);
+  const int64_t vecs = a.frame_bytes >> 4;
+  auto word = [salt](int64_t byte0) {
+    const uint32_t x = salt + static_cast<uint32_t>(byte0);
+    return (x & 0xFF) | (((x + 1) & 0xFF) << 8) | (((x + 2) & 0xFF) << 16) | (((x + 3) & 0xFF) << 24);
+  };
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < vecs;
+       i += static_cast<int64_t>(gridDim.x) * kThreads)
+    __builtin_nontemporal_store(
+        u32x4{word(i * 16), word(i * 16 + 4), word(i * 16 + 8), word(i * 16 + 12)}, out + i);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int32_t* next = a.counters + (1 - turn) * 2 * n;
+    next[2 * e] = count;
+    next[2 * e + 1] = done ? 1 : 0;
+    a.reward[e] = restart ? 0.f : static_cast<float>(count % 7);
     is_first[e] = restart ? 1 : 0;
     is_last[e] = done ? 1 : 0;
     is_terminal[e] = done ? 1 : 0;
@@ -1547,16 +1806,32 @@ hipError_t launch_gae(const float* rew, const float* val, const uint8_t* last,
                       float* adv, float* tar, hipStream_t stream, int64_t group,
                       int64_t group_stride_bytes) {
   if (B <= 0 || T < 2) return hipSuccess;
-  if (group < 0 || (group && group_stride_bytes % 4 != 0)) return hipErrorInvalidValue;
-  return launch_scan(GaeOp{rew, val, last, term, T, live_scale, lam, adv, tar,
-                           group, group_stride_bytes / 4, group_stride_bytes}, B, T - 1, stream);
+  if (group < 0 || (group && group_stride_bytes % 4 != 0) || B > INT32_MAX || T > INT32_MAX)
+    return hipErrorInvalidValue;
+  if (group) {
+    GaeOp<true> op;
+    op.group = group;
+    op.gs_rew = group_stride_bytes / 4;
+    op.gs_flag = group_stride_bytes;
+    op.rew = rew; op.val = val; op.last = last; op.term = term; op.adv = adv; op.tar = tar;
+    op.T = static_cast<int32_t>(T); op.B = static_cast<int32_t>(B);
+    op.live_scale = live_scale; op.lam = lam;
+    return launch_scan(op, stream);
+  }
+  GaeOp<false> op;
+  op.rew = rew; op.val = val; op.last = last; op.term = term; op.adv = adv; op.tar = tar;
+  op.T = static_cast<int32_t>(T); op.B = static_cast<int32_t>(B);
+  op.live_scale = live_scale; op.lam = lam;
+  return launch_scan(op, stream);
 }
 
 hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term, const float* rew,
                                 const float* boot, int64_t B, int64_t T, float disc, float lam,
                                 float* ret, hipStream_t stream) {
   if (B <= 0 || T < 2) return hipSuccess;
-  return launch_scan(LambdaOp{last, term, rew, boot, T, disc, lam, ret}, B, T - 1, stream);
+  if (B > INT32_MAX || T > INT32_MAX) return hipErrorInvalidValue;
+  return launch_scan(LambdaOp{last, term, rew, boot, ret, static_cast<int32_t>(T),
+                              static_cast<int32_t>(B), disc, lam}, stream);
 }
 
 hipError_t launch_director_score(const float* rew, const float* cont, const float* value,
@@ -1580,13 +1855,117 @@ hipError_t launch_abstract_traj(const float* reward, const float* cont, int64_t 
 
 hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, uint8_t* is_last,
                             uint8_t* is_terminal, int64_t n, int64_t frame_bytes, int64_t env0,
-                            int64_t episode_len, const uint8_t* reset, int32_t* counters,
+                            int64_t episode_len, const uint8_t* reset, int32_t* counters, int turn,
                             hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  if (frame_bytes % 16 != 0 || reinterpret_cast<uint64_t>(image) % 16 != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(synth_env_kernel, dim3(1, static_cast<uint32_t>(n)), dim3(kThreads), 0, stream,
-                     counters, reset, image, frame_bytes, env0, episode_len, reward, is_first,
-                     is_last, is_terminal);
+  if (frame_bytes % 16 != 0 || reinterpret_cast<uint64_t>(image) % 16 != 0 || n > (1 << 29) ||
+      frame_bytes > INT32_MAX || env0 > INT32_MAX || episode_len > INT32_MAX)
+    return hipErrorInvalidValue;
+  SynthArgs a;
+  a.counters = counters;
+  a.reset = reset;
+  a.image = image;
+  a.reward = reward;
+  a.frame_bytes = static_cast<int32_t>(frame_bytes);
+  a.env0 = static_cast<int32_t>(env0);
+  a.episode_len = static_cast<int32_t>(episode_len);
+  a.n_turn = static_cast<int32_t>(n << 1 | (turn & 1));
+  // A frame over a few workgroups: 64 envs x 4 = one workgroup per CU.
+  const int64_t vecs = frame_bytes >> 4;
+  const uint32_t gx = static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(4, vecs / kThreads)));
+  const dim3 grid(gx, static_cast<uint32_t>(n));
+  const int64_t base = reinterpret_cast<int64_t>(reward);
+  const int64_t of = reinterpret_cast<int64_t>(is_first) - base, ol = reinterpret_cast<int64_t>(is_last) - base,
+                ot = reinterpret_cast<int64_t>(is_terminal) - base;
+  auto fits = [](int64_t x) { return x >= INT32_MIN && x <= INT32_MAX; };
+  if (fits(of) && fits(ol) && fits(ot)) {
+    a.off_first = static_cast<int32_t>(of);
+    a.off_last = static_cast<int32_t>(ol);
+    a.off_terminal = static_cast<int32_t>(ot);
+    hipLaunchKernelGGL(synth_env_kernel, grid, dim3(kThreads), 0, stream, a);
+  } else {
+    a.off_first = a.off_last = a.off_terminal = 0;
+    hipLaunchKernelGGL(synth_env_far_kernel, grid, dim3(kThreads), 0, stream, a, is_first, is_last,
+                       is_terminal);
+  }
+  return hipGetLastError();
+}
+
+bool prewrite_supported(const PrewritePlan& p) {
+  return p.n > 0 && p.pixels > 0 && p.pixels % 4 == 0 && p.channels >= 1 && p.channels <= 4 &&
+         reinterpret_cast<uint64_t>(p.frames) % 16 == 0 &&
+         reinterpret_cast<uint64_t>(p.frame_pool) % 16 == 0 &&
+         (p.pixels * p.channels) % 16 == 0 &&
+         reinterpret_cast<uint64_t>(p.dst) % 16 == 0 && p.n_narrow >= 0 && p.n_narrow <= kPreNarrow &&
+         (p.out_dtype == kU8 || p.out_dtype == kF16 || p.out_dtype == kBF16 || p.out_dtype == kF32);
+}
+
+size_t prewrite_table_bytes(int64_t n) {
+  return offsetof(PreTable, words) + static_cast<size_t>(n) * 6 * sizeof(uint32_t);
+}
+
+void prewrite_fill_table(void* dst, const PrewritePlan& p, const int32_t* rows, const uint8_t* stepids) {
+  // (dst may be write-combined device memory behind the BAR: written once, front to back.)
+  PreTable head;
+  head.stepid_pool = p.stepid_pool;
+  head.pad_ = 0;
+  for (int k = 0; k < kPreNarrow; ++k)
+    head.narrow[k] = k < p.n_narrow ? PreKey{p.narrow[k].src, p.narrow[k].pool, p.narrow[k].rowbytes}
+                                    : PreKey{nullptr, nullptr, 0};
+  uint8_t* out = static_cast<uint8_t*>(dst);
+  std::memcpy(out, &head, offsetof(PreTable, words));
+  out += offsetof(PreTable, words);
+  std::memcpy(out, rows, static_cast<size_t>(p.n) * sizeof(int32_t));
+  std::memcpy(out + static_cast<size_t>(p.n) * sizeof(int32_t), stepids,
+              static_cast<size_t>(p.n) * kStepBytes);
+}
+
+hipError_t launch_obs_stack_insert(const PrewritePlan& p, hipStream_t stream, hipEvent_t stop) {
+  if (!prewrite_supported(p) || !p.table_dev) return hipErrorInvalidValue;
+  PrewriteArgs a;
+  a.frames = p.frames;
+  a.dst = p.dst;
+  a.frame_pool = p.frame_pool;
+  a.pixels = p.pixels;
+  a.scale = p.scale;
+  a.offset = p.offset;
+  a.n = p.n;
+  a.n_narrow = p.n_narrow;
+  a.table = static_cast<const PreTable*>(p.table_dev);
+  a.rows_out = p.rows_out;
+  switch (p.out_dtype) {
+    case kU8: return obs_stack_insert_typed<uint8_t>(a, p.channels, p.layout, stream, stop);
+    case kF16: return obs_stack_insert_typed<__half>(a, p.channels, p.layout, stream, stop);
+    case kBF16: return obs_stack_insert_typed<__hip_bfloat16>(a, p.channels, p.layout, stream, stop);
+    default: return obs_stack_insert_typed<float>(a, p.channels, p.layout, stream, stop);
+  }
+}
+
+hipError_t launch_publish_one(const void* src, void* pool, void* out, const int32_t* rows_dev,
+                              const uint8_t* flags, int64_t n, int64_t rowbytes, int dtype,
+                              hipStream_t stream, hipEvent_t stop) {
+  if (n <= 0 || rowbytes <= 0) return hipSuccess;
+  PublishArgs a;
+  a.src = static_cast<const uint8_t*>(src);
+  a.pool = static_cast<uint8_t*>(pool);
+  a.out = static_cast<uint8_t*>(out);
+  a.rows = rows_dev;
+  a.flags = flags;
+  a.n = static_cast<int32_t>(n);
+  a.rowbytes = static_cast<int32_t>(rowbytes);
+  if (flags) {
+    a.dtype = dtype;
+    a.elem = dtype_size(dtype);
+    if (a.elem == 0 || rowbytes % a.elem) return hipErrorInvalidValue;
+  } else {
+    a.dtype = kU8;       // plain copy: bytes
+    a.elem = 1;
+  }
+  const int64_t elems = n * (rowbytes / a.elem);
+  if (n > INT32_MAX || rowbytes > INT32_MAX) return hipErrorInvalidValue;
+  const dim3 grid(static_cast<uint32_t>((elems + kThreads - 1) / kThreads));
+  if (stop) hipExtLaunchKernelGGL(publish_one_kernel, grid, dim3(kThreads), 0, stream, nullptr, stop, 0, a);
+  else hipLaunchKernelGGL(publish_one_kernel, grid, dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
 

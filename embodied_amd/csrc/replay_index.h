@@ -154,6 +154,22 @@ class ReplayIndex {
     return row;
   }
 
+  // The pool row and step id the NEXT add(worker) will use, without changing
+  // anything: a worker's next step always goes to its open chunk's cursor (add
+  // rotates eagerly, right after it fills a chunk's last row).  False for a
+  // worker that has no chunk yet (its first add creates one) or that was
+  // already peeked under the same `mark` (listed twice in one batch).
+  bool peek(int64_t worker, uint64_t mark, int64_t* row, StepId* stepid) {
+    Worker* w = find_worker(worker);
+    if (!w || w->peek_mark == mark) return false;
+    w->peek_mark = mark;
+    const uint64_t uid = w->cursor.first;
+    if (!w->open || w->open->uid != uid) w->open = &chunks_.at(uid);
+    *row = w->open->slot * cfg_.chunksize + w->cursor.second;
+    *stepid = make_stepid(uid, w->cursor.second);
+    return true;
+  }
+
   // Windows waiting in the online queue (replay.py:114-118): a train-mode
   // sample serves these before it asks the selector.
   int64_t online_pending() const { return static_cast<int64_t>(fresh_.size()); }
@@ -359,6 +375,7 @@ class ReplayIndex {
     Chunk* open = nullptr;      // cached node of the open chunk
     PosRing pending;            // steps not yet the start of an item
     int64_t steps_seen = 0;     // online mode
+    uint64_t peek_mark = 0;     // last peek() batch that listed this worker
   };
 
   // Worker ids are usually 0..N-1: a flat table in front of the general map.
@@ -441,14 +458,14 @@ class ReplayIndex {
   std::shared_ptr<Selector> selector_;
   std::unordered_map<uint64_t, Chunk> chunks_;
   std::vector<std::deque<int64_t>> free_;   // per owner, FIFO: a freed slot is recycled as late as possible
-  std::deque<Pos> items_;
+  Ring<Pos> items_;
   int64_t first_item_ = 0;
   int64_t next_item_ = 0;
   uint64_t next_uid_ = 1;
   int64_t loaded_ = 0;
   std::unordered_map<int64_t, std::unique_ptr<Worker>> workers_;
   std::vector<Worker*> dense_;
-  std::deque<Pos> fresh_;
+  Ring<Pos> fresh_;
   static constexpr uint64_t kHints = 256;
   Chunk* evict_hint_[kHints] = {};
   int64_t metrics_[3] = {0, 0, 0};

@@ -22,6 +22,44 @@ namespace emb {
 
 constexpr int kStepIdBytes = 20;
 
+// A queue with indexing, for the hot paths of the index (items, the Uniform
+// selector's key window, the online queue): a power-of-two ring over one array,
+// so push_back / pop_front / operator[] are a mask and an add each
+// (std::deque pays a division and two indirections per access, which showed up
+// as a third of the per-step bookkeeping time).
+template <typename T>
+class Ring {
+ public:
+  bool empty() const { return count_ == 0; }
+  size_t size() const { return count_; }
+  T& operator[](size_t i) { return data_[(head_ + i) & mask_]; }
+  const T& operator[](size_t i) const { return data_[(head_ + i) & mask_]; }
+  T& front() { return data_[head_]; }
+  const T& front() const { return data_[head_]; }
+  void push_back(const T& v) {
+    if (count_ == data_.size()) grow();
+    data_[(head_ + count_) & mask_] = v;
+    ++count_;
+  }
+  void pop_front() {
+    head_ = (head_ + 1) & mask_;
+    --count_;
+  }
+  void clear() { head_ = count_ = 0; }
+
+ private:
+  void grow() {
+    const size_t cap = data_.empty() ? 64 : data_.size() * 2;
+    std::vector<T> bigger(cap);
+    for (size_t i = 0; i < count_; ++i) bigger[i] = data_[(head_ + i) & mask_];
+    data_.swap(bigger);
+    head_ = 0;
+    mask_ = cap - 1;
+  }
+  std::vector<T> data_;
+  size_t head_ = 0, count_ = 0, mask_ = 0;
+};
+
 struct StepId {
   uint8_t b[kStepIdBytes];
   bool operator==(const StepId& o) const { return !std::memcmp(b, o.b, kStepIdBytes); }
@@ -147,7 +185,7 @@ class Uniform : public Selector {
   std::vector<int64_t> keys_;
   bool dense_ = true;
   int64_t base_ = 0;
-  std::deque<int64_t> window_;
+  Ring<int64_t> window_;
   std::unordered_map<int64_t, int64_t> sparse_;
 };
 

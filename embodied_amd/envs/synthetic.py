@@ -27,11 +27,17 @@ class SyntheticBatchEnv:
     self.device = torch.device(device)
     if self.device.index is None:
       self.device = torch.device('cuda', torch.cuda.current_device())
-    self.counters = torch.zeros(2 * n, dtype=torch.int32, device=self.device)
+    # {count, done} per env in two generations: a step reads one and writes the
+    # other, so every workgroup of an env may read the state while one writes.
+    self.counters = torch.zeros((2, 2 * n), dtype=torch.int32, device=self.device)
+    self.generation = 0
     # ring > 0: observations are written into `ring` rotating sets of output
     # buffers instead of fresh tensors (like vector envs that own their output
     # arrays): a returned dict is overwritten `ring` steps later.
     self.ring = [self._alloc() for _ in range(ring)]
+    # (the ring's tensors never change: their addresses are taken once)
+    self._ring_ptrs = [tuple(v.data_ptr() for v in obs.values()) for obs in self.ring]
+    self._counters_ptr = self.counters.data_ptr()
     self.turn = 0
 
   def __len__(self):
@@ -68,16 +74,17 @@ class SyntheticBatchEnv:
     n, dev = self.n, self.device
     if self.ring:
       obs = dict(self.ring[self.turn])
+      image, reward, is_first, is_last, is_terminal = self._ring_ptrs[self.turn]
       self.turn = (self.turn + 1) % len(self.ring)
     else:
       obs = self._alloc()
+      image, reward, is_first, is_last, is_terminal = (v.data_ptr() for v in obs.values())
     reset = acts['reset']
     fast.emb_synth_env_step(
-        obs['image'].data_ptr(), obs['reward'].data_ptr(),
-        obs['is_first'].data_ptr(), obs['is_last'].data_ptr(),
-        obs['is_terminal'].data_ptr(), n, self.frame_bytes, self.env0,
-        self.episode_len, reset.data_ptr(), self.counters.data_ptr(),
-        _lib.raw_stream(dev))
+        image, reward, is_first, is_last, is_terminal, n, self.frame_bytes, self.env0,
+        self.episode_len, reset.data_ptr(), self._counters_ptr,
+        self.generation, _lib.raw_stream(dev))
+    self.generation ^= 1
     return obs
 
 

@@ -38,6 +38,15 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
     raise ValueError(f'obs_stack out= must be contiguous {shape} {dtype} on {frames.device}')
   if out.numel() == 0:
     return out                       # no envs / empty frames: nothing to launch
+  tag = getattr(frames, '_emb_offer', None)
+  if tag is not None and ids is None:
+    # A Driver offered this step's observations to its Replay (Replay.offer):
+    # the launch that builds the policy batch also writes the observation keys
+    # into the step's pool rows, every frame is read once.
+    replay = tag()
+    if replay is not None and replay._early_insert(
+        frames, h * w, c, first, dtype, float(scale), float(offset), out):
+      return out
   fast.emb_obs_stack(
       frames.data_ptr(), _lib.ptr(ids), n, h * w, c,
       _lib.LAYOUT_CHANNELS_FIRST if first else _lib.LAYOUT_SAME, _OUT[dtype],

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define EMB_ABI_VERSION 1
+#define EMB_ABI_VERSION 2
 
 #define EMB_OK 0
 #define EMB_ERR_INVALID (-1)   /* bad argument / state                         */
@@ -204,6 +204,41 @@ int32_t emb_replay_add_masked(emb_replay_t* rep, int64_t n, const int64_t* worke
                               const void* const* src, int32_t n_masked,
                               const int32_t* masked_keys, const int32_t* masked_dtypes,
                               void* const* masked_out, const void* is_last, void* stream);
+
+/* Early insert: the vectorised step's observation keys go to their pool rows
+ * BEFORE the policy runs, in the launch that builds the policy batch, so that
+ * every frame is read once (driver.py:65 np.stack + jax/agent.py:230 layout /
+ * dtype change + replay.py:77-118 / chunk.py:41-50 row copy in one pass).
+ *
+ * obs_stack_insert = emb_obs_stack(frames -> dst as `spec` says) and, when the
+ * rows of the next add of exactly `workers` (one step each) are known — every
+ * worker already has an open chunk and is listed once — the same launch also
+ * writes: the frames to the pool rows of key `frame_key`, every other key k
+ * with src[k] != NULL and rowbytes <= 256 (device (n, rowbytes[k]): reward,
+ * flags ...; at most 8) and the step ids.  Nothing in the index changes: a
+ * worker's next row is the cursor of its open chunk, and no item can reach a
+ * row before it is published.  *token_out = a non-zero token if the early
+ * insert happened, 0 if the call only did the obs stack (unknown worker, odd
+ * frame shape, src[frame_key] != frames).
+ *
+ * publish = emb_replay_add_masked for the same step.  With the token of the
+ * early insert, the same workers and stream, keys whose src[k] is the buffer
+ * the early insert copied from are not copied again; what is left (the action)
+ * goes out with a 56-byte-argument launch when it is a single small key.  With
+ * token 0, or when anything does not match, publish is add_masked.            */
+typedef struct emb_obs_spec {
+  int64_t pixels, channels;     /* frames are (n, pixels, channels) uint8           */
+  int32_t layout, out_dtype;    /* EMB_LAYOUT_*, EMB_U8 / EMB_F16 / EMB_BF16 / EMB_F32 */
+  float scale, offset;          /* float outputs: value * scale + offset            */
+} emb_obs_spec_t;
+int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                                    int32_t frame_key, const void* frames,
+                                    const emb_obs_spec_t* spec, void* dst, const void* const* src,
+                                    void* stream, uint64_t* token_out);
+int32_t emb_replay_publish(emb_replay_t* rep, int64_t n, const int64_t* workers,
+                           const void* const* src, int32_t n_masked, const int32_t* masked_keys,
+                           const int32_t* masked_dtypes, void* const* masked_out,
+                           const void* is_last, uint64_t token, void* stream);
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
                           uint8_t* online_out, uint8_t* first_stepids_out, void* stream);
 /* The same with the batch side cut into groups of `group` sequences whose
@@ -360,11 +395,13 @@ int32_t emb_comm_destroy(emb_comm_t* comm);
 
 /* ---- synthetic vector env (benchmark / test input) ---------- */
 /* Episode logic of embodied/envs/dummy.py:38-48 for n device-resident envs;
- * counters = device int32[2n] state; reset = device u8[n] or NULL.           */
+ * counters = device int32[2][2n] state in two generations: the step reads
+ * generation `turn` (0/1) and writes the other one (the caller alternates);
+ * reset = device u8[n] or NULL.                                               */
 int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_last,
                            void* is_terminal, int64_t n, int64_t frame_bytes, int64_t env0,
                            int64_t episode_len, const void* reset, void* counters,
-                           void* stream);
+                           int32_t turn, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,190 @@
+"""The early insert (Replay.offer -> ops.obs_stack -> emb_replay_obs_stack_insert
+-> emb_replay_publish): observation keys go to their pool rows in the launch
+that builds the policy batch, the action follows after the policy.  Everything
+the Replay hands out afterwards must be what the reference's Driver -> Replay.add
+produces (embodied/core/driver.py:55-82, replay.py:77-118): checked against the
+numpy oracle driven by the same envs and policy, and against the plain insert
+path of this library.  Need a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle
+from tests.conftest import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def emb():
+  import embodied_amd
+  assert torch.cuda.is_available(), 'these tests need the MI355X'
+  return embodied_amd
+
+
+def _host(batch):
+  return {k: v.cpu().numpy() for k, v in batch.items()}
+
+
+def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, out_dtype=torch.bfloat16,
+              layout='channels_first', extra_out=False, sample_every=7, episode_len=5):
+  """Device Driver + Replay next to the oracle Driver + Replay on the same
+  envs, policy and seeds; `stack` = the policy builds its batch with
+  ops.obs_stack (which takes up the Driver's offer).  Returns the replay, the
+  policy batches the agent saw and the number of early inserts."""
+  from embodied_amd.envs import synthetic
+  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=episode_len, ring=4)
+  rep = emb.Replay(length=length, capacity=capacity, chunksize=chunksize, online=online, seed=0)
+  ref = np_oracle.Replay(length, capacity, chunksize, online, seed=0)
+  hosts = [synthetic.HostSyntheticEnv(e, shape=shape, episode_len=episode_len) for e in range(n)]
+  oracle = np_oracle.Driver(hosts)
+  oracle.on_step(ref.add)
+  driver = emb.Driver(batch_env=env, device='cuda')
+  driver.on_step(rep.add)
+  tick = {'dev': 0, 'host': 0}
+  seen = []
+
+  def acts_at(t):
+    # negative values too: the mask is a multiply (-x -> -0 for floats)
+    return ((np.arange(n) * 3 + t * 5) % 7 - 3).astype(np.int32)
+
+  def outs_at(t):
+    return (np.arange(n * 6).reshape(n, 6) + t).astype(np.float32)
+
+  def policy(carry, obs, **kw):
+    t = tick['dev']
+    tick['dev'] += 1
+    if stack:
+      batch = emb.ops.obs_stack(obs['image'], layout=layout, dtype=out_dtype, scale=1 / 255)
+      seen.append((batch, obs['image'].clone()))
+    outs = {'feat': torch.as_tensor(outs_at(t)).cuda()} if extra_out else {}
+    return carry, {'action': torch.as_tensor(acts_at(t)).cuda()}, outs
+
+  def host_policy(carry, obs):
+    t = tick['host']
+    tick['host'] += 1
+    outs = {'feat': outs_at(t)} if extra_out else {}
+    return carry, {'action': acts_at(t)}, outs
+
+  driver.reset()
+  for t in range(steps):
+    driver(policy, steps=n)
+    oracle.step(host_policy)
+    assert len(rep) == len(ref), t
+    if len(ref) and t % sample_every == 0:
+      mode = 'train' if t % 2 else 'report'
+      assert_same(_host(rep.sample(3, mode)), ref.sample(3, mode), f'step {t}')
+  return rep, ref, seen
+
+
+@pytest.mark.parametrize('online', [False, True])
+@pytest.mark.parametrize('shape', [(8, 8, 4), (8, 8, 3), (4, 8, 2), (4, 4, 1)])
+def test_early_insert_matches_oracle(emb, online, shape):
+  """Small frames, chunks of 8 rows (many rotations), capacity churn, the online
+  queue: every sampled batch equals the oracle's, with the early insert taken on
+  every step after the first."""
+  n, steps = 5, 90
+  rep, ref, seen = _run_pair(emb, n, shape, length=4, capacity=60, chunksize=8, steps=steps,
+                             online=online, stack=True)
+  assert rep.early_inserts == steps - 1       # the first step opens the workers' chunks
+  got, want = rep.stats(), ref.stats()
+  for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
+    assert got[k] == want[k], k
+  # the policy batches are what the plain obs stack produces
+  for batch, frames in seen[::9]:
+    want = emb.ops.obs_stack(frames, layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+    assert torch.equal(batch.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize('out_dtype,layout', [
+    (torch.uint8, 'same'), (torch.float32, 'channels_first'), (torch.float16, 'same')])
+def test_early_insert_other_policy_layouts(emb, out_dtype, layout):
+  rep, ref, seen = _run_pair(emb, 6, (8, 12, 4), length=5, capacity=80, chunksize=16, steps=60,
+                             online=True, stack=True, out_dtype=out_dtype, layout=layout)
+  assert rep.early_inserts == 59
+  for batch, frames in seen[::7]:
+    want = emb.ops.obs_stack(frames, layout=layout, dtype=out_dtype, scale=1 / 255)
+    assert torch.equal(batch, want)
+
+
+def test_early_insert_with_agent_outputs(emb):
+  """A policy that also returns replay outputs (wider keys: the general insert
+  launch carries action + outputs, the observation keys are already in place)."""
+  rep, ref, _ = _run_pair(emb, 4, (8, 8, 4), length=3, capacity=50, chunksize=8, steps=70,
+                          online=False, stack=True, extra_out=True)
+  assert rep.early_inserts == 69
+
+
+def test_full_size_early_insert_equals_plain_insert(emb):
+  """BASELINE shapes (64 envs, 84x84x4, L=65, chunksize 1024): two replays fed by
+  the same envs, one through the early insert, one through the plain fused
+  insert; identical pools as seen through identical samples, and equal to the
+  oracle's flags / step ids."""
+  n, L = 64, 65
+  a, ref, _ = _run_pair(emb, n, (84, 84, 4), length=L, capacity=3000, chunksize=1024, steps=150,
+                        online=True, stack=True, sample_every=50, episode_len=40)
+  b, _, _ = _run_pair(emb, n, (84, 84, 4), length=L, capacity=3000, chunksize=1024, steps=150,
+                      online=True, stack=False, sample_every=50, episode_len=40)
+  assert a.early_inserts == 149 and b.early_inserts == 0
+  for _ in range(3):
+    assert_same(_host(a.sample(16)), _host(b.sample(16)), 'early vs plain')
+
+
+def test_many_envs_take_the_table_through_the_ring(emb):
+  """More envs than fit the kernel arguments (> 112): rows and step ids reach
+  the launch through the pinned ring."""
+  rep, ref, _ = _run_pair(emb, 150, (4, 4, 4), length=3, capacity=2000, chunksize=8, steps=40,
+                          online=False, stack=True, sample_every=5)
+  assert rep.early_inserts == 39
+
+
+def test_offer_not_taken_or_stale_is_harmless(emb):
+  """An agent that stacks only now and then, stacks twice, or stacks a tensor of
+  an older step: the replay still equals the oracle."""
+  from embodied_amd.envs import synthetic
+  n, shape = 4, (8, 8, 4)
+  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=6, ring=2)
+  rep = emb.Replay(length=3, capacity=40, chunksize=8, seed=0)
+  ref = np_oracle.Replay(3, 40, 8, False, seed=0)
+  hosts = [synthetic.HostSyntheticEnv(e, shape=shape, episode_len=6) for e in range(n)]
+  oracle = np_oracle.Driver(hosts)
+  oracle.on_step(ref.add)
+  driver = emb.Driver(batch_env=env, device='cuda')
+  driver.on_step(rep.add)
+  tick = [0]
+  old = []
+
+  def policy(carry, obs, **kw):
+    t = tick[0]
+    tick[0] += 1
+    if t % 3 == 0:
+      emb.ops.obs_stack(obs['image'], dtype=torch.float32)
+    if t % 6 == 0:
+      emb.ops.obs_stack(obs['image'], dtype=torch.float32)      # second call: plain stack
+    if t % 5 == 1 and old:
+      emb.ops.obs_stack(old[-1], dtype=torch.float32)           # another step's tensor (ring of 2)
+    old.append(obs['image'])
+    return carry, {'action': torch.full((n,), t, dtype=torch.int32, device='cuda')}, {}
+
+  host_tick = [0]
+
+  def host_policy(carry, obs):
+    t = host_tick[0]
+    host_tick[0] += 1
+    return carry, {'action': np.full(n, t, np.int32)}, {}
+
+  driver.reset()
+  for t in range(60):
+    driver(policy, steps=n)
+    oracle.step(host_policy)
+    if len(ref) and t % 4 == 0:
+      assert_same(_host(rep.sample(5)), ref.sample(5), f'step {t}')
+
+
+def test_publish_survives_pool_growth(emb):
+  """The pool fills up between the early insert and the publish: the publish
+  raises PoolFull inside, the pool grows (device-to-device copy behind the early
+  insert on the same stream) and the retry keeps the early rows."""
+  rep, ref, _ = _run_pair(emb, 6, (8, 8, 4), length=4, capacity=None, chunksize=4, steps=120,
+                          online=False, stack=True, sample_every=6)
+  assert rep.early_inserts == 119
