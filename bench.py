@@ -150,6 +150,10 @@ def parse():
                  help='train steps run after the fill and before --warmup, so that a short '
                       '--warmup still times a warm train path')
   p.add_argument('--no-cpu-baseline', action='store_true')
+  p.add_argument('--no-dreamer-leg', action='store_true',
+                 help='skip the short configs[2] run (1M-step uniform replay, latents written back) '
+                      'that the default single-GPU PPO run appends as `workloads.dreamer`')
+  p.add_argument('--dreamer-leg-steps', type=int, default=4000)
   p.add_argument('--prefetch', type=int, default=1, help='train batches gathered per launch')
   p.add_argument('--reuse-outputs', type=int, default=0,
                  help='Replay(reuse_outputs=K): sampled batches rotate through K output sets '
@@ -489,7 +493,8 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-  launches, gather_ms = replay.profile_read(reset=True)
+  launches, gather_ms, gather_kernel = replay.profile_report('sample', reset=True)
+  wb_launches, wb_ms, wb_kernel = replay.profile_report('update', reset=True)
   headline = dict(counters)
 
   # The same loop for >= --sustained-seconds more (the headline region is as
@@ -518,7 +523,8 @@ def main():
       t = torch.tensor([s_elapsed], dtype=torch.float64, device=device)
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
       s_elapsed = float(t.item())
-    s_launches, s_ms = replay.profile_read(reset=True)
+    s_launches, s_ms, _ = replay.profile_report('sample', reset=True)
+    s_wb_launches, s_wb_ms, _ = replay.profile_report('update', reset=True)
     sustained = {
         'seconds': round(s_elapsed, 3), 'steps': s_steps,
         'env_steps_per_s': round(s_steps * args.envs * world / s_elapsed, 1),
@@ -527,6 +533,7 @@ def main():
         'ms_per_step': round(s_elapsed / s_steps * 1e3, 5),
         'gather_avg_us': round(s_ms / s_launches * 1e3, 2) if s_launches else None,
         'gather_launches': s_launches,
+        **({'writeback_avg_us': round(s_wb_ms / s_wb_launches * 1e3, 2)} if s_wb_launches else {}),
     }
   # Ranks only, context: the same loop with the collectives switched off (N
   # independent replicas: no exchange, no gradient all-reduce) -- what the path
@@ -582,15 +589,30 @@ def main():
     achieved = algo_bytes / avg_s / 1e9
     roofline = {
         'bound': 'hbm',
-        'kernel': ('span_move_kernel<gather> (Replay.sample)' if algo_bytes // 2 <= 160_000_000
-                   or os.environ.get('HIP_FORCE_DEV_KERNARG') == '0'
-                   else 'gather_kernel (Replay.sample)'),
+        # the kernel the last stamped Replay.sample launch ran (emb_replay_profile_report)
+        'kernel': f'{gather_kernel} (Replay.sample)',
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        # frac counts read + written bytes (a copy moves two bytes per payload byte); the
+        # HBM-READ fraction SURVEY 8d defines, (B*L*S / t) / 8e12, is read_frac
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
         'traffic_source': traffic_source,
         'read_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
         'bytes_per_launch': algo_bytes, 'avg_launch_us': round(avg_s * 1e6, 2),
         'launches': launches, 'stamped_one_in': stamp_every,
+    }
+
+  # configs[2]: the write-back of the agent's latents over the sampled steps
+  # (Replay.update, dreamerv3/agent.py:144-150), stamped like the gathers.
+  writeback = None
+  if wb_launches:
+    wb_keys = [k for k in replay._keys if k.name in ('dyn/deter', 'dyn/stoch')]
+    wb_bytes = 2 * B * args.prefetch * (T + args.context) * sum(k.rowbytes for k in wb_keys)
+    wb_s = wb_ms / wb_launches / 1e3
+    writeback = {
+        'kernel': f'{wb_kernel} (Replay.update)', 'bytes_per_launch': wb_bytes,
+        'avg_launch_us': round(wb_s * 1e6, 2), 'launches': wb_launches,
+        'achieved': round(wb_bytes / wb_s / 1e9, 1), 'unit': 'GB/s',
+        'frac': round(wb_bytes / wb_s / 1e9 / HBM_PEAK_GBS, 4),
     }
 
   # Outside the timed region, measured context (no credit): SURVEY 8d's
@@ -627,6 +649,22 @@ def main():
   cpu = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'ppo' and not args.host_envs:
     cpu = cpu_baseline(args)
+
+  # BASELINE configs[2] beside the headline (same command, own process): a short
+  # DreamerV3-shaped run -- 1M-step uniform replay (78 GB of HBM), train_ratio
+  # 32, 40 KB of latents per step written back -- so that its rates and the
+  # roofline fractions of its 144 MB gathers and 84 MB write-backs are part of
+  # every record.  Never part of `value`.
+  workloads = None
+  if (rank == 0 and world == 1 and not use_dist and args.workload == 'ppo' and not args.no_dreamer_leg
+      and not args.host_envs and args.selector == 'uniform' and args.envs == 64
+      and args.consec == 1 and args.prefetch == 1):
+    del driver, env, stream, policy
+    replay = None
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    workloads = {'dreamer': dreamer_leg(args)}
 
   if rank == 0:
     # Libraries that wrote to C stdio (RCCL's version banner) come out first, so
@@ -671,6 +709,8 @@ def main():
         },
         'sustained': sustained,
         'roofline': roofline, 'cpu_baseline': cpu,
+        **({'writeback': writeback} if writeback is not None else {}),
+        **({'workloads': workloads} if workloads is not None else {}),
         **({'native_comm': native} if native is not None else {}),
         **({'replicas_only': replicas_only} if replicas_only is not None else {}),
     }), flush=True)
@@ -792,6 +832,38 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
   if kept and usable is None and not stuck:
     kept[0].close()
   return dict(result), stuck, usable
+
+
+def dreamer_leg(args):
+  """`python bench.py --workload dreamer` for a few seconds in a process of its
+  own (HIP state, allocator and CPU placement as in a stand-alone run); returns
+  the part of its line that a reader of the PPO record needs."""
+  import subprocess
+  cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'dreamer', '--no-dreamer-leg',
+         '--steps', str(args.dreamer_leg_steps), '--warmup', '200', '--sustained-seconds', '3',
+         '--no-cpu-baseline', '--no-context']
+  began = time.perf_counter()
+  try:
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    if res.returncode or not lines:
+      return {'error': (res.stderr or res.stdout)[-300:], 'returncode': res.returncode}
+    line = json.loads(lines[-1])
+  except Exception as e:
+    return {'error': f'{type(e).__name__}: {e}'[:300]}
+  roof, wb = line.get('roofline') or {}, line.get('writeback') or {}
+  return {
+      'workload': line['config']['workload'],
+      'command': ' '.join(['python', 'bench.py'] + cmd[2:]),
+      'env_steps_per_s': line['value'], 'train_steps_per_s': line['train_steps_per_s'],
+      'ms_per_step': line['ms_per_step'], 'steps': line['steps'],
+      'sustained': line.get('sustained'),
+      'gather': {k: roof.get(k) for k in (
+          'kernel', 'avg_launch_us', 'bytes_per_launch', 'achieved', 'frac', 'read_frac', 'launches')},
+      'writeback': {k: wb.get(k) for k in (
+          'kernel', 'avg_launch_us', 'bytes_per_launch', 'achieved', 'frac', 'launches')},
+      'wall_s': round(time.perf_counter() - began, 1),
+  }
 
 
 def plain_copy_reference(replay, rows, device, iters=200):

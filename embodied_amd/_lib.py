@@ -154,6 +154,7 @@ SIGNATURES = {
     'emb_replay_profile': [p, i32],
     'emb_replay_multistream': [p, i32],
     'emb_replay_profile_read': [p, p, p, i32],
+    'emb_replay_profile_report': [p, i32, p, p, i32, p, i32],
     'emb_replay_complete_all': [p],
     'emb_replay_open_chunks': [p, p],
     'emb_replay_reserve_uids': [p, u64],

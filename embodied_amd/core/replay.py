@@ -983,6 +983,15 @@ class Replay:
         self._handle, C.byref(launches), C.byref(ms), int(reset))
     return launches.value, ms.value
 
+  def profile_report(self, which='sample', reset=True):
+    """(stamped launches, their total ms, kernel name) of the sample gathers or
+    of the `update` write-backs since the last reset."""
+    launches, ms, name = C.c_int64(), C.c_double(), C.create_string_buffer(128)
+    api.emb_replay_profile_report(
+        self._handle, {'sample': 0, 'update': 1}[which], C.byref(launches), C.byref(ms),
+        int(reset), name, len(name))
+    return launches.value, ms.value, name.value.decode()
+
 
 def _numpy_of(dtype):
   for np_dtype, t in _TORCH_OF.items():

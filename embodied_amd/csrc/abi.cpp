@@ -368,7 +368,9 @@ struct emb_replay {
   int key_stepid = -1, key_is_first = -1, key_is_last = -1;
   TableRing ring;
   ArgRing arg_ring;
-  LaunchTimer timer, timer_other;
+  LaunchTimer timer, timer_other, timer_update;   // gathers, unread predecessor stamps, write-backs
+  std::string timed_kernel[2];                    // the kernel the last stamped gather / write-back ran
+  bool timing_update = false;                     // set by emb_replay_update around its launches
   std::vector<int32_t> rows, spans;
   std::vector<std::pair<int32_t, int32_t>> runs;   // update: [first, last) pool rows per run
   std::vector<uint32_t> stamp;                     // update: last-writer-wins marks per pool row
@@ -795,7 +797,10 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   // Processes that keep kernel arguments in host memory (HIP_FORCE_DEV_KERNARG=0,
   // cheaper launches) pay PCIe latency on every wave's argument reads: for big
   // moves hand the kernel a device copy of its arguments instead.
-  const bool stamp_this = gather && rep->timer.due();
+  // Stamped launches: sample gathers, and (when asked for) the write-backs of
+  // emb_replay_update, each with its own counter.
+  LaunchTimer& own = gather ? rep->timer : rep->timer_update;
+  const bool stamp_this = (gather || rep->timing_update) && own.due();
   TableRing::Lease args_lease{-1, nullptr, nullptr};
   const void* device_args = nullptr;
   bool args_in_bar = false;
@@ -832,8 +837,10 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   }
   rep->order_before(gather, stream);
   hipEvent_t start = nullptr, stop = nullptr;
-  if (stamp_this) rep->timer.next(&start, &stop);
-  else if (!gather && rep->timer.enabled && stamp_predecessors() && !host_kernargs()) {
+  if (stamp_this) {
+    own.next(&start, &stop);
+    rep->timed_kernel[gather ? 0 : 1] = emb::move_kernel_name(launch, gather, device_args != nullptr);
+  } else if (!gather && rep->timer.enabled && stamp_predecessors() && !host_kernargs()) {
     // (With host-resident kernel arguments every big gather already follows its
     // stamped argument-writer launch, and a stamp on each insert would cost
     // ~10 % of the step rate there; with device-resident arguments it is free.)
@@ -1210,8 +1217,15 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
         else rep->stamp[row] = rep->stamp_epoch;
       }
     }
-    run_move_all(rep, list, rep->rows.data(), B * T, nullptr, false, static_cast<hipStream_t>(stream),
-                 &rep->spans);
+    rep->timing_update = rep->timer_update.enabled;
+    try {
+      run_move_all(rep, list, rep->rows.data(), B * T, nullptr, false, static_cast<hipStream_t>(stream),
+                   &rep->spans);
+    } catch (...) {
+      rep->timing_update = false;
+      throw;
+    }
+    rep->timing_update = false;
   });
 }
 
@@ -1272,10 +1286,28 @@ int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) {
     rep->timer.enabled = enable != 0;
     rep->timer.every = enable > 1 ? enable : 1;      // enable = n > 1: stamp every n-th gather
     rep->timer.tick = 0;
+    rep->timer_update.enabled = rep->timer.enabled;  // write-backs of emb_replay_update alike
+    rep->timer_update.every = rep->timer.every;
+    rep->timer_update.tick = 0;
     if (enable) {                       // create the stamp pools now, not inside a timed region
       rep->timer.reserve(emb_timer_pool());
+      rep->timer_update.reserve(emb_timer_pool());
       rep->timer_other.discard = true;
       rep->timer_other.reserve(256);
+    }
+  });
+}
+
+int32_t emb_replay_profile_report(emb_replay_t* rep, int32_t which, int64_t* launches, double* total_ms,
+                                  int32_t reset, char* kernel_out, int32_t kernel_cap) {
+  REP_OP({
+    need(launches && total_ms && (which == 0 || which == 1), "profile_report: bad arguments");
+    (which == 0 ? rep->timer : rep->timer_update).read(launches, total_ms, reset != 0);
+    if (kernel_out && kernel_cap > 0) {
+      const std::string& name = rep->timed_kernel[which];
+      const size_t n = std::min<size_t>(name.size(), static_cast<size_t>(kernel_cap) - 1);
+      std::memcpy(kernel_out, name.data(), n);
+      kernel_out[n] = 0;
     }
   });
 }

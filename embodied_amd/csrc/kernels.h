@@ -85,6 +85,10 @@ hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStr
 hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device_args,
                        hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
+// Name of the kernel launch_move runs for `launch` (as rocprofv3 prints it,
+// without namespaces and parameters); valid until the thread's next call.
+const char* move_kernel_name(const MoveLaunch& launch, bool gather, bool indirect);
+
 // pool[rows[r]] -> batch[r]   (Replay.sample: replay.py:255-292 on device)
 // start/stop (optional): events stamped with the dispatch's own begin/end
 // (hipExtLaunchKernelGGL), i.e. the kernel duration rocprofv3 reports.

@@ -911,6 +911,22 @@ hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device
   return hipGetLastError();
 }
 
+// The kernel launch_move picks for this launch, spelled as the profiler prints
+// it (without namespaces and parameter list).
+const char* move_kernel_name(const MoveLaunch& launch, bool gather, bool indirect) {
+  static thread_local char name[96];
+  if (launch.span) {
+    const SpanVariant& sv = span_variant();
+    std::snprintf(name, sizeof(name), "span_move_kernel%s<%s, %d, %d>", indirect ? "_indirect" : "",
+                  gather ? "true" : "false", sv.unroll == 2 ? 2 : 4, gather ? sv.nt : sv.nt_scatter);
+  } else {
+    const MoveVariant& v = move_variant();
+    std::snprintf(name, sizeof(name), "%s_kernel%s<%d, %d>", gather ? "gather" : "scatter",
+                  indirect ? "_indirect" : launch.stage_tables ? "_staged" : "", v.unroll, v.nt);
+  }
+  return name;
+}
+
 namespace {
 
 // ---------------------------------------------------------------- windowing --

@@ -96,6 +96,24 @@ def test_bench_short_run_keeps_its_shape():
   assert cpus is None or (len(cpus) == 4 and cpus == sorted(cpus))
 
 
+def test_default_single_gpu_run_appends_the_dreamer_workload():
+  """BASELINE configs[2] rides in the driver's own command: the PPO line carries
+  `workloads.dreamer` with the rates and the gather / write-back roofline figures
+  of a short DreamerV3-shaped run (1M-step uniform replay, latents written back)."""
+  rec = run_bench('--steps', '20', '--warmup', '5', '--sustained-seconds', '0', '--no-cpu-baseline',
+                  '--no-context', '--dreamer-leg-steps', '400')
+  assert rec['config']['workload'].startswith('ppo_atari_pong_64env')     # metric / value unchanged
+  assert 'span_move_kernel' in rec['roofline']['kernel'] or 'gather_kernel' in rec['roofline']['kernel']
+  leg = rec['workloads']['dreamer']
+  assert 'error' not in leg, leg
+  assert 'dreamerv3_1M_uniform' in leg['workload'] and 'capacity=1000000' in leg['workload']
+  assert leg['env_steps_per_s'] > 0 and leg['train_steps_per_s'] > 0
+  assert leg['gather']['bytes_per_launch'] == 2 * 16 * 65 * (28255 + 40960)
+  assert 0 < leg['gather']['frac'] < 1 and leg['gather']['launches'] >= 1
+  assert leg['writeback']['bytes_per_launch'] == 2 * 16 * 65 * 40960
+  assert 0 < leg['writeback']['frac'] < 1 and 'Replay.update' in leg['writeback']['kernel']
+
+
 def test_bench_refuses_more_rccl_ranks_than_gpus():
   import torch
   want = torch.cuda.device_count() + 1
