@@ -470,7 +470,18 @@ def main():
       native_comm.wait()
     torch.cuda.synchronize(device)
     if use_dist:
-      dist.barrier()
+      # The sliced / not-sliced choice of a train step is taken from local replay
+      # state (`online_pending`); the ranks run the same schedule, so they take
+      # it alike -- checked here, where the ranks meet anyway: a rank that ever
+      # chose differently would have paired its collectives wrongly.
+      digest = torch.tensor([float(collectives['sliced']), -float(collectives['sliced']),
+                             float(counters['train_steps']), -float(counters['train_steps'])],
+                            dtype=torch.float64, device=device)
+      dist.all_reduce(digest, op=dist.ReduceOp.MAX)      # doubles as the barrier
+      hi_s, neg_lo_s, hi_t, neg_lo_t = digest.tolist()
+      if hi_s != -neg_lo_s or hi_t != -neg_lo_t:
+        raise SystemExit(f'rank {rank}: ranks disagree on the exchange schedule '
+                         f'(sliced {-neg_lo_s:.0f}..{hi_s:.0f}, train steps {-neg_lo_t:.0f}..{hi_t:.0f})')
     torch.cuda.synchronize(device)
 
   fence()

@@ -96,10 +96,18 @@ def build(force=False, verbose=True):
       raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
     spills = scratch_users(res.stderr)
     if spills:
-      # A by-value argument block whose address escapes, or a register spill:
-      # either turns a 10 us mover into a 250 us one.  Never ship that silently.
-      raise RuntimeError('kernels that use scratch memory:\n' + '\n'.join(
-          f'  {kernel}: {nbytes} bytes/lane' for kernel, nbytes in spills))
+      # A by-value argument block whose address escapes, or a register spill,
+      # turns a 10 us mover into a 250 us one: never ship THAT silently.  Other
+      # kernels (scans, env, obs stack) only get a warning -- a small spill on
+      # another compiler version must not make the package uninstallable --
+      # unless EMB_STRICT_SCRATCH=1 (what this repo's own builds use).
+      listing = '\n'.join(f'  {kernel}: {nbytes} bytes/lane' for kernel, nbytes in spills)
+      movers = [k for k, _ in spills if any(
+          tag in (k or '') for tag in ('gather_kernel', 'scatter_kernel', 'span_move_kernel',
+                                       'obs_stack_insert_kernel'))]
+      if movers or os.environ.get('EMB_STRICT_SCRATCH') == '1':
+        raise RuntimeError('kernels that use scratch memory:\n' + listing)
+      print('warning: kernels that use scratch memory:\n' + listing, file=sys.stderr)
     import re
     rest = [l for l in res.stderr.splitlines() if 'kernel-resource-usage' not in l
             and not re.match(r'^\s*(\d+\s*)?\|', l) and not l.lstrip().startswith('^')

@@ -128,6 +128,7 @@ class Replay:
     self._pending_count = C.c_int64()
     self._pending_ref = C.byref(self._pending_count)
     self._saved = set()
+    self._foreign = {}              # chunk ids of files other writers left -> local serials
     self._updates = 0
     self._workers_seen = None
     self._last_stream = None
@@ -912,14 +913,28 @@ class Replay:
       loaded_uids = {self._full_uid(c['uid']) for c in table}
       ondisk = sorted((p.name for p in directory.glob('*.npz')), reverse=True)
       ondisk = [x for x in ondisk if parse_filename(x)[1] not in loaded_uids]
-      # Chunk ids are `replica << 64 | serial` here (chunk.py:15-16 draws random
-      # 128-bit UUIDs): files whose upper half is another replica's — or a
-      # reference-written UUID — cannot be addressed by this index.
+      # Chunk ids are `replica << 64 | serial` here; chunk.py:15-16 draws random
+      # 128-bit UUIDs, and another replica's files carry its id in the upper
+      # half.  The reference's load() takes every file in the directory whoever
+      # wrote it (replay.py:311-359), so such files are loaded too, under fresh
+      # local serials: the uid -> succ links are kept, the step ids inside are
+      # re-issued (stepid[:16] names the chunk) and a file is never taken twice.
+      live = {c['uid'] for c in table}
+      ondisk = [x for x in ondisk
+                if self._foreign.get(parse_filename(x)[1], -1) not in live]
       foreign = [x for x in ondisk if parse_filename(x)[1] >> 64 != self._replica]
       if foreign:
-        print(f'Skipping {len(foreign)} chunk file(s) written under another replica id '
-              f'(this replay is replica {self._replica}): {foreign[0]} ...')
-        ondisk = [x for x in ondisk if x not in set(foreign)]
+        top = max([c['uid'] for c in table] + [
+            u & _MASK64 for x in ondisk for u in parse_filename(x)[1:3]
+            if u >> 64 == self._replica] + list(self._foreign.values()) + [0])
+        for name in reversed(foreign):                     # oldest first
+          for uid in parse_filename(name)[1:3]:
+            if uid and uid >> 64 != self._replica and uid not in self._foreign:
+              top += 1
+              self._foreign[uid] = top
+        api.emb_replay_reserve_uids(self._handle, top + 1)
+        print(f'Loading {len(foreign)} chunk file(s) written under other chunk ids '
+              f'(reference UUIDs or another replica) as local chunks: {foreign[0]} ...')
       if not ondisk:
         return
       counts = count_items(loaded + ondisk, self.length)
@@ -957,18 +972,32 @@ class Replay:
         time_ms, uid, succ, length = parse_filename(name)
         slot = C.c_int64()
         api.emb_replay_load_chunk(
-            self._handle, uid & _MASK64, succ & _MASK64, length, time_ms,
+            self._handle, self._local_uid(uid), self._local_uid(succ), length, time_ms,
             C.byref(slot))
         lo = slot.value * self.chunksize
+        if uid >> 64 != self._replica:
+          # re-issue the step ids: 16-byte big-endian chunk id | 4-byte row
+          ids = np.array(arrays['stepid'][:length], np.uint8)
+          ids[:, :16] = np.frombuffer(
+              ((self._replica << 64) | self._local_uid(uid)).to_bytes(16, 'big'), np.uint8)
+          arrays = {**arrays, 'stepid': ids}
         for key in self._keys:
           host = np.ascontiguousarray(arrays[key.name][:length])
           flat = torch.from_numpy(host.reshape(-1).view(np.uint8))
           key.pool[lo * key.rowbytes: (lo + length) * key.rowbytes].copy_(flat)
-        self._saved.add(uid & _MASK64)
+        self._saved.add(self._local_uid(uid))
       for name, _ in reversed(chunks):
         _, uid, _, _ = parse_filename(name)
-        api.emb_replay_load_items(self._handle, uid & _MASK64, int(counts[uid]))
+        api.emb_replay_load_items(self._handle, self._local_uid(uid), int(counts[uid]))
       self._reraise()
+
+  def _local_uid(self, uid):
+    """The 64-bit chunk serial this replay uses for a chunk id found in a file
+    name: its lower half if this replica issued it, else the serial `load`
+    assigned to the foreign id."""
+    if uid == 0 or uid >> 64 == self._replica:
+      return uid & _MASK64
+    return self._foreign[uid]
 
   # ------------------------------------------------------------- profiling --
 

@@ -183,7 +183,9 @@ def sample_packed(replay, batch, mode='train', groups=1):
           replay._h, batch, _lib.MODES[mode], ptrs, batch // groups, layout.nbytes,
           _lib.ptr(online), None, replay._stream())
       views = PackedViews(flat.view(groups, layout.nbytes), layout)
-  return flat, views, SampleInfo(layout, online.view(np.bool_))
+  # (a private copy: the layout's scratch buffers are shared by every caller
+  # with this batch shape and are written again four samples later)
+  return flat, views, SampleInfo(layout, online.view(np.bool_).copy())
 
 
 def gae_packed(flat, info, value, hor=200, lam=0.8):
@@ -198,6 +200,10 @@ def gae_packed(flat, info, value, hor=200, lam=0.8):
   assert value.shape == (B, T) and value.dtype == torch.float32 and value.is_contiguous()
   base = flat.data_ptr()
   index = layout.index
+  # The kernel reads raw bytes at these offsets: float32 rewards, 1-byte flags.
+  assert index['reward'][1] == torch.float32, index['reward'][1]
+  for name in ('is_last', 'is_terminal'):
+    assert index[name][1] in (torch.bool, torch.uint8), (name, index[name][1])
   both = _lib.empty((2, B, T - 1), torch.float32, flat.device)
   adv, tar = both.unbind(0)
   _lib.fast.emb_scan_gae_grouped(

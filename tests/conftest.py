@@ -17,6 +17,8 @@ _spec = importlib.util.spec_from_file_location(
     '_emb_build', ROOT / 'embodied_amd' / 'build.py')   # not via the package:
 _build = importlib.util.module_from_spec(_spec)         # its __init__ needs the .so
 _spec.loader.exec_module(_build)
+import os  # noqa: E402
+os.environ.setdefault('EMB_STRICT_SCRATCH', '1')   # this repo's own builds: no kernel may spill
 _build.build(verbose=False)
 
 

@@ -88,16 +88,54 @@ def test_fresh_replay_in_a_used_directory_issues_new_chunk_ids(emb, tmp_path):
   assert len(third) == len(first) + len(second)
 
 
-def test_load_skips_chunks_of_other_replicas(emb, tmp_path, capsys):
+def test_load_takes_chunks_of_other_replicas_under_local_ids(emb, tmp_path, capsys):
+  """The reference's load() takes every file in the directory whoever wrote it
+  (replay.py:311-359).  Files saved under another replica id (a world-size or
+  rank remap between runs) come back complete: same items, same payload, step
+  ids re-issued so that `update` can address them."""
   a = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, save_wait=True, replica=3)
   fill(a, 6, 1)
   a.save()
-  b = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, replica=0)
+  b = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, replica=0, seed=0)
   b.load()
-  assert len(b) == 0 and 'another replica' in capsys.readouterr().out
+  assert len(b) == len(a) and 'other chunk ids' in capsys.readouterr().out
+  b.load()                                  # a second load takes nothing twice
+  assert len(b) == len(a)
+  batch = b.sample(32)
+  sid = batch['stepid'].cpu().numpy()
+  assert (sid[..., :8] == 0).all()          # replica 0's ids now
+  # a write-back through the re-issued ids lands on the loaded rows
+  new = torch.full_like(batch['step'], 77)
+  b.update({'stepid': batch['stepid'], 'step': new})
+  assert (b.sample(16)['step'] == 77).all()
   c = emb.Replay(length=2, capacity=100, directory=tmp_path, chunksize=4, replica=3)
   c.load()
   assert len(c) == len(a)
+
+
+def test_load_of_a_reference_written_directory(emb):
+  """Chunk files written by the real reference Replay (random 128-bit UUIDs in
+  the file names and in the stored step ids; tests/golden/ref_chunks, generated
+  by oracle/gen_ref_chunks.py): load() restores exactly the items the
+  reference's own load() restores from them."""
+  import pathlib
+  golden = pathlib.Path(__file__).parent / 'golden'
+  with np.load(golden / 'ref_chunks_expected.npz') as f:
+    want_items, want = int(f['items']), f['windows']
+    length, chunksize = int(f['length']), int(f['chunksize'])
+  rep = emb.Replay(length=length, capacity=None, directory=golden / 'ref_chunks',
+                   chunksize=chunksize, seed=0)
+  rep.load()
+  assert len(rep) == want_items
+  seen = set()
+  for _ in range(40):
+    batch = rep.sample(16)
+    worker, step = batch['worker'].cpu().numpy(), batch['step'].cpu().numpy()
+    vec = batch['vec'].cpu().numpy()
+    assert (vec == (np.arange(3) + 10 * step[..., None] + worker[..., None])).all()
+    for w, t in zip(worker, step):
+      seen.add(tuple(np.stack([w, t], -1).reshape(-1).tolist()))
+  assert seen == {tuple(x.reshape(-1).tolist()) for x in want}
 
 
 def test_sharded_pool_refuses_checkpoints(emb, tmp_path):

@@ -49,3 +49,28 @@ def test_parity_with_the_argument_writer_kernel():
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
+
+
+def test_parity_with_the_plain_python_modules():
+  """Git tracks the `.py` sources; the GPU suite normally runs their Cython
+  copies (embodied_amd/_compiled).  EMB_PURE_PYTHON=1 (read at import) runs the
+  plain modules: the golden scenarios, the full-size sample, the device Driver,
+  the early insert and the replay suite must give the same bytes.  The child also
+  proves which form it ran."""
+  env = dict(os.environ, EMB_PURE_PYTHON='1')
+  probe = subprocess.run(
+      [sys.executable, '-c',
+       'import embodied_amd as e; print(sorted(e.compiled.loaded)); '
+       'import embodied_amd.core.replay as r; print(r.__file__)'],
+      cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+  assert probe.returncode == 0, probe.stderr[-2000:]
+  assert probe.stdout.splitlines()[0] == '[]', probe.stdout      # no compiled module in use
+  assert probe.stdout.splitlines()[1].endswith('embodied_amd/core/replay.py'), probe.stdout
+  res = subprocess.run(
+      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', 'tests/test_gpu_early_insert.py',
+       'tests/test_gpu_replay_suite.py', '-m', 'gpu', '-q', '-x',
+       '-k', 'golden or full_size or device_driver or mask or early or replay or update_table '
+             'or random_histories'],
+      cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+  assert ' passed' in res.stdout
