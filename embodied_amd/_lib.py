@@ -179,6 +179,8 @@ SIGNATURES = {
     'emb_comm_allreduce_grads': [p, p, i64, i32, p],
     'emb_comm_allreduce_grads_as': [p, p, i64, i32, i32, p],
     'emb_comm_alltoall_slices': [p, p, p, i64, p],
+    'emb_comm_allgather_returns': [p, p, p, i64, p],
+    'emb_comm_pmean_scalars': [p, p, i64, p],
     'emb_comm_exchange': [p, p, p, p, i64, p, i64, i32, i32],
     'emb_comm_wait': [p, p],
     'emb_comm_destroy': [p],

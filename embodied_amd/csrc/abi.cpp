@@ -1681,6 +1681,27 @@ int32_t emb_comm_allgather_traj(emb_comm_t* comm, const void* send, void* recv,
   });
 }
 
+int32_t emb_comm_allgather_returns(emb_comm_t* comm, const void* send, void* recv, int64_t count,
+                                   void* stream) {
+  return guarded([&] {
+    need(comm && send && recv && count >= 0, "comm_allgather_returns: bad arguments");
+    if (count == 0) return;
+    rccl_ok(rccl().all_gather(send, recv, static_cast<size_t>(count), ncclFloat32, comm->comm,
+                              static_cast<hipStream_t>(stream)),
+            "ncclAllGather");
+  });
+}
+
+int32_t emb_comm_pmean_scalars(emb_comm_t* comm, void* values, int64_t count, void* stream) {
+  return guarded([&] {
+    need(comm && values && count >= 0, "comm_pmean_scalars: bad arguments");
+    if (count == 0) return;
+    rccl_ok(rccl().all_reduce(values, values, static_cast<size_t>(count), ncclFloat32, ncclAvg,
+                              comm->comm, static_cast<hipStream_t>(stream)),
+            "ncclAllReduce");
+  });
+}
+
 int32_t emb_comm_alltoall_slices(emb_comm_t* comm, const void* send, void* recv,
                                  int64_t bytes_per_rank, void* stream) {
   return guarded([&] {

@@ -538,6 +538,100 @@ class GlobalClock:
     return bool(due) and not bool(skipped)
 
 
+def pmean(x, comm=None, group=None):
+  """Mean over the data-parallel ranks of a (small) float32 tensor, e.g. a local
+  mean (embodied/jax/utils.py:76-81: `x.mean()` then `jax.lax.pmean`).  `comm`:
+  a NativeComm (RCCL through the C ABI); else the process group; one rank: x."""
+  x = x.to(torch.float32).contiguous()
+  if comm is not None:
+    return comm.pmean(x.clone())
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return x
+  out = x.clone()
+  dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+  return out / dist.get_world_size(group)
+
+
+def percentile_over_ranks(x, q, comm=None, group=None):
+  """`jnp.percentile(all_gather(x), q)` (embodied/jax/utils.py:83-88): the q-th
+  percentile (linear interpolation) of every rank's values together.  Every
+  rank must pass the same number of values.  q may be a list."""
+  flat = x.reshape(-1).to(torch.float32).contiguous()
+  if comm is not None:
+    flat = comm.all_gather_returns(flat)
+  elif dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    gathered = torch.empty(dist.get_world_size(group) * flat.numel(), dtype=torch.float32,
+                           device=flat.device)
+    dist.all_gather_into_tensor(gathered, flat, group=group)
+    flat = gathered
+  qs = torch.as_tensor(q, dtype=torch.float32, device=flat.device) / 100
+  if flat.numel() > 1 << 24:                 # torch.quantile's size limit: sort instead
+    ordered = flat.sort().values
+    pos = qs * (flat.numel() - 1)
+    lo = pos.floor().long()
+    hi = (lo + 1).clamp(max=flat.numel() - 1)
+    return ordered[lo] + (ordered[hi] - ordered[lo]) * (pos - lo)
+  return torch.quantile(flat, qs, interpolation='linear')
+
+
+class Normalize:
+  """Running normaliser statistics kept alike on every data-parallel rank
+  (embodied/jax/utils.py:16-88): `impl` 'none' | 'meanstd' | 'perc'.  The
+  cross-rank parts are `pmean` (means of the local batch) and
+  `percentile_over_ranks` (percentiles of all ranks' values together);
+  everything else is local float32 arithmetic in the reference's order."""
+
+  def __init__(self, impl, rate=0.01, limit=1e-8, perclo=5.0, perchi=95.0, debias=True,
+               comm=None, group=None):
+    if impl not in ('none', 'meanstd', 'perc'):
+      raise NotImplementedError(impl)
+    self.impl, self.rate, self.limit = impl, rate, limit
+    self.perclo, self.perchi, self.debias = perclo, perchi, debias
+    self.comm, self.group = comm, group
+    self.state = {}
+
+  def _var(self, name, like):
+    if name not in self.state:
+      self.state[name] = torch.zeros((), dtype=torch.float32, device=like.device)
+    return self.state[name]
+
+  def _update(self, name, value, like):
+    var = self._var(name, like)
+    self.state[name] = (1 - self.rate) * var + self.rate * value
+
+  def __call__(self, x, update=True):
+    if update:
+      self.update(x)
+    return self.stats(x)
+
+  def update(self, x):
+    x = x.detach().to(torch.float32)
+    if self.impl == 'meanstd':
+      means = pmean(torch.stack([x.mean(), x.square().mean()]), self.comm, self.group)
+      self._update('mean', means[0], x)
+      self._update('sqrs', means[1], x)
+    elif self.impl == 'perc':
+      lo, hi = percentile_over_ranks(x, [self.perclo, self.perchi], self.comm, self.group)
+      self._update('lo', lo, x)
+      self._update('hi', hi, x)
+    if self.debias and self.impl != 'none':
+      self._update('corr', 1.0, x)
+
+  def stats(self, like=None):
+    like = like if like is not None else next(iter(self.state.values()))
+    if self.impl == 'none':
+      return 0.0, 1.0
+    corr = 1.0
+    if self.debias:
+      corr = 1.0 / torch.clamp(self._var('corr', like), min=self.rate)
+    if self.impl == 'meanstd':
+      mean = self._var('mean', like) * corr
+      std = torch.sqrt(torch.relu(self._var('sqrs', like) * corr - mean ** 2))
+      return mean, torch.clamp(std, min=self.limit)
+    lo, hi = self._var('lo', like) * corr, self._var('hi', like) * corr
+    return lo, torch.clamp(hi - lo, min=self.limit)
+
+
 class NativeComm:
   """The two collectives on RCCL through the library's own C ABI
   (`emb_comm_*`, include/embodied_hip.h) instead of torch.distributed: for hosts
@@ -598,6 +692,25 @@ class NativeComm:
         self._handle, flat.data_ptr(), out.data_ptr(), flat.numel() // self.world,
         self._lib.raw_stream(flat.device))
     return out
+
+  def all_gather_returns(self, values, out=None):
+    """Every rank's float32 values, concatenated in rank order, on every rank
+    (the `perc` normaliser's all-gather, embodied/jax/utils.py:83-88)."""
+    assert values.dtype == torch.float32 and values.is_contiguous() and values.is_cuda
+    if out is None:
+      out = torch.empty(self.world * values.numel(), dtype=torch.float32, device=values.device)
+    self._api.emb_comm_allgather_returns(
+        self._handle, values.data_ptr(), out.data_ptr(), values.numel(),
+        self._lib.raw_stream(values.device))
+    return out
+
+  def pmean(self, values):
+    """In-place mean over the ranks of a small float32 tensor (Normalize._mean's
+    pmean, embodied/jax/utils.py:76-81)."""
+    assert values.dtype == torch.float32 and values.is_contiguous() and values.is_cuda
+    self._api.emb_comm_pmean_scalars(
+        self._handle, values.data_ptr(), values.numel(), self._lib.raw_stream(values.device))
+    return values
 
   def exchange(self, slices=None, received=None, grads=None, mean=True):
     """One train step's collectives on the communicator's own stream, after

@@ -386,6 +386,18 @@ int32_t emb_comm_allreduce_grads_as(emb_comm_t* comm, void* buf, int64_t count, 
  * local copy).  One fused group of RCCL point-to-point transfers.            */
 int32_t emb_comm_alltoall_slices(emb_comm_t* comm, const void* send, void* recv,
                                  int64_t bytes_per_rank, void* stream);
+/* Normaliser statistics over the data-parallel ranks (embodied/jax/utils.py:76-88;
+ * used by the agents' return / advantage / value normalisers, ppo/agent.py:35-36,
+ * dreamerv3/agent.py:70-72).
+ * allgather_returns: every rank's `count` float32 values -> recv[world * count],
+ *   rank order: the `perc` normaliser's jax.lax.all_gather in front of
+ *   jnp.percentile (utils.py:83-88).
+ * pmean_scalars: in-place mean over the ranks of `count` float32 values: the
+ *   jax.lax.pmean of Normalize._mean (utils.py:76-81).                         */
+int32_t emb_comm_allgather_returns(emb_comm_t* comm, const void* send, void* recv, int64_t count,
+                                   void* stream);
+int32_t emb_comm_pmean_scalars(emb_comm_t* comm, void* values, int64_t count, void* stream);
+
 /* One train step's exchange, asynchronous on the communicator's OWN stream so
  * that it overlaps what the caller queues next (the reference hands train
  * outputs out one step late for the same reason, embodied/jax/agent.py:286-294):

@@ -776,3 +776,52 @@ def scan_closed_form(a, b, seed):
         w *= b[i, s]
       out[i, t] = acc + w * float(seed[i])
   return out
+
+
+# ----------------------------------------------------------------------------
+# Normaliser statistics over data-parallel ranks (embodied/jax/utils.py:16-88).
+# Restated, not executed: the class is a ninjax module (JAX absent) and the
+# reference has no test for it -- parity of this restatement is UNPINNED; it
+# serves as the single-process statement of what the ranks must agree on.
+# ----------------------------------------------------------------------------
+
+
+class Normalize:
+  """`update(parts)` takes the list of every rank's values of one step:
+  Normalize._mean = local mean then pmean over ranks (utils.py:76-81),
+  Normalize._perc = percentile of the all-gathered values (utils.py:83-88)."""
+
+  def __init__(self, impl, rate=0.01, limit=1e-8, perclo=5.0, perchi=95.0, debias=True):
+    assert impl in ('none', 'meanstd', 'perc'), impl
+    self.impl, self.rate, self.limit = impl, f32(rate), f32(limit)
+    self.perclo, self.perchi, self.debias = perclo, perchi, debias
+    self.var = {k: f32(0) for k in ('corr', 'mean', 'sqrs', 'lo', 'hi')}
+
+  def _update(self, name, x):                       # utils.py:90-91
+    self.var[name] = f32((f32(1) - self.rate) * self.var[name] + self.rate * f32(x))
+
+  def update(self, parts):                          # utils.py:44-57
+    parts = [np.asarray(p, np.float32) for p in parts]
+    if self.impl == 'meanstd':
+      self._update('mean', np.mean([p.mean(dtype=np.float32) for p in parts], dtype=np.float32))
+      self._update('sqrs', np.mean([np.square(p).mean(dtype=np.float32) for p in parts],
+                                   dtype=np.float32))
+    elif self.impl == 'perc':
+      together = np.concatenate([p.reshape(-1) for p in parts])
+      self._update('lo', np.percentile(together, self.perclo).astype(np.float32))
+      self._update('hi', np.percentile(together, self.perchi).astype(np.float32))
+    if self.debias and self.impl != 'none':
+      self._update('corr', 1.0)
+
+  def stats(self):                                  # utils.py:59-74
+    if self.impl == 'none':
+      return f32(0), f32(1)
+    corr = f32(1)
+    if self.debias:
+      corr = f32(corr / np.maximum(self.rate, self.var['corr']))
+    if self.impl == 'meanstd':
+      mean = f32(self.var['mean'] * corr)
+      std = np.sqrt(np.maximum(f32(0), f32(self.var['sqrs'] * corr - mean ** 2)))
+      return mean, np.maximum(self.limit, std)
+    lo, hi = f32(self.var['lo'] * corr), f32(self.var['hi'] * corr)
+    return lo, np.maximum(self.limit, f32(hi - lo))

@@ -232,3 +232,47 @@ def test_global_clock_without_a_group_is_a_local_clock():
   clock = D.GlobalClock(-1)
   assert not clock.multihost and clock(0) is True and clock(1, skip=True) is False
   assert D.GlobalClock(0)(0) is False
+
+
+def _returns_of(rank, t, n=96):
+  gen = np.random.default_rng(1000 * t + rank)
+  return (gen.standard_normal(n) * (1 + rank) + 0.3 * t).astype(np.float32)
+
+
+def _normalizer_job(rank, world, D):
+  """The normalisers' collectives (embodied/jax/utils.py:76-88) as library calls:
+  every rank feeds ITS returns, all ranks must end with the same statistics."""
+  out = {}
+  for impl in ('meanstd', 'perc', 'none'):
+    norm = D.Normalize(impl, rate=0.05)
+    for t in range(6):
+      norm.update(torch.as_tensor(_returns_of(rank, t)))
+    out[impl] = [float(v) for v in norm.stats(torch.zeros(()))]
+  x = torch.as_tensor(_returns_of(rank, 0))
+  out['pmean_of_means'] = D.pmean(torch.stack([x.mean(), x.square().mean()])).numpy()
+  out['percentiles'] = D.percentile_over_ranks(x, [5.0, 50.0, 95.0]).numpy()
+  return out
+
+
+def test_normalizer_collectives_match_the_single_process_statement():
+  """pmean of local means and percentiles of the all-gathered returns, with 2 and
+  3 gloo ranks, against numpy on the concatenation and against the oracle's
+  single-process Normalize fed every rank's values."""
+  from oracle import np_oracle
+  for world in (2, 3):
+    got = run_world(_normalizer_job, world)
+    parts0 = [_returns_of(r, 0) for r in range(world)]
+    want_perc = np.percentile(np.concatenate(parts0), [5.0, 50.0, 95.0])
+    want_mean = [np.mean([p.mean() for p in parts0]), np.mean([np.square(p).mean() for p in parts0])]
+    for r in range(world):
+      np.testing.assert_allclose(got[r]['percentiles'], want_perc, rtol=1e-6, atol=1e-6)
+      np.testing.assert_allclose(got[r]['pmean_of_means'], want_mean, rtol=1e-6, atol=1e-6)
+      assert got[r]['none'] == [0.0, 1.0]
+    for impl in ('meanstd', 'perc'):
+      ref = np_oracle.Normalize(impl, rate=0.05)
+      for t in range(6):
+        ref.update([_returns_of(r, t) for r in range(world)])
+      want = [float(v) for v in ref.stats()]
+      for r in range(world):
+        np.testing.assert_allclose(got[r][impl], want, rtol=1e-5, atol=1e-6)
+        assert got[r][impl] == got[0][impl]            # every rank holds the same statistics

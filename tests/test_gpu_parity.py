@@ -754,6 +754,20 @@ def test_native_rccl_collectives_world1(emb):
   with pytest.raises(Exception, match='dtype'):
     comm._api.emb_comm_allreduce_grads_as(
         comm._handle, flat.data_ptr(), 16, comm._lib.U8, 0, comm._lib.raw_stream(flat.device))
+  # The normalisers' collectives (embodied/jax/utils.py:76-88) through the same
+  # communicator: all-gather of returns + percentile, pmean of local means.
+  returns = torch.randn(16 * 63, device='cuda')
+  got = D.percentile_over_ranks(returns, [5.0, 95.0], comm=comm).cpu().numpy()
+  np.testing.assert_allclose(got, np.percentile(returns.cpu().numpy(), [5.0, 95.0]), rtol=1e-5, atol=1e-6)
+  means = torch.stack([returns.mean(), returns.square().mean()])
+  assert torch.equal(D.pmean(means, comm=comm), means)
+  norm = D.Normalize('perc', comm=comm)
+  ref = np_oracle.Normalize('perc')
+  for _ in range(3):
+    norm.update(returns)
+    ref.update([returns.cpu().numpy()])
+  np.testing.assert_allclose([float(v) for v in norm.stats()], [float(v) for v in ref.stats()],
+                             rtol=1e-5, atol=1e-6)
   comm.close()
 
 
