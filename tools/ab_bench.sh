@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for i in $(seq 1 $N); do
   for v in A B; do
     if [ $v = A ]; then E="$A"; else E="$B"; fi
-    env $E python "$R/bench.py" --no-cpu-baseline --no-context --sustained-seconds 4 "$@" 2>/dev/null | grep '^{' > "$O/ab_${v}_$i.json"
+    env $E python "$R/bench.py" --no-cpu-baseline --no-context --no-dreamer-leg --sustained-seconds 4 "$@" 2>/dev/null | grep '^{' > "$O/ab_${v}_$i.json"
     python - "$O/ab_${v}_$i.json" "$v$i [$E]" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Reproduce profiles/rNN_* on the GPU box (run from the repo root):
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r03
 # Counters are collected in their own passes (never together with a trace domain
 # other than --kernel-trace); FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -12,23 +12,25 @@ cd /tmp && export TMPDIR=/tmp
 # the headline line, un-profiled (bench.py's default: kernel arguments in host memory)
 python "$R/bench.py" > "$O/bench_default.json" 2>/dev/null
 # the runtime's default argument placement, for DESIGN.md 4's A/B
-HIP_FORCE_DEV_KERNARG=1 python "$R/bench.py" --no-cpu-baseline > "$O/bench_device_kernargs.json" 2>/dev/null
-python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 3 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
+HIP_FORCE_DEV_KERNARG=1 python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg > "$O/bench_device_kernargs.json" 2>/dev/null
+python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 3 --no-dreamer-leg 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
+# the A/B of the early insert on this box (alternating runs; same everything else)
+"$R/tools/ab_bench.sh" "gpurun_out/$TAG/ab_early_insert" "EMB_EARLY_INSERT=0" "EMB_EARLY_INSERT=1" 2 > "$O/ab_early_insert.txt" 2>&1 || true
 # the driver's short form
 python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | grep '^{' > "$O/bench_steps20.json"
 # --stats of the SAME default command
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -o st -- \
-  python "$R/bench.py" --no-cpu-baseline > "$O/bench_under_rocprof.json" 2>"$O/stats_bench.log"
+  python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg > "$O/bench_under_rocprof.json" 2>"$O/stats_bench.log"
 cp /tmp/st/st_kernel_stats.csv "$O/kernel_stats_bench.csv"
 HIP_FORCE_DEV_KERNARG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st1 -o st -- \
-  python "$R/bench.py" --no-cpu-baseline > "$O/bench_device_kernargs_under_rocprof.json" 2>/dev/null
+  python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg > "$O/bench_device_kernargs_under_rocprof.json" 2>/dev/null
 cp /tmp/st1/st_kernel_stats.csv "$O/kernel_stats_bench_device_kernargs.csv"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st2 -o st -- \
   python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 0 --no-cpu-baseline > /dev/null 2>&1
 cp /tmp/st2/st_kernel_stats.csv "$O/kernel_stats_dreamer.csv"
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter --kernel-trace --output-format csv -d /tmp/p_$counter -o p -- \
-    python "$R/bench.py" --steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context > /dev/null 2>&1
+    python "$R/bench.py" --steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context --no-dreamer-leg > /dev/null 2>&1
   python "$R/tools/summarize_pmc.py" /tmp/p_$counter/p_counter_collection.csv > "$O/pmc_$counter.csv"
 done
 # the same two counter passes for the configs[2] gather (144 MB per launch)
@@ -81,6 +83,23 @@ json.dump({
     'traffic_bytes_per_launch': int(round((2 * fetch + write) * 1024)),
     'algorithmic_bytes_per_launch': 2 * 16 * 65 * 28255,
 }, open(f'{out}/pmc_gather.json', 'w'), indent=1)
+# the three launches of a vectorised step: how often is a frame fetched?
+step = {}
+for needle, what in (('obs_stack_insert_kernel', 'obs stack + early insert: 64 frames read once, written as bf16 policy batch and as pool rows'),
+                     ('publish_one_kernel', 'masked action to its pool rows and to the next step\'s action buffer'),
+                     ('synth_env_kernel', 'synthetic env frames (benchmark input)'),
+                     ('scatter_kernel', 'plain insert (EMB_EARLY_INSERT=0 / first step)'),
+                     ('obs_stack_kernel', 'plain obs stack')):
+  try:
+    f, n, name = mean(f'{out}/pmc_FETCH_SIZE.csv', needle)
+    w, _, _ = mean(f'{out}/pmc_WRITE_SIZE.csv', needle)
+    step[name] = {'what': what, 'dispatches': n, 'fetch_kb': f, 'write_kb': w,
+                  'traffic_bytes_per_launch': int(round((2 * f + w) * 1024))}
+  except Exception:
+    pass
+json.dump({'frames_bytes_per_step': 64 * 28224, 'kernels': step,
+           'correction': 'FETCH_SIZE doubled (gfx950, 16 B/lane streams)'},
+          open(f'{out}/pmc_step.json', 'w'), indent=1)
 try:
   fetch, n, name = mean(f'{out}/dreamer_pmc_FETCH_SIZE.csv', 'span_move_kernel_indirect<true')
   write, _, _ = mean(f'{out}/dreamer_pmc_WRITE_SIZE.csv', 'span_move_kernel_indirect<true')
