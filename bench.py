@@ -324,6 +324,7 @@ def main():
     else:
       issue = D.Done
   use_native = False
+  link = None               # who carries a train step's collectives (set after the self-check)
   collectives = {'on': True, 'sliced': 0}
 
   def train_step():
@@ -339,14 +340,9 @@ def main():
       emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
       replay.update({'stepid': batch['stepid'], 'dyn/deter': batch['dyn/deter'],
                      'dyn/stoch': batch['dyn/stoch']})
-      if use_native and grads is not None and collectives['on']:
-        native_comm.wait()
-        native_comm.exchange(grads=grads)
-      elif use_dist and args.grad_numel and collectives['on']:
-        for future in pending:
-          future.result().wait()
-        pending.clear()
-        pending.append(issue(lambda: D.async_all_reduce(grads)))
+      if use_dist and grads is not None and collectives['on']:
+        link.wait()
+        link.exchange(grads=grads)
     elif not use_dist or not collectives['on']:
       batch = next(stream)
       adv, tar = emb.scans.gae(
@@ -365,22 +361,21 @@ def main():
         flat, batch, layout = D.sample_packed(replay, rows, groups=world)
       else:
         flat, batch, layout = D.sample_packed(replay, rows)
+      # Last train step's collectives (they ran behind the env steps since):
+      # `link` is the library's own RCCL exchange (emb_comm_exchange, its own
+      # stream) or the same contract on the process group (D.GroupComm).
       for future in pending:
         future.result().wait()
       pending.clear()
-      if use_native:
-        native_comm.wait()
+      link.wait()
       send = None
       if sliced:
         # This rank's slice of the global batch = block `rank` of every rank's
         # batch; it is complete one train step later (the wait above) and is
-        # what the learner then computes returns on.
-        if use_native:     # slices and gradients in ONE library call, on its own stream
-          received = torch.empty_like(flat)
-          native_comm.exchange(flat, received, grads)
-        else:
-          work, received, views = D.exchange_dp_slices(flat, layout)
-          pending.append(D.Done(lambda w=work: w))
+        # what the learner then computes returns on.  Slices and gradients go
+        # out in ONE exchange call.
+        received = torch.empty_like(flat)
+        link.exchange(flat, received, grads)
         state_keep[:] = [flat, received]
         late, slice_state['recv'] = slice_state.get('recv'), (received, layout)
         source, source_info = late if late is not None else (flat, layout)
@@ -391,19 +386,15 @@ def main():
           send = flat
         elif args.exchange == 'returns':
           send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
-      # Process-group level async collectives (no Python-side checking), issued
-      # inline in the same order on every rank.  EMB_BENCH_COMM=thread issues
-      # them from a helper thread instead (measured slower: the GIL changes
-      # hands at every library call of the stepping thread).
-      if send is not None:
-        gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
-        pending.append(issue(lambda g=gathered, s=send: D.async_all_gather(g, s)))
-        state_keep[:] = [gathered, send]
-      if use_native:
-        if not sliced and grads is not None:
-          native_comm.exchange(grads=grads)
-      elif args.grad_numel:
-        pending.append(issue(lambda: D.async_all_reduce(grads)))
+        # The all-gather forms stay on torch.distributed, issued inline in the
+        # same order on every rank (EMB_BENCH_COMM=thread: from a helper thread;
+        # measured slower, the GIL changes hands at every library call).
+        if send is not None:
+          gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
+          pending.append(issue(lambda g=gathered, s=send: D.async_all_gather(g, s)))
+          state_keep[:] = [gathered, send]
+        if grads is not None:
+          link.exchange(grads=grads)
       # When the links are the bottleneck the host could queue train steps far
       # ahead of the GPU (one gathered buffer each): stay within 8 train steps.
       if counters['train_steps'] % 4 == 0:       # one mark per 4 train steps, 8 marks deep
@@ -439,6 +430,8 @@ def main():
     # (all-gather forms of the exchange stay on torch.distributed.)
     use_native = native_comm is not None and args.exchange in ('dp_slice', 'none')
     native['timed_path'] = 'native' if use_native else 'c10d'
+  if use_dist:
+    link = native_comm if use_native else D.GroupComm()
   # EMB_BENCH_NO_TIMER=1: no dispatch stamps (roofline is then null) -- for a
   # rocprofv3 run that sees the gather without the timed-dispatch perturbation.
   # Switched on before the warm-up so that the stamps' events exist by then.
@@ -466,8 +459,8 @@ def main():
     for future in pending:
       future.result().wait()
     pending.clear()
-    if use_native:
-      native_comm.wait()
+    if link is not None:
+      link.wait()
     torch.cuda.synchronize(device)
     if use_dist:
       # The sliced / not-sliced choice of a train step is taken from local replay
@@ -521,8 +514,7 @@ def main():
       s_steps += 256
       go_on = time.perf_counter() - s_start < args.sustained_seconds
       if use_dist:          # every rank must leave the loop after the same step
-        if use_native:      # the process group's collective queues up behind the library's
-          native_comm.wait()
+        link.wait()         # the process group's collective queues up behind the exchange's
         flag = torch.tensor([1.0 if go_on else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         go_on = bool(flag.item())
@@ -584,6 +576,10 @@ def main():
         'issue_period_us': round(elapsed / done * 1e6, 1),
         'sliced_share': round(share, 3),
     }
+    # links bound the job when RCCL needs longer for one train step's collectives
+    # than the path takes to issue the next train step
+    native['per_train_step']['link_bound'] = bool(
+        native['per_train_step']['collectives_us'] > native['per_train_step']['issue_period_us'])
   counters.update(headline)
   env_steps = (counters['env_steps'] - base['env_steps']) * world
   train_steps = (counters['train_steps'] - base['train_steps']) * world
@@ -723,6 +719,8 @@ def main():
         **({'writeback': writeback} if writeback is not None else {}),
         **({'workloads': workloads} if workloads is not None else {}),
         **({'native_comm': native} if native is not None else {}),
+        **({'link_bound': native['per_train_step']['link_bound']}
+           if native is not None and 'per_train_step' in native else {}),
         **({'replicas_only': replicas_only} if replicas_only is not None else {}),
     }), flush=True)
   if native_stuck:       # a collective of the check never returned: leave without the teardown

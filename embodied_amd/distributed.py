@@ -632,6 +632,45 @@ class Normalize:
     return lo, torch.clamp(hi - lo, min=self.limit)
 
 
+class GroupComm:
+  """NativeComm's train-step contract on a torch.distributed process group (RCCL,
+  or gloo on a box with fewer GPUs than ranks): `exchange` issues the DP-slice
+  all-to-all and / or the gradient all-reduce asynchronously, `wait` -- one
+  train step later -- completes them.  Between the two calls the buffers belong
+  to the exchange.  Same order of collectives on every rank: all-to-all first,
+  then the all-reduce."""
+
+  def __init__(self, group=None):
+    self.group = group
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self._pending = []
+    self._scale = None
+
+  def exchange(self, slices=None, received=None, grads=None, mean=True):
+    assert not self._pending, 'GroupComm.exchange: wait() for the previous exchange first'
+    if slices is not None:
+      assert received is not None and received.numel() == slices.numel()
+      assert slices.numel() % self.world == 0
+      if self.world == 1:
+        received.copy_(slices)
+      else:
+        self._pending.append(async_all_to_all(received, slices))
+    if grads is not None and self.world > 1:
+      self._pending.append(async_all_reduce(grads))        # sum; the mean is taken in wait()
+      self._scale = grads if mean else None
+
+  def wait(self, device=None):
+    for work in self._pending:
+      work.wait()
+    self._pending.clear()
+    if self._scale is not None:
+      self._scale.div_(self.world)
+      self._scale = None
+
+  def close(self):
+    self.wait()
+
+
 class NativeComm:
   """The two collectives on RCCL through the library's own C ABI
   (`emb_comm_*`, include/embodied_hip.h) instead of torch.distributed: for hosts

@@ -276,3 +276,49 @@ def test_normalizer_collectives_match_the_single_process_statement():
       for r in range(world):
         np.testing.assert_allclose(got[r][impl], want, rtol=1e-5, atol=1e-6)
         assert got[r][impl] == got[0][impl]            # every rank holds the same statistics
+
+
+def _exchange_contract_job(rank, world, D):
+  """A train step's collectives through the exchange / wait contract that
+  bench.py's timed path uses (NativeComm on RCCL, GroupComm on a process group):
+  issue now, complete one train step later, buffers untouched in between."""
+  comm = D.GroupComm()
+  block, steps = 64, 5
+  sent, recv, grads, log = [], [], [], []
+  for k in range(steps):
+    # block d of rank r's batch k carries the byte (16 * r + 4 * k + d) & 0xFF
+    flat = torch.cat([torch.full((block,), (16 * rank + 4 * k + d) & 0xFF, dtype=torch.uint8)
+                      for d in range(world)])
+    sent.append(flat)
+    recv.append(torch.zeros_like(flat))
+    grads.append(torch.full((1000,), float(rank + 10 * k)))
+    comm.wait()                                   # completes exchange k-1 (a no-op at k = 0)
+    if k:
+      log.append((recv[k - 1].clone().numpy(), grads[k - 1].clone().numpy()))
+    if k % 2 == 0:
+      comm.exchange(sent[k], recv[k], grads[k])   # slices + gradients in one exchange
+    else:
+      comm.exchange(grads=grads[k])               # a batch without fresh windows: gradients only
+  try:
+    comm.exchange(grads=grads[0])
+    double = False
+  except AssertionError:
+    double = True                                 # a second exchange before wait() is refused
+  comm.wait()
+  log.append((recv[-1].numpy(), grads[-1].numpy()))
+  return log, double
+
+
+def test_exchange_wait_contract_with_two_and_three_ranks():
+  for world in (2, 3):
+    got = run_world(_exchange_contract_job, world)
+    for rank in range(world):
+      log, double = got[rank]
+      assert double and len(log) == 5
+      for k, (received, grads) in enumerate(log):
+        np.testing.assert_allclose(grads, np.mean([r + 10 * k for r in range(world)]))
+        want = np.zeros(64 * world, np.uint8)
+        if k % 2 == 0:        # block s came from rank s: its block `rank` of batch k
+          want = np.concatenate([np.full(64, (16 * s + 4 * k + rank) & 0xFF, np.uint8)
+                                 for s in range(world)])
+        assert (received == want).all(), (world, rank, k)
