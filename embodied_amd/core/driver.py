@@ -73,6 +73,8 @@ class Driver:
       self.device = torch.device('cuda', torch.cuda.current_device())
     self.batch_env = batch_env
     self.parallel = parallel and batch_env is None
+    self._upload_src, self._upload_ring, self._upload_turn = None, [], 0
+    self._acts_on_host, self._acts_pinned, self._acts_landed = None, {}, None
     if batch_env is not None:
       assert self.device is not None and self.device.type == 'cuda'
       self.length = len(batch_env)
@@ -86,8 +88,8 @@ class Driver:
         fns = [cloudpickle.dumps(fn) for fn in make_env_fns]
         self._wake = [context.Semaphore(0) for _ in range(self.length)]
         self.procs = [
-            context.Process(target=_env_server, args=(i, pipe, fn, wake), daemon=True)
-            for i, (fn, pipe, wake) in enumerate(zip(fns, pipes, self._wake))]
+            context.Process(target=_env_server, args=(i, pipe, fn, self._wake), daemon=True)
+            for i, (fn, pipe) in enumerate(zip(fns, pipes))]
         [proc.start() for proc in self.procs]
         self.pipes[0].send(('act_space',))
         self.act_space = self._receive(self.pipes[0])
@@ -123,6 +125,7 @@ class Driver:
           k: np.zeros((self.length,) + tuple(v.shape), v.dtype)
           for k, v in self.act_space.items()}
       self.acts['reset'] = np.ones(self.length, bool)
+    self._acts_on_host = None          # actions fetched ahead belong to the old episode
     self.carry = init_policy and init_policy(self.length)
 
   def _attach_shared_slab(self):
@@ -138,17 +141,36 @@ class Driver:
           if not k.startswith('log/')}
     except Exception:
       return
-    layout = {}
+    # ONE block for all observation keys (each key's (N, ...) array at a
+    # 256-byte aligned offset): in device mode the whole step's observations go
+    # up with a single host-to-device copy instead of one per key.
+    layout, offset = {}, 0
     for key, (shape, dtype) in spec.items():
       nbytes = max(1, self.length * int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize)
-      block = shared_memory.SharedMemory(create=True, size=nbytes)
-      view = np.ndarray((self.length, *shape), dtype, buffer=block.buf)
-      self._shared[key] = (block, view)
-      layout[key] = (block.name, shape, dtype)
-      if self.device is not None:
-        tensor = torch.from_numpy(view)
-        if torch.cuda.cudart().cudaHostRegister(tensor.data_ptr(), nbytes, 0) == 0:
-          self._registered = getattr(self, '_registered', []) + [tensor.data_ptr()]
+      layout[key] = [None, shape, dtype, offset, nbytes]
+      offset += -(-nbytes // 256) * 256
+    total = max(offset, 256)
+    block = shared_memory.SharedMemory(create=True, size=total)
+    for key, entry in layout.items():
+      entry[0] = block.name
+      _, shape, dtype, at, _ = entry
+      self._shared[key] = (block, np.ndarray((self.length, *shape), dtype, buffer=block.buf, offset=at))
+    layout = {k: tuple(v) for k, v in layout.items()}
+    if self.device is not None:
+      whole = torch.from_numpy(np.ndarray(total, np.uint8, buffer=block.buf))
+      if torch.cuda.cudart().cudaHostRegister(whole.data_ptr(), total, 0) == 0:
+        self._registered = getattr(self, '_registered', []) + [whole.data_ptr()]
+      # Four device copies used in turn (like a vector env's own output ring):
+      # the tensors of a step are overwritten four steps later.
+      self._upload_src = whole
+      self._upload_ring, self._upload_turn = [], 0
+      for _ in range(4):
+        dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+        views = {}
+        for key, (_, shape, dtype, at, nbytes) in layout.items():
+          kind = replaylib._TORCH_OF[np.dtype(dtype)]
+          views[key] = dev[at: at + nbytes].view(kind).view(self.length, *shape)
+        self._upload_ring.append((dev, views))
     # Actions go down and completion flags come up through shared memory too:
     # per step the parent copies (N, ...) actions into the action slabs, bumps a
     # sequence number, wakes the workers (one semaphore each) and polls the
@@ -187,8 +209,11 @@ class Driver:
       for ptr in getattr(self, '_registered', []):
         torch.cuda.cudart().cudaHostUnregister(ptr)
       self._registered = []
-      blocks = [b for b, _ in getattr(self, '_shared', {}).values()]
-      blocks += [b for b, _ in getattr(self, '_act_slab', {}).values()]
+      blocks = []
+      for b, _ in list(getattr(self, '_shared', {}).values()) + list(getattr(self, '_act_slab', {}).values()):
+        if not any(b is seen for seen in blocks):
+          blocks.append(b)
+      self._upload_src, self._upload_ring = None, []
       if getattr(self, '_ctrl_block', None) is not None:
         self._ctrl = self._done = self._extra = None
         blocks.append(self._ctrl_block)
@@ -233,7 +258,15 @@ class Driver:
       return self._step_device_env(policy, step, episode)
     acts = self.acts
     assert all(len(x) == self.length for x in acts.values())
-    host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
+    host = self._acts_on_host
+    if host is not None:
+      # The copies of the last step's (masked) actions into pinned memory were
+      # queued right behind the policy; the replay insert's host work ran
+      # meanwhile.  Now they are needed.
+      self._acts_landed.synchronize()
+      self._acts_on_host = None
+    else:
+      host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
     assert all(isinstance(v, np.ndarray) for v in host.values())
     self._wait_uploads()        # env results overwrite the slab the last upload read
     if self.parallel and self._fast:
@@ -249,6 +282,9 @@ class Driver:
     logs = {k: v for k, v in obs.items() if k.startswith('log/')}
     obs = {k: v for k, v in obs.items() if not k.startswith('log/')}
     assert all(len(x) == self.length for x in obs.values()), obs
+    if (self.device is not None and _EARLY_INSERT and len(self._sinks) == 1
+        and self._sinks[0] is not None and not logs and not self.callbacks):
+      self._sinks[0].offer(obs, self._workers)     # see _step_device_env
     self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
     assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
     is_last = obs['is_last']
@@ -264,9 +300,31 @@ class Driver:
       if ended.any():
         acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
       self.acts = {**acts, 'reset': is_last.copy()}
+    if self.device is not None:
+      self._fetch_acts()
     trans = {**obs, **acts, **outs, **logs}
     self._dispatch(trans)
     return step + self.length, episode + int(ended.sum())
+
+  def _fetch_acts(self):
+    """Device mode with host envs: start bringing the next step's actions to
+    pinned host memory now (asynchronously, behind the policy's kernels), so
+    that the copy and its latency run under the replay insert's host work
+    instead of in front of the next env step."""
+    if not all(torch.is_tensor(v) and v.is_cuda for v in self.acts.values()):
+      self._acts_on_host = None
+      return
+    host = {}
+    for k, v in self.acts.items():
+      pinned = self._acts_pinned.get(k)
+      if pinned is None or pinned.shape != v.shape or pinned.dtype != v.dtype:
+        pinned = self._acts_pinned[k] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+      pinned.copy_(v, non_blocking=True)
+      host[k] = pinned.numpy()
+    if self._acts_landed is None:
+      self._acts_landed = torch.cuda.Event()
+    self._acts_landed.record()
+    self._acts_on_host = host
 
   def _step_device_env(self, policy, step, episode):
     """Same step with a device-resident vector env: nothing is read back, so
@@ -332,7 +390,10 @@ class Driver:
     self._seq += 1
     seq = self._seq
     self._ctrl[0] = seq
-    for wake in self._wake:
+    # Wake-up as a tree (a semaphore release is ~1.4 us: 64 of them in a row
+    # were 90 us of a 250 us step): the Driver wakes the first _FANOUT workers,
+    # every worker wakes its own children before it steps its env.
+    for wake in self._wake[:_FANOUT]:
       wake.release()
     done, deadline, spins = self._done, None, 0
     while True:
@@ -377,10 +438,14 @@ class Driver:
       return out
     out, self._host_flags = {}, {}
     if shared:
-      for k, (_, view) in shared.items():
-        if k in ('is_first', 'is_last', 'is_terminal'):
-          self._host_flags[k] = view.copy()
-        out[k] = torch.from_numpy(view).to(self.device, non_blocking=True)
+      for k in ('is_first', 'is_last', 'is_terminal'):
+        if k in shared:
+          self._host_flags[k] = shared[k][1].copy()
+      # the whole observation slab in one copy, into the next device buffer of the ring
+      self._upload_turn = (self._upload_turn + 1) & 3
+      dev, views = self._upload_ring[self._upload_turn]
+      dev.copy_(self._upload_src, non_blocking=True)
+      out.update(views)
     for k in keys:
       first = np.asarray(results[0][k])
       slab = self._slab.get(k)
@@ -428,7 +493,17 @@ class Driver:
     raise failure
 
 
-def _env_server(envid, pipe, ctor, wake=None):
+_FANOUT = 8
+
+
+def _wake_children(envid, wakes):
+  """Workers (envid + 1) * _FANOUT ... + _FANOUT - 1 (heap order under the Driver)."""
+  first = (envid + 1) * _FANOUT
+  for child in range(first, min(first + _FANOUT, len(wakes))):
+    wakes[child].release()
+
+
+def _env_server(envid, pipe, ctor, wakes=None):
   """Worker process.  Pipe protocol as the reference's (driver.py:101-137):
   ('step', act) -> ('result', obs), 'obs_space', 'act_space'.  After
   ('attach', obs layout, n, act layout, ctrl name) it switches to the shared
@@ -437,12 +512,27 @@ def _env_server(envid, pipe, ctor, wake=None):
   env = None
   blocks, slabs = [], {}
 
+  def open_block(name):
+    # (Attaching registers the block with this process's resource tracker, which
+    # would try to unlink the parent's memory at exit and warn about "leaks".)
+    block = shared_memory.SharedMemory(name=name)
+    try:
+      from multiprocessing import resource_tracker
+      resource_tracker.unregister(block._name, 'shared_memory')
+    except Exception:
+      pass
+    blocks.append(block)
+    return block
+
+  opened = {}
+
   def attach(layout, n):
     out = {}
-    for key, (name, shape, dtype) in layout.items():
-      block = shared_memory.SharedMemory(name=name)
-      blocks.append(block)
-      out[key] = np.ndarray((n, *shape), dtype, buffer=block.buf)
+    for key, (name, shape, dtype, *where) in layout.items():
+      if name not in opened:
+        opened[name] = open_block(name)
+      out[key] = np.ndarray((n, *shape), dtype, buffer=opened[name].buf,
+                            offset=where[0] if where else 0)
     return out
 
   def put(obs):
@@ -459,17 +549,18 @@ def _env_server(envid, pipe, ctor, wake=None):
     """'attach': from now on observations go into the shared slab; with action
     slabs and a control block the whole step protocol does."""
     slabs.update(attach(layout, n))
-    if act_layout is None or wake is None:
+    if act_layout is None or wakes is None:
       pipe.send(('result', True))
       return
     acts = attach(act_layout, n)
-    ctrl_block = shared_memory.SharedMemory(name=ctrl_name)
-    blocks.append(ctrl_block)
+    ctrl_block = open_block(ctrl_name)
     ctrl = np.ndarray(2 + 2 * n, np.int64, buffer=ctrl_block.buf)
     done, extra = ctrl[2: 2 + n], ctrl[2 + n:]
     pipe.send(('result', True))
+    wake = wakes[envid]
     while True:
       wake.acquire()
+      _wake_children(envid, wakes)        # first: they are woken even if this env then fails
       seq = int(ctrl[0])
       try:
         rest = put(env.step({k: v[envid].copy() for k, v in acts.items()}))

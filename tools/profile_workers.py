@@ -24,28 +24,11 @@ def policy(carry, obs, **kw):
 driver.reset()
 driver(policy, steps=n * 50)
 host = {'action': act, 'reset': np.zeros(n, bool)}
-T = {'release': 0.0, 'wait': 0.0, 'total': 0.0}
 iters = 500
-orig = driver._step_workers
+t0 = time.perf_counter()
 for _ in range(iters):
-  t0 = time.perf_counter()
-  for key, (_, slab) in driver._act_slab.items():
-    slab[...] = host[key]
-  driver._seq += 1
-  seq = driver._seq
-  driver._ctrl[0] = seq
-  t1 = time.perf_counter()
-  for wake in driver._wake:
-    wake.release()
-  t2 = time.perf_counter()
-  while not (driver._done == seq).all():
-    pass
-  t3 = time.perf_counter()
-  T['release'] += t2 - t1
-  T['wait'] += t3 - t2
-  T['total'] += t3 - t0
-for k, v in T.items():
-  print(f'{k:8s} {v / iters * 1e6:8.1f} us')
+  driver._step_workers(host)
+print(f'_step_workers (actions down, wake, env steps, done flags up) {(time.perf_counter() - t0) / iters * 1e6:8.1f} us')
 t0 = time.perf_counter()
 driver(policy, steps=n * 300)
 print(f'driver step {(time.perf_counter() - t0) / 300 * 1e6:8.1f} us  ({os.cpu_count()} cpus)')
