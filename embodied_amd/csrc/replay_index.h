@@ -147,7 +147,7 @@ class ReplayIndex {
     if (w->pending.count >= cfg_.length) {
       metrics_[kInserts] += 1;
       const Pos start = w->pending.pop();
-      insert_item(start);
+      insert_item(start, w, stepid);
       if (cfg_.online && w->steps_seen % cfg_.length == 0) fresh_.push_back(start);
     }
     if (cfg_.online) w->steps_seen += 1;
@@ -376,6 +376,7 @@ class ReplayIndex {
     PosRing pending;            // steps not yet the start of an item
     int64_t steps_seen = 0;     // online mode
     uint64_t peek_mark = 0;     // last peek() batch that listed this worker
+    int64_t last_item = -1;     // key of the newest item of this stream
   };
 
   // Worker ids are usually 0..N-1: a flat table in front of the general map.
@@ -414,11 +415,17 @@ class ReplayIndex {
   }
 
   // replay.py:171-179
-  void insert_item(const Pos& start) {
+  // `worker` / `newest` (add() only): the worker stream this window continues and
+  // the id of its last step, for selectors that take sliding windows one new
+  // step at a time (Selector::insert_successor).
+  void insert_item(const Pos& start, Worker* worker = nullptr, const StepId* newest = nullptr) {
     while (cfg_.capacity && size() >= cfg_.capacity) evict();
     const int64_t key = next_item_++;
     items_.push_back(start);
+    const int64_t prev_key = worker ? worker->last_item : -1;
+    if (worker) worker->last_item = key;
     if (selector_->needs_stepids()) {
+      if (prev_key >= first_item_ && newest && selector_->insert_successor(key, prev_key, *newest)) return;
       if (!spans(start, cfg_.length, &scratch_))
         throw std::logic_error("replay: inserted window is incomplete");
       ids_.clear();

@@ -79,6 +79,88 @@ struct StepIdHash {
   }
 };
 
+// int64 key -> V for keys that arrive in increasing order and mostly leave
+// oldest first (item ids of a Replay): a ring indexed by key - base serves them
+// without hashing; any other pattern falls back to a hash map for good, with
+// the same contents.  `V()` must mean "absent" (a null pointer / null first).
+template <typename V>
+class SlidingMap {
+ public:
+  static bool present(const V& v) { return !(v == V()); }
+  size_t size() const { return live_; }
+  bool empty() const { return live_ == 0; }
+  V* find(int64_t key) {
+    if (dense_) {
+      const int64_t i = key - base_;
+      if (i < 0 || i >= static_cast<int64_t>(window_.size()) || !present(window_[i])) return nullptr;
+      return &window_[i];
+    }
+    auto it = sparse_.find(key);
+    return it == sparse_.end() ? nullptr : &it->second;
+  }
+  bool count(int64_t key) { return find(key) != nullptr; }
+  void put(int64_t key, const V& value) {
+    if (dense_) {
+      if (window_.empty()) base_ = key;
+      const int64_t i = key - base_;
+      if (i >= 0 && i < static_cast<int64_t>(window_.size())) {
+        if (!present(window_[i])) ++live_;
+        window_[i] = value;
+        return;
+      }
+      if (i == static_cast<int64_t>(window_.size())) {
+        window_.push_back(value);
+        ++live_;
+        return;
+      }
+      for (size_t j = 0; j < window_.size(); ++j)        // pattern broken: migrate
+        if (present(window_[j])) sparse_[base_ + static_cast<int64_t>(j)] = window_[j];
+      window_.clear();
+      dense_ = false;
+    }
+    if (sparse_.emplace(key, value).second) ++live_;
+    else sparse_[key] = value;
+  }
+  bool erase(int64_t key) {
+    if (dense_) {
+      V* slot = find(key);
+      if (!slot) return false;
+      *slot = V();
+      --live_;
+      while (!window_.empty() && !present(window_.front())) {
+        window_.pop_front();
+        ++base_;
+      }
+      return true;
+    }
+    if (!sparse_.erase(key)) return false;
+    --live_;
+    return true;
+  }
+  void clear() {
+    window_.clear();
+    sparse_.clear();
+    live_ = 0;
+    dense_ = true;
+  }
+  template <typename Fn>
+  void for_each(Fn&& fn) const {
+    if (dense_) {
+      for (size_t j = 0; j < window_.size(); ++j)
+        if (present(window_[j])) fn(base_ + static_cast<int64_t>(j), window_[j]);
+    } else {
+      for (const auto& kv : sparse_) fn(kv.first, kv.second);
+    }
+  }
+
+ private:
+  bool dense_ = true;
+  int64_t base_ = 0;
+  size_t live_ = 0;
+  Ring<V> window_;
+  std::unordered_map<int64_t, V> sparse_;
+};
+
 class Selector {
  public:
   virtual ~Selector() = default;
@@ -86,6 +168,11 @@ class Selector {
   virtual int64_t size() const = 0;
   virtual void insert(int64_t key, const StepId* steps, int n) = 0;
   virtual void remove(int64_t key) = 0;
+  // Shortcut for sliding windows: item `key` is item `prev_key` moved on by one
+  // step, its last step is `newest` (all its other steps are prev_key's steps
+  // but the first).  True if the selector took it; false = not handled, nothing
+  // changed, the caller inserts the full step list.
+  virtual bool insert_successor(int64_t key, int64_t prev_key, const StepId& newest) { return false; }
   // False if insert() ignores the step ids (lets the replay skip building them).
   virtual bool needs_stepids() const { return true; }
   virtual bool can_prioritize() const { return false; }
@@ -242,16 +329,16 @@ class SampleTree {
     leaf->key = key;
     leaf->mass = mass;
     attach(spot, leaf);
-    leaves_[key] = leaf;
+    leaves_.put(key, leaf);
     tail_ = leaf;
     return leaf;
   }
 
   void remove(int64_t key) {
-    auto it = leaves_.find(key);
-    if (it == leaves_.end()) throw std::out_of_range("SampleTree: unknown key");
-    Node* leaf = it->second;
-    leaves_.erase(it);
+    Node** found = leaves_.find(key);
+    if (!found) throw std::out_of_range("SampleTree: unknown key");
+    Node* leaf = *found;
+    leaves_.erase(key);
     Node* hole_parent = leaf->up;
     Node* tail_parent = tail_->up;
     detach(hole_parent, leaf);
@@ -273,10 +360,10 @@ class SampleTree {
   }
 
   void update(int64_t key, double mass) {
-    auto it = leaves_.find(key);
-    if (it == leaves_.end()) throw std::out_of_range("SampleTree: unknown key");
-    it->second->mass = mass;
-    resum(it->second->up);
+    Node** found = leaves_.find(key);
+    if (!found) throw std::out_of_range("SampleTree: unknown key");
+    (*found)->mass = mass;
+    resum((*found)->up);
   }
 
   // Several leaves at once: set every mass, then re-sum each ancestor (a node
@@ -285,9 +372,9 @@ class SampleTree {
   void update_many(const int64_t* keys, const double* masses, int64_t n) {
     handles_.resize(static_cast<size_t>(n));
     for (int64_t i = 0; i < n; ++i) {
-      auto it = leaves_.find(keys[i]);
-      if (it == leaves_.end()) throw std::out_of_range("SampleTree: unknown key");
-      handles_[static_cast<size_t>(i)] = it->second;
+      Node** found = leaves_.find(keys[i]);
+      if (!found) throw std::out_of_range("SampleTree: unknown key");
+      handles_[static_cast<size_t>(i)] = *found;
     }
     update_leaves(handles_.data(), masses, n);
   }
@@ -304,6 +391,7 @@ class SampleTree {
       for (Node* node : dirty_) {
         double total = 0.0;
         for (Node* kid : node->kids) total += kid->mass;
+        if (same_bits(total, node->mass)) continue;      // ancestors stay as they are
         node->mass = total;
         if (node->up) next_.push_back(node->up);
       }
@@ -337,10 +425,21 @@ class SampleTree {
   }
 
  private:
+  // Re-sum `node` and its ancestors.  A node whose fresh sum is bit for bit the
+  // mass it holds leaves every ancestor as it is (each is the left-to-right sum
+  // of its children's masses): the walk stops there.  With +inf masses around
+  // -- `initial: inf` -- that is usually the first level.
+  static bool same_bits(double a, double b) {
+    uint64_t x, y;
+    std::memcpy(&x, &a, 8);
+    std::memcpy(&y, &b, 8);
+    return x == y;
+  }
   static void resum(Node* node) {
     while (node) {
       double total = 0.0;
       for (Node* kid : node->kids) total += kid->mass;
+      if (same_bits(total, node->mass)) return;
       node->mass = total;
       node = node->up;
     }
@@ -366,7 +465,7 @@ class SampleTree {
   NpRandom rng_;
   Node* root_;
   Node* tail_ = nullptr;
-  std::unordered_map<int64_t, Node*> leaves_;
+  SlidingMap<Node*> leaves_;
   std::vector<double> mass_, prob_, cdf_;
   std::vector<Node*> dirty_, next_, handles_;
 };
@@ -408,7 +507,10 @@ class Prioritized : public Selector {
       refresh_touched();
       return key;
     }
-    const auto [st, start] = owner_.at(key);
+    const auto* own = owner_.find(key);
+    if (!own) throw std::out_of_range("Prioritized: unknown key");
+    Stream* st = own->first;
+    const int64_t start = own->second;
     ranges_.clear();
     for (int64_t pos = start; pos < start + st->n; ++pos) {
       set_slot(*st, pos, 0.0);
@@ -427,16 +529,39 @@ class Prioritized : public Selector {
     if (general_) general_insert(key, steps, n);
   }
 
+  // The next window of a stream (what a Replay inserts step after step): one
+  // new step record, no list of L step ids to build, hash and compare.
+  bool insert_successor(int64_t key, int64_t prev_key, const StepId& newest) override {
+    if (general_) return false;
+    const auto* prev = owner_.find(prev_key);
+    if (!prev || owner_.count(key)) return false;
+    Stream* st = prev->first;
+    const int64_t start = prev->second + 1;
+    // prev_key must be the stream's newest item, ending at its newest step
+    if (start != st->item0 + static_cast<int64_t>(st->items.size())) return false;
+    const int64_t last = st->step0 + st->n_steps() - 1;
+    if (start + st->n - 2 != last || where_.count(newest)) return false;
+    st->push_step(newest, initial_, powered(initial_));
+    where_.emplace(newest, std::make_pair(st, last + 1));
+    st->items.push_back(key);
+    owner_.put(key, std::make_pair(st, start));
+    const double mass = stream_mass(*st, start);
+    st->leaves.push_back(tree_.insert(key, mass));
+    st->mass.push_back(mass);
+    return true;
+  }
+
   void remove(int64_t key) override {
     if (!general_) {
-      auto it = owner_.find(key);
-      if (it == owner_.end()) throw std::out_of_range("Prioritized: unknown key");
-      Stream* st = it->second.first;
+      const auto* own = owner_.find(key);
+      if (!own) throw std::out_of_range("Prioritized: unknown key");
+      Stream* st = own->first;
       if (st->items[0] == key) {
         tree_.remove(key);
-        owner_.erase(it);
+        owner_.erase(key);
         st->items.pop_front();
         st->leaves.pop_front();
+        st->mass.pop_front();
         st->item0 += 1;
         // Steps in front of the oldest remaining item belong to no item any
         // more: their priority goes with them (selectors.py:180-185).
@@ -499,7 +624,14 @@ class Prioritized : public Selector {
 
  private:
   // ---------------------------------------------------------- shared pieces --
-  double powered(double prio) const { return exponent_ != 1.0 ? std::pow(prio, exponent_) : prio; }
+  // prio ** exponent.  0, 1 and +inf are fixed points of x ** e for e > 0 (what
+  // pow returns for them, exactly): the shipped PPO config (initial inf,
+  // zero_on_sample) only ever holds those, and pow is ~40 ns a call.
+  double powered(double prio) const {
+    if (exponent_ == 1.0) return prio;
+    if (exponent_ > 0 && (prio == 0.0 || prio == 1.0 || prio == INFINITY)) return prio;
+    return std::pow(prio, exponent_);
+  }
   // maxfrac * max + (1 - maxfrac) * mean over prio ** exponent, summed left to
   // right like the reference's sum() (selectors.py:187-197).
   double finish(double total, double top, int64_t count) const {
@@ -547,7 +679,10 @@ class Prioritized : public Selector {
     }
     Sliding<int64_t> items; // keys
     Sliding<SampleTree::Node*> leaves;   // their tree leaves
+    Sliding<double> mass;                // and the mass each leaf holds (a copy next to its
+                                         // neighbours': comparing against it touches no tree node)
   };
+  static constexpr int64_t kRegion = 1024;      // steps a refresh may scan for the +inf shortcut
   struct Range {
     Stream* st;
     int64_t lo, hi;         // item start positions, inclusive
@@ -574,6 +709,28 @@ class Prioritized : public Selector {
     constexpr int kLanes = 8;
     const double* base = &st.powered[start - st.step0];
     int64_t done = 0;
+    // Windows that hold a +inf step (and nothing that is NaN or negative) sum to
+    // +inf with maximum +inf whatever else they hold: one pass over the region
+    // finds them (running counts), only the others are summed.  With `initial:
+    // inf` that is nearly every window.
+    const int64_t span = count + st.n - 1;
+    if (span <= kRegion) {
+      int32_t hot[kRegion + 1], odd[kRegion + 1];
+      hot[0] = odd[0] = 0;
+      for (int64_t i = 0; i < span; ++i) {
+        const double v = base[i];
+        hot[i + 1] = hot[i] + (v == INFINITY ? 1 : 0);
+        odd[i + 1] = odd[i] + ((v >= 0.0) ? 0 : 1);           // NaN or negative
+      }
+      if (hot[span] > 0 && odd[span] == 0) {
+        const double all_inf = finish(INFINITY, INFINITY, st.n);
+        for (int64_t j = 0; j < count; ++j) {
+          if (hot[j + st.n] - hot[j] > 0) out->push_back(all_inf);
+          else out->push_back(stream_mass(st, start + j));
+        }
+        return;
+      }
+    }
     for (; done + kLanes <= count; done += kLanes) {
       double total[kLanes], top[kLanes];
       for (int j = 0; j < kLanes; ++j) total[j] = 0.0, top[j] = -INFINITY;
@@ -607,7 +764,7 @@ class Prioritized : public Selector {
     });
     leaves_.clear();
     masses_.clear();
-    const Stream* st = nullptr;
+    Stream* st = nullptr;
     int64_t done = 0;        // next start position not yet emitted for `st`
     for (const Range& r : ranges_) {
       if (r.st != st) {
@@ -616,8 +773,27 @@ class Prioritized : public Selector {
       }
       const int64_t from = std::max(done, r.lo);
       if (from <= r.hi) {
-        for (int64_t start = from; start <= r.hi; ++start) leaves_.push_back(st->leaves[start - st->item0]);
-        stream_masses(*st, from, r.hi - from + 1, &masses_);
+        fresh_.clear();
+        stream_masses(*st, from, r.hi - from + 1, &fresh_);
+        // A leaf whose freshly aggregated mass is bit for bit what it holds
+        // already needs no update: every ancestor is the left-to-right sum of its
+        // children's current masses, so re-summing it would reproduce the value
+        // it has (selectors.py:150-158 re-aggregates and updates every touched
+        // item; the result is the same tree).  With priorities in {0, inf} --
+        // zero_on_sample over `initial: inf` -- a drawn window changes its own
+        // mass and almost never its neighbours': one leaf update per draw
+        // instead of 2L - 1.
+        for (int64_t start = from; start <= r.hi; ++start) {
+          double& held = st->mass[start - st->item0];
+          const double now = fresh_[static_cast<size_t>(start - from)];
+          uint64_t a, b;
+          std::memcpy(&a, &now, 8);
+          std::memcpy(&b, &held, 8);
+          if (a == b) continue;
+          held = now;
+          leaves_.push_back(st->leaves[start - st->item0]);
+          masses_.push_back(now);
+        }
       }
       done = std::max(done, r.hi + 1);
     }
@@ -646,8 +822,10 @@ class Prioritized : public Selector {
       st->push_step(ids[n - 1], initial_, powered(initial_));
       where_.emplace(ids[n - 1], std::make_pair(st, pos + 1));
       st->items.push_back(key);
-      owner_.emplace(key, std::make_pair(st, start));
-      st->leaves.push_back(tree_.insert(key, stream_mass(*st, start)));
+      owner_.put(key, std::make_pair(st, start));
+      const double mass = stream_mass(*st, start);
+      st->leaves.push_back(tree_.insert(key, mass));
+      st->mass.push_back(mass);
       return true;
     }
     // First window of a new stream: none of its steps may be known, and they
@@ -665,8 +843,10 @@ class Prioritized : public Selector {
       where_.emplace(ids[i], std::make_pair(st, static_cast<int64_t>(i)));
     }
     st->items.push_back(key);
-    owner_.emplace(key, std::make_pair(st, int64_t{0}));
-    st->leaves.push_back(tree_.insert(key, stream_mass(*st, 0)));
+    owner_.put(key, std::make_pair(st, int64_t{0}));
+    const double mass = stream_mass(*st, 0);
+    st->leaves.push_back(tree_.insert(key, mass));
+    st->mass.push_back(mass);
     return true;
   }
 
@@ -676,11 +856,11 @@ class Prioritized : public Selector {
   void migrate() {
     std::vector<int64_t> keys;
     keys.reserve(owner_.size());
-    for (const auto& kv : owner_) keys.push_back(kv.first);
+    owner_.for_each([&](int64_t key, const std::pair<Stream*, int64_t>&) { keys.push_back(key); });
     std::sort(keys.begin(), keys.end());
     std::vector<StepId> ids;
     for (int64_t key : keys) {
-      const auto [st, start] = owner_.at(key);
+      const auto [st, start] = *owner_.find(key);
       ids.clear();
       for (int64_t pos = start; pos < start + st->n; ++pos) ids.push_back(st->ids[pos - st->step0]);
       general_link(key, ids.data(), st->n);
@@ -795,7 +975,7 @@ class Prioritized : public Selector {
   // stream mode
   std::unordered_set<Stream*> streams_;
   std::unordered_map<StepId, std::pair<Stream*, int64_t>, StepIdHash> where_;  // id -> stream, position
-  std::unordered_map<int64_t, std::pair<Stream*, int64_t>> owner_;            // key -> stream, start
+  SlidingMap<std::pair<Stream*, int64_t>> owner_;                             // key -> stream, start
   std::vector<Range> ranges_;
   std::vector<SampleTree::Node*> leaves_;
   // general mode
@@ -805,7 +985,7 @@ class Prioritized : public Selector {
   uint64_t epoch_ = 0;
   // both
   std::vector<int64_t> keys_;
-  std::vector<double> masses_;
+  std::vector<double> masses_, fresh_;
 };
 
 class Mixture : public Selector {
