@@ -638,12 +638,18 @@ def main():
           replay.sample(big, 'report')
         torch.cuda.synchronize(device)
         replay.profile_read(reset=True)
-        for _ in range(20):
-          replay.sample(big, 'report')
-        torch.cuda.synchronize(device)
-        count, ms = replay.profile_read(reset=True)
-        if count:
-          us = ms / count * 1e3
+        # three rounds of 20 launches, the quietest one counts: these boxes are
+        # shared, and one disturbed round once read 0.48 between 0.72 and 0.71
+        best = None
+        for _ in range(3):
+          for _ in range(20):
+            replay.sample(big, 'report')
+          torch.cuda.synchronize(device)
+          count, ms = replay.profile_read(reset=True)
+          if count and (best is None or ms / count < best):
+            best = ms / count
+        if best is not None:
+          us = best * 1e3
           gbs = 2 * big * L * S / (us * 1e-6) / 1e9
           sweep[str(per_launch)] = {
               'sequences': big, 'avg_launch_us': round(us, 2), 'achieved': round(gbs, 1),

@@ -1888,7 +1888,12 @@ hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, ui
   a.n_turn = static_cast<int32_t>(n << 1 | (turn & 1));
   // A frame over a few workgroups: 64 envs x 4 = one workgroup per CU.
   const int64_t vecs = frame_bytes >> 4;
-  const uint32_t gx = static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(4, vecs / kThreads)));
+  static const int64_t per_env = [] {       // EMB_SYNTH_BLOCKS: workgroups per env (A/B)
+    const char* e = std::getenv("EMB_SYNTH_BLOCKS");
+    const int64_t v = e ? std::atoll(e) : 4;
+    return v >= 1 && v <= 64 ? v : 4;
+  }();
+  const uint32_t gx = static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(per_env, vecs / kThreads)));
   const dim3 grid(gx, static_cast<uint32_t>(n));
   const int64_t base = reinterpret_cast<int64_t>(reward);
   const int64_t of = reinterpret_cast<int64_t>(is_first) - base, ol = reinterpret_cast<int64_t>(is_last) - base,

@@ -76,3 +76,43 @@ def test_integration_stub_runs_the_path():
   ns['obs_stack'](frames.data_ptr(), 2, 16, 3, stacked.data_ptr(), 7, 1 / 255, stream)
   torch.testing.assert_close(stacked, frames.permute(0, 3, 1, 2).float() / 255)
   ns['lib'].emb_replay_destroy(h)
+  # The early insert: observation keys with the obs stack, the action after the
+  # policy -- against the oracle's plain Replay.add of the same steps.
+  n, L, chunksize, slots = 3, 2, 8, 16
+  h = ns['replay_create'](L, 40, chunksize, slots, False, seed=1)
+  specs = [('image', torch.uint8, (4, 4, 4)), ('is_first', torch.bool, ()), ('is_last', torch.bool, ()),
+           ('action', torch.float32, ()), ('stepid', torch.uint8, (20,))]
+  rowbytes = [int(np.prod(s, dtype=np.int64)) * torch.empty((), dtype=d).element_size() for _, d, s in specs]
+  pools = [torch.zeros(slots * chunksize * rb, dtype=torch.uint8, device='cuda') for rb in rowbytes]
+  ns['replay_set_keys'](h, [k for k, _, _ in specs], rowbytes, [p.data_ptr() for p in pools])
+  ref = np_oracle.Replay(L, 40, chunksize, seed=1)
+  spec = ns['ObsSpec'](16, 4, 1, 7, 1 / 255, 0.0)          # (N, 16, 4) u8 -> (N, 4, 16) f32 / 255
+  tokens = []
+  for t in range(12):
+    image = torch.randint(0, 255, (n, 4, 4, 4), dtype=torch.uint8, device='cuda')
+    first = torch.full((n,), t == 0, device='cuda')
+    last = torch.tensor([t % 5 == 4, False, t % 3 == 2], device='cuda')
+    batch = torch.empty((n, 4, 4, 4), dtype=torch.float32, device='cuda')
+    token = ns['obs_stack_insert'](h, list(range(n)), 0, image.data_ptr(), spec, batch.data_ptr(),
+                                   [image.data_ptr(), first.data_ptr(), last.data_ptr(), 0, 0], stream)
+    tokens.append(token)
+    torch.testing.assert_close(batch, image.permute(0, 3, 1, 2).float() / 255)
+    action = torch.full((n,), -1.0 - t, device='cuda')       # the policy's answer
+    masked = torch.empty_like(action)
+    ns['replay_publish'](h, list(range(n)), [image.data_ptr(), first.data_ptr(), last.data_ptr(),
+                                             action.data_ptr(), 0],
+                         [3], [7], [masked.data_ptr()], last.data_ptr(), token, stream)
+    torch.cuda.synchronize()
+    want_masked = action.cpu().numpy() * ~last.cpu().numpy()
+    assert np.array_equal(masked.cpu().numpy(), want_masked) and np.array_equal(
+        np.signbit(masked.cpu().numpy()), np.signbit(want_masked))
+    for w in range(n):
+      ref.add({'image': image[w].cpu().numpy(), 'is_first': bool(first[w]), 'is_last': bool(last[w]),
+               'action': np.float32(want_masked[w])}, w)
+  assert tokens[0] == 0 and all(tokens[1:])      # the first step opens the workers' chunks
+  outs = [torch.empty((6, L, *s), dtype=d, device='cuda') for _, d, s in specs]
+  ns['replay_sample'](h, 6, 'train', [o.data_ptr() for o in outs], stream)
+  want = ref.sample(6)
+  for (name, _, _), got in zip(specs, outs):
+    assert np.array_equal(got.cpu().numpy(), want[name]), name
+  ns['lib'].emb_replay_destroy(h)
