@@ -130,12 +130,51 @@ def test_full_size_early_insert_equals_plain_insert(emb):
     assert_same(_host(a.sample(16)), _host(b.sample(16)), 'early vs plain')
 
 
-def test_many_envs_take_the_table_through_the_ring(emb):
-  """More envs than fit the kernel arguments (> 112): rows and step ids reach
-  the launch through the pinned ring."""
-  rep, ref, _ = _run_pair(emb, 150, (4, 4, 4), length=3, capacity=2000, chunksize=8, steps=40,
+@pytest.mark.parametrize('n', [150, 200])
+def test_many_envs_tables(emb, n):
+  """The per-env table (rows, step ids, narrow keys) reaches the launch in device
+  memory: written through the BAR while it fits a 4 KiB slot of the argument ring
+  (<= 162 envs), through the pinned staging ring + one copy beyond that."""
+  rep, ref, _ = _run_pair(emb, n, (4, 4, 4), length=3, capacity=2000, chunksize=8, steps=40,
                           online=False, stack=True, sample_every=5)
   assert rep.early_inserts == 39
+
+
+def test_checkpoint_between_early_insert_and_publish(emb, tmp_path):
+  """save() inside the policy closes every open chunk after the observation keys
+  went to their (old) rows: the publish notices that its rows are not the
+  reserved ones and writes the whole step; nothing of the stale rows shows."""
+  from embodied_amd.envs import synthetic
+  n, shape = 4, (8, 8, 4)
+  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=6, ring=4)
+  rep = emb.Replay(length=3, capacity=60, chunksize=8, seed=0, directory=tmp_path, save_wait=True)
+  ref = np_oracle.Replay(3, 60, 8, False, seed=0)
+  hosts = [synthetic.HostSyntheticEnv(e, shape=shape, episode_len=6) for e in range(n)]
+  oracle = np_oracle.Driver(hosts)
+  oracle.on_step(ref.add)
+  driver = emb.Driver(batch_env=env, device='cuda')
+  driver.on_step(rep.add)
+  tick = [0, 0]
+
+  def policy(carry, obs, **kw):
+    emb.ops.obs_stack(obs['image'], dtype=torch.float32)
+    tick[0] += 1
+    if tick[0] % 7 == 3:
+      rep.save()
+    return carry, {'action': torch.full((n,), tick[0], dtype=torch.int32, device='cuda')}, {}
+
+  def host_policy(carry, obs):
+    tick[1] += 1
+    return carry, {'action': np.full(n, tick[1], np.int32)}, {}
+
+  for t in range(40):
+    driver(policy, steps=n)
+    oracle.step(host_policy)
+    if len(ref) and t % 3 == 0:
+      got, want = _host(rep.sample(4)), ref.sample(4)
+      # (closing chunks early changes chunk ids and rows, not contents: compare payload)
+      for key in ('image', 'reward', 'action', 'is_first', 'is_last'):
+        assert np.array_equal(got[key], want[key]), (t, key)
 
 
 def test_offer_not_taken_or_stale_is_harmless(emb):
