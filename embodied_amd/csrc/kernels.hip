@@ -1100,7 +1100,7 @@ struct PreKey {
 };
 struct alignas(16) PreTable {
   uint8_t* stepid_pool;
-  int64_t pad_;
+  int32_t* rows_out;            // device int32[n]: the rows again, for the publish launch (may be null)
   PreKey narrow[kPreNarrow];
   uint32_t words[1];            // rows[n] | step ids, 5 words per row (6 * n words)
 };
@@ -1112,9 +1112,8 @@ struct PrewriteArgs {
   float scale, offset;
   int32_t n, n_narrow;
   const PreTable* table;        // device memory
-  int32_t* rows_out;            // device int32[n]: the rows again, for the publish launch (may be null)
 };
-static_assert(sizeof(PrewriteArgs) == 64, "obs_stack_insert_kernel's arguments are preloaded");
+static_assert(sizeof(PrewriteArgs) == 56, "obs_stack_insert_kernel's arguments (passed one by one) fit the 14 preloaded dwords");
 
 // The narrow keys, the step id and the row for the publish launch of env n: one
 // extra workgroup per env (blockIdx.x == gridDim.x - 1), so that this chain of
@@ -1145,12 +1144,19 @@ __device__ __forceinline__ void prewrite_narrow(const PrewriteArgs& a, int64_t n
       gstore<uint8_t>(key[k].pool + row * key[k].rowbytes + threadIdx.x, v[k]);
   if (t.stepid_pool && threadIdx.x < kStepBytes / 4)
     gstore<uint32_t>(t.stepid_pool + row * kStepBytes + threadIdx.x * 4, sid);
-  if (a.rows_out && threadIdx.x == 0) a.rows_out[n] = static_cast<int32_t>(row);
+  if (t.rows_out && threadIdx.x == 0) t.rows_out[n] = static_cast<int32_t>(row);
 }
 static_assert(kThreads >= 256, "a narrow key (<= 256 bytes per step) is one byte per lane");
 
+// (Scalar parameters, not the struct: the kernel-argument preload only takes
+// arguments passed as scalars / pointers -- a by-value struct is fetched with
+// s_load by every wave, `.amdhsa_user_sgpr_kernarg_preload_length 0`.)
 template <typename Out, int C, bool kChannelsFirst>
-__global__ __launch_bounds__(kThreads) void obs_stack_insert_kernel(const PrewriteArgs a) {
+// (The preload covers 14 dwords = 56 bytes: exactly these.)
+__global__ __launch_bounds__(kThreads) void obs_stack_insert_kernel(
+    const uint8_t* frames, const PreTable* table, uint8_t* frame_pool, void* dst,
+    int64_t pixels_, int32_t n_envs, int32_t n_narrow, float scale, float offset) {
+  const PrewriteArgs a{frames, dst, frame_pool, pixels_, scale, offset, n_envs, n_narrow, table};
   const int64_t n = blockIdx.y;
   if (blockIdx.x == gridDim.x - 1) {
     prewrite_narrow(a, n);
@@ -1207,7 +1213,8 @@ __global__ __launch_bounds__(kThreads) void obs_stack_insert_kernel(const Prewri
 // key is the action: rows[r] comes from the table that launch left in device
 // memory, the value is written as src * !flags[r] (driver.py:72-74; a real
 // multiply in the key's dtype) to its pool row and to `out`, the actions the
-// next env step receives.  56 bytes of arguments: all of them preloaded.
+// next env step receives.  56 bytes of arguments, passed one by one: exactly
+// the 14 dwords the kernel-argument preload covers.
 struct PublishArgs {
   const uint8_t* src;
   uint8_t* pool;
@@ -1218,7 +1225,10 @@ struct PublishArgs {
 };
 static_assert(sizeof(PublishArgs) <= 64, "publish_one_kernel's arguments are preloaded");
 
-__global__ __launch_bounds__(kThreads) void publish_one_kernel(const PublishArgs a) {
+__global__ __launch_bounds__(kThreads) void publish_one_kernel(
+    const uint8_t* src_, uint8_t* pool_, uint8_t* out_, const int32_t* rows, const uint8_t* flags,
+    int32_t n, int32_t rowbytes, int32_t dtype, int32_t elem) {
+  const PublishArgs a{src_, pool_, out_, rows, flags, n, rowbytes, dtype, elem};
   const int64_t epr = a.rowbytes / a.elem;
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (e >= epr * a.n) return;
@@ -1252,15 +1262,16 @@ hipError_t obs_stack_insert_typed(const PrewriteArgs& a, int64_t channels, int l
   const bool cf = layout == kLayoutChannelsFirst && channels > 1;
   // (hipExtLaunchKernelGGL only when a completion stamp is wanted: the plain
   // launch is the cheaper call.)
+#define EMB_PRE_ARGS a.frames, a.table, a.frame_pool, a.dst, a.pixels, a.n, a.n_narrow, a.scale, a.offset
 #define EMB_PRE(C)                                                                                \
   if (cf && stop) hipExtLaunchKernelGGL((obs_stack_insert_kernel<Out, C, true>), grid,            \
-                                        dim3(kThreads), 0, stream, nullptr, stop, 0, a);          \
+                                        dim3(kThreads), 0, stream, nullptr, stop, 0, EMB_PRE_ARGS); \
   else if (cf) hipLaunchKernelGGL((obs_stack_insert_kernel<Out, C, true>), grid, dim3(kThreads),  \
-                                  0, stream, a);                                                  \
+                                  0, stream, EMB_PRE_ARGS);                                       \
   else if (stop) hipExtLaunchKernelGGL((obs_stack_insert_kernel<Out, C, false>), grid,            \
-                                       dim3(kThreads), 0, stream, nullptr, stop, 0, a);           \
+                                       dim3(kThreads), 0, stream, nullptr, stop, 0, EMB_PRE_ARGS); \
   else hipLaunchKernelGGL((obs_stack_insert_kernel<Out, C, false>), grid, dim3(kThreads), 0,      \
-                          stream, a);
+                          stream, EMB_PRE_ARGS);
   switch (channels) {
     case 1: EMB_PRE(1) break;
     case 2: EMB_PRE(2) break;
@@ -1268,6 +1279,7 @@ hipError_t obs_stack_insert_typed(const PrewriteArgs& a, int64_t channels, int l
     default: EMB_PRE(4) break;
   }
 #undef EMB_PRE
+#undef EMB_PRE_ARGS
   return hipGetLastError();
 }
 
@@ -1384,6 +1396,26 @@ struct GaeOp : std::conditional_t<kGrouped, Groups, NoGroups> {   // ppo/agent.p
   // (distributed.py): row b then starts (b / group) * gs + (b % group) * T
   // elements into its key (gs_rew in floats, gs_flag in bytes).
   // `val` (the critic's output) and the results are always dense.
+  // The op travels to the kernel as SCALAR arguments (unpack -> make): the
+  // kernel-argument preload takes scalars and pointers, not by-value structs.
+  template <typename F>
+  void unpack(F&& f) const {
+    if constexpr (kGrouped) f(rew, val, last, term, adv, tar, T, B, live_scale, lam, this->group, this->gs_rew, this->gs_flag);
+    else f(rew, val, last, term, adv, tar, T, B, live_scale, lam);
+  }
+  template <typename... G>
+  __host__ __device__ static GaeOp make(const float* rew, const float* val, const uint8_t* last,
+                                        const uint8_t* term, float* adv, float* tar, int32_t T, int32_t B,
+                                        float live_scale, float lam, G... groups) {
+    GaeOp op;
+    op.rew = rew; op.val = val; op.last = last; op.term = term; op.adv = adv; op.tar = tar;
+    op.T = T; op.B = B; op.live_scale = live_scale; op.lam = lam;
+    if constexpr (kGrouped) {
+      const int64_t g[3] = {groups...};
+      op.group = g[0]; op.gs_rew = g[1]; op.gs_flag = g[2];
+    }
+    return op;
+  }
   __device__ float seed(int64_t) const { return 0.f; }
   __device__ void where(int64_t b, int64_t t, int64_t& ir, int64_t& il) const {
     ir = il = b * T + t;
@@ -1418,11 +1450,28 @@ struct GaeOp : std::conditional_t<kGrouped, Groups, NoGroups> {   // ppo/agent.p
     // (it exists: t0 + valid <= T - 1).
     float v[5], r[4];
     uint8_t tm[4], ls[4];
-    load4(val + i, valid, v);
-    const float after = gload<float>(val + i + valid);
-    load4(rew + ir + 1, valid, r);
-    load4(term + il + 1, valid, tm);
-    load4(last + il + 1, valid, ls);
+    float after;
+    if (valid >= 4) {
+      // the usual lane: all five loads issued back to back, one wait
+      const F4 v4 = gload<F4>(val + i);
+      after = gload<float>(val + i + 4);
+      const F4 r4 = gload<F4>(rew + ir + 1);
+      const B4 t4 = gload<B4>(term + il + 1);
+      const B4 l4 = gload<B4>(last + il + 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = v4[k];
+        r[k] = r4[k];
+        tm[k] = t4[k];
+        ls[k] = l4[k];
+      }
+    } else {
+      load4(val + i, valid, v);
+      after = gload<float>(val + i + valid);
+      load4(rew + ir + 1, valid, r);
+      load4(term + il + 1, valid, tm);
+      load4(last + il + 1, valid, ls);
+    }
     v[4] = after;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1448,6 +1497,13 @@ static_assert(sizeof(GaeOp<false>) == 64, "the dense GAE op is covered by the ke
 struct LambdaOp {   // dreamerv3/agent.py:482-490
   const uint8_t* last; const uint8_t* term; const float* rew; const float* boot;
   float* ret; int32_t T, B; float disc, lam;
+  template <typename F>
+  void unpack(F&& f) const { f(last, term, rew, boot, ret, T, B, disc, lam); }
+  __host__ __device__ static LambdaOp make(const uint8_t* last, const uint8_t* term, const float* rew,
+                                           const float* boot, float* ret, int32_t T, int32_t B,
+                                           float disc, float lam) {
+    return LambdaOp{last, term, rew, boot, ret, T, B, disc, lam};
+  }
   __device__ float seed(int64_t b) const { return boot[b * T + T - 1]; }
   __device__ void coef(int64_t b, int64_t t, float& a, float& bc, float& keep) const {
     const int64_t i = b * T + t;
@@ -1484,8 +1540,9 @@ static_assert(sizeof(LambdaOp) <= 64, "covered by the kernel-argument preload");
 // Short rows: a W-lane segment per row, rows longer than W walked right to
 // left with the running value in a register.
 
-template <int W, typename Op>
-__global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op) {
+template <int W, typename Op, typename... Args>
+__global__ __launch_bounds__(kThreads) void scan_rows_kernel(Args... args) {
+  const Op op = Op::make(args...);
   const int64_t B = op.B, n = op.T - 1;
   const int sl = threadIdx.x % W;
   const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
@@ -1510,8 +1567,9 @@ __global__ __launch_bounds__(kThreads) void scan_rows_kernel(const Op op) {
 // once per four elements, the loads are 16-byte / 4-byte vectors, the four
 // elements of a lane are folded sequentially (3 fma pairs) and the Kogge-Stone
 // runs over W = rowlen/4 lanes (4 rounds for T = 64 instead of 6).
-template <int W, typename Op>
-__global__ __launch_bounds__(kThreads) void scan_rows4_kernel(const Op op) {
+template <int W, typename Op, typename... Args>
+__global__ __launch_bounds__(kThreads) void scan_rows4_kernel(Args... args) {
+  const Op op = Op::make(args...);
   const int64_t B = op.B;
   const int n = op.T - 1;
   const int sl = threadIdx.x % W;
@@ -1551,8 +1609,9 @@ __global__ __launch_bounds__(kThreads) void scan_rows4_kernel(const Op op) {
 // folds the maps to its right into its carry, and the workgroup walks the row
 // right to left in pieces of 64 * waves steps with the carry handed on through
 // LDS.
-template <typename Op>
-__global__ __launch_bounds__(1024) void scan_long_rows_kernel(const Op op) {
+template <typename Op, typename... Args>
+__global__ __launch_bounds__(1024) void scan_long_rows_kernel(Args... args) {
+  const Op op = Op::make(args...);
   const int64_t n = op.T - 1;
   __shared__ float s_a[16], s_b[16], s_carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
@@ -1585,8 +1644,10 @@ hipError_t launch_scan(const Op& op, hipStream_t stream) {
   const int64_t B = op.B, n = op.T - 1;
   if (n > 256) {
     const int waves = static_cast<int>(std::min<int64_t>(16, (n + 63) / 64));
-    hipLaunchKernelGGL(scan_long_rows_kernel<Op>, dim3(static_cast<uint32_t>(B)), dim3(64 * waves),
-                       0, stream, op);
+    op.unpack([&](auto... a) {
+      hipLaunchKernelGGL((scan_long_rows_kernel<Op, decltype(a)...>), dim3(static_cast<uint32_t>(B)),
+                         dim3(64 * waves), 0, stream, a...);
+    });
     return hipGetLastError();
   }
   // EMB_SCAN_FORM=1: the one-element-per-lane kernel (A/B against rows4).
@@ -1600,24 +1661,28 @@ hipError_t launch_scan(const Op& op, hipStream_t stream) {
     const int W = n <= 16 ? 16 : n <= 32 ? 32 : 64;
     const int64_t rows_per_block = kThreads / W;
     const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
-    if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op>), grid, dim3(kThreads), 0, stream, op);
-    else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op>), grid, dim3(kThreads), 0, stream, op);
-    else hipLaunchKernelGGL((scan_rows_kernel<64, Op>), grid, dim3(kThreads), 0, stream, op);
+    op.unpack([&](auto... a) {
+      if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...);
+      else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...);
+      else hipLaunchKernelGGL((scan_rows_kernel<64, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...);
+    });
     return hipGetLastError();
   }
   const int W = n <= 16 ? 4 : n <= 32 ? 8 : n <= 64 ? 16 : n <= 128 ? 32 : 64;
   const int64_t rows_per_block = kThreads / W;
   const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
+  op.unpack([&](auto... a) {
 #define EMB_SCAN4(W_) \
-  hipLaunchKernelGGL((scan_rows4_kernel<W_, Op>), grid, dim3(kThreads), 0, stream, op)
-  switch (W) {
-    case 4: EMB_SCAN4(4); break;
-    case 8: EMB_SCAN4(8); break;
-    case 16: EMB_SCAN4(16); break;
-    case 32: EMB_SCAN4(32); break;
-    default: EMB_SCAN4(64); break;
-  }
+  hipLaunchKernelGGL((scan_rows4_kernel<W_, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...)
+    switch (W) {
+      case 4: EMB_SCAN4(4); break;
+      case 8: EMB_SCAN4(8); break;
+      case 16: EMB_SCAN4(16); break;
+      case 32: EMB_SCAN4(32); break;
+      default: EMB_SCAN4(64); break;
+    }
 #undef EMB_SCAN4
+  });
   return hipGetLastError();
 }
 
@@ -1665,14 +1730,15 @@ __global__ __launch_bounds__(kThreads) void abstract_traj_kernel(
 // Device-resident stand-in for N simulators: the episode logic
 // of envs/dummy.py:38-48 with counter-hash frames, so gathers are verifiable.
 //
-// 60 bytes of arguments, all inside the kernel-argument preload (with
-// host-resident arguments anything behind the first 64 bytes costs every wave
-// a PCIe read before its first instruction): the three flag outputs travel as
-// 32-bit offsets from the reward pointer (the launcher falls back to the
-// five-pointer form when they do not fit).  The per-env state is read from one
-// half of `counters` and written to the other (`turn`), so that every
-// workgroup of an env may read it while the last one writes: a frame is cut
-// over gridDim.x workgroups instead of one.
+// 56 bytes of arguments, passed as scalars so that the kernel-argument preload
+// takes them (14 dwords; a by-value struct is not preloaded at all -- with
+// host-resident arguments every wave would start with a PCIe read): the three
+// flag outputs travel as 32-bit offsets from the reward pointer (the launcher
+// falls back to the five-pointer form when they do not fit), the env count is
+// the grid's y size, the generation bit rides in the sign bit of the episode
+// length.  The per-env state is read from one half of `counters` and written to
+// the other (`turn`), so that every workgroup of an env may read it while the
+// last one writes: a frame is cut over gridDim.x workgroups instead of one.
 struct SynthArgs {
   int32_t* counters;          // 2 x int32[2n]: {count, done} per env, two generations
   const uint8_t* reset;
@@ -1681,9 +1747,16 @@ struct SynthArgs {
   int32_t off_first, off_last, off_terminal;   // bytes from `reward`
   int32_t frame_bytes, env0, episode_len, n_turn;   // n << 1 | turn
 };
-static_assert(sizeof(SynthArgs) <= 64, "synth_env_kernel's arguments are preloaded");
+static_assert(sizeof(SynthArgs) <= 64, "synth_env_kernel's arguments (passed one by one, n from the grid) are preloaded");
 
-__global__ __launch_bounds__(kThreads) void synth_env_kernel(const SynthArgs a) {
+__global__ __launch_bounds__(kThreads) void synth_env_kernel(
+    int32_t* counters, const uint8_t* reset, uint8_t* image, float* reward, int32_t off_first,
+    int32_t off_last, int32_t off_terminal, int32_t frame_bytes, int32_t env0, int32_t len_turn) {
+  // 56 bytes = the 14 dwords the preload covers: the env count is the grid's y
+  // size, the generation bit rides in the sign bit of the episode length.
+  const SynthArgs a{counters, reset, image, reward, off_first, off_last, off_terminal,
+                    frame_bytes, env0, len_turn & 0x7FFFFFFF,
+                    static_cast<int32_t>(gridDim.y << 1 | (static_cast<uint32_t>(len_turn) >> 31))};
   const int64_t e = blockIdx.y;
   const int32_t n = a.n_turn >> 1, turn = a.n_turn & 1;
   const int32_t* __restrict__ in = a.counters + turn * 2 * n;
@@ -1903,7 +1976,10 @@ hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, ui
     a.off_first = static_cast<int32_t>(of);
     a.off_last = static_cast<int32_t>(ol);
     a.off_terminal = static_cast<int32_t>(ot);
-    hipLaunchKernelGGL(synth_env_kernel, grid, dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL(synth_env_kernel, grid, dim3(kThreads), 0, stream, a.counters, a.reset, a.image,
+                       a.reward, a.off_first, a.off_last, a.off_terminal, a.frame_bytes, a.env0,
+                       static_cast<int32_t>(static_cast<uint32_t>(a.episode_len) |
+                                            (static_cast<uint32_t>(turn & 1) << 31)));
   } else {
     a.off_first = a.off_last = a.off_terminal = 0;
     hipLaunchKernelGGL(synth_env_far_kernel, grid, dim3(kThreads), 0, stream, a, is_first, is_last,
@@ -1929,7 +2005,7 @@ void prewrite_fill_table(void* dst, const PrewritePlan& p, const int32_t* rows, 
   // (dst may be write-combined device memory behind the BAR: written once, front to back.)
   PreTable head;
   head.stepid_pool = p.stepid_pool;
-  head.pad_ = 0;
+  head.rows_out = p.rows_out;
   for (int k = 0; k < kPreNarrow; ++k)
     head.narrow[k] = k < p.n_narrow ? PreKey{p.narrow[k].src, p.narrow[k].pool, p.narrow[k].rowbytes}
                                     : PreKey{nullptr, nullptr, 0};
@@ -1953,7 +2029,6 @@ hipError_t launch_obs_stack_insert(const PrewritePlan& p, hipStream_t stream, hi
   a.n = p.n;
   a.n_narrow = p.n_narrow;
   a.table = static_cast<const PreTable*>(p.table_dev);
-  a.rows_out = p.rows_out;
   switch (p.out_dtype) {
     case kU8: return obs_stack_insert_typed<uint8_t>(a, p.channels, p.layout, stream, stop);
     case kF16: return obs_stack_insert_typed<__half>(a, p.channels, p.layout, stream, stop);
@@ -1985,8 +2060,10 @@ hipError_t launch_publish_one(const void* src, void* pool, void* out, const int3
   const int64_t elems = n * (rowbytes / a.elem);
   if (n > INT32_MAX || rowbytes > INT32_MAX) return hipErrorInvalidValue;
   const dim3 grid(static_cast<uint32_t>((elems + kThreads - 1) / kThreads));
-  if (stop) hipExtLaunchKernelGGL(publish_one_kernel, grid, dim3(kThreads), 0, stream, nullptr, stop, 0, a);
-  else hipLaunchKernelGGL(publish_one_kernel, grid, dim3(kThreads), 0, stream, a);
+  if (stop) hipExtLaunchKernelGGL(publish_one_kernel, grid, dim3(kThreads), 0, stream, nullptr, stop, 0,
+                                  a.src, a.pool, a.out, a.rows, a.flags, a.n, a.rowbytes, a.dtype, a.elem);
+  else hipLaunchKernelGGL(publish_one_kernel, grid, dim3(kThreads), 0, stream,
+                          a.src, a.pool, a.out, a.rows, a.flags, a.n, a.rowbytes, a.dtype, a.elem);
   return hipGetLastError();
 }
 
