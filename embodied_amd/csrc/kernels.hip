@@ -641,7 +641,19 @@ const SpanVariant& span_variant() {
   }();
   return variant;
 }
-constexpr int kCUs = 256;
+// Compute units of the current device (MI355X: 256), asked once: the persistent
+// span mover sizes its grid by it.
+int compute_units() {
+  static const int value = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    (void)hipGetLastError();
+    return n;
+  }();
+  return value;
+}
 
 int pick_unit(const KeyDesc& key) {
   const uint64_t mix = reinterpret_cast<uint64_t>(key.pool) |
@@ -813,7 +825,7 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
       const char* e = std::getenv("EMB_SPAN_BALANCE");
       return !(e && e[0] == '0');
     }();
-    int64_t workers = std::min<int64_t>(h.ntiles, int64_t(kCUs) * sv.per_cu);
+    int64_t workers = std::min<int64_t>(h.ntiles, int64_t(compute_units()) * sv.per_cu);
     if (balance && workers > 0) {
       const int64_t rounds = (h.ntiles + workers - 1) / workers;
       workers = (h.ntiles + rounds - 1) / rounds;
