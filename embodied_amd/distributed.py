@@ -656,8 +656,14 @@ class GroupComm:
       else:
         self._pending.append(async_all_to_all(received, slices))
     if grads is not None and self.world > 1:
-      self._pending.append(async_all_reduce(grads))        # sum; the mean is taken in wait()
-      self._scale = grads if mean else None
+      if mean and dist.get_backend(self.group) == 'nccl':
+        # RCCL averages in the collective itself (no second pass over the buffer)
+        opts = dist.AllreduceOptions()
+        opts.reduceOp = dist.ReduceOp.AVG
+        self._pending.append((self.group or _default_pg()).allreduce([grads], opts))
+      else:
+        self._pending.append(async_all_reduce(grads))      # sum; the mean is taken in wait()
+        self._scale = grads if mean else None
 
   def wait(self, device=None):
     for work in self._pending:

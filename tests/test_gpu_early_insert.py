@@ -227,3 +227,42 @@ def test_publish_survives_pool_growth(emb):
   rep, ref, _ = _run_pair(emb, 6, (8, 8, 4), length=4, capacity=None, chunksize=4, steps=120,
                           online=False, stack=True, sample_every=6)
   assert rep.early_inserts == 119
+
+
+@pytest.mark.parametrize('parallel', [False, True])
+def test_early_insert_with_host_envs(emb, parallel):
+  """Real simulators on the host (in-process, and one process per env writing
+  into the shared observation slab): the uploaded step is offered to the replay
+  as well, the agent's obs stack on the uploaded frames is the early insert."""
+  from embodied_amd.envs import synthetic
+  n, shape = 4, (8, 8, 4)
+  fns = [(lambda e=e: synthetic.HostSyntheticEnv(e, shape=shape, episode_len=6)) for e in range(n)]
+  driver = emb.Driver(fns, parallel=parallel, device='cuda')
+  rep = emb.Replay(length=3, capacity=50, chunksize=8, online=True, seed=0)
+  ref = np_oracle.Replay(3, 50, 8, True, seed=0)
+  oracle = np_oracle.Driver([synthetic.HostSyntheticEnv(e, shape=shape, episode_len=6) for e in range(n)])
+  oracle.on_step(ref.add)
+  driver.on_step(rep.add)
+  tick = [0, 0]
+
+  def policy(carry, obs, **kw):
+    batch = emb.ops.obs_stack(obs['image'], layout='channels_first', dtype=torch.float32, scale=1 / 255)
+    assert torch.equal(batch, obs['image'].permute(0, 3, 1, 2).float() / 255)
+    tick[0] += 1
+    return carry, {'action': np.full(n, tick[0], np.int32)}, {}
+
+  def host_policy(carry, obs):
+    tick[1] += 1
+    return carry, {'action': np.full(n, tick[1], np.int32)}, {}
+
+  try:
+    driver.reset()
+    for t in range(45):
+      driver(policy, steps=n)
+      oracle.step(host_policy)
+      if len(ref) and t % 4 == 0:
+        mode = 'train' if t % 8 else 'report'
+        assert_same(_host(rep.sample(3, mode)), ref.sample(3, mode), f'step {t}')
+    assert rep.early_inserts == 44
+  finally:
+    driver.close()
