@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -540,9 +541,11 @@ class Prioritized : public Selector {
     // prev_key must be the stream's newest item, ending at its newest step
     if (start != st->item0 + static_cast<int64_t>(st->items.size())) return false;
     const int64_t last = st->step0 + st->n_steps() - 1;
-    if (start + st->n - 2 != last || where_.count(newest)) return false;
+    // (`newest` is a new id: the caller's guarantee -- a Replay issues every step
+    // id once.  The general insert() checks it.)
+    if (start + st->n - 2 != last) return false;
     st->push_step(newest, initial_, powered(initial_));
-    where_.emplace(newest, std::make_pair(st, last + 1));
+    where_log(newest, st, last + 1, true);
     st->items.push_back(key);
     owner_.put(key, std::make_pair(st, start));
     const double mass = stream_mass(*st, start);
@@ -567,7 +570,7 @@ class Prioritized : public Selector {
         // more: their priority goes with them (selectors.py:180-185).
         const int64_t keep_from = st->items.size() ? st->item0 : st->step0 + st->n_steps();
         while (st->step0 < keep_from) {
-          where_.erase(st->ids[0]);
+          where_log(st->ids[0], nullptr, 0, false);
           st->pop_step();
           st->step0 += 1;
         }
@@ -608,7 +611,7 @@ class Prioritized : public Selector {
       if (st && pos + 1 < st->step0 + st->n_steps() && st->ids[pos + 1 - st->step0] == steps[i]) {
         pos += 1;
       } else {
-        auto it = where_.find(steps[i]);
+        auto it = where().find(steps[i]);
         if (it == where_.end()) {
           st = nullptr;
           continue;                  // step no longer in any item
@@ -804,7 +807,7 @@ class Prioritized : public Selector {
   // caller migrates).  Nothing is modified when it returns false.
   bool stream_insert(int64_t key, const StepId* ids, int n) {
     if (n < 2 || owner_.count(key)) return false;
-    auto newest = where_.find(ids[n - 1]);
+    auto newest = where().find(ids[n - 1]);
     if (newest != where_.end()) return false;           // the newest step must be new
     auto prev = where_.find(ids[n - 2]);
     Stream* st = nullptr;
@@ -873,6 +876,8 @@ class Prioritized : public Selector {
     for (Stream* st : streams_) delete st;
     streams_.clear();
     where_.clear();
+    where_pending_.clear();
+    where_stale_ = false;
     owner_.clear();
     general_ = true;
   }
@@ -974,7 +979,48 @@ class Prioritized : public Selector {
   bool general_ = false;
   // stream mode
   std::unordered_set<Stream*> streams_;
-  std::unordered_map<StepId, std::pair<Stream*, int64_t>, StepIdHash> where_;  // id -> stream, position
+  // id -> stream, position.  Only `prioritize` by step id and the general insert
+  // read it, so the per-step add / erase of the sliding-window fast path (two
+  // random accesses into a table of 100 k ids: cache misses, a third of an
+  // insert + evict) are logged and applied in order when somebody asks: the PPO
+  // config (zero_on_sample addresses the drawn item's steps by position, the
+  // agent sets no priorities) never does.
+  struct WhereOp { StepId id; Stream* st; int64_t pos; bool add; };
+  std::unordered_map<StepId, std::pair<Stream*, int64_t>, StepIdHash> where_;
+  std::vector<WhereOp> where_pending_;
+  bool where_stale_ = false;       // the backlog was dropped: rebuild from the streams when asked
+  void where_log(const StepId& id, Stream* st, int64_t pos, bool add) {
+    if (where_stale_) return;
+    where_pending_.push_back({id, st, pos, add});
+    static const size_t limit = [] {        // EMB_WHERE_BACKLOG: entries kept before giving up (tests)
+      const char* e = std::getenv("EMB_WHERE_BACKLOG");
+      const long v = e ? std::atol(e) : 0;
+      return v > 0 ? static_cast<size_t>(v) : (size_t{1} << 16);
+    }();
+    if (where_pending_.size() >= limit) {
+      // Nobody has asked for `limit` (65 536) steps: stop keeping a backlog at all.  The
+      // table is rebuilt from the streams' own id arrays if it is ever needed.
+      where_pending_.clear();
+      where_pending_.shrink_to_fit();
+      where_.clear();
+      where_stale_ = true;
+    }
+  }
+  std::unordered_map<StepId, std::pair<Stream*, int64_t>, StepIdHash>& where() {
+    if (where_stale_) {
+      where_.clear();
+      for (Stream* st : streams_)
+        for (int64_t i = 0; i < st->n_steps(); ++i)
+          where_.emplace(st->ids[i], std::make_pair(st, st->step0 + i));
+      where_stale_ = false;
+    }
+    for (const WhereOp& op : where_pending_) {
+      if (op.add) where_.emplace(op.id, std::make_pair(op.st, op.pos));
+      else where_.erase(op.id);
+    }
+    where_pending_.clear();
+    return where_;
+  }
   SlidingMap<std::pair<Stream*, int64_t>> owner_;                             // key -> stream, start
   std::vector<Range> ranges_;
   std::vector<SampleTree::Node*> leaves_;

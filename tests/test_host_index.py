@@ -504,3 +504,24 @@ def test_reserved_chunk_serials_are_not_reissued():
   rep.add({'t': np.int32(0)}, 1)
   api.emb_replay_chunks(rep.h, 4, _lib.ptr(uid), None, None, None, None, C.byref(n))
   assert sorted(uid[:2].tolist()) == [41, 42]
+
+
+def test_prioritized_with_a_tiny_step_id_backlog():
+  """The Prioritized selector keeps its step-id table lazily: adds / erases of
+  the sliding-window fast path are logged and applied when `prioritize` (or a
+  general insert) needs the table, and after EMB_WHERE_BACKLOG unasked entries
+  the log is dropped and the table rebuilt from the streams on demand.  With a
+  backlog of 7 (read once per process: child process) the rebuild path runs all
+  the time; the oracle comparisons must not notice."""
+  import os
+  import pathlib
+  import subprocess
+  import sys
+  root = pathlib.Path(__file__).resolve().parent.parent
+  env = dict(os.environ, EMB_WHERE_BACKLOG='7')
+  res = subprocess.run(
+      [sys.executable, '-m', 'pytest', 'tests/test_host_index.py', '-q', '-x', '-m', 'not gpu',
+       '-k', 'prioritized and not tiny_step_id_backlog or golden or mixture'],
+      cwd=root, env=env, capture_output=True, text=True, timeout=900)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+  assert ' passed' in res.stdout
