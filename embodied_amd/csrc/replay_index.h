@@ -139,14 +139,32 @@ class ReplayIndex {
     *stepid = make_stepid(uid, index);
     const int64_t row = chunk.slot * cfg_.chunksize + index;
     chunk.fill += 1;
-    w->pending.push(Pos(uid, index));
+    // The steps that are not yet the start of an item are the last `length - 1`
+    // of the stream: consecutive rows, so their oldest one (a position and its
+    // chunk) and a count say it all.
+    if (w->pending == 0) {
+      w->oldest = Pos(uid, index);
+      w->oldest_chunk = &chunk;
+    }
+    w->pending += 1;
     chunk.refs += 1;
     index += 1;
     if (index < cfg_.chunksize) w->cursor.second = index;
     else rotate(chunk, *w);
-    if (w->pending.count >= cfg_.length) {
+    if (w->pending >= cfg_.length) {
       metrics_[kInserts] += 1;
-      const Pos start = w->pending.pop();
+      const Pos start = w->oldest;
+      w->pending -= 1;
+      if (w->pending > 0) {
+        // the stream's next step: the next row of the same chunk, or row 0 of
+        // its successor (a chunk may have been closed early by a checkpoint)
+        if (start.second + 1 < w->oldest_chunk->fill) {
+          w->oldest.second = start.second + 1;
+        } else {
+          w->oldest_chunk = &chunks_.at(w->oldest_chunk->succ);      // node addresses are stable
+          w->oldest = Pos(w->oldest_chunk->uid, 0);
+        }
+      }
       insert_item(start, w, stepid);
       if (cfg_.online && w->steps_seen % cfg_.length == 0) fresh_.push_back(start);
     }
@@ -351,29 +369,12 @@ class ReplayIndex {
     return chunks_[c.uid] = c;
   }
 
-  // The last `length` steps of a worker: a fixed ring (a deque would allocate
-  // and free a block every few dozen steps).
-  struct PosRing {
-    std::vector<Pos> slot;
-    int64_t head = 0, count = 0;
-    void push(const Pos& p) {
-      int64_t at = head + count;
-      if (at >= static_cast<int64_t>(slot.size())) at -= static_cast<int64_t>(slot.size());
-      slot[at] = p;
-      ++count;
-    }
-    Pos pop() {
-      const Pos p = slot[head];
-      if (++head == static_cast<int64_t>(slot.size())) head = 0;
-      --count;
-      return p;
-    }
-  };
-
   struct Worker {
     Pos cursor;                 // (open chunk uid, next row)
     Chunk* open = nullptr;      // cached node of the open chunk
-    PosRing pending;            // steps not yet the start of an item
+    Pos oldest;                 // the oldest step that is not yet the start of an item ...
+    Chunk* oldest_chunk = nullptr;   // ... its chunk ...
+    int64_t pending = 0;        // ... and how many such steps there are (they are consecutive)
     int64_t steps_seen = 0;     // online mode
     uint64_t peek_mark = 0;     // last peek() batch that listed this worker
     int64_t last_item = -1;     // key of the newest item of this stream
@@ -383,15 +384,16 @@ class ReplayIndex {
   Worker* find_worker(int64_t id) const {
     if (id >= 0 && id < static_cast<int64_t>(dense_.size())) return dense_[id];
     auto it = workers_.find(id);
-    return it == workers_.end() ? nullptr : it->second.get();
+    return it == workers_.end() ? nullptr : it->second;
   }
   Worker& make_worker(int64_t id) {
-    auto& slot = workers_[id];
-    slot = std::make_unique<Worker>();
-    slot->pending.slot.resize(static_cast<size_t>(cfg_.length));
+    // (records of workers made one after another sit next to each other: a
+    // vectorised step touches a few KB of them, not one allocation per worker)
+    worker_pool_.emplace_back();
+    Worker* slot = workers_[id] = &worker_pool_.back();
     if (id >= 0 && id < 65536) {
       if (id >= static_cast<int64_t>(dense_.size())) dense_.resize(id + 1, nullptr);
-      dense_[id] = slot.get();
+      dense_[id] = slot;
     }
     return *slot;
   }
@@ -470,7 +472,8 @@ class ReplayIndex {
   int64_t next_item_ = 0;
   uint64_t next_uid_ = 1;
   int64_t loaded_ = 0;
-  std::unordered_map<int64_t, std::unique_ptr<Worker>> workers_;
+  std::deque<Worker> worker_pool_;                      // stable addresses, contiguous blocks
+  std::unordered_map<int64_t, Worker*> workers_;
   std::vector<Worker*> dense_;
   Ring<Pos> fresh_;
   static constexpr uint64_t kHints = 256;
