@@ -443,8 +443,12 @@ def main():
     stamp_every = 1
   elif expected >= 256:
     stamp_every = args.stamp_every
-  else:                       # three or four gathers in the region: at least one is stamped
-    stamp_every = 2 if expected >= 3 else 1
+  else:
+    # A handful of gathers in the region (the driver's --steps 20 has four):
+    # every second one is stamped, beginning with the second (the stamp counter
+    # restarts right before the timed region; the region's first gather runs on
+    # a GPU that the fence has just drained).
+    stamp_every = 2 if expected >= 2 else 1
   replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1', every=stamp_every)
   # The fill runs no train step: warm the train path (allocator, online queue,
   # caches) whatever --warmup says, then the caller's warmup steps.
@@ -453,6 +457,8 @@ def main():
   for _ in range(args.warmup):
     one_step()
   replay.profile_read(reset=True)
+  if os.environ.get('EMB_BENCH_NO_TIMER') != '1':
+    replay.profile(True, every=stamp_every)       # restart the stamp counter (first stamped gather: the stamp_every-th)
   base = dict(counters)
 
   def fence():

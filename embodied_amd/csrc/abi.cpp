@@ -1285,10 +1285,12 @@ int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) {
   REP_OP({
     rep->timer.enabled = enable != 0;
     rep->timer.every = enable > 1 ? enable : 1;      // enable = n > 1: stamp every n-th gather
-    rep->timer.tick = 0;
+    // ... starting with the n-th: the first launch after (re)starting the counter
+    // is often the first one on an idle GPU, the worst sample there is
+    rep->timer.tick = static_cast<uint64_t>(rep->timer.every - 1);
     rep->timer_update.enabled = rep->timer.enabled;  // write-backs of emb_replay_update alike
     rep->timer_update.every = rep->timer.every;
-    rep->timer_update.tick = 0;
+    rep->timer_update.tick = rep->timer.tick;
     if (enable) {                       // create the stamp pools now, not inside a timed region
       rep->timer.reserve(emb_timer_pool());
       rep->timer_update.reserve(emb_timer_pool());
