@@ -691,6 +691,9 @@ class Replay:
       self._flush()
       stream = self._stream()
       out, ptrs = self._alloc_batch(batch, length)
+      # (a reused output set: the host copy of stepid[:, 0] that `sample` leaves on
+      # the tensor for `update` belongs to an older batch)
+      out['stepid'].__dict__.pop('_emb_first', None)
       api.emb_replay_gather_rows(
           self._handle, _lib.ptr(rows), rows.size, length, ptrs, stream)
     return self._finish(out)

@@ -266,3 +266,34 @@ def test_early_insert_with_host_envs(emb, parallel):
     assert rep.early_inserts == 44
   finally:
     driver.close()
+
+
+def test_reused_output_sets_do_not_leak_state(emb):
+  """`sample` hands an output set out again once nobody references it.  Held
+  batches, views and detached tensors keep their set out of rotation; a reused
+  'stepid' tensor never carries the first-step ids of an older batch into
+  `update`."""
+  rep = emb.Replay(length=4, capacity=200, chunksize=16, seed=0)
+  for t in range(60):
+    rep.add({'x': np.float32(t), 'is_first': t == 0, 'is_last': False}, 0)
+  held = rep.sample(5)
+  snapshot = {k: v.clone() for k, v in held.items()}
+  view = rep.sample(5)['x'][:, :2]              # only a view survives
+  view_copy = view.clone()
+  detached = rep.sample(5)['x'].detach()        # only a detached alias survives
+  detached_copy = detached.clone()
+  ptrs = set()
+  for _ in range(12):                           # dropped at once: these may share storage
+    ptrs.add(rep.sample(5)['x'].data_ptr())
+  assert len(ptrs) <= 4
+  for k, v in held.items():
+    assert torch.equal(v, snapshot[k]), k
+  assert torch.equal(view, view_copy) and torch.equal(detached, detached_copy)
+  assert held['x'].data_ptr() not in ptrs and view.data_ptr() not in ptrs
+  # gather() through a reused set, then update(): rows come from THIS batch's ids
+  rows, _ = rep.sample_index(5)
+  batch = rep.gather(rows)
+  assert getattr(batch['stepid'], '_emb_first', None) is None
+  rep.update({'stepid': batch['stepid'], 'x': torch.full_like(batch['x'], -7.0)})
+  again = rep.gather(rows)
+  assert (again['x'] == -7.0).all()
