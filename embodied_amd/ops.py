@@ -22,6 +22,26 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
   `x * scale + offset` for float outputs; batch row j is env `env_ids[j]`.
   `out`: a contiguous tensor of that shape and dtype to write into (an agent
   that owns its input staging saves the allocation, ~2.5 us of host time)."""
+  if env_ids is None and out is not None and type(frames) is torch.Tensor:
+    # The same frame tensor into the same staging tensor with the same options as
+    # before (a vector env's output ring, an agent's staging buffers): both
+    # passed the checks below then, and a tensor's dtype, shape, device and
+    # strides do not change behind its back -- see Replay._collect.
+    memo = frames.__dict__.get('_emb_stack')
+    if (memo is not None and memo[0] is out and memo[1] == layout and memo[2] is dtype
+        and memo[3] == scale and memo[4] == offset):
+      _, _, _, scale_f, offset_f, n, pixels, c, first = memo[:9]
+      tag = frames.__dict__.get('_emb_offer')
+      if tag is not None:
+        replay = tag()
+        if replay is not None and replay._early_insert(
+            frames, pixels, c, first, dtype, scale_f, offset_f, out):
+          return out
+      fast.emb_obs_stack(
+          frames.data_ptr(), None, n, pixels, c,
+          _lib.LAYOUT_CHANNELS_FIRST if first else _lib.LAYOUT_SAME, _OUT[dtype],
+          scale_f, offset_f, out.data_ptr(), _stream(frames))
+      return out
   if not (torch.is_tensor(frames) and frames.is_cuda and frames.dtype == torch.uint8):
     raise RuntimeError('obs_stack needs a uint8 CUDA tensor (no CPU fallback)')
   if not frames.is_contiguous():
@@ -38,6 +58,8 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
     raise ValueError(f'obs_stack out= must be contiguous {shape} {dtype} on {frames.device}')
   if out.numel() == 0:
     return out                       # no envs / empty frames: nothing to launch
+  if ids is None and type(frames) is torch.Tensor:
+    frames._emb_stack = (out, layout, dtype, float(scale), float(offset), n, h * w, c, first)
   tag = getattr(frames, '_emb_offer', None)
   if tag is not None and ids is None:
     # A Driver offered this step's observations to its Replay (Replay.offer):
