@@ -146,6 +146,7 @@ class Replay:
     self._stage_busy, self._stage_pending = None, False
     self._rowbytes_total = None
     self._out_pool = {} if _STORAGE_USE_COUNT is not None else None
+    self._nonempty = False
     self._pool_bytes = 0
     probe = [object()]
     self._ref_base = sys.getrefcount(probe[0])
@@ -582,8 +583,13 @@ class Replay:
     """`batch` sequences of `length` steps -> dict of (batch, length, ...)
     (replay.py:121-127): index draws on the host, one gather launch."""
     assert mode in _lib.MODES, mode
-    limiters.wait(
-        lambda: len(self._native), f'Replay buffer {self.name} is empty')
+    if not self._nonempty:
+      # (items only leave when a new one pushes them out at capacity: a sampler
+      # that has held an item once never runs empty again -- asked once, not with
+      # a C call and a clock read per sample)
+      limiters.wait(
+          lambda: len(self._native), f'Replay buffer {self.name} is empty')
+      self._nonempty = True
     with self._lock:
       self._flush()
       stream = self._stream()

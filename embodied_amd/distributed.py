@@ -154,7 +154,9 @@ def sample_packed(replay, batch, mode='train', groups=1):
   from . import _lib
   from .core import limiters
   assert batch % groups == 0, (batch, groups)
-  limiters.wait(lambda: len(replay._native), f'Replay buffer {replay.name} is empty')
+  if not replay._nonempty:
+    limiters.wait(lambda: len(replay._native), f'Replay buffer {replay.name} is empty')
+    replay._nonempty = True
   with replay._lock:
     replay._flush()
     cache = replay.__dict__.setdefault('_packed_layouts', {})
