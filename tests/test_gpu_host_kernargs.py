@@ -15,9 +15,10 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 def test_parity_with_kernel_arguments_in_host_memory():
   env = dict(os.environ, HIP_FORCE_DEV_KERNARG='0')
   res = subprocess.run(
-      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-m', 'gpu', '-q', '-x',
+      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', 'tests/test_gpu_early_insert.py',
+       '-m', 'gpu', '-q', '-x',
        '-k', 'golden or full_size or large_tables or update_roundtrip or sharded or very_large_rows '
-             'or span_mover or fused_sample'],
+             'or span_mover or fused_sample or early or many_envs or host_envs or checkpoint_between'],
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
