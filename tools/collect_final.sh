@@ -9,5 +9,5 @@ python $R/bench.py --host-envs --parallel-envs --no-cpu-baseline --no-dreamer-le
 python $R/tools/bench_index.py > $O/bench_index.txt 2>&1
 HIP_FORCE_DEV_KERNARG=0 python $R/tools/profile_host_step.py > $O/profile_host_step.txt 2>&1
 cd $R
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/gpu_tests.txt
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 >> $O/gpu_tests.txt
