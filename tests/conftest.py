@@ -19,6 +19,10 @@ _build = importlib.util.module_from_spec(_spec)         # its __init__ needs the
 _spec.loader.exec_module(_build)
 import os  # noqa: E402
 os.environ.setdefault('EMB_STRICT_SCRATCH', '1')   # this repo's own builds: no kernel may spill
+# The suite runs on the HIP runtime's own argument placement (device memory); the
+# package's default (host memory, embodied_amd/__init__.py) has its own tests in
+# child processes (tests/test_gpu_host_kernargs.py).
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 _build.build(verbose=False)
 
 

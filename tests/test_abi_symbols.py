@@ -156,3 +156,21 @@ def test_plain_c_program_against_the_abi(tmp_path):
   lines = run.stdout.strip().splitlines()
   assert lines[0] == 'uniform: 8 6 5 2 3 0 0 0 1 8 6 9 5 6 9 7'
   assert lines[1] == 'replay: 50 items; sampled workers 0 1 2 2'
+
+
+def test_import_chooses_host_resident_kernel_arguments_unless_told_otherwise():
+  """embodied_amd/__init__.py: HIP_FORCE_DEV_KERNARG defaults to 0 for the
+  process (the HIP runtime reads it at its first API call); a value the process
+  already has is left alone."""
+  import os
+  import subprocess
+  import sys
+  code = ('import os, embodied_amd; '
+          'print(os.environ["HIP_FORCE_DEV_KERNARG"])')
+  base = {k: v for k, v in os.environ.items() if k != 'HIP_FORCE_DEV_KERNARG'}
+  for given, want in ((None, '0'), ('1', '1'), ('0', '0')):
+    env = dict(base) if given is None else dict(base, HIP_FORCE_DEV_KERNARG=given)
+    out = subprocess.run([sys.executable, '-c', code], env=env, cwd=str(ROOT),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == want, (given, out.stdout)

@@ -16,7 +16,10 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 def run_bench(*flags, env=None):
   full = dict(os.environ, **(env or {}))
-  for name in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+  # (HIP_FORCE_DEV_KERNARG: conftest pins the suite to the runtime's placement; the
+  # bench is run as the driver runs it, with its own default)
+  for name in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+               'HIP_FORCE_DEV_KERNARG'):
     full.pop(name, None)
   res = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *flags], cwd=ROOT, env=full,
                        capture_output=True, text=True, timeout=600)
