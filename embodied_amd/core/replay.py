@@ -145,7 +145,7 @@ class Replay:
     self._add_plan = None
     self._stage_busy, self._stage_pending = None, False
     self._rowbytes_total = None
-    self._out_pool = {} if _STORAGE_USE_COUNT is not None else None
+    self._out_pool = {} if _STORAGE_USE_COUNT is not None and hasattr(torch.Tensor, '_use_count') else None
     self._nonempty = False
     self._pool_bytes = 0
     probe = [object()]
@@ -611,7 +611,9 @@ class Replay:
     more are used again: a set goes back into rotation only when every tensor's
     Python reference count and every storage's use count say that this pool is
     the only holder (a view, a detach(), a tensor kept in a list all keep the
-    set out), which no caller can tell from a fresh allocation.  Work queued on
+    set out; so does a tensor handed to another framework through DLPack: that
+    consumer owns the tensor in C++, `Tensor._use_count()`), which no caller can
+    tell from a fresh allocation.  Work queued on
     the same stream is ordered before the next gather as it would be with the
     caching allocator handing the block out again; sets are never shared across
     streams."""
@@ -630,8 +632,10 @@ class Replay:
         continue
       for i in range(len(tensors)):
         # `held` = what getrefcount reports for an object only a list holds;
-        # 2 = the tensor and the storage handle this pool keeps.
-        if refs(tensors[i]) != held or uses(cdata[i]) != 2:
+        # 2 = the tensor and the storage handle this pool keeps; 1 = nothing in
+        # C++ (a DLPack consumer, an autograd node) owns the tensor itself.
+        t = tensors[i]
+        if refs(t) != held or uses(cdata[i]) != 2 or t._use_count() != 1:
           break
       else:
         return dict(zip(self._key_names, tensors)), ptrs

@@ -100,10 +100,10 @@ _HELD = sys.getrefcount(_PROBE[0])
 def _pair(B, n, dev):
   """Two fresh (B, n) float32 results out of one (2, B, n) allocation.  Sets that
   nobody references any more (Python reference counts of both views, holders of
-  the storage) are handed out again instead of allocating: to the caller they
+  the storage, C++ owners of the views such as a DLPack consumer) are handed out again instead of allocating: to the caller they
   are indistinguishable from new tensors, and the host saves the allocation and
   the two view constructions (~3 us of a ~6 us call)."""
-  if _STORAGE_USE_COUNT is None:
+  if _STORAGE_USE_COUNT is None or not hasattr(torch.Tensor, '_use_count'):
     return _lib.empty((2, B, n), torch.float32, dev).unbind(0)
   key = (B, n, dev, _lib.raw_stream(dev))
   sets = _PAIRS.get(key)
@@ -114,7 +114,8 @@ def _pair(B, n, dev):
   for views, cdata, _ in sets:
     # holders of the storage: the (2, B, n) base, its two views, our handle
     if (sys.getrefcount(views[0]) == _HELD and sys.getrefcount(views[1]) == _HELD
-        and _STORAGE_USE_COUNT(cdata) == 4):
+        and _STORAGE_USE_COUNT(cdata) == 4
+        and views[0]._use_count() == 1 and views[1]._use_count() == 1):
       return views[0], views[1]
   both = _lib.empty((2, B, n), torch.float32, dev)
   adv, tar = both.unbind(0)

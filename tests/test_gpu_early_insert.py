@@ -282,10 +282,16 @@ def test_reused_output_sets_do_not_leak_state(emb):
   view_copy = view.clone()
   detached = rep.sample(5)['x'].detach()        # only a detached alias survives
   detached_copy = detached.clone()
+  leaving = rep.sample(5)['x']                  # only an unconsumed DLPack capsule survives
+  exported_copy, exported_ptr = leaving.clone(), leaving.data_ptr()
+  capsule = leaving.__dlpack__()
+  del leaving
   ptrs = set()
   for _ in range(12):                           # dropped at once: these may share storage
     ptrs.add(rep.sample(5)['x'].data_ptr())
   assert len(ptrs) <= 4
+  assert exported_ptr not in ptrs
+  assert torch.equal(torch.from_dlpack(capsule), exported_copy)
   for k, v in held.items():
     assert torch.equal(v, snapshot[k]), k
   assert torch.equal(view, view_copy) and torch.equal(detached, detached_copy)
