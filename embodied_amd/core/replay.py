@@ -15,6 +15,7 @@ host arrays like the reference's).  There is no CPU implementation.
 import concurrent.futures
 import ctypes as C
 import io
+import os
 import pathlib
 import sys
 import threading
@@ -145,7 +146,8 @@ class Replay:
     self._add_plan = None
     self._stage_busy, self._stage_pending = None, False
     self._rowbytes_total = None
-    self._out_pool = {} if _STORAGE_USE_COUNT is not None and hasattr(torch.Tensor, '_use_count') else None
+    self._out_pool = {} if (_STORAGE_USE_COUNT is not None and hasattr(torch.Tensor, '_use_count')
+                            and os.environ.get('EMB_SAMPLE_POOL') != '0') else None
     self._nonempty = False
     self._pool_bytes = 0
     probe = [object()]
@@ -616,7 +618,11 @@ class Replay:
     tell from a fresh allocation.  Work queued on
     the same stream is ordered before the next gather as it would be with the
     caching allocator handing the block out again; sets are never shared across
-    streams."""
+    streams.  One thing differs from fresh allocations: `Tensor.record_stream`
+    defers the allocator's reuse of a block, not this pool's -- a consumer that
+    reads a batch on a side stream and drops it before that work is ordered
+    after the sampling stream should hold on to the batch until then, or run
+    with EMB_SAMPLE_POOL=0 (every sample allocates)."""
     if self._reuse:
       return self._alloc_batch_now(batch, length)
     pool = self._out_pool

@@ -303,3 +303,20 @@ def test_reused_output_sets_do_not_leak_state(emb):
   rep.update({'stepid': batch['stepid'], 'x': torch.full_like(batch['x'], -7.0)})
   again = rep.gather(rows)
   assert (again['x'] == -7.0).all()
+
+
+def test_sample_pool_can_be_switched_off(emb, monkeypatch):
+  """EMB_SAMPLE_POOL=0: every `sample` allocates (for consumers that keep a
+  dropped batch alive for a side stream with `record_stream`)."""
+  monkeypatch.setenv('EMB_SAMPLE_POOL', '0')
+  off = emb.Replay(length=4, capacity=200, chunksize=16, seed=0)
+  monkeypatch.delenv('EMB_SAMPLE_POOL')
+  on = emb.Replay(length=4, capacity=200, chunksize=16, seed=0)
+  for rep in (off, on):
+    for t in range(40):
+      rep.add({'x': np.float32(t), 'is_first': t == 0, 'is_last': False}, 0)
+  assert off._out_pool is None and on._out_pool is not None
+  for _ in range(6):
+    a, b = off.sample(5), on.sample(5)
+    assert torch.equal(a['x'], b['x']) and torch.equal(a['stepid'], b['stepid'])
+  assert not off._out_pool and on._out_pool
