@@ -640,8 +640,8 @@ class Replay:
         # `held` = what getrefcount reports for an object only a list holds;
         # 2 = the tensor and the storage handle this pool keeps; 1 = nothing in
         # C++ (a DLPack consumer, an autograd node) owns the tensor itself.
-        t = tensors[i]
-        if refs(t) != held or uses(cdata[i]) != 2 or t._use_count() != 1:
+        # (no local alias of the tensor here: it would count as a reference)
+        if refs(tensors[i]) != held or uses(cdata[i]) != 2 or tensors[i]._use_count() != 1:
           break
       else:
         return dict(zip(self._key_names, tensors)), ptrs

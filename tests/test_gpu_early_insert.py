@@ -276,6 +276,16 @@ def test_reused_output_sets_do_not_leak_state(emb):
   rep = emb.Replay(length=4, capacity=200, chunksize=16, seed=0)
   for t in range(60):
     rep.add({'x': np.float32(t), 'is_first': t == 0, 'is_last': False}, 0)
+  # batches dropped at once are served from ONE set: nothing is allocated after the first
+  made, plain = [0], rep._new_batch
+  def counting(*a):
+    made[0] += 1
+    return plain(*a)
+  rep._new_batch = counting
+  for _ in range(10):
+    rep.sample(5)
+  assert made[0] == 1, made
+  del rep._new_batch
   held = rep.sample(5)
   snapshot = {k: v.clone() for k, v in held.items()}
   view = rep.sample(5)['x'][:, :2]              # only a view survives
