@@ -7,8 +7,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -20,6 +22,51 @@
 #include "selectors.h"
 
 namespace {
+
+// EMB_HOST_PROFILE=1: cycle counts of the host sections of the hot entry points,
+// printed to stderr when the process ends (tools/profile_step.py's native view).
+// Off: one predictable branch per lap.
+struct HostProfile {
+  enum { kSlots = 32 };
+  bool on = false;
+  uint64_t cycles[kSlots] = {}, laps[kSlots] = {};
+  const char* label[kSlots] = {};
+  uint64_t tsc0 = 0;
+  timespec wall0{};
+  HostProfile() {
+    const char* e = std::getenv("EMB_HOST_PROFILE");
+    on = e && e[0] == '1';
+    if (on) {
+      clock_gettime(CLOCK_MONOTONIC, &wall0);
+      tsc0 = __builtin_ia32_rdtsc();
+    }
+  }
+  ~HostProfile() {
+    if (!on) return;
+    timespec now{};
+    clock_gettime(CLOCK_MONOTONIC, &now);
+    const double ns = (now.tv_sec - wall0.tv_sec) * 1e9 + (now.tv_nsec - wall0.tv_nsec);
+    const double per_cycle = ns / static_cast<double>(__builtin_ia32_rdtsc() - tsc0);
+    std::fprintf(stderr, "[emb host profile]  section                          laps      ns/lap\n");
+    for (int i = 0; i < kSlots; ++i)
+      if (laps[i])
+        std::fprintf(stderr, "[emb host profile]  %-30s %8llu %10.0f\n", label[i],
+                     static_cast<unsigned long long>(laps[i]), cycles[i] * per_cycle / laps[i]);
+  }
+};
+HostProfile g_host_profile;
+struct HostLap {
+  uint64_t t;
+  HostLap() : t(g_host_profile.on ? __builtin_ia32_rdtsc() : 0) {}
+  void lap(int slot, const char* name) {
+    if (!g_host_profile.on) return;
+    const uint64_t now = __builtin_ia32_rdtsc();
+    g_host_profile.cycles[slot] += now - t;
+    g_host_profile.laps[slot] += 1;
+    g_host_profile.label[slot] = name;
+    t = __builtin_ia32_rdtsc();
+  }
+};
 
 thread_local std::string g_error;
 
@@ -792,8 +839,10 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     rep->ring.upload(lease, total, stream);
     plan.rows = reinterpret_cast<const int32_t*>(lease.device);
   }
+  HostLap hp;
   emb::MoveLaunch launch;
   HIP_OK(emb::prepare_move(plan, &launch, gather));
+  hp.lap(gather ? 11 : 16, gather ? "gather: prepare_move" : "scatter: prepare_move");
   // Processes that keep kernel arguments in host memory (HIP_FORCE_DEV_KERNARG=0,
   // cheaper launches) pay PCIe latency on every wave's argument reads: for big
   // moves hand the kernel a device copy of its arguments instead.
@@ -835,6 +884,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
       }
     }
   }
+  hp.lap(gather ? 12 : 17, gather ? "gather: args -> device (+marker)" : "scatter: args -> device");
   rep->order_before(gather, stream);
   hipEvent_t start = nullptr, stop = nullptr;
   if (stamp_this) {
@@ -850,9 +900,12 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   }
   HIP_OK(emb::launch_move(launch, gather, device_args, stream, start, stop));
   rep->order_after(gather, stream);
+  hp.lap(gather ? (stamp_this ? 14 : 13) : 18,
+         gather ? (stamp_this ? "gather: launch (stamped)" : "gather: launch") : "scatter: launch");
   if (args_in_bar) rep->arg_ring.retire(stream);
   if (args_lease.slot >= 0) rep->ring.retire(args_lease, stream);
   if (lease.slot >= 0) rep->ring.retire(lease, stream);
+  hp.lap(gather ? 15 : 19, gather ? "gather: retire" : "scatter: retire");
 }
 
 // Any number of keys: launches of at most kMaxKeys keys each (the kernel
@@ -940,9 +993,11 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     for (int32_t j = 0; j < n_masked; ++j)     // a masked key must not have been written unmasked
       need(!rep->pre.src[masked_keys[j]] || rep->pre.src[masked_keys[j]] != src[masked_keys[j]],
            "add: a masked key was part of the early insert");
+  HostLap hp;
   rep->rows.resize(n);
   rep->ids.resize(n);
   add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());   // PoolFull: nothing changed yet
+  hp.lap(0, "add: index bookkeeping");
   // Keys that emb_replay_obs_stack_insert already wrote: same token, same
   // workers, same stream, and the rows this add was given are the peeked ones.
   emb_replay::Prewritten& pre = rep->pre;
@@ -969,6 +1024,7 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     }
   }
   if (list.key.empty()) return;
+  hp.lap(1, "add: early check + key list");
   if (early && list.key.size() == 1 && list.key_stepid < 0 &&
       list.key[0].rowbytes * n <= (int64_t{1} << 20)) {
     // All that is left is one small key (the action): the rows are in device
@@ -980,10 +1036,12 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
                                    list.key[0].rowbytes, masked ? list.mask_dtype[0] : emb::kU8, stream,
                                    write_stamp(rep)));
     rep->order_after(false, stream);
+    hp.lap(2, "add: publish_one launch");
     return;
   }
   run_move_all(rep, list, rep->rows.data(), n, list.key_stepid >= 0 ? rep->ids.data() : nullptr,
                false, stream);
+  hp.lap(3, "add: mover launch (run_move)");
 }
 
 int32_t emb_replay_add(emb_replay_t* rep, int64_t n, const int64_t* workers, const void* const* src,
@@ -1020,6 +1078,7 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
     *token_out = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) return;
+    HostLap hp;
     emb_replay::Prewritten& pre = rep->pre;
     pre.token = 0;
     const int n_keys = static_cast<int>(rep->keys.size());
@@ -1046,6 +1105,7 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
         rep->rows[i] = static_cast<int32_t>(row);
       }
     }
+    hp.lap(4, "early insert: peek");
     if (early) {
       plan.frame_pool = rep->keys[frame_key].pool;
       pre.src.assign(n_keys, nullptr);
@@ -1084,6 +1144,7 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
       rep->dev_rows_cap = cap;
     }
     plan.rows_out = rep->dev_rows;
+    hp.lap(5, "early insert: key plan");
     // The per-env table goes to device memory: written by the CPU through the
     // BAR when it fits a slot of the argument ring, else staged and copied.
     const size_t bytes = emb::prewrite_table_bytes(n);
@@ -1102,9 +1163,11 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
       rep->ring.upload(lease, bytes, s);
       plan.table_dev = lease.device;
     }
+    hp.lap(6, "early insert: table -> device");
     rep->order_before(false, s);
     HIP_OK(emb::launch_obs_stack_insert(plan, s, write_stamp(rep)));
     rep->order_after(false, s);
+    hp.lap(7, "early insert: launch");
     if (in_bar) rep->arg_ring.retire(s);
     if (lease.slot >= 0) rep->ring.retire(lease, s);
     pre.workers.assign(workers, workers + n);
@@ -1112,6 +1175,7 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
     pre.stream = s;
     pre.token = ++rep->pre_serial;
     *token_out = pre.token;
+    hp.lap(8, "early insert: retire + record");
   });
 }
 
@@ -1134,9 +1198,12 @@ static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* co
   list.seq_len = static_cast<int32_t>(L);
   list.group = group;
   list.group_stride = group_stride;
+  HostLap hp;
   rep->rows.resize(batch * L);
   sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
+  hp.lap(9, "sample: index draws + spans");
   run_move_all(rep, list, rep->rows.data(), batch * L, nullptr, true, stream, &rep->spans);
+  hp.lap(10, "sample: run_move (all of it)");
 }
 
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
@@ -1484,10 +1551,12 @@ int32_t emb_scan_gae(const void* rew, const void* val, const void* last, const v
                      int64_t T, float live_scale, float lam, void* adv, void* tar, void* stream) {
   return guarded([&] {
     need(rew && val && last && term && adv && tar && B >= 0 && T >= 1, "scan_gae: bad arguments");
+    HostLap hp;
     HIP_OK(emb::launch_gae(static_cast<const float*>(rew), static_cast<const float*>(val),
                            static_cast<const uint8_t*>(last), static_cast<const uint8_t*>(term), B, T,
                            live_scale, lam, static_cast<float*>(adv), static_cast<float*>(tar),
                            static_cast<hipStream_t>(stream)));
+    hp.lap(20, "gae: launch");
   });
 }
 
@@ -1540,11 +1609,13 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
   return guarded([&] {
     need(image && reward && is_first && is_last && is_terminal && counters && n >= 0 && episode_len >= 1,
          "synth_env_step: bad arguments");
+    HostLap hp;
     HIP_OK(emb::launch_synth_env(static_cast<uint8_t*>(image), static_cast<float*>(reward),
                                  static_cast<uint8_t*>(is_first), static_cast<uint8_t*>(is_last),
                                  static_cast<uint8_t*>(is_terminal), n, frame_bytes, env0, episode_len,
                                  static_cast<const uint8_t*>(reset), static_cast<int32_t*>(counters),
                                  turn, static_cast<hipStream_t>(stream)));
+    hp.lap(21, "synthetic env: launch");
   });
 }
 
