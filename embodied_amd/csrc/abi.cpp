@@ -6,7 +6,12 @@
 
 #include <dlfcn.h>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -393,6 +399,140 @@ struct emb_rng {
   explicit emb_rng(const std::vector<uint32_t>& w) : impl(w) {}
 };
 
+// Deferred index work (emb_replay_publish): ONE job at a time, run by a helper
+// thread while the caller goes on (its launch, then the interpreter's work up to
+// the next library call).  Rules that make it race-free without the helper
+// taking a lock: a job is posted only by a thread that holds the replay's and the
+// selector handle's mutex; every operation that holds either of them drains the
+// gate before it touches the index or the selector; the job touches nothing else.
+// The helper spins for a while after a job (the next one is ~15 us away in a
+// stepping loop), then sleeps; it is not joined (it keeps the gate alive itself)
+// and a forked child starts its own.
+std::atomic<uint64_t> g_fork_epoch{0};
+struct DeferGate : std::enable_shared_from_this<DeferGate> {
+  std::atomic<int> state{0};             // 0 idle, 1 posted or running
+  void (*fn)(void*) = nullptr;
+  void* ctx = nullptr;
+  std::exception_ptr error;              // written by the helper before state -> 0
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<bool> sleeping{false};
+  std::atomic<bool> stop{false};
+  uint64_t started_epoch = ~uint64_t{0};
+
+  static void* run(void* self_owned) {
+    std::shared_ptr<DeferGate> self(*static_cast<std::shared_ptr<DeferGate>*>(self_owned));
+    delete static_cast<std::shared_ptr<DeferGate>*>(self_owned);
+    DeferGate& g = *self;
+    for (;;) {
+      int spins = 0;
+      while (g.state.load(std::memory_order_acquire) != 1 || g.fn == nullptr) {
+        if (g.stop.load(std::memory_order_relaxed) || self.use_count() == 1) return nullptr;
+        if (++spins < 40000) {           // ~100 us of polling, then sleep
+          __builtin_ia32_pause();
+          continue;
+        }
+        std::unique_lock<std::mutex> lock(g.m);
+        g.sleeping.store(true);
+        g.cv.wait_for(lock, std::chrono::milliseconds(200), [&] {
+          return g.state.load() == 1 || g.stop.load();
+        });
+        g.sleeping.store(false);
+        spins = 0;
+      }
+      void (*fn)(void*) = g.fn;
+      g.fn = nullptr;
+      try {
+        fn(g.ctx);
+      } catch (...) {
+        g.error = std::current_exception();
+      }
+      g.state.store(0, std::memory_order_release);
+    }
+  }
+
+  // Caller holds the mutexes named above and has drained.
+  void post(void (*f)(void*), void* c) {
+    const uint64_t epoch = g_fork_epoch.load();
+    if (started_epoch != epoch) {        // first job, or first job in a forked child
+      auto* owned = new std::shared_ptr<DeferGate>(shared_from_this());
+      pthread_t th;
+      pthread_attr_t attr;
+      pthread_attr_init(&attr);
+      pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_DETACHED);
+      if (pthread_create(&th, &attr, &DeferGate::run, owned) != 0) {
+        pthread_attr_destroy(&attr);
+        delete owned;
+        f(c);                            // no helper: do it here
+        return;
+      }
+      pthread_attr_destroy(&attr);
+      started_epoch = epoch;
+    }
+    ctx = c;
+    fn = f;
+    state.store(1, std::memory_order_seq_cst);
+    if (sleeping.load(std::memory_order_seq_cst)) {
+      std::lock_guard<std::mutex> lock(m);
+      cv.notify_one();
+    }
+  }
+
+  void drain() {
+    if (state.load(std::memory_order_acquire) == 0 && !error) return;
+    for (int spins = 0; state.load(std::memory_order_acquire) != 0; ++spins) {
+      if (spins < 4000) __builtin_ia32_pause();
+      else sched_yield();                // the helper may be waiting for this very CPU
+    }
+    if (error) {
+      std::exception_ptr e = error;
+      error = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+};
+
+// fork(): the parent finishes the job in flight first (the child would wait for a
+// helper it does not have); the child's gates start helpers of their own.
+std::mutex g_gates_mu;
+std::vector<std::weak_ptr<DeferGate>> g_gates;
+void gates_before_fork() {
+  std::lock_guard<std::mutex> lock(g_gates_mu);
+  for (auto& weak : g_gates)
+    if (auto gate = weak.lock())
+      while (gate->state.load(std::memory_order_acquire) != 0) sched_yield();
+}
+void gates_in_child() { g_fork_epoch.fetch_add(1); }
+std::shared_ptr<DeferGate> make_gate() {
+  static const bool hooked = [] {
+    pthread_atfork(&gates_before_fork, nullptr, &gates_in_child);
+    return true;
+  }();
+  (void)hooked;
+  auto gate = std::make_shared<DeferGate>();
+  std::lock_guard<std::mutex> lock(g_gates_mu);
+  g_gates.erase(std::remove_if(g_gates.begin(), g_gates.end(),
+                               [](const std::weak_ptr<DeferGate>& w) { return w.expired(); }),
+                g_gates.end());
+  g_gates.push_back(gate);
+  return gate;
+}
+
+// EMB_DEFER_INDEX=0: emb_replay_publish does its index bookkeeping itself.
+// A process confined to one CPU keeps it too: the helper would only take turns
+// with the thread that waits for it.
+bool defer_index() {
+  static const bool value = [] {
+    const char* e = std::getenv("EMB_DEFER_INDEX");
+    if (e && e[0] == '0') return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) < 2) return false;
+    return true;
+  }();
+  return value;
+}
+
 struct emb_tree {
   std::mutex mu;
   emb::SampleTree impl;
@@ -401,6 +541,7 @@ struct emb_tree {
 
 struct emb_selector {
   std::shared_ptr<std::mutex> mu = std::make_shared<std::mutex>();
+  std::shared_ptr<DeferGate> gate = make_gate();     // see DeferGate: drained by every operation
   std::shared_ptr<emb::Selector> impl;
 };
 
@@ -411,6 +552,10 @@ struct emb_replay {
   // The selector handle's own lock (emb_selector_* take it): replay operations
   // hold it too, so direct calls on the handle cannot interleave with them.
   std::shared_ptr<std::mutex> selector_mu = std::make_shared<std::mutex>();
+  std::shared_ptr<DeferGate> gate;                 // the selector handle's, or this replay's own
+  bool may_defer = false;                          // selector is a native Uniform / Prioritized
+  std::vector<int32_t> defer_rows;                 // the helper's outputs (checked, not used)
+  std::vector<emb::StepId> defer_ids;
   std::vector<KeyInfo> keys;
   int key_stepid = -1, key_is_first = -1, key_is_last = -1;
   TableRing ring;
@@ -443,6 +588,8 @@ struct emb_replay {
   size_t dev_rows_cap = 0;
 
   ~emb_replay() {
+    if (gate)
+      while (gate->state.load(std::memory_order_acquire) != 0) sched_yield();
     if (wrote) (void)hipEventDestroy(wrote);
     if (read) (void)hipEventDestroy(read);
     if (dev_rows) (void)hipFree(dev_rows);
@@ -636,6 +783,7 @@ int32_t emb_selector_create_callback(const emb_selector_callbacks_t* cb, emb_sel
   return guarded([&] {                                \
     need(sel, "selector handle is null");             \
     std::lock_guard<std::mutex> lock(*sel->mu);       \
+    sel->gate->drain();                               \
     __VA_ARGS__;                                      \
   })
 
@@ -672,6 +820,11 @@ int32_t emb_replay_create(const emb_replay_config_t* cfg, emb_selector_t* select
     auto rep = std::make_unique<emb_replay>();
     rep->selector = selector ? selector->impl : std::make_shared<emb::Uniform>(seed);
     if (selector) rep->selector_mu = selector->mu;
+    rep->gate = selector ? selector->gate : make_gate();
+    // (a callback selector runs Python, a mixture may hold one: their work stays
+    // on the calling thread)
+    rep->may_defer = dynamic_cast<emb::Uniform*>(rep->selector.get()) != nullptr ||
+                     dynamic_cast<emb::Prioritized*>(rep->selector.get()) != nullptr;
     rep->index = std::make_unique<emb::ReplayIndex>(c, rep->selector);
     *out = rep.release();
   });
@@ -687,6 +840,7 @@ int32_t emb_replay_destroy(emb_replay_t* rep) {
     need(rep, "replay handle is null");               \
     std::lock_guard<std::mutex> lock(rep->mu);        \
     std::lock_guard<std::mutex> sel_lock(*rep->selector_mu); \
+    rep->gate->drain();                               \
     __VA_ARGS__;                                      \
   })
 
@@ -972,6 +1126,19 @@ static hipEvent_t write_stamp(emb_replay* rep) {
   return stop;
 }
 
+// The helper thread's job (DeferGate): the index bookkeeping of a publish whose
+// rows were fixed by the early insert.  `pre.workers` / `pre.rows` are not
+// written again before the next replay operation, which drains the gate first.
+static void deferred_add(void* ctx) {
+  emb_replay* rep = static_cast<emb_replay*>(ctx);
+  const int64_t n = static_cast<int64_t>(rep->pre.workers.size());
+  rep->defer_rows.resize(n);
+  rep->defer_ids.resize(n);
+  add_index_locked(rep, n, rep->pre.workers.data(), rep->defer_rows.data(), rep->defer_ids.data());
+  if (!std::equal(rep->defer_rows.begin(), rep->defer_rows.end(), rep->pre.rows.begin()))
+    throw std::logic_error("replay: a deferred add left the rows of its early insert");
+}
+
 static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const void* const* src,
                        int32_t n_masked, const int32_t* masked_keys, const int32_t* masked_dtypes,
                        void* const* masked_out, const void* is_last, hipStream_t stream,
@@ -994,17 +1161,46 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
       need(!rep->pre.src[masked_keys[j]] || rep->pre.src[masked_keys[j]] != src[masked_keys[j]],
            "add: a masked key was part of the early insert");
   HostLap hp;
-  rep->rows.resize(n);
-  rep->ids.resize(n);
-  add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());   // PoolFull: nothing changed yet
-  hp.lap(0, "add: index bookkeeping");
   // Keys that emb_replay_obs_stack_insert already wrote: same token, same
-  // workers, same stream, and the rows this add was given are the peeked ones.
+  // workers, same stream, and the rows this add is given are the peeked ones.
   emb_replay::Prewritten& pre = rep->pre;
   bool early = token != 0 && pre.token == token && pre.stream == stream &&
                static_cast<int64_t>(pre.workers.size()) == n &&
-               std::equal(workers, workers + n, pre.workers.begin()) &&
-               std::equal(rep->rows.begin(), rep->rows.end(), pre.rows.begin());
+               std::equal(workers, workers + n, pre.workers.begin());
+  const int32_t* rows = nullptr;
+  bool deferred = false;
+  if (early && rep->may_defer && defer_index() && rep->index->config().owners == 1) {
+    // The rows an add hands out are the cursors peek reads: if they still are
+    // what the early insert saw, the bookkeeping (which the launch below does not
+    // need -- rows and step ids are in device memory already) runs on the helper
+    // thread while this thread launches and goes back to the interpreter.
+    const uint64_t mark = ++rep->peek_mark;
+    const int64_t chunksize = rep->index->config().chunksize;
+    int64_t rotations = 0;               // workers that fill their chunk's last row: one new slot each
+    bool same = true;
+    for (int64_t i = 0; i < n && same; ++i) {
+      int64_t row = 0;
+      emb::StepId sid;
+      same = rep->index->peek(workers[i], mark, &row, &sid) && row == pre.rows[i];
+      rotations += (row % chunksize) + 1 >= chunksize;
+    }
+    // (PoolFull must be raised before anything changes: only a batch that cannot
+    // run out of slots goes to the helper)
+    if (same && rotations <= rep->index->free_slots()) {
+      rep->gate->post(&deferred_add, rep);
+      rows = pre.rows.data();
+      deferred = true;
+      hp.lap(22, "add: peek check + post");
+    }
+  }
+  if (!deferred) {
+    rep->rows.resize(n);
+    rep->ids.resize(n);
+    add_index_locked(rep, n, workers, rep->rows.data(), rep->ids.data());   // PoolFull: nothing changed yet
+    hp.lap(0, "add: index bookkeeping");
+    early = early && std::equal(rep->rows.begin(), rep->rows.end(), pre.rows.begin());
+    rows = rep->rows.data();
+  }
   pre.token = 0;        // any add consumes an outstanding early insert
   KeyList list;
   for (size_t k = 0; k < rep->keys.size(); ++k) {
@@ -1039,8 +1235,8 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     hp.lap(2, "add: publish_one launch");
     return;
   }
-  run_move_all(rep, list, rep->rows.data(), n, list.key_stepid >= 0 ? rep->ids.data() : nullptr,
-               false, stream);
+  // (a deferred add never has the step ids in the list: the early insert wrote them)
+  run_move_all(rep, list, rows, n, list.key_stepid >= 0 ? rep->ids.data() : nullptr, false, stream);
   hp.lap(3, "add: mover launch (run_move)");
 }
 

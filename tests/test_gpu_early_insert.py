@@ -27,7 +27,7 @@ def _host(batch):
 
 
 def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, out_dtype=torch.bfloat16,
-              layout='channels_first', extra_out=False, sample_every=7, episode_len=5):
+              layout='channels_first', extra_out=False, sample_every=7, episode_len=5, on_replay=None):
   """Device Driver + Replay next to the oracle Driver + Replay on the same
   envs, policy and seeds; `stack` = the policy builds its batch with
   ops.obs_stack (which takes up the Driver's offer).  Returns the replay, the
@@ -36,6 +36,8 @@ def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, 
   env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=episode_len, ring=4)
   rep = emb.Replay(length=length, capacity=capacity, chunksize=chunksize, online=online, seed=0)
   ref = np_oracle.Replay(length, capacity, chunksize, online, seed=0)
+  if on_replay:
+    on_replay(rep)
   hosts = [synthetic.HostSyntheticEnv(e, shape=shape, episode_len=episode_len) for e in range(n)]
   oracle = np_oracle.Driver(hosts)
   oracle.on_step(ref.add)
@@ -330,3 +332,31 @@ def test_sample_pool_can_be_switched_off(emb, monkeypatch):
     a, b = off.sample(5), on.sample(5)
     assert torch.equal(a['x'], b['x']) and torch.equal(a['stepid'], b['stepid'])
   assert not off._out_pool and on._out_pool
+
+
+def test_deferred_bookkeeping_with_readers_on_other_threads(emb):
+  """emb_replay_publish hands its index bookkeeping to the library's helper
+  thread (abi.cpp DeferGate); every later operation on the replay OR on its
+  selector handle waits for it first.  Two threads read the replay's and the
+  selector's length all the time while the loop runs: every length they see is
+  one the oracle passes through, and every sampled batch equals the oracle's."""
+  import threading
+  box, seen_lengths, stop = [], set(), threading.Event()
+
+  def reader(via_selector):
+    while not stop.is_set():
+      if box:
+        seen_lengths.add(len(box[0].sampler) if via_selector else len(box[0]))
+
+  threads = [threading.Thread(target=reader, args=(flag,), daemon=True) for flag in (False, True)]
+  [t.start() for t in threads]
+  try:
+    rep, ref, _ = _run_pair(emb, 16, (8, 8, 4), length=4, capacity=300, chunksize=8, steps=400,
+                            online=True, stack=True, sample_every=3, on_replay=box.append)
+  finally:
+    stop.set()
+    [t.join() for t in threads]
+  assert rep.early_inserts == 399
+  assert len(seen_lengths) > 3 and max(seen_lengths) <= 300
+  # lengths grow by whole steps of the 16 workers until the capacity is reached
+  assert all(x % 16 == 0 or x == 300 for x in seen_lengths), sorted(seen_lengths)[:20]

@@ -75,3 +75,14 @@ def test_parity_with_the_plain_python_modules():
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
+
+
+def test_early_insert_with_the_index_bookkeeping_on_the_calling_thread():
+  """EMB_DEFER_INDEX=0 (read once per process): emb_replay_publish does its index
+  bookkeeping itself instead of posting it to the helper thread."""
+  env = dict(os.environ, EMB_DEFER_INDEX='0')
+  res = subprocess.run(
+      [sys.executable, '-m', 'pytest', 'tests/test_gpu_early_insert.py', '-m', 'gpu', '-q', '-x'],
+      cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+  assert ' passed' in res.stdout
