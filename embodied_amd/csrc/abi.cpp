@@ -481,13 +481,13 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
   }
 
   // May this publish be deferred?  (caller holds the mutexes)  Only in a loop
-  // that publishes every few tens of microseconds: the helper polls between
+  // that publishes every few tens of microseconds (< ~80 us): the helper polls between
   // jobs, and a poll that lasts a 100 us step of host simulators takes a CPU
   // from them for a 3 us job (measured with 64 env processes: 490 -> 270-370 k).
   uint64_t last_publish = 0;
   bool allowed() {
     const uint64_t now = __builtin_ia32_rdtsc();
-    const bool quick = now - last_publish < 120000;      // ~40 us of a 3 GHz counter
+    const bool quick = now - last_publish < 250000;      // ~80 us of a 3 GHz counter
     last_publish = now;
     if (skip > 0) {
       --skip;
