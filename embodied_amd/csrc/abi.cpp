@@ -463,9 +463,13 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
     char path[128];
     cpu_set_t l3, siblings, allowed, want;
     std::snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
-    if (!read_cpu_list(path, &l3)) return;
     CPU_ZERO(&allowed);
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    if (!read_cpu_list(path, &l3) || sched_getaffinity(0, sizeof(allowed), &allowed) != 0) {
+      // no cache topology to go by: leave the helper to the scheduler, and do not ask again
+      for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &helper_cpus);
+      placed = true;
+      return;
+    }
     CPU_AND(&want, &l3, &allowed);
     helper_cpus = want;                  // (membership test above: includes the poster's own CPU)
     placed = true;
