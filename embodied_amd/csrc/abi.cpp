@@ -554,8 +554,8 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
     place_helper();
     if (++jobs >= 4096) {
       // more than ~2 us of waiting per job (6000 cycles of a 3 GHz counter):
-      // the next 2^17 publishes do their bookkeeping themselves, then try again
-      if (wait_cycles / jobs > 6000) skip = uint64_t{1} << 17;
+      // the next 2^15 publishes do their bookkeeping themselves, then try again
+      if (wait_cycles / jobs > 6000) skip = uint64_t{1} << 15;
       wait_cycles = jobs = 0;
     }
     ctx = c;
@@ -574,7 +574,9 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
       if (spins < 4000) __builtin_ia32_pause();
       else sched_yield();                // the helper may be waiting for this very CPU
     }
-    wait_cycles += __builtin_ia32_rdtsc() - began;
+    // (one long wait -- the helper lost its CPU for a time slice -- counts like a
+    // slow job, not like a thousand of them)
+    wait_cycles += std::min<uint64_t>(__builtin_ia32_rdtsc() - began, 24000);
     if (error) {
       std::exception_ptr e = error;
       error = nullptr;
