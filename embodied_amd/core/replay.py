@@ -1033,10 +1033,11 @@ class Replay:
 
   def profile_report(self, which='sample', reset=True):
     """(stamped launches, their total ms, kernel name) of the sample gathers or
-    of the `update` write-backs since the last reset."""
+    of the `update` write-backs since the last reset; 'deferred': how many
+    publishes handed their index bookkeeping to the library's helper thread."""
     launches, ms, name = C.c_int64(), C.c_double(), C.create_string_buffer(128)
     api.emb_replay_profile_report(
-        self._handle, {'sample': 0, 'update': 1}[which], C.byref(launches), C.byref(ms),
+        self._handle, {'sample': 0, 'update': 1, 'deferred': 2}[which], C.byref(launches), C.byref(ms),
         int(reset), name, len(name))
     return launches.value, ms.value, name.value.decode()
 

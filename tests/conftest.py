@@ -23,6 +23,10 @@ os.environ.setdefault('EMB_STRICT_SCRATCH', '1')   # this repo's own builds: no 
 # package's default (host memory, embodied_amd/__init__.py) has its own tests in
 # child processes (tests/test_gpu_host_kernargs.py).
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+# Tests step slowly (an oracle step between two device steps): let the publish
+# defer its index bookkeeping to the helper thread whatever the pace, so that the
+# suite runs that path (tests/test_gpu_host_kernargs.py covers EMB_DEFER_INDEX=0).
+os.environ.setdefault('EMB_DEFER_MAX_GAP_US', '1e9')
 _build.build(verbose=False)
 
 

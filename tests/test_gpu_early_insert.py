@@ -89,6 +89,11 @@ def test_early_insert_matches_oracle(emb, online, shape):
   rep, ref, seen = _run_pair(emb, n, shape, length=4, capacity=60, chunksize=8, steps=steps,
                              online=online, stack=True)
   assert rep.early_inserts == steps - 1       # the first step opens the workers' chunks
+  # ... and their publishes left the bookkeeping to the helper thread (conftest
+  # lifts the pace condition; EMB_DEFER_INDEX=0 runs in a child process)
+  import os
+  if os.environ.get('EMB_DEFER_INDEX') != '0':
+    assert rep.profile_report('deferred')[0] >= steps - 3      # (the first one has no pace yet)
   got, want = rep.stats(), ref.stats()
   for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
     assert got[k] == want[k], k
@@ -357,6 +362,33 @@ def test_deferred_bookkeeping_with_readers_on_other_threads(emb):
     stop.set()
     [t.join() for t in threads]
   assert rep.early_inserts == 399
+  import os
+  if os.environ.get('EMB_DEFER_INDEX') != '0':
+    # (the self-check may pause deferral when readers make every job a wait)
+    assert rep.profile_report('deferred')[0] > 50
   assert len(seen_lengths) > 3 and max(seen_lengths) <= 300
   # lengths grow by whole steps of the 16 workers until the capacity is reached
   assert all(x % 16 == 0 or x == 300 for x in seen_lengths), sorted(seen_lengths)[:20]
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_early_insert_random_configurations_against_oracle(emb, seed):
+  """Random replay geometry (length, capacity, chunk size, env count, episode
+  length, online queue, sampling cadence) through the early insert and the
+  deferred bookkeeping: every sampled batch, every length and the final
+  statistics equal the oracle's."""
+  rng = np.random.default_rng(1000 + seed)
+  n = int(rng.integers(2, 24))
+  length = int(rng.integers(1, 7))
+  chunksize = int(rng.integers(max(2, length // 2), 20))
+  capacity = int(rng.integers(max(n, 8), 400))
+  steps = int(rng.integers(40, 160))
+  shape = [(8, 8, 4), (4, 8, 2), (8, 4, 1), (4, 4, 4)][int(rng.integers(0, 4))]
+  rep, ref, _ = _run_pair(
+      emb, n, shape, length=length, capacity=capacity, chunksize=chunksize, steps=steps,
+      online=bool(rng.integers(0, 2)), stack=True, sample_every=int(rng.integers(1, 9)),
+      episode_len=int(rng.integers(2, 12)), extra_out=bool(rng.integers(0, 2)))
+  assert rep.early_inserts == steps - 1
+  got, want = rep.stats(), ref.stats()
+  for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
+    assert got[k] == want[k], (k, got[k], want[k])
