@@ -392,3 +392,41 @@ def test_early_insert_random_configurations_against_oracle(emb, seed):
   got, want = rep.stats(), ref.stats()
   for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
     assert got[k] == want[k], (k, got[k], want[k])
+
+
+def test_env_processes_forked_while_the_helper_thread_is_running(emb):
+  """A parallel host-env Driver is created (its env processes are forked) after
+  a device loop has started the library's helper thread: fork waits for the job
+  in flight, the children never wait for a helper they do not have, and both
+  loops go on with oracle parity."""
+  from embodied_amd.envs import synthetic
+  rep, ref, _ = _run_pair(emb, 8, (8, 8, 4), length=3, capacity=100, chunksize=8, steps=40,
+                          online=False, stack=True)
+  n, shape = 4, (8, 8, 4)
+  fns = [(lambda e=e: synthetic.HostSyntheticEnv(e, shape=shape, episode_len=6)) for e in range(n)]
+  driver = emb.Driver(fns, parallel=True, device='cuda')          # forks here
+  rep2 = emb.Replay(length=3, capacity=50, chunksize=8, seed=1)
+  ref2 = np_oracle.Replay(3, 50, 8, False, seed=1)
+  oracle = np_oracle.Driver([synthetic.HostSyntheticEnv(e, shape=shape, episode_len=6) for e in range(n)])
+  oracle.on_step(ref2.add)
+  driver.on_step(rep2.add)
+  tick = [0, 0]
+
+  def policy(carry, obs, **kw):
+    emb.ops.obs_stack(obs['image'], dtype=torch.float32)
+    tick[0] += 1
+    return carry, {'action': np.full(n, tick[0], np.int32)}, {}
+
+  def host_policy(carry, obs):
+    tick[1] += 1
+    return carry, {'action': np.full(n, tick[1], np.int32)}, {}
+
+  try:
+    driver.reset()
+    for t in range(20):
+      driver(policy, steps=n)
+      oracle.step(host_policy)
+    assert_same(_host(rep2.sample(4)), ref2.sample(4), 'forked driver')
+    assert_same(_host(rep.sample(4)), ref.sample(4), 'first replay after the fork')
+  finally:
+    driver.close()
