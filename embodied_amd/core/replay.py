@@ -596,13 +596,17 @@ class Replay:
       self._flush()
       stream = self._stream()
       out, ptrs = self._alloc_batch(batch, self.length)
-      first = (C.c_uint8 * (batch * _lib.STEPID_BYTES))()
+      # Host copy of stepid[:, 0] rides on the tensor object so `update` with
+      # the same tensor needs no device read-back (a sync).  A set that
+      # `_alloc_batch` hands out again (nobody holds its tensors any more) brings
+      # its buffer along.
+      sid = out['stepid']
+      first = sid.__dict__.get('_emb_first')
+      if first is None or len(first) != batch * _lib.STEPID_BYTES:
+        first = sid._emb_first = (C.c_uint8 * (batch * _lib.STEPID_BYTES))()
       fast.emb_replay_sample(
           self._h, batch, _lib.MODES[mode], ptrs, None, first, stream)
       self._reraise()
-      # Host copy of stepid[:, 0] rides on the tensor object so `update` with
-      # the same tensor needs no device read-back (a sync).
-      out['stepid']._emb_first = first
     return self._finish(out)
 
   def _alloc_batch(self, batch, length):

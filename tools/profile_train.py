@@ -16,11 +16,18 @@ stream = iter(emb.streams.Consec(emb.streams.Stateless(replay.sample, 16, 'train
                                  length=64, consec=1, prefix=1, strict=True, contiguous=True))
 value = torch.randn(16, 65, device=device)
 
-def timeit(name, fn, iters=2000):
+def timeit(name, fn, iters=2000, burst=8):
+  # Bursts of a few calls with the GPU drained in between (not timed): back to
+  # back, 11 us gathers fill the queue and the launch call then waits for the
+  # GPU -- that is back-pressure, not host cost (a train step comes every five
+  # env steps in the loop).
   for _ in range(50): fn()
-  torch.cuda.synchronize(); t0 = time.perf_counter()
-  for _ in range(iters): fn()
-  host = (time.perf_counter() - t0) / iters * 1e6
+  host = 0.0
+  for _ in range(iters // burst):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(burst): fn()
+    host += time.perf_counter() - t0
+  host = host / (iters // burst * burst) * 1e6
   torch.cuda.synchronize()
   print(f'{name:30s} host {host:7.2f} us', flush=True)
 
