@@ -417,7 +417,6 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
   std::mutex m;
   std::condition_variable cv;
   std::atomic<bool> sleeping{false};
-  std::atomic<bool> stop{false};
   uint64_t started_epoch = ~uint64_t{0};
   pthread_t helper{};
   cpu_set_t helper_cpus;                 // where the helper may run: the poster's L3 group
@@ -513,7 +512,7 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
     for (;;) {
       int spins = 0;
       while (g.state.load(std::memory_order_acquire) != 1 || g.fn == nullptr) {
-        if (g.stop.load(std::memory_order_relaxed) || self.use_count() == 1) return nullptr;
+        if (self.use_count() == 1) return nullptr;      // every replay / selector handle is gone
         if (++spins < 40000) {           // ~100 us of polling, then sleep
           __builtin_ia32_pause();
           continue;
@@ -521,7 +520,7 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
         std::unique_lock<std::mutex> lock(g.m);
         g.sleeping.store(true);
         g.cv.wait_for(lock, std::chrono::milliseconds(200), [&] {
-          return g.state.load() == 1 || g.stop.load();
+          return g.state.load() == 1;
         });
         g.sleeping.store(false);
         spins = 0;
