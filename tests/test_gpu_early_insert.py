@@ -430,3 +430,17 @@ def test_env_processes_forked_while_the_helper_thread_is_running(emb):
     assert_same(_host(rep.sample(4)), ref.sample(4), 'first replay after the fork')
   finally:
     driver.close()
+
+
+def test_soak_stepping_loop_with_sampler_threads():
+  """tools/soak_early_insert.py for a few seconds: the device Driver steps
+  through the early insert and the helper thread while two sampler threads draw
+  on their own streams; every sampled window must follow the env's generator."""
+  import pathlib
+  import subprocess
+  import sys
+  root = pathlib.Path(__file__).resolve().parent.parent
+  res = subprocess.run([sys.executable, str(root / 'tools' / 'soak_early_insert.py'), '--seconds', '4'],
+                       cwd=root, capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+  assert 'errors []' in res.stdout, res.stdout[-2000:]
