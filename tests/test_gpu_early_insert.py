@@ -27,7 +27,8 @@ def _host(batch):
 
 
 def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, out_dtype=torch.bfloat16,
-              layout='channels_first', extra_out=False, sample_every=7, episode_len=5, on_replay=None):
+              layout='channels_first', extra_out=False, sample_every=7, episode_len=5, on_replay=None,
+              block=1):
   """Device Driver + Replay next to the oracle Driver + Replay on the same
   envs, policy and seeds; `stack` = the policy builds its batch with
   ops.obs_stack (which takes up the Driver's offer).  Returns the replay, the
@@ -69,12 +70,15 @@ def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, 
     return carry, {'action': acts_at(t)}, outs
 
   driver.reset()
-  for t in range(steps):
-    driver(policy, steps=n)
-    oracle.step(host_policy)
+  # `block` steps per Driver call, nothing else touching the replay in between
+  # (the early inserts inside a block take their rows from the publish before them)
+  for t in range(0, steps, block):
+    driver(policy, steps=n * block)
+    for _ in range(block):
+      oracle.step(host_policy)
     assert len(rep) == len(ref), t
-    if len(ref) and t % sample_every == 0:
-      mode = 'train' if t % 2 else 'report'
+    if len(ref) and (t // block) % sample_every == 0:
+      mode = 'train' if (t // block) % 2 else 'report'
       assert_same(_host(rep.sample(3, mode)), ref.sample(3, mode), f'step {t}')
   return rep, ref, seen
 
@@ -444,3 +448,28 @@ def test_soak_stepping_loop_with_sampler_threads():
                        cwd=root, capture_output=True, text=True, timeout=300)
   assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
   assert 'errors []' in res.stdout, res.stdout[-2000:]
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_blocks_of_steps_per_driver_call(emb, seed):
+  """Several steps per Driver call with nothing else touching the replay in
+  between (publish -> next early insert back to back, the helper thread at the
+  bookkeeping meanwhile): small chunks, so that rotations fall inside blocks;
+  samples after every block equal the oracle's."""
+  import os
+  rng = np.random.default_rng(2000 + seed)
+  n = int(rng.integers(2, 20))
+  length = int(rng.integers(1, 6))
+  chunksize = int(rng.integers(max(3, length), 24))
+  block = int(rng.integers(3, 12))
+  steps = block * int(rng.integers(8, 20))
+  rep, ref, _ = _run_pair(
+      emb, n, (8, 8, 4), length=length, capacity=int(rng.integers(max(n, 8), 300)), chunksize=chunksize,
+      steps=steps, online=bool(rng.integers(0, 2)), stack=True, sample_every=int(rng.integers(1, 4)),
+      episode_len=int(rng.integers(2, 12)), block=block)
+  assert rep.early_inserts == steps - 1
+  if os.environ.get('EMB_DEFER_INDEX') != '0':
+    assert rep.profile_report('deferred')[0] >= steps - 3
+  got, want = rep.stats(), ref.stats()
+  for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
+    assert got[k] == want[k], (k, got[k], want[k])
