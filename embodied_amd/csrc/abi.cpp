@@ -1947,6 +1947,14 @@ struct Rccl {
 const Rccl& rccl() {
   static const Rccl table = [] {
     void* lib = nullptr;
+    // EMB_RCCL_LIB=<path>: bind the ten symbols below from that library and no
+    // other (a site's own RCCL build; the suite's loopback transport between
+    // processes that share one GPU, tests/fake_rccl/).  No fallback: a path
+    // that does not load is an error.
+    if (const char* chosen = std::getenv("EMB_RCCL_LIB"); chosen && *chosen) {
+      lib = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+      if (!lib) throw std::runtime_error(std::string("EMB_RCCL_LIB: cannot load ") + chosen + ": " + dlerror());
+    }
     for (const char* name : {"librccl.so.1", "librccl.so"})
       if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})

@@ -42,6 +42,46 @@ def test_bench_gpus_2_spawns_two_ranks():
   assert rec['replicas_only']['env_steps_per_s'] > 0 and rec['replicas_only']['steps'] % 256 == 0
 
 
+def test_bench_gpus_2_native_exchange_between_two_real_ranks():
+  """`--comm auto` with two ranks: the run-time self-check of the library's own
+  collective entry points (emb_comm_*) against torch.distributed passes between
+  two REAL ranks and the timed path then issues one emb_comm_exchange per train
+  step.  Transport: the suite's loopback stand-in for RCCL (RCCL itself refuses
+  two ranks on one GPU), selected with EMB_RCCL_LIB; process group: gloo."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('_fake_rccl_build', ROOT / 'tests' / 'fake_rccl' / 'build.py')
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  lib = str(mod.build())
+  rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
+                  env={'EMB_BENCH_BACKEND': 'gloo', 'EMB_RCCL_LIB': lib})
+  assert rec['n_gpus'] == 2 and rec['backend'] == 'gloo'
+  native = rec['native_comm']
+  assert native['status'] == 'ok' and native['ranks'] == 2 and all(native['checks'].values()), native
+  assert native['transport'] == lib
+  assert native['timed_path'] == 'native' and 'emb_comm_exchange' in rec['config']['parallelism']
+  assert rec['train_steps_per_s'] > 0 and rec['value'] > 0
+  exp = rec['expected']                         # DESIGN.md 5's link budget, printed with the line
+  assert exp['replicas_only_x'] == 2.0 and exp['links'] == 1
+  assert exp['link_time_us_at_60pct'] > exp['link_time_us_at_100pct'] > 0
+  assert 0 < exp['link_bound_x_at_60pct'] <= 2.0 and exp['measured_x']['value'] > 0
+
+
+def test_bench_gpus_8_control_flow():
+  """The driver's largest form, `python bench.py --gpus 8`: eight ranks start,
+  agree on their exchange schedule at every fence and rank 0 prints one line
+  (gloo: the eight ranks share the test box's one GPU)."""
+  rec = run_bench('--gpus', '8', '--steps', '20', '--warmup', '5', '--capacity', '6000',
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '10',
+                  env={'EMB_BENCH_BACKEND': 'gloo'})
+  assert rec['n_gpus'] == 8 and rec['rccl_ranks'] == 8 and rec['backend'] == 'gloo'
+  assert rec['config']['global_envs'] == 8 * rec['config']['envs_per_gpu']
+  assert rec['scaling'] == 'weak' and rec['value'] > 0 and rec['train_steps_per_s'] > 0
+  assert rec['replicas_only']['env_steps_per_s'] > 0
+  assert rec['expected']['replicas_only_x'] == 8.0 and rec['expected']['links'] == 7
+
+
 def test_bench_dreamer_workload_with_ranks():
   """configs[3]'s shape of parallelism: per-rank Replay (sample, lambda-return,
   latent write-back) and one gradient all-reduce per train step."""
