@@ -302,9 +302,15 @@ def main():
 
   emb, env, replay, driver, policy = build_path(args, rank, device)
   B, T, L = args.batch, args.length, args.consec * args.length + args.context
+  # The learner lends nothing out: a batch is consumed inside its train step, so
+  # the stream takes every batch back one draw later (two output sets circulate
+  # instead of seven fresh tensors per sample), and the GAE results go into two
+  # agent-owned pairs used in turn -- explicit reuse, no liveness guessing.
   stream = iter(emb.streams.Consec(
-      emb.streams.Stateless(replay.sample, B * args.prefetch, 'train'),
+      emb.streams.Stateless(replay.sample, B * args.prefetch, 'train', recycle=1),
       length=T, consec=args.consec, prefix=args.context, strict=True, contiguous=True))
+  gae_out = [tuple(torch.empty(B * args.prefetch, T + args.context - 1, device=device) for _ in range(2))
+             for _ in range(2)]
   should_train = Ratio(args.train_ratio / (B * T))
   value = torch.randn(B * args.prefetch, T + args.context, device=device)
   imag_rew = torch.randn(B * T, 16, device=device)
@@ -346,7 +352,8 @@ def main():
     elif not use_dist or not collectives['on']:
       batch = next(stream)
       adv, tar = emb.scans.gae(
-          batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
+          batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8,
+          out=gae_out[(counters['train_steps'] // args.prefetch) & 1])
     else:
       # Sample straight into one packed buffer so the trajectory exchange is a
       # single RCCL all-gather; both collectives run async on RCCL's stream and

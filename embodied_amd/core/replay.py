@@ -46,9 +46,18 @@ _DTYPE_CODE = {
 }
 
 
-# Holders of a tensor's storage (tensors, views, storage handles): lets `sample`
-# prove that nobody can see an output set any more before it is used again.
+# Holders of a tensor's storage (tensors, views, storage handles): with
+# EMB_SAMPLE_POOL=1 `sample` uses them to prove that nobody can see an output set
+# any more before it is used again (opt-in; the explicit form is `recycle`).
 _STORAGE_USE_COUNT = getattr(torch._C, '_storage_Use_Count', None)
+
+
+class Batch(dict):
+  """A sampled batch: a dict name -> (batch, length, ...) tensor that remembers
+  the addresses, shape and stream it was gathered with, so that
+  `Replay.recycle(batch)` / `Replay.sample(..., out=batch)` cost no per-key
+  checks.  Behaves like the plain dict the reference returns."""
+  __slots__ = ('_emb_ptrs', '_emb_shape', '_emb_stream', '_emb_owner')
 
 
 def _itemsize(dtype):
@@ -146,8 +155,17 @@ class Replay:
     self._add_plan = None
     self._stage_busy, self._stage_pending = None, False
     self._rowbytes_total = None
-    self._out_pool = {} if (_STORAGE_USE_COUNT is not None and hasattr(torch.Tensor, '_use_count')
-                            and os.environ.get('EMB_SAMPLE_POOL') != '0') else None
+    # Output sets handed back with `recycle` (explicit) and, opt-in, the pool that
+    # finds unreferenced sets itself (EMB_SAMPLE_POOL=1, see _alloc_batch).
+    self._free = {}
+    self._out_pool = None
+    if os.environ.get('EMB_SAMPLE_POOL') == '1':
+      if _STORAGE_USE_COUNT is None or not hasattr(torch.Tensor, '_use_count'):
+        raise RuntimeError(
+            'EMB_SAMPLE_POOL=1 needs torch._C._storage_Use_Count and Tensor._use_count, which this '
+            f'torch ({torch.__version__}) does not have: use Replay.recycle / streams.Stateless('
+            'recycle=K) instead')
+      self._out_pool = {}
     self._nonempty = False
     self._pool_bytes = 0
     probe = [object()]
@@ -581,9 +599,14 @@ class Replay:
 
   # ----------------------------------------------------------------- sample --
 
-  def sample(self, batch, mode='train'):
+  def sample(self, batch, mode='train', out=None):
     """`batch` sequences of `length` steps -> dict of (batch, length, ...)
-    (replay.py:121-127): index draws on the host, one gather launch."""
+    (replay.py:121-127): index draws on the host, one gather launch.
+
+    The returned tensors are the caller's, like the reference's fresh arrays.
+    `out=` gathers into tensors the caller already owns instead (a batch an
+    earlier `sample` returned, or any dict with this replay's keys as contiguous
+    (batch, length, *shape) tensors on its device)."""
     assert mode in _lib.MODES, mode
     if not self._nonempty:
       # (items only leave when a new one pushes them out at capacity: a sampler
@@ -595,11 +618,13 @@ class Replay:
     with self._lock:
       self._flush()
       stream = self._stream()
-      out, ptrs = self._alloc_batch(batch, self.length)
+      if out is None:
+        out, ptrs = self._alloc_batch(batch, self.length)
+      else:
+        out, ptrs = self._adopt(out, batch, self.length)
       # Host copy of stepid[:, 0] rides on the tensor object so `update` with
-      # the same tensor needs no device read-back (a sync).  A set that
-      # `_alloc_batch` hands out again (nobody holds its tensors any more) brings
-      # its buffer along.
+      # the same tensor needs no device read-back (a sync).  A set that is used
+      # again (recycled, `out=`) brings its buffer along.
       sid = out['stepid']
       first = sid.__dict__.get('_emb_first')
       if first is None or len(first) != batch * _lib.STEPID_BYTES:
@@ -609,30 +634,71 @@ class Replay:
       self._reraise()
     return self._finish(out)
 
+  def recycle(self, batch):
+    """Hand a sampled batch back: its tensors become the output of a later
+    `sample` / `gather` of the same shape instead of a fresh allocation (seven
+    `torch.empty` per batch are ~9 us of host time).  A promise by the caller:
+    nothing reads these tensors any more, except work already queued on the
+    stream the batch was sampled on (the next gather is ordered behind it, as
+    with the caching allocator handing a freed block out again).  A consumer
+    that read the batch on ANOTHER stream orders that stream first.
+    `streams.Stateless(replay.sample, B, recycle=K)` does this for batches that
+    are K draws old."""
+    if type(batch) is not Batch or batch._emb_owner is not self._offer_tag:
+      raise TypeError('Replay.recycle takes a batch that this replay\'s sample() / gather() returned')
+    sets = self._free.setdefault(batch._emb_shape, [])
+    if len(sets) < 8 and all(b is not batch for b in sets):
+      sets.append(batch)
+
+  def _adopt(self, out, batch, length):
+    """`out=`: a Batch of this replay with the right shape is taken as is;
+    anything else is checked key by key."""
+    if type(out) is Batch and out._emb_owner is self._offer_tag and out._emb_shape == (batch, length):
+      out._emb_stream = self._last_stream
+      return out, out._emb_ptrs
+    if self._keys is None or set(out) != {k.name for k in self._keys}:
+      raise KeyError(f'sample(out=): keys {sorted(out)} are not this replay\'s')
+    ptrs = (C.c_void_p * len(self._keys))()
+    for i, key in enumerate(self._keys):
+      tensor = out[key.name]
+      want = (batch, length, *key.shape)
+      if (not torch.is_tensor(tensor) or tensor.dtype != key.dtype or tuple(tensor.shape) != want
+          or tensor.device != self.device or not tensor.is_contiguous()):
+        raise ValueError(f'sample(out=): {key.name!r} must be a contiguous {key.dtype} tensor of shape '
+                         f'{want} on {self.device}')
+      ptrs[i] = tensor.data_ptr()
+    adopted = Batch((k.name, out[k.name]) for k in self._keys)
+    adopted._emb_ptrs, adopted._emb_shape = ptrs, (batch, length)
+    adopted._emb_stream, adopted._emb_owner = self._last_stream, self._offer_tag
+    return adopted, ptrs
+
   def _alloc_batch(self, batch, length):
-    """Output tensors for one sampled batch: (dict name -> tensor, ctypes array
+    """Output tensors for one sampled batch: (Batch name -> tensor, ctypes array
     of their addresses).  `sample` returns tensors the caller owns, like the
-    reference's fresh arrays (replay.py:255-275) -- but seven `torch.empty` per
-    batch are ~9 us of host time, so sets whose tensors NOBODY references any
-    more are used again: a set goes back into rotation only when every tensor's
-    Python reference count and every storage's use count say that this pool is
-    the only holder (a view, a detach(), a tensor kept in a list all keep the
-    set out; so does a tensor handed to another framework through DLPack: that
-    consumer owns the tensor in C++, `Tensor._use_count()`), which no caller can
-    tell from a fresh allocation.  Work queued on
-    the same stream is ordered before the next gather as it would be with the
-    caching allocator handing the block out again; sets are never shared across
-    streams.  One thing differs from fresh allocations: `Tensor.record_stream`
-    defers the allocator's reuse of a block, not this pool's -- a consumer that
-    reads a batch on a side stream and drops it before that work is ordered
-    after the sampling stream should hold on to the batch until then, or run
-    with EMB_SAMPLE_POOL=0 (every sample allocates)."""
+    reference's fresh arrays (replay.py:255-275): fresh allocations, unless
+
+    * the caller handed sets back (`recycle`) -- taken first, same stream only;
+    * `Replay(reuse_outputs=K)` rotates K sets;
+    * EMB_SAMPLE_POOL=1 (opt-in): sets whose tensors NOBODY references any more
+      are found by their Python reference counts, storage use counts and
+      `Tensor._use_count()` (private torch internals, checked by
+      tests/test_gpu_output_pool.py) and used again -- indistinguishable from a
+      fresh allocation for a caller that stays on one stream, but
+      `Tensor.record_stream` defers only the allocator's reuse of a block, not
+      this pool's: a consumer that reads a batch on a side stream and drops it
+      before that work is ordered after the sampling stream must not use it."""
     if self._reuse:
       return self._alloc_batch_now(batch, length)
+    stream = self._last_stream
+    sets = self._free.get((batch, length))
+    if sets:
+      for i in range(len(sets) - 1, -1, -1):
+        if sets[i]._emb_stream == stream:
+          out = sets.pop(i)
+          return out, out._emb_ptrs
     pool = self._out_pool
     if pool is None or self._multistream:
       return self._new_batch(batch, length)
-    stream = self._last_stream
     sets = pool.get((batch, length))
     if sets is None:
       sets = pool[(batch, length)] = []
@@ -648,11 +714,10 @@ class Replay:
         if refs(tensors[i]) != held or uses(cdata[i]) != 2 or tensors[i]._use_count() != 1:
           break
       else:
-        return dict(zip(self._key_names, tensors)), ptrs
+        return self._as_batch(tensors, ptrs, batch, length), ptrs
     out, ptrs = self._new_batch(batch, length)
     if self._rowbytes_total is None:
       self._rowbytes_total = sum(k.rowbytes for k in self._keys)
-      self._key_names = [k.name for k in self._keys]
     nbytes = batch * length * self._rowbytes_total
     if len(sets) < 4 and self._pool_bytes + nbytes <= 2 << 30:
       tensors = list(out.values())
@@ -663,13 +728,19 @@ class Replay:
         sets.append((tensors, cdata, ptrs, stream, stores))
     return out, ptrs
 
+  def _as_batch(self, tensors, ptrs, batch, length):
+    out = Batch(zip(self._key_names, tensors))
+    out._emb_ptrs, out._emb_shape = ptrs, (batch, length)
+    out._emb_stream, out._emb_owner = self._last_stream, self._offer_tag
+    return out
+
   def _alloc_batch_now(self, batch, length):
     ring = self._out_ring.setdefault((batch, length), [[], 0])
     if len(ring[0]) < self._reuse:
       ring[0].append(self._new_batch(batch, length))
     out, ptrs = ring[0][ring[1] % len(ring[0])]
     ring[1] += 1
-    return dict(out), ptrs
+    return self._as_batch(list(out.values()), ptrs, batch, length), ptrs
 
   def _new_batch(self, batch, length):
     # torch.empty_like on a zero-stride, one-element template is about twice as
@@ -680,10 +751,13 @@ class Replay:
       templates = self._templates[(batch, length)] = [
           torch.empty(1, dtype=key.dtype, device=self.device).expand(
               batch, length, *key.shape) for key in self._keys]
-    out, ptrs = {}, (C.c_void_p * len(self._keys))()
+      self._key_names = [k.name for k in self._keys]
+    out, ptrs = Batch(), (C.c_void_p * len(self._keys))()
     for i, key in enumerate(self._keys):
       tensor = out[key.name] = torch.empty_like(templates[i])
       ptrs[i] = tensor.data_ptr()
+    out._emb_ptrs, out._emb_shape = ptrs, (batch, length)
+    out._emb_stream, out._emb_owner = self._last_stream, self._offer_tag
     return out, ptrs
 
   def _finish(self, out):

@@ -20,20 +20,43 @@ from . import base
 class Stateless(base.Stream):
   """An endless stream that calls `fn(*args, **kwargs)` for every batch; an
   iterator may be given instead of a function (streams.py:12-29).  It carries
-  no state of its own: `save()` is None and `load` ignores its argument."""
+  no state of its own: `save()` is None and `load` ignores its argument.
 
-  def __init__(self, fn, *args, **kwargs):
+  `recycle=K` (this package's `Replay.sample` only; not in the reference, whose
+  batches are fresh arrays): the stream lends its batches instead of giving them
+  away -- a batch belongs to the stream again once K further batches have been
+  drawn and is then handed back to the replay (`Replay.recycle`), which gathers
+  a later batch into the same tensors instead of allocating seven new ones.  The
+  consumer of such a stream keeps no batch (and no view of one) for longer than
+  K draws, and reads it on the stream it was sampled on."""
+
+  def __init__(self, fn, *args, recycle=0, **kwargs):
     if not callable(fn):
       if not hasattr(fn, '__next__'):
         raise TypeError(f'Stateless needs a callable or an iterator, got {type(fn).__name__}')
       fn = fn.__next__
     self.fn, self.args, self.kwargs = fn, args, kwargs
+    self.recycle = int(recycle)
+    self._lent = collections.deque()
+    self._give_back = None
+    if self.recycle:
+      owner = getattr(fn, '__self__', None)
+      self._give_back = getattr(owner, 'recycle', None)
+      if self.recycle < 0 or self._give_back is None or getattr(fn, '__name__', '') != 'sample':
+        raise TypeError('Stateless(recycle=K) needs K >= 1 and a Replay.sample of this package as `fn`')
 
   def __iter__(self):
     return self
 
   def __next__(self):
-    return self.fn(*self.args, **self.kwargs)
+    if not self.recycle:
+      return self.fn(*self.args, **self.kwargs)
+    lent = self._lent
+    if len(lent) > self.recycle:
+      self._give_back(lent.popleft())
+    batch = self.fn(*self.args, **self.kwargs)
+    lent.append(batch)
+    return batch
 
   def save(self):
     return None
@@ -222,8 +245,17 @@ class Prefetch(base.Stream):
   """
 
   def __init__(self, source, transform=None, amount=1):
-    self.source = iter(source) if hasattr(source, '__iter__') else source()
     self.amount = int(amount)
+    # A source that lends its batches (Stateless(recycle=K)) takes one back K
+    # draws later; this stream holds `amount` batches ready and the consumer one
+    # more while the producer draws the next.
+    inner = source
+    while inner is not None and not isinstance(inner, Stateless):
+      inner = getattr(inner, 'source', None)
+    if inner is not None and 0 < inner.recycle < self.amount + 2:
+      raise ValueError(f'Prefetch(amount={self.amount}) over Stateless(recycle={inner.recycle}): '
+                       f'needs recycle >= amount + 2 = {self.amount + 2}')
+    self.source = iter(source) if hasattr(source, '__iter__') else source()
     self._transform = transform
     self._state = self._snapshot()
     self._cond = threading.Condition()

@@ -4,6 +4,7 @@
 
 Inputs are torch CUDA tensors; bool flags may be torch.bool or uint8.
 """
+import os
 import sys
 
 import numpy as np
@@ -93,6 +94,12 @@ def _device(*xs):
 
 _PAIRS = {}
 _STORAGE_USE_COUNT = getattr(torch._C, '_storage_Use_Count', None)
+# Opt-in (EMB_SAMPLE_POOL=1, as for Replay.sample): result pairs that nobody
+# references any more are found through private torch internals and used again.
+# The explicit form is `gae(..., out=(adv, tar))`.
+_POOL = os.environ.get('EMB_SAMPLE_POOL') == '1'
+if _POOL and (_STORAGE_USE_COUNT is None or not hasattr(torch.Tensor, '_use_count')):
+  raise RuntimeError('EMB_SAMPLE_POOL=1 needs torch._C._storage_Use_Count and Tensor._use_count')
 _PROBE = [object()]
 _HELD = sys.getrefcount(_PROBE[0])
 
@@ -103,7 +110,7 @@ def _pair(B, n, dev):
   the storage, C++ owners of the views such as a DLPack consumer) are handed out again instead of allocating: to the caller they
   are indistinguishable from new tensors, and the host saves the allocation and
   the two view constructions (~3 us of a ~6 us call)."""
-  if _STORAGE_USE_COUNT is None or not hasattr(torch.Tensor, '_use_count'):
+  if not _POOL:
     return _lib.empty((2, B, n), torch.float32, dev).unbind(0)
   key = (B, n, dev, _lib.raw_stream(dev))
   sets = _PAIRS.get(key)
@@ -126,15 +133,22 @@ def _pair(B, n, dev):
   return adv, tar
 
 
-def gae(rew, val, last, term, hor=200, lam=0.8):
+def gae(rew, val, last, term, hor=200, lam=0.8, out=None):
   """adv_t = delta_t + live_t*cont_t*adv_{t+1}; tar = adv + val[:, :-1].
-  rew, val (B,T) f32; last, term (B,T) bool -> adv, tar (B,T-1)."""
+  rew, val (B,T) f32; last, term (B,T) bool -> adv, tar (B,T-1).
+  `out=(adv, tar)`: write into the caller's contiguous float32 (B,T-1) tensors."""
   dev = _device(rew, val, last, term)
   rew, val = _f32(rew, dev), _f32(val, dev)
   last, term = _flag(last, dev), _flag(term, dev)
   B, T = rew.shape
   assert val.shape == last.shape == term.shape == (B, T)
-  if B * T <= 1 << 20:
+  if out is not None:
+    adv, tar = out
+    for result in (adv, tar):
+      if (result.dtype != torch.float32 or tuple(result.shape) != (B, T - 1) or result.device != dev
+          or not result.is_contiguous()):
+        raise ValueError(f'gae(out=): needs contiguous float32 {(B, T - 1)} tensors on {dev}')
+  elif B * T <= 1 << 20:
     adv, tar = _pair(B, T - 1, dev)                         # one allocation, two views
   else:       # bandwidth-bound sizes: two write streams a power-of-two-ish distance apart
     adv = _lib.empty((B, T - 1), torch.float32, dev)        # collide on HBM channels (-19 %)

@@ -279,70 +279,6 @@ def test_early_insert_with_host_envs(emb, parallel):
     driver.close()
 
 
-def test_reused_output_sets_do_not_leak_state(emb):
-  """`sample` hands an output set out again once nobody references it.  Held
-  batches, views and detached tensors keep their set out of rotation; a reused
-  'stepid' tensor never carries the first-step ids of an older batch into
-  `update`."""
-  rep = emb.Replay(length=4, capacity=200, chunksize=16, seed=0)
-  for t in range(60):
-    rep.add({'x': np.float32(t), 'is_first': t == 0, 'is_last': False}, 0)
-  # batches dropped at once are served from ONE set: nothing is allocated after the first
-  made, plain = [0], rep._new_batch
-  def counting(*a):
-    made[0] += 1
-    return plain(*a)
-  rep._new_batch = counting
-  for _ in range(10):
-    rep.sample(5)
-  assert made[0] == 1, made
-  del rep._new_batch
-  held = rep.sample(5)
-  snapshot = {k: v.clone() for k, v in held.items()}
-  view = rep.sample(5)['x'][:, :2]              # only a view survives
-  view_copy = view.clone()
-  detached = rep.sample(5)['x'].detach()        # only a detached alias survives
-  detached_copy = detached.clone()
-  leaving = rep.sample(5)['x']                  # only an unconsumed DLPack capsule survives
-  exported_copy, exported_ptr = leaving.clone(), leaving.data_ptr()
-  capsule = leaving.__dlpack__()
-  del leaving
-  ptrs = set()
-  for _ in range(12):                           # dropped at once: these may share storage
-    ptrs.add(rep.sample(5)['x'].data_ptr())
-  assert len(ptrs) <= 4
-  assert exported_ptr not in ptrs
-  assert torch.equal(torch.from_dlpack(capsule), exported_copy)
-  for k, v in held.items():
-    assert torch.equal(v, snapshot[k]), k
-  assert torch.equal(view, view_copy) and torch.equal(detached, detached_copy)
-  assert held['x'].data_ptr() not in ptrs and view.data_ptr() not in ptrs
-  # gather() through a reused set, then update(): rows come from THIS batch's ids
-  rows, _ = rep.sample_index(5)
-  batch = rep.gather(rows)
-  assert getattr(batch['stepid'], '_emb_first', None) is None
-  rep.update({'stepid': batch['stepid'], 'x': torch.full_like(batch['x'], -7.0)})
-  again = rep.gather(rows)
-  assert (again['x'] == -7.0).all()
-
-
-def test_sample_pool_can_be_switched_off(emb, monkeypatch):
-  """EMB_SAMPLE_POOL=0: every `sample` allocates (for consumers that keep a
-  dropped batch alive for a side stream with `record_stream`)."""
-  monkeypatch.setenv('EMB_SAMPLE_POOL', '0')
-  off = emb.Replay(length=4, capacity=200, chunksize=16, seed=0)
-  monkeypatch.delenv('EMB_SAMPLE_POOL')
-  on = emb.Replay(length=4, capacity=200, chunksize=16, seed=0)
-  for rep in (off, on):
-    for t in range(40):
-      rep.add({'x': np.float32(t), 'is_first': t == 0, 'is_last': False}, 0)
-  assert off._out_pool is None and on._out_pool is not None
-  for _ in range(6):
-    a, b = off.sample(5), on.sample(5)
-    assert torch.equal(a['x'], b['x']) and torch.equal(a['stepid'], b['stepid'])
-  assert not off._out_pool and on._out_pool
-
-
 def test_deferred_bookkeeping_with_readers_on_other_threads(emb):
   """emb_replay_publish hands its index bookkeeping to the library's helper
   thread (abi.cpp DeferGate); every later operation on the replay OR on its

@@ -1,6 +1,10 @@
-"""The movers' indirect-argument kernels: a process that keeps kernel arguments
-in host memory (HIP_FORCE_DEV_KERNARG=0) must produce the same bytes.  The
-setting is read at HIP start-up, so the parity cases run in a child process."""
+"""Process-wide settings that are read once, each in a child process.  The suite
+itself runs on the package's defaults (kernel arguments in host memory, the
+movers' indirect-argument kernels, index bookkeeping on the helper thread); the
+children cover the other choices: the HIP runtime's own argument placement
+(HIP_FORCE_DEV_KERNARG=1), the flat mover only, the argument-writer kernel, the
+plain Python modules, bookkeeping on the calling thread, the helper thread's
+default pace rule."""
 import os
 import pathlib
 import subprocess
@@ -12,8 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
-def test_parity_with_kernel_arguments_in_host_memory():
-  env = dict(os.environ, HIP_FORCE_DEV_KERNARG='0')
+def test_parity_with_kernel_arguments_in_device_memory():
+  """HIP_FORCE_DEV_KERNARG=1 (the runtime's default, read at HIP start-up): the
+  movers take their by-value argument blocks, inserts carry completion stamps."""
+  env = dict(os.environ, HIP_FORCE_DEV_KERNARG='1')
   res = subprocess.run(
       [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', 'tests/test_gpu_early_insert.py',
        '-m', 'gpu', '-q', '-x',
@@ -86,3 +92,45 @@ def test_early_insert_with_the_index_bookkeeping_on_the_calling_thread():
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
+
+
+def test_helper_thread_pace_rule_at_its_default():
+  """Without EMB_DEFER_MAX_GAP_US (conftest lifts it for the suite) only a loop
+  that publishes every < ~80 us hands its index bookkeeping to the helper
+  thread: a tight stepping loop does, a loop that pauses 2 ms per step does
+  not -- and both leave the replay the oracle expects (the early-insert parity
+  case of the suite, at the default gate)."""
+  env = {k: v for k, v in os.environ.items() if k != 'EMB_DEFER_MAX_GAP_US'}
+  code = '''
+import time, torch
+import embodied_amd as emb
+from embodied_amd.envs import synthetic
+def run(pause, steps=300):
+  n = 8
+  env = synthetic.SyntheticBatchEnv(n, shape=(8, 8, 4), episode_len=50, ring=4)
+  rep = emb.Replay(length=3, capacity=4000, chunksize=64, online=True, seed=0)
+  drv = emb.Driver(batch_env=env, device='cuda')
+  drv.on_step(rep.add)
+  act = {'action': torch.zeros(n, dtype=torch.int32, device='cuda')}
+  def policy(carry, obs, **kw):
+    emb.ops.obs_stack(obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+    return carry, act, {}
+  drv.reset()
+  for _ in range(steps):
+    drv(policy, steps=n)
+    if pause:
+      time.sleep(pause)
+  torch.cuda.synchronize()
+  return rep.early_inserts, rep.profile_report('deferred')[0], len(rep)
+fast = run(0)
+slow = run(0.002)
+print('RESULT', fast, slow)
+assert fast[0] >= 298 and slow[0] >= 298, (fast, slow)      # the early insert ran either way
+assert fast[1] >= 250, fast                                 # tight loop: deferred
+assert slow[1] <= 3, slow                                   # 2 ms between publishes: not deferred
+assert fast[2] == slow[2], (fast, slow)
+'''
+  res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+  assert 'RESULT' in res.stdout
