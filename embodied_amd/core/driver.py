@@ -16,6 +16,17 @@ Three ways to run the same loop:
 Callbacks registered with `on_step(fn)` keep the reference contract
 `fn(tran, worker, **kwargs)` per env in order; `on_batch(fn)` receives the
 stacked transition once per step.
+
+Lifetime of a step's tensors in device mode.  The reference stacks fresh arrays
+every step (driver.py:65), and so does this Driver whenever user code can see
+them: with `on_step` / `on_batch` callbacks registered, every transition is made
+of tensors that are never written again.  Only when the step's sole consumer is
+this package's `Replay.add` (which copies the step into its pool before the next
+one) do observations of env processes and masked actions rotate through FOUR
+sets of device buffers: a policy that keeps `obs` (or a reader of
+`driver.acts`) then sees them overwritten four steps later.
+`Driver(..., fresh_obs=True)` (or EMB_FRESH_OBS=1) switches the rotation off;
+a device vector env (`batch_env=`) owns its outputs and states its own rule.
 """
 import multiprocessing as mp
 import os
@@ -66,8 +77,11 @@ def mask_actions(value, is_last):
 class Driver:
 
   def __init__(self, make_env_fns=None, parallel=True, device=None,
-               batch_env=None, shared_obs=True, **kwargs):
+               batch_env=None, shared_obs=True, fresh_obs=None, **kwargs):
     self.kwargs = kwargs
+    if fresh_obs is None and os.environ.get('EMB_FRESH_OBS') == '1':
+      fresh_obs = True
+    self._fresh_obs = fresh_obs
     self.device = torch.device(device) if device is not None else None
     if self.device is not None and self.device.type == 'cuda' and self.device.index is None:
       self.device = torch.device('cuda', torch.cuda.current_device())
@@ -160,8 +174,9 @@ class Driver:
       whole = torch.from_numpy(np.ndarray(total, np.uint8, buffer=block.buf))
       if torch.cuda.cudart().cudaHostRegister(whole.data_ptr(), total, 0) == 0:
         self._registered = getattr(self, '_registered', []) + [whole.data_ptr()]
-      # Four device copies used in turn (like a vector env's own output ring):
-      # the tensors of a step are overwritten four steps later.
+      # Four device copies used in turn (like a vector env's own output ring)
+      # while nobody but the Replay sink sees them (`_rotate`); fresh ones otherwise.
+      self._upload_layout = layout
       self._upload_src = whole
       self._upload_ring, self._upload_turn = [], 0
       for _ in range(4):
@@ -240,6 +255,15 @@ class Driver:
     else:
       self.callbacks.append(callback)
       self._sinks.append(None)
+
+  def _rotate(self):
+    """May this step's tensors come from the rotating buffers?  Only while the
+    one consumer of a step is a Replay.add sink (it copies the step into its
+    pool before the next one): user callbacks may keep what they are given, as
+    they may with the reference's freshly stacked arrays."""
+    if self._fresh_obs is not None:
+      return not self._fresh_obs
+    return len(self._sinks) == 1 and self._sinks[0] is not None and not self.callbacks
 
   def on_batch(self, callback):
     """fn(trans, workers, **kwargs) once per step with (N, ...) values."""
@@ -354,14 +378,18 @@ class Driver:
     acts = {k: self._to_device(v) for k, v in acts.items()}
     if sink is not None:
       # (The masked actions rotate through four sets of buffers, like a vector
-      # env's own outputs: a set is overwritten four steps later.)
+      # env's own outputs: a set is overwritten four steps later.  The sink is the
+      # step's only consumer; `fresh_obs=True` gives `driver.acts` fresh tensors.)
       names = tuple(acts)
-      ring = self._mask_ring
-      if ring is None or ring[0] != names:
-        ring = self._mask_ring = (names, [{} for _ in range(4)], [0])
-      ring[2][0] = turn = (ring[2][0] + 1) & 3
-      acts = sink.add_batch(
-          {**obs, **acts, **outs}, self._workers, mask=(names, is_last, ring[1][turn]))
+      if self._fresh_obs:
+        mask = (names, is_last)
+      else:
+        ring = self._mask_ring
+        if ring is None or ring[0] != names:
+          ring = self._mask_ring = (names, [{} for _ in range(4)], [0])
+        ring[2][0] = turn = (ring[2][0] + 1) & 3
+        mask = (names, is_last, ring[1][turn])
+      acts = sink.add_batch({**obs, **acts, **outs}, self._workers, mask=mask)
       self.acts = {**acts, 'reset': is_last}
     else:
       acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
@@ -441,9 +469,16 @@ class Driver:
       for k in ('is_first', 'is_last', 'is_terminal'):
         if k in shared:
           self._host_flags[k] = shared[k][1].copy()
-      # the whole observation slab in one copy, into the next device buffer of the ring
-      self._upload_turn = (self._upload_turn + 1) & 3
-      dev, views = self._upload_ring[self._upload_turn]
+      # the whole observation slab in one copy: into the next device buffer of
+      # the ring, or into a fresh one when user callbacks see the tensors
+      if self._rotate():
+        self._upload_turn = (self._upload_turn + 1) & 3
+        dev, views = self._upload_ring[self._upload_turn]
+      else:
+        dev = torch.empty(self._upload_src.numel(), dtype=torch.uint8, device=self.device)
+        views = {}
+        for key, (_, shape, dtype, at, nbytes) in self._upload_layout.items():
+          views[key] = dev[at: at + nbytes].view(replaylib._TORCH_OF[np.dtype(dtype)]).view(self.length, *shape)
       dev.copy_(self._upload_src, non_blocking=True)
       out.update(views)
     for k in keys:

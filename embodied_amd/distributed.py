@@ -232,20 +232,20 @@ def async_all_gather(out, tensor):
     return dist.all_gather_into_tensor(out, tensor, async_op=True)
 
 
-def async_all_reduce(tensor):
+def async_all_reduce(tensor, group=None):
   """Async in-place sum over ranks; returns a Work handle."""
-  pg = _default_pg()
+  pg = group or _default_pg()
   try:
     return pg.allreduce([tensor])
   except AttributeError:
     return dist.all_reduce(tensor, async_op=True)
 
 
-def async_all_to_all(out, tensor):
+def async_all_to_all(out, tensor, group=None):
   """Async equal-split all-to-all: block d of `tensor` goes to rank d, block s
   of `out` comes from rank s.  Returns a Work handle (`.wait()`)."""
-  pg = _default_pg()
-  if dist.get_backend() == 'gloo' and tensor.is_cuda:
+  pg = group or _default_pg()
+  if dist.get_backend(group) == 'gloo' and tensor.is_cuda:
     # gloo moves host memory only (test transport: the multi-rank control flow
     # on a box with fewer GPUs than ranks); RCCL takes the device buffers as is.
     host_in, host_out = tensor.cpu(), torch.empty(out.shape, dtype=out.dtype)
@@ -620,9 +620,12 @@ class Normalize:
       self._update('corr', 1.0, x)
 
   def stats(self, like=None):
-    like = like if like is not None else next(iter(self.state.values()))
     if self.impl == 'none':
       return 0.0, 1.0
+    if like is None:        # the device of the running statistics; before the first update: the default
+      like = next(iter(self.state.values()), None)
+      if like is None:
+        like = torch.zeros((), device='cuda' if torch.cuda.is_available() else 'cpu')
     corr = 1.0
     if self.debias:
       corr = 1.0 / torch.clamp(self._var('corr', like), min=self.rate)
@@ -656,7 +659,7 @@ class GroupComm:
       if self.world == 1:
         received.copy_(slices)
       else:
-        self._pending.append(async_all_to_all(received, slices))
+        self._pending.append(async_all_to_all(received, slices, self.group))
     if grads is not None and self.world > 1:
       if mean and dist.get_backend(self.group) == 'nccl':
         # RCCL averages in the collective itself (no second pass over the buffer)
@@ -664,7 +667,7 @@ class GroupComm:
         opts.reduceOp = dist.ReduceOp.AVG
         self._pending.append((self.group or _default_pg()).allreduce([grads], opts))
       else:
-        self._pending.append(async_all_reduce(grads))      # sum; the mean is taken in wait()
+        self._pending.append(async_all_reduce(grads, self.group))      # sum; the mean is taken in wait()
         self._scale = grads if mean else None
 
   def wait(self, device=None):

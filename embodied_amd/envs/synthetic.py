@@ -80,9 +80,16 @@ class SyntheticBatchEnv:
       obs = self._alloc()
       image, reward, is_first, is_last, is_terminal = (v.data_ptr() for v in obs.values())
     reset = acts['reset']
+    reset_ptr = reset.data_ptr()
+    if reset_ptr == is_last or reset_ptr == is_first or reset_ptr == is_terminal:
+      # `reset` is a flag buffer this very step writes (ring=1: the Driver passes
+      # the previous is_last): the workgroups that share an env's frame would
+      # read it before and after workgroup 0's store -- step on a copy.
+      reset = reset.clone()
+      reset_ptr = reset.data_ptr()
     fast.emb_synth_env_step(
         image, reward, is_first, is_last, is_terminal, n, self.frame_bytes, self.env0,
-        self.episode_len, reset.data_ptr(), self._counters_ptr,
+        self.episode_len, reset_ptr, self._counters_ptr,
         self.generation, _lib.raw_stream(dev))
     self.generation ^= 1
     return obs

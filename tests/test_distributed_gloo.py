@@ -322,3 +322,39 @@ def test_exchange_wait_contract_with_two_and_three_ranks():
           want = np.concatenate([np.full(64, (16 * s + 4 * k + rank) & 0xFF, np.uint8)
                                  for s in range(world)])
         assert (received == want).all(), (world, rank, k)
+
+
+def _subgroup_job(rank, world, D):
+  """GroupComm on a sub-group: its collectives must run on THAT communicator
+  (two of three ranks exchange while the third does nothing)."""
+  import torch.distributed as dist
+  pair = dist.new_group([0, 1])                  # every rank makes the group
+  if rank == 2:
+    return None
+  comm = D.GroupComm(pair)
+  assert comm.world == 2
+  flat = torch.cat([torch.full((32,), 10 * rank + d, dtype=torch.uint8) for d in range(2)])
+  received = torch.zeros_like(flat)
+  grads = torch.full((100,), float(rank + 1))
+  comm.exchange(flat, received, grads)
+  comm.wait()
+  return received.numpy(), grads.numpy()
+
+
+def test_group_comm_uses_its_own_group_world3():
+  got = run_world(_subgroup_job, 3)
+  assert got[2] is None
+  for rank in (0, 1):
+    received, grads = got[rank]
+    want = np.concatenate([np.full(32, 10 * s + rank, np.uint8) for s in range(2)])
+    assert (received == want).all()
+    np.testing.assert_allclose(grads, 1.5)       # mean over the group's two ranks, not over three
+
+
+def test_normalize_stats_before_any_update():
+  from embodied_amd import distributed as D
+  assert D.Normalize('none').stats() == (0.0, 1.0)
+  lo, scale = D.Normalize('perc').stats()
+  assert float(lo) == 0.0 and float(scale) == float(np.float32(1e-8))       # zero statistics, the limit as scale
+  mean, std = D.Normalize('meanstd', debias=False).stats(torch.zeros(()))
+  assert float(mean) == 0.0 and float(std) == float(np.float32(1e-8))

@@ -399,6 +399,52 @@ def test_parallel_env_workers_upload_from_shared_slab(emb):
     assert_same(b, a, 'parallel-device')
 
 
+def test_callbacks_may_keep_the_tensors_of_a_step(emb):
+  """The reference stacks fresh arrays per step (driver.py:65): a callback that
+  keeps a step's tensors (episode / video accumulators) must find them unchanged
+  many steps later -- with env processes behind the shared slab the device
+  buffers rotate only while the Replay sink is the step's sole consumer."""
+  from functools import partial
+
+  def run(keep_in, **kw):
+    fns = [partial(scenarios.ScriptEnv, i, 3 + i) for i in range(4)]
+    driver = emb.Driver(fns, parallel=True, device='cuda', **kw)
+    rep = emb.Replay(length=3, capacity=200, chunksize=16, seed=0)
+    kept = []
+    if keep_in == 'on_batch':
+      driver.on_batch(lambda trans, workers, **k: kept.append((trans, {
+          key: v.clone() for key, v in trans.items() if torch.is_tensor(v)})))
+    elif keep_in == 'on_step':
+      driver.on_step(lambda tran, worker, **k: kept.append((tran, {
+          key: v.clone() for key, v in tran.items() if torch.is_tensor(v)})))
+    driver.on_step(rep.add)
+    driver.reset(lambda n: 0)
+    ptrs = []
+
+    def policy(carry, obs):
+      n = len(obs['is_first'])
+      ptrs.append(obs['is_first'].data_ptr())
+      act = {'act_disc': (np.arange(n) + carry).astype(np.int32),
+             'act_cont': np.full((n, 3), carry, np.float32)}
+      return carry + 1, act, {}
+
+    driver(policy, steps=48)
+    torch.cuda.synchronize()
+    driver.close()
+    return kept, ptrs
+
+  for where in ('on_batch', 'on_step'):
+    kept, ptrs = run(where)
+    assert len(kept) >= 12 and len(set(ptrs)) == len(ptrs)      # fresh device buffers every step
+    for held, snapshot in kept:
+      for key, want in snapshot.items():
+        assert torch.equal(held[key], want), (where, key)
+  _, ptrs = run(None)
+  assert len(set(ptrs)) == 4                                    # Replay sink only: four sets in rotation
+  _, ptrs = run(None, fresh_obs=True)
+  assert len(set(ptrs)) == len(ptrs)
+
+
 def test_replay_with_mixture_of_all_selectors(emb):
   """ppo/main.py:196-205 builds Mixture(uniform, priority, recency) when
   fracs.uniform < 1; with the reference's own Mixture this cannot sample
@@ -522,6 +568,31 @@ def test_env_output_ring_does_not_change_what_the_replay_stores(emb):
     return {k: v.cpu().numpy() for k, v in rep.sample(12).items()}
 
   assert_same(run(3), run(0), 'ring')
+
+
+def test_env_ring_of_one_with_frames_shared_by_several_workgroups(emb):
+  """ring=1: the Driver's `reset` (= the previous is_last) is the very buffer the
+  step writes.  With frames big enough for several workgroups per env the ones
+  that read `reset` after workgroup 0's store would draw a torn frame on the
+  step an episode ends; every frame must equal the generator's."""
+  from embodied_amd.envs import synthetic
+  n, shape, steps = 5, (84, 84, 4), 40
+  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=3, ring=1)
+  hosts = [synthetic.HostSyntheticEnv(e, shape=shape, episode_len=3) for e in range(n)]
+  driver = emb.Driver(batch_env=env, device='cuda')
+  frames = []
+  driver.on_batch(lambda trans, workers, **k: frames.append(
+      (trans['image'].cpu().numpy(), trans['is_last'].cpu().numpy())))
+  act = torch.zeros(n, dtype=torch.int32, device='cuda')
+  driver.reset()
+  driver(lambda carry, obs: (carry, {'action': act}, {}), steps=n * steps)
+  reset = np.ones(n, bool)
+  for image, is_last in frames:
+    want = [h.step({'reset': reset[e], 'action': 0}) for e, h in enumerate(hosts)]
+    assert np.array_equal(is_last, np.array([w['is_last'] for w in want]))
+    assert np.array_equal(image, np.stack([w['image'] for w in want]))
+    reset = is_last
+  assert sum(int(l.sum()) for _, l in frames) > 10
 
 
 def test_more_keys_than_one_launch_holds(emb):
