@@ -309,6 +309,9 @@ def main():
   stream = iter(emb.streams.Consec(
       emb.streams.Stateless(replay.sample, B * args.prefetch, 'train', recycle=1),
       length=T, consec=args.consec, prefix=args.context, strict=True, contiguous=True))
+  lambda_pair = os.environ.get('EMB_BENCH_LAMBDA_PAIR', '1') != '0'
+  lambda_out = [[torch.empty(B * args.prefetch, T + args.context - 1, device=device),
+                 torch.empty(B * T, 15, device=device)] for _ in range(2)]
   gae_out = [tuple(torch.empty(B * args.prefetch, T + args.context - 1, device=device) for _ in range(2))
              for _ in range(2)]
   should_train = Ratio(args.train_ratio / (B * T))
@@ -341,9 +344,17 @@ def main():
       # collective per train step is the gradient all-reduce, waited for one
       # train step later.
       batch = next(stream)
-      adv = emb.scans.lambda_return(
-          batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95)
-      emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
+      # (both return scans of the train step -- replay (B,T) and imagination
+      # (B*K,H+1), agent.py:401-405,464-466 -- in one launch; EMB_BENCH_LAMBDA_PAIR=0: two)
+      if lambda_pair:
+        adv, _ = emb.scans.lambda_returns(
+            [(batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95),
+             (imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)],
+            out=lambda_out[counters['train_steps'] & 1])
+      else:
+        adv = emb.scans.lambda_return(
+            batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95)
+        emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
       replay.update({'stepid': batch['stepid'], 'dyn/deter': batch['dyn/deter'],
                      'dyn/stoch': batch['dyn/stoch']})
       if use_dist and grads is not None and collectives['on']:
@@ -536,6 +547,7 @@ def main():
         go_on = bool(flag.item())
       if not go_on:
         break
+    s_issued = time.perf_counter()
     fence()
     s_elapsed = time.perf_counter() - s_start
     if use_dist:
@@ -553,6 +565,9 @@ def main():
         'gather_avg_us': round(s_ms / s_launches * 1e3, 2) if s_launches else None,
         'gather_launches': s_launches,
         **({'writeback_avg_us': round(s_wb_ms / s_wb_launches * 1e3, 2)} if s_wb_launches else {}),
+        # how far the GPU was behind the host when the last step had been issued:
+        # a few steps' worth = the host sets the pace, milliseconds = the GPU does
+        'closing_fence_us': round((s_start + s_elapsed - s_issued) * 1e6, 1),
     }
   # Ranks only, context: the same loop with the collectives switched off (N
   # independent replicas: no exchange, no gradient all-reduce) -- what the path

@@ -53,6 +53,13 @@ PRIORITIZE_FN = C.CFUNCTYPE(
     None, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.c_int64)
 
 
+class LambdaProblem(C.Structure):
+  """emb_lambda_problem_t: one problem of emb_scan_lambda_multi."""
+  _fields_ = [
+      ('last', C.c_void_p), ('term', C.c_void_p), ('rew', C.c_void_p), ('boot', C.c_void_p),
+      ('ret', C.c_void_p), ('B', C.c_int64), ('T', C.c_int64), ('disc', C.c_float), ('lam', C.c_float)]
+
+
 class ObsSpec(C.Structure):
   """emb_obs_spec_t: how emb_replay_obs_stack_insert lays out the policy batch."""
   _fields_ = [
@@ -170,6 +177,7 @@ SIGNATURES = {
     'emb_scan_gae': [p, p, p, p, i64, i64, f32, f32, p, p, p],
     'emb_scan_gae_grouped': [p, p, p, p, i64, i64, f32, f32, p, p, i64, i64, p],
     'emb_scan_lambda': [p, p, p, p, i64, i64, f32, f32, p, p],
+    'emb_scan_lambda_multi': [i32, p, p],
     'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],
     'emb_abstract_traj': [p, p, i64, i64, i32, p, p, p],
     'emb_synth_env_step': [p, p, p, p, p, i64, i64, i64, i64, p, p, i32, p],
@@ -267,7 +275,7 @@ class _FastApi:
       'emb_replay_sample': 'ints', 'emb_replay_sample_grouped': 'ints', 'emb_replay_update': 'ints',
       'emb_replay_gather_rows': 'ints', 'emb_replay_scatter_rows': 'ints',
       'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',
-      'emb_scan_gae_grouped': 'scan',
+      'emb_scan_gae_grouped': 'scan', 'emb_scan_lambda_multi': 'ints',
       'emb_comm_exchange': 'ints', 'emb_comm_wait': 'ints',
   }
 

@@ -167,6 +167,9 @@ class Replay:
             'recycle=K) instead')
       self._out_pool = {}
     self._nonempty = False
+    self._full = False
+    self._len_out = C.c_int64()
+    self._len_ref = C.byref(self._len_out)
     self._pool_bytes = 0
     probe = [object()]
     self._ref_base = sys.getrefcount(probe[0])
@@ -192,8 +195,17 @@ class Replay:
   # ------------------------------------------------------------------ state --
 
   def __len__(self):
-    n = C.c_int64()
-    api.emb_replay_len(self._handle, C.byref(n))
+    # A replay with a capacity that has filled up stays at its capacity: an
+    # insert evicts first (replay.py:171-179) and nothing else removes items.
+    # Run loops ask on every env step (run/train.py:70): no library call then
+    # (which would also wait for the helper thread's bookkeeping of the step
+    # just published).
+    if self._full:
+      return self.capacity
+    n = self._len_out
+    api.emb_replay_len(self._handle, self._len_ref)
+    if self.capacity and n.value == self.capacity and self._owners == 1:
+      self._full = True
     return n.value
 
   def online_pending(self):

@@ -662,6 +662,7 @@ struct emb_replay {
   LaunchTimer timer, timer_other, timer_update;   // gathers, unread predecessor stamps, write-backs
   std::string timed_kernel[2];                    // the kernel the last stamped gather / write-back ran
   bool timing_update = false;                     // set by emb_replay_update around its launches
+  bool writes_back = false;                       // emb_replay_update has moved payload on this replay
   std::vector<int32_t> rows, spans;
   std::vector<std::pair<int32_t, int32_t>> runs;   // update: [first, last) pool rows per run
   std::vector<uint32_t> stamp;                     // update: last-writer-wins marks per pool row
@@ -1169,6 +1170,7 @@ struct KeyList {
   int32_t seq_len = 1;
   int32_t group = 0;            // gather: destination groups (MovePlan::group)
   int64_t group_stride = 0;
+  bool dst_read_soon = false;   // gather: MovePlan::dst_read_soon
   // Masked insert: per key a DType code (-1 = plain copy) and the buffer that
   // also receives the masked value; mask_flags = is_last of the rows.
   std::vector<int8_t> mask_dtype;
@@ -1197,6 +1199,7 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
     plan.seq_len = list.seq_len;
     plan.group = list.group;
     plan.group_stride = list.group_stride;
+    plan.dst_read_soon = list.dst_read_soon;
     plan.is_first_pool = first_pool;
     for (int k = lo; k < hi; ++k) {
       if (list.mask_flags && list.mask_dtype[k] >= 0) {
@@ -1495,6 +1498,12 @@ static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* co
   list.seq_len = static_cast<int32_t>(L);
   list.group = group;
   list.group_stride = group_stride;
+  // A replay whose sampled batches come back through emb_replay_update (agent
+  // outputs written over the sampled steps, dreamerv3/agent.py:144-150): the
+  // write-back reads the batch tensors right after the learner -- sampled with
+  // plain stores it finds them in cache (84 MB: 13.0-13.4 us instead of
+  // 16.6-18.3 behind non-temporal stores; the gather itself costs the same).
+  list.dst_read_soon = rep->writes_back;
   HostLap hp;
   rep->rows.resize(batch * L);
   sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
@@ -1582,6 +1591,7 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
       }
     }
     rep->timing_update = rep->timer_update.enabled;
+    rep->writes_back = true;
     try {
       run_move_all(rep, list, rep->rows.data(), B * T, nullptr, false, static_cast<hipStream_t>(stream),
                    &rep->spans);
@@ -1884,6 +1894,27 @@ int32_t emb_scan_lambda(const void* last, const void* term, const void* rew, con
     HIP_OK(emb::launch_lambda_return(static_cast<const uint8_t*>(last), static_cast<const uint8_t*>(term),
                                      static_cast<const float*>(rew), static_cast<const float*>(boot), B, T,
                                      disc, lam, static_cast<float*>(ret), static_cast<hipStream_t>(stream)));
+  });
+}
+
+int32_t emb_scan_lambda_multi(int32_t n_problems, const emb_lambda_problem_t* problems, void* stream) {
+  return guarded([&] {
+    need(n_problems >= 0 && (problems || n_problems == 0), "scan_lambda_multi: bad arguments");
+    std::vector<emb::LambdaProblem> list;
+    list.reserve(n_problems);
+    for (int i = 0; i < n_problems; ++i) {
+      const emb_lambda_problem_t& q = problems[i];
+      need(q.B >= 0 && q.T >= 1, "scan_lambda_multi: bad shape");
+      if (q.B == 0 || q.T < 2) continue;
+      need(q.last && q.term && q.rew && q.boot && q.ret, "scan_lambda_multi: null buffer");
+      list.push_back({static_cast<const uint8_t*>(q.last), static_cast<const uint8_t*>(q.term),
+                      static_cast<const float*>(q.rew), static_cast<const float*>(q.boot),
+                      static_cast<float*>(q.ret), q.B, q.T, q.disc, q.lam});
+    }
+    HostLap hp;
+    HIP_OK(emb::launch_lambda_return_multi(static_cast<int>(list.size()), list.data(),
+                                           static_cast<hipStream_t>(stream)));
+    hp.lap(23, "lambda-return (multi): launch");
   });
 }
 

@@ -55,6 +55,11 @@ struct MovePlan {
   int8_t mask_dtype[kMaxKeys] = {};
   uint8_t* mask_out[kMaxKeys] = {};
   const uint8_t* mask_flags = nullptr;
+  // Gather only: the batch is read again right away by a kernel that matters
+  // (the learner writes agent outputs back over the sampled steps with the same
+  // tensors as source, Replay.update): leave it in L2 / Infinity Cache -- plain
+  // stores instead of the span mover's non-temporal ones.
+  bool dst_read_soon = false;
 };
 
 // True if this plan's tables fit the kernel-argument block (else the caller
@@ -69,6 +74,7 @@ struct MoveLaunch {
   uint32_t threads = 0;
   bool span = false;       // persistent span mover (wide keys of a span table)
   bool stage_tables = false;   // arguments in host memory: by-value flat movers stage their tables in LDS
+  int nt = 3;              // span mover: non-temporal hints of this launch (bit 0 loads, bit 1 stores)
 };
 hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather = true);
 size_t move_args_bytes();
@@ -132,6 +138,16 @@ hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term,
                                 const float* rew, const float* boot, int64_t B,
                                 int64_t T, float disc, float lam, float* ret,
                                 hipStream_t stream);
+
+// One lambda-return problem of emb_scan_lambda_multi (same meaning as the
+// arguments of launch_lambda_return).
+struct LambdaProblem {
+  const uint8_t* last; const uint8_t* term; const float* rew; const float* boot; float* ret;
+  int64_t B, T; float disc, lam;
+};
+// All problems in one launch when every row has at most 257 steps (else one
+// launch each).
+hipError_t launch_lambda_return_multi(int n_problems, const LambdaProblem* problems, hipStream_t stream);
 // Time-major: rew (T-1, B), cont/value (T, B) -> ret (T-1, B).
 hipError_t launch_director_score(const float* rew, const float* cont,
                                  const float* value, int64_t T, int64_t B,

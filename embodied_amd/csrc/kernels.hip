@@ -625,13 +625,13 @@ const MoveVariant& move_variant() {
 // +-0.3-1 us).  The default keeps the gather kernel itself fastest;
 // EMB_SPAN_VARIANT=4,1 is the setting for a learner that reads the whole batch
 // right after sampling.
-struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; int nt_scatter; };
+struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; int nt_scatter; bool nt_given; };
 const SpanVariant& span_variant() {
   static const SpanVariant variant = [] {
-    SpanVariant v{4, 3, 512, 2, 160, 3};
+    SpanVariant v{4, 3, 512, 2, 160, 3, false};
     if (const char* s = std::getenv("EMB_SPAN_VARIANT"))
-      std::sscanf(s, "%d,%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb,
-                  &v.nt_scatter);
+      v.nt_given = std::sscanf(s, "%d,%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb,
+                               &v.nt_scatter) >= 2;
     if (v.unroll != 2 && v.unroll != 4) v.unroll = 4;
     if (v.nt < 0 || v.nt > 3) v.nt = 3;
     if (v.nt_scatter < 0 || v.nt_scatter > 3) v.nt_scatter = 3;
@@ -735,6 +735,11 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   const int threads = span_path ? sv.threads : variant.threads;
   out->span = span_path;
   out->stage_tables = plan.args_in_host_memory;
+  // Hints of this launch: the variant's, except that a batch which a write-back
+  // is about to read again is stored with plain stores (unless EMB_SPAN_VARIANT
+  // names the hints itself: the A/B).
+  out->nt = gather ? sv.nt : sv.nt_scatter;
+  if (gather && plan.dst_read_soon && !sv.nt_given) out->nt = sv.nt & 1;
   MoveArgs& a = *reinterpret_cast<MoveArgs*>(out->args);
   SpanHead& h = a.head;
   MoveTables& t = a.t;
@@ -884,7 +889,7 @@ hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device
     else hipExtLaunchKernelGGL((span_move_kernel<G_, U_, NT_>), grid, block, 0, stream, start, stop, 0, a);             \
   } while (0)
 #define EMB_SPAN_NT(G_, U_)                                                      \
-  switch (G_ ? sv.nt : sv.nt_scatter) {                                          \
+  switch (launch.nt) {                                                           \
     case 0: EMB_SPAN(G_, U_, 0); break;                                          \
     case 1: EMB_SPAN(G_, U_, 1); break;                                          \
     case 2: EMB_SPAN(G_, U_, 2); break;                                          \
@@ -930,7 +935,7 @@ const char* move_kernel_name(const MoveLaunch& launch, bool gather, bool indirec
   if (launch.span) {
     const SpanVariant& sv = span_variant();
     std::snprintf(name, sizeof(name), "span_move_kernel%s<%s, %d, %d>", indirect ? "_indirect" : "",
-                  gather ? "true" : "false", sv.unroll == 2 ? 2 : 4, gather ? sv.nt : sv.nt_scatter);
+                  gather ? "true" : "false", sv.unroll == 2 ? 2 : 4, launch.nt);
   } else {
     const MoveVariant& v = move_variant();
     std::snprintf(name, sizeof(name), "%s_kernel%s<%d, %d>", gather ? "gather" : "scatter",
@@ -1579,13 +1584,12 @@ __global__ __launch_bounds__(kThreads) void scan_rows_kernel(Args... args) {
 // once per four elements, the loads are 16-byte / 4-byte vectors, the four
 // elements of a lane are folded sequentially (3 fma pairs) and the Kogge-Stone
 // runs over W = rowlen/4 lanes (4 rounds for T = 64 instead of 6).
-template <int W, typename Op, typename... Args>
-__global__ __launch_bounds__(kThreads) void scan_rows4_kernel(Args... args) {
-  const Op op = Op::make(args...);
+template <int W, typename Op>
+__device__ __forceinline__ void scan_rows4_body(const Op& op, uint32_t block) {
   const int64_t B = op.B;
   const int n = op.T - 1;
   const int sl = threadIdx.x % W;
-  const int64_t b = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / W;
+  const int64_t b = (static_cast<int64_t>(block) * kThreads + threadIdx.x) / W;
   const int t0 = 4 * sl;
   const bool row_ok = b < B;
   const int valid = row_ok ? (n - t0 >= 4 ? 4 : (n - t0 > 0 ? n - t0 : 0)) : 0;
@@ -1614,6 +1618,46 @@ __global__ __launch_bounds__(kThreads) void scan_rows4_kernel(Args... args) {
 #pragma unroll
   for (int k = 2; k >= 0; --k) y[k] = fmaf(bc[k], y[k + 1], a[k]);
   if (valid > 0) op.store4(b, t0, valid, y, keep);
+}
+template <int W, typename Op, typename... Args>
+__global__ __launch_bounds__(kThreads) void scan_rows4_kernel(Args... args) {
+  scan_rows4_body<W>(Op::make(args...), blockIdx.x);
+}
+
+// Several lambda-return problems of one train step in ONE launch (DreamerV3
+// computes the replay returns (B, T) and the imagined returns (B*K, H+1) in the
+// same step, dreamerv3/agent.py:401-405,464-466): at these sizes each scan is
+// pure launch latency, so two launches cost twice what one does.  Workgroups
+// [first[i], first[i+1]) belong to problem i; every problem runs the
+// four-steps-per-lane form with its own segment width.
+constexpr int kScanMulti = 4;
+struct LambdaMulti {
+  LambdaOp op[kScanMulti];
+  int32_t first[kScanMulti + 1];
+  int32_t width[kScanMulti];
+};
+__global__ __launch_bounds__(kThreads) void lambda_multi_kernel(const LambdaMulti m) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kScanMulti; ++k)
+    if (blockIdx.x >= static_cast<uint32_t>(m.first[k])) i = k;
+  const uint32_t block = blockIdx.x - static_cast<uint32_t>(m.first[i]);
+  // (a copy selected with a uniform index: the by-value argument stays in SGPRs)
+  LambdaOp op = m.op[0];
+#pragma unroll
+  for (int k = 1; k < kScanMulti; ++k)
+    if (i == k) op = m.op[k];
+  int width = m.width[0];
+#pragma unroll
+  for (int k = 1; k < kScanMulti; ++k)
+    if (i == k) width = m.width[k];
+  switch (width) {
+    case 4: scan_rows4_body<4>(op, block); break;
+    case 8: scan_rows4_body<8>(op, block); break;
+    case 16: scan_rows4_body<16>(op, block); break;
+    case 32: scan_rows4_body<32>(op, block); break;
+    default: scan_rows4_body<64>(op, block); break;
+  }
 }
 
 // Long rows: one workgroup of `waves` wavefronts per row.  Each wave reduces its
@@ -1933,6 +1977,47 @@ hipError_t launch_lambda_return(const uint8_t* last, const uint8_t* term, const 
   if (B > INT32_MAX || T > INT32_MAX) return hipErrorInvalidValue;
   return launch_scan(LambdaOp{last, term, rew, boot, ret, static_cast<int32_t>(T),
                               static_cast<int32_t>(B), disc, lam}, stream);
+}
+
+hipError_t launch_lambda_return_multi(int n_problems, const LambdaProblem* problems, hipStream_t stream) {
+  if (n_problems < 1) return hipSuccess;
+  bool together = n_problems <= kScanMulti;
+  for (int i = 0; i < n_problems; ++i) {
+    const LambdaProblem& q = problems[i];
+    if (q.B > INT32_MAX || q.T > INT32_MAX) return hipErrorInvalidValue;
+    together = together && q.T - 1 <= 256;        // long rows have a kernel of their own
+  }
+  if (!together || n_problems == 1) {
+    for (int i = 0; i < n_problems; ++i) {
+      const LambdaProblem& q = problems[i];
+      const hipError_t err = launch_lambda_return(q.last, q.term, q.rew, q.boot, q.B, q.T, q.disc, q.lam,
+                                                  q.ret, stream);
+      if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
+  }
+  LambdaMulti m;
+  std::memset(&m, 0, sizeof(m));
+  int64_t blocks = 0;
+  int used = 0;
+  for (int i = 0; i < n_problems; ++i) {
+    const LambdaProblem& q = problems[i];
+    if (q.B <= 0 || q.T < 2) continue;
+    const int64_t n = q.T - 1;
+    const int W = n <= 16 ? 4 : n <= 32 ? 8 : n <= 64 ? 16 : n <= 128 ? 32 : 64;
+    m.op[used] = LambdaOp{q.last, q.term, q.rew, q.boot, q.ret, static_cast<int32_t>(q.T),
+                          static_cast<int32_t>(q.B), q.disc, q.lam};
+    m.width[used] = W;
+    m.first[used] = static_cast<int32_t>(blocks);
+    const int64_t rows_per_block = kThreads / W;
+    blocks += (q.B + rows_per_block - 1) / rows_per_block;
+    if (blocks > INT32_MAX) return hipErrorInvalidValue;
+    ++used;
+  }
+  if (used == 0) return hipSuccess;
+  for (int k = used; k <= kScanMulti; ++k) m.first[k] = static_cast<int32_t>(blocks);
+  hipLaunchKernelGGL(lambda_multi_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(kThreads), 0, stream, m);
+  return hipGetLastError();
 }
 
 hipError_t launch_director_score(const float* rew, const float* cont, const float* value,

@@ -181,6 +181,54 @@ def lambda_return(last, term, rew, val, boot, disc, lam):
   return ret
 
 
+_MULTI = {}
+
+
+def lambda_returns(problems, out=None):
+  """Several `lambda_return` problems of one train step in ONE launch:
+  `problems` = [(last, term, rew, val, boot, disc, lam), ...] (the arguments of
+  `lambda_return`), result = [ret, ...].  DreamerV3 computes the replay returns
+  (B, T) and the imagined returns (B*K, H+1) in the same train step
+  (dreamerv3/agent.py:401-405, 464-466); at those sizes each scan is launch
+  latency, so one launch costs half of two.  `out=[ret, ...]`: the caller's
+  contiguous float32 (B, T-1) tensors."""
+  import ctypes as C
+  prepared, shapes = [], []
+  for last, term, rew, val, boot, disc, lam in problems:
+    dev = _device(rew, boot, last, term)
+    rew, boot = _f32(rew, dev), _f32(boot, dev)
+    last, term = _flag(last, dev), _flag(term, dev)
+    B, T = rew.shape
+    assert boot.shape == last.shape == term.shape == (B, T)
+    assert val is None or tuple(val.shape) == (B, T)
+    prepared.append((last, term, rew, boot, dev))
+    shapes.append((B, T, _round32(disc), _round32(lam)))
+  key = tuple(shapes)
+  table = _MULTI.get(key)
+  if table is None:
+    if len(_MULTI) > 64:
+      _MULTI.clear()
+    table = _MULTI[key] = (_lib.LambdaProblem * len(shapes))()
+    for entry, (B, T, disc, lam) in zip(table, shapes):
+      entry.B, entry.T, entry.disc, entry.lam = B, T, disc, lam
+  rets = []
+  for i, ((last, term, rew, boot, dev), (B, T, _, _)) in enumerate(zip(prepared, shapes)):
+    if out is not None:
+      ret = out[i]
+      if (ret.dtype != torch.float32 or tuple(ret.shape) != (B, T - 1) or ret.device != dev
+          or not ret.is_contiguous()):
+        raise ValueError(f'lambda_returns(out=): needs contiguous float32 {(B, T - 1)} tensors on {dev}')
+    else:
+      ret = _lib.empty((B, T - 1), torch.float32, dev)
+    entry = table[i]
+    entry.last, entry.term, entry.rew = last.data_ptr(), term.data_ptr(), rew.data_ptr()
+    entry.boot, entry.ret = boot.data_ptr(), ret.data_ptr()
+    rets.append(ret)
+  if prepared:
+    fast.emb_scan_lambda_multi(len(prepared), table, _stream(prepared[0][2]))
+  return rets
+
+
 def director_score(rew, cont, value, horizon=333, lam=0.95):
   """Time-major: rew (T-1,B), cont, value (T,B) -> ret (T-1,B)."""
   dev = _device(rew, cont, value)

@@ -346,6 +346,18 @@ int32_t emb_scan_gae_grouped(const void* rew, const void* val, const void* last,
 /* DreamerV3 lambda-return (dreamerv3/agent.py:482-490) -> ret (B,T-1).       */
 int32_t emb_scan_lambda(const void* last, const void* term, const void* rew, const void* boot,
                         int64_t B, int64_t T, float disc, float lam, void* ret, void* stream);
+/* Several lambda-return problems of one train step in ONE launch: DreamerV3
+ * computes the replay returns (B,T) and the imagined returns (B*K,H+1) in the
+ * same step (dreamerv3/agent.py:401-405 imag_loss, :464-466 repl_loss, both
+ * through lambda_return :482-490); at those sizes each scan is launch latency.
+ * Same arithmetic as emb_scan_lambda per problem.  Up to 4 problems with rows of
+ * at most 257 steps share a launch; anything else runs one launch each.        */
+typedef struct emb_lambda_problem {
+  const void* last; const void* term; const void* rew; const void* boot; void* ret;
+  int64_t B, T;
+  float disc, lam;
+} emb_lambda_problem_t;
+int32_t emb_scan_lambda_multi(int32_t n_problems, const emb_lambda_problem_t* problems, void* stream);
 /* Director critic target, time-major (director/agent.py:430-445): rew (T-1,B),
  * cont,value (T,B) -> ret (T-1,B).  discount = 1 - 1/horizon.                */
 int32_t emb_scan_director(const void* rew, const void* cont, const void* value, int64_t T,

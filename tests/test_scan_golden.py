@@ -134,6 +134,46 @@ def test_hip_gae_and_lambda_match_reference_fixture(emb, batch_major, seed, shap
 
 
 @pytest.mark.gpu
+def test_hip_lambda_returns_in_one_launch_match_reference_fixture(emb, batch_major):
+  """scans.lambda_returns: the replay-shaped (16,64) and the imagination-shaped
+  (1024,16) problems of a DreamerV3 train step in ONE launch, with different
+  disc / lam per problem -- each result within 1e-5 of the reference fixture (and
+  of the single-problem launch, which may pick another kernel form); 1 to 4
+  problems per launch, long rows and more than four problems (one launch each),
+  an empty problem, caller-owned outputs."""
+  import torch
+  problems, wants, singles = [], [], []
+  for seed, shape in BT:
+    inp = cases.batch_major(seed, shape)
+    i, params = lambda_sets(seed)[-1]
+    args = (dev(inp['last']), dev(inp['term']), dev(inp['rew']), dev(inp['val']), dev(inp['boot']))
+    problems.append((*args, params['disc'], params['lam']))
+    wants.append(batch_major[f'lambda{i}_' + tag(seed, shape)])
+    singles.append(emb.scans.lambda_return(*args, **params))
+  shapes = {tuple(p[2].shape) for p in problems}
+  assert (16, 64) in shapes and (1024, 16) in shapes
+  short = [i for i, p in enumerate(problems) if p[2].shape[1] <= 257]
+  assert len(short) >= 4
+  for pick in (short[:1], short[:2], short[:3], short[:4], short, list(range(len(problems)))):
+    got = emb.scans.lambda_returns([problems[i] for i in pick])
+    assert len(got) == len(pick)
+    for ret, i in zip(got, pick):
+      np.testing.assert_allclose(ret.cpu().numpy(), wants[i], **TOL)
+      np.testing.assert_allclose(ret.cpu().numpy(), singles[i].cpu().numpy(), **TOL)
+  own = [torch.empty_like(s) for s in singles[:2]]
+  got = emb.scans.lambda_returns(problems[:2], out=own)
+  assert got[0] is own[0]
+  np.testing.assert_allclose(own[1].cpu().numpy(), wants[1], **TOL)
+  with pytest.raises(ValueError):
+    emb.scans.lambda_returns(problems[:2], out=[own[0], own[0][:, :3]])
+  empty = tuple(t[:0] for t in problems[0][:5]) + problems[0][5:]
+  got = emb.scans.lambda_returns([empty, problems[1]])
+  assert got[0].shape[0] == 0
+  np.testing.assert_allclose(got[1].cpu().numpy(), wants[1], **TOL)
+  assert emb.scans.lambda_returns([]) == []
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('seed,shape', TB)
 def test_hip_director_score_matches_reference_fixture(emb, director, seed, shape):
   inp = cases.time_major(seed, shape)
