@@ -167,6 +167,12 @@ def parse():
   p.add_argument('--selector', default='uniform', choices=['uniform', 'prioritized'],
                  help='prioritized = ppo/configs.yaml:42 (exponent .8, maxfrac .5, initial inf, '
                       'zero_on_sample) instead of the default fracs.uniform 1.0')
+  p.add_argument('--streams', type=int, default=2, choices=[1, 2],
+                 help='2 (default): the learner\'s work of a train step -- sample gather, return '
+                      'scans, write-back -- is issued on a HIP stream of its own (the actor / learner '
+                      'split of run/actor_learner.py; the reference dispatches its train step '
+                      'asynchronously as well), so the HBM-bound gathers run beside the '
+                      'latency-bound kernels of the env steps; 1: everything on one stream')
   p.add_argument('--host-envs', action='store_true',
                  help='step 64 numpy envs on the host and upload through the pinned slab '
                       '(PCIe-inclusive rate; never the headline value)')
@@ -426,12 +432,34 @@ def main():
   state_keep = []
   slice_state = {}
 
+  # The learner's stream (--streams 2): the Replay orders its pool accesses across
+  # the two streams itself (emb_replay_multistream; abi.cpp StreamOrder).
+  learner = torch.cuda.Stream(device) if args.streams == 2 else None
+  if learner is not None:
+    main_stream = torch.cuda.current_stream(device)
+    set_stream = torch._C._cuda_setStream
+    to_learner = dict(stream_id=learner.stream_id, device_index=learner.device_index,
+                      device_type=learner.device_type)
+    to_main = dict(stream_id=main_stream.stream_id, device_index=main_stream.device_index,
+                   device_type=main_stream.device_type)
+    learner.wait_stream(main_stream)       # the buffers made above are ready before the learner uses them
+
   def one_step():
     driver(policy, steps=args.envs)            # exactly one vectorised step
     counters['env_steps'] += args.envs
     if len(replay) >= B * T:
-      for _ in range(should_train(counters['env_steps'])):
-        train_step()
+      repeats = should_train(counters['env_steps'])
+      if repeats:
+        if learner is None:
+          for _ in range(repeats):
+            train_step()
+        else:
+          set_stream(**to_learner)
+          try:
+            for _ in range(repeats):
+              train_step()
+          finally:
+            set_stream(**to_main)
 
   # Fill the buffer so sampled windows come from all over HBM, not from cache.
   driver.reset()
@@ -473,8 +501,12 @@ def main():
   replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1', every=stamp_every)
   # The fill runs no train step: warm the train path (allocator, online queue,
   # caches) whatever --warmup says, then the caller's warmup steps.
+  if learner is not None:
+    set_stream(**to_learner)
   for _ in range(args.prewarm_train_steps):
     train_step()
+  if learner is not None:
+    set_stream(**to_main)
   for _ in range(args.warmup):
     one_step()
   replay.profile_read(reset=True)
@@ -769,6 +801,8 @@ def main():
                 f'{"lambda-return" if args.workload == "dreamer" else "GAE"}'),
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
+            # 2: the train step's gather / scans / write-back on the learner's own HIP stream
+            'streams': args.streams,
             'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
             'cpus': PINNED,         # CPUs this process was pinned to (pin_cpus), None = scheduler's choice
             # the per-step Python of Driver / Replay / streams: Cython-compiled copies of the

@@ -15,6 +15,7 @@ from . import _compiled_finder
 compiled = _compiled_finder.install()   # compiled copies of the hot host modules, if built and fresh
 
 from . import _lib  # raises if libembodied_hip.so is missing: no CPU fallback
+from ._lib import configure
 
 from .space import Space
 from .core.base import Agent, Env, Stream

@@ -110,6 +110,7 @@ pp = C.POINTER(C.c_void_p)
 # name -> argtypes; every function returns int32 status unless listed below.
 SIGNATURES = {
     'emb_device_count': [p],
+    'emb_configure': [C.c_char_p, C.c_char_p],
     'emb_rng_create': [p, i32, pp],
     'emb_rng_integers': [p, i64, i64, p],
     'emb_rng_random': [p, i64, p],
@@ -333,6 +334,14 @@ def empty(shape, dtype, device):
 def ptr(array):
   """Address of a numpy array's buffer (None -> NULL)."""
   return None if array is None else array.ctypes.data
+
+
+def configure(**knobs):
+  """`configure(EMB_DEFER_INDEX=0, EMB_SPAN_VARIANT='4,1')`: the library's tuning
+  knobs from the host program instead of the environment (emb_configure).  Each
+  knob is read once by the first call that needs it; setting it later raises."""
+  for name, value in knobs.items():
+    api.emb_configure(name.encode(), None if value is None else str(value).encode())
 
 
 def device_count():

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "knobs.h"
 #include "np_random.h"
 #include "replay_index.h"
 #include "selectors.h"
@@ -40,7 +41,7 @@ struct HostProfile {
   uint64_t tsc0 = 0;
   timespec wall0{};
   HostProfile() {
-    const char* e = std::getenv("EMB_HOST_PROFILE");
+    const char* e = emb::knob("EMB_HOST_PROFILE");
     on = e && e[0] == '1';
     if (on) {
       clock_gettime(CLOCK_MONOTONIC, &wall0);
@@ -207,7 +208,7 @@ class ArgRing {
   bool usable() {
     if (state_ == 0) {
       state_ = -1;
-      const char* knob = std::getenv("EMB_ARGS_BAR");
+      const char* knob = emb::knob("EMB_ARGS_BAR");
       int dev = 0, large = 0;
       if (!(knob && knob[0] == '0') && hipGetDevice(&dev) == hipSuccess &&
           hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && large &&
@@ -358,7 +359,7 @@ class LaunchTimer {
 // HIP_FORCE_DEV_KERNARG=0: the runtime leaves kernel arguments in host memory.
 bool host_kernargs() {
   static const bool value = [] {
-    if (const char* o = std::getenv("EMB_ARGS_INDIRECT")) return o[0] == '1';   // A/B override
+    if (const char* o = emb::knob("EMB_ARGS_INDIRECT")) return o[0] == '1';   // A/B override
     const char* e = std::getenv("HIP_FORCE_DEV_KERNARG");
     return e && e[0] == '0';
   }();
@@ -377,7 +378,7 @@ bool host_kernargs() {
 // EMB_STAMP_PRED=0 turns it off.
 bool stamp_predecessors() {
   static const bool value = [] {
-    const char* e = std::getenv("EMB_STAMP_PRED");
+    const char* e = emb::knob("EMB_STAMP_PRED");
     return !(e && e[0] == '0');
   }();
   return value;
@@ -398,6 +399,35 @@ struct emb_rng {
   emb::NpRandom impl;
   explicit emb_rng(const std::vector<uint32_t>& w) : impl(w) {}
 };
+
+// Ticks of the time-stamp counter per microsecond, measured (not assumed): one
+// (tsc, CLOCK_MONOTONIC) pair when the library is loaded, a second one at the
+// first question -- at least 200 us later, waited for if need be.
+struct TscClock {
+  uint64_t tsc0;
+  timespec wall0;
+  TscClock() {
+    clock_gettime(CLOCK_MONOTONIC, &wall0);
+    tsc0 = __builtin_ia32_rdtsc();
+  }
+  double per_us() const {
+    static const double value = [this] {
+      for (;;) {
+        timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        const uint64_t tsc = __builtin_ia32_rdtsc();
+        const double us = (now.tv_sec - wall0.tv_sec) * 1e6 + (now.tv_nsec - wall0.tv_nsec) * 1e-3;
+        if (us >= 200.0) {
+          const double rate = static_cast<double>(tsc - tsc0) / us;
+          return rate > 100.0 && rate < 20000.0 ? rate : 3000.0;     // 0.1 .. 20 GHz, else a guess
+        }
+      }
+    }();
+    return value;
+  }
+};
+static const TscClock g_tsc;
+static uint64_t tsc_ticks(double us) { return static_cast<uint64_t>(us * g_tsc.per_us()); }
 
 // Deferred index work (emb_replay_publish): ONE job at a time, run by a helper
 // thread while the caller goes on (its launch, then the interpreter's work up to
@@ -492,8 +522,9 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
   uint64_t last_publish = 0;
   bool allowed() {
     static const uint64_t max_gap = [] {
-      const char* e = std::getenv("EMB_DEFER_MAX_GAP_US");
-      return e ? static_cast<uint64_t>(std::atof(e) * 3000.0) : uint64_t{250000};   // cycles of a ~3 GHz counter
+      const char* e = emb::knob("EMB_DEFER_MAX_GAP_US");
+      const double us = e ? std::atof(e) : 80.0;
+      return us >= 1e9 ? ~uint64_t{0} : tsc_ticks(us);
     }();
     const uint64_t now = __builtin_ia32_rdtsc();
     const bool quick = now - last_publish < max_gap;
@@ -558,9 +589,9 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
     }
     place_helper();
     if (++jobs >= 4096) {
-      // more than ~2 us of waiting per job (6000 cycles of a 3 GHz counter):
-      // the next 2^15 publishes do their bookkeeping themselves, then try again
-      if (wait_cycles / jobs > 6000) skip = uint64_t{1} << 15;
+      // more than ~2 us of waiting per job: the next 2^15 publishes do their
+      // bookkeeping themselves, then try again
+      if (wait_cycles / jobs > tsc_ticks(2.0)) skip = uint64_t{1} << 15;
       wait_cycles = jobs = 0;
     }
     ctx = c;
@@ -581,7 +612,7 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
     }
     // (one long wait -- the helper lost its CPU for a time slice -- counts like a
     // slow job, not like a thousand of them)
-    wait_cycles += std::min<uint64_t>(__builtin_ia32_rdtsc() - began, 24000);
+    wait_cycles += std::min<uint64_t>(__builtin_ia32_rdtsc() - began, tsc_ticks(8.0));
     if (error) {
       std::exception_ptr e = error;
       error = nullptr;
@@ -621,7 +652,7 @@ std::shared_ptr<DeferGate> make_gate() {
 // with the thread that waits for it.
 bool defer_index() {
   static const bool value = [] {
-    const char* e = std::getenv("EMB_DEFER_INDEX");
+    const char* e = emb::knob("EMB_DEFER_INDEX");
     if (e && e[0] == '0') return false;
     cpu_set_t set;
     CPU_ZERO(&set);
@@ -643,6 +674,89 @@ struct emb_selector {
   std::shared_ptr<emb::Selector> impl;
 };
 
+// Pool accesses from several HIP streams (actor / learner split: inserts on one
+// stream, sample + write-back on another) ordered with as few events as the
+// hazards need -- an event record costs the host ~4 us, a stepping loop inserts
+// every ~12 us:
+//   read  (sample gather)            after every earlier WRITE on another stream;
+//   write to live rows (update,      after every earlier write AND read on another
+//     scatter_rows)                    stream;
+//   write to fresh rows (add: rows   after the other streams' work only when a chunk
+//     of the workers' open chunks)     slot has been opened since the last look --
+//                                      rows of an open chunk belong to no item, so no
+//                                      gather reads them and no write-back targets
+//                                      them, unless the slot was recycled.
+// Nothing is recorded when work is issued: counters only.  The stream that has to
+// wait records an event on the OTHER stream at that moment (it covers everything
+// queued there so far) and waits for it.  The caller holds the replay's mutex.
+struct StreamOrder {
+  enum { kRead = 0, kWriteLive = 1, kWriteFresh = 2 };
+  static constexpr int kMax = 6;
+  struct Entry {
+    hipStream_t stream = nullptr;
+    uint64_t writes = 0, reads = 0;          // issued so far
+    hipEvent_t event = nullptr;
+    uint64_t cover_w = 0, cover_r = 0;       // what the event's last record covers
+  };
+  Entry e[kMax];
+  uint64_t seen_w[kMax][kMax] = {}, seen_r[kMax][kMax] = {};    // [waiter][other]
+  int n = 0;
+  int64_t opens_seen = -1;
+
+  ~StreamOrder() {
+    for (int i = 0; i < n; ++i)
+      if (e[i].event) (void)hipEventDestroy(e[i].event);
+  }
+  int entry(hipStream_t stream) {
+    for (int i = 0; i < n; ++i)
+      if (e[i].stream == stream) return i;
+    if (n == kMax) {
+      // More streams than the table holds (not a stepping loop any more): drain
+      // the device and start over.
+      HIP_OK(hipDeviceSynchronize());
+      for (int i = 0; i < n; ++i) {
+        e[i].stream = nullptr;
+        e[i].writes = e[i].reads = e[i].cover_w = e[i].cover_r = 0;
+      }
+      std::memset(seen_w, 0, sizeof(seen_w));
+      std::memset(seen_r, 0, sizeof(seen_r));
+      n = 0;
+    }
+    e[n].stream = stream;
+    if (!e[n].event) HIP_OK(hipEventCreateWithFlags(&e[n].event, hipEventDisableTiming));
+    return n++;
+  }
+  void wait_for(int i, int j) {
+    Entry& other = e[j];
+    if (other.cover_w < other.writes || other.cover_r < other.reads) {
+      HIP_OK(hipEventRecord(other.event, other.stream));
+      other.cover_w = other.writes;
+      other.cover_r = other.reads;
+    }
+    HIP_OK(hipStreamWaitEvent(e[i].stream, other.event, 0));
+    seen_w[i][j] = other.cover_w;
+    seen_r[i][j] = other.cover_r;
+  }
+  void before(int kind, hipStream_t stream, int64_t chunks_opened) {
+    const int i = entry(stream);
+    bool reads_too = kind == kWriteLive;
+    if (kind == kWriteFresh) {
+      if (chunks_opened == opens_seen) return;
+      opens_seen = chunks_opened;
+      reads_too = true;
+    }
+    for (int j = 0; j < n; ++j) {
+      if (j == i) continue;
+      if (e[j].writes > seen_w[i][j] || (reads_too && e[j].reads > seen_r[i][j])) wait_for(i, j);
+    }
+  }
+  void after(int kind, hipStream_t stream) {
+    Entry& mine = e[entry(stream)];
+    if (kind == kRead) ++mine.reads;
+    else ++mine.writes;
+  }
+};
+
 struct emb_replay {
   std::mutex mu;
   std::unique_ptr<emb::ReplayIndex> index;
@@ -658,7 +772,6 @@ struct emb_replay {
   std::vector<KeyInfo> keys;
   int key_stepid = -1, key_is_first = -1, key_is_last = -1;
   TableRing ring;
-  ArgRing arg_ring;
   LaunchTimer timer, timer_other, timer_update;   // gathers, unread predecessor stamps, write-backs
   std::string timed_kernel[2];                    // the kernel the last stamped gather / write-back ran
   bool timing_update = false;                     // set by emb_replay_update around its launches
@@ -668,12 +781,9 @@ struct emb_replay {
   std::vector<uint32_t> stamp;                     // update: last-writer-wins marks per pool row
   uint32_t stamp_epoch = 0;
   std::vector<emb::StepId> ids;
-  // Actor and learner on different HIP streams: pool writes (add/update) and
-  // pool reads (sample) are ordered across streams with one event each way.
+  // Actor and learner on different HIP streams (StreamOrder below).
   bool multistream = false;
-  hipEvent_t wrote = nullptr, read = nullptr;
-  hipStream_t wrote_on = nullptr, read_on = nullptr;
-  bool has_wrote = false, has_read = false;
+  StreamOrder order;
   // Early insert (emb_replay_obs_stack_insert): the keys of the next add for
   // `workers` that are already in their pool rows, and where they came from.
   struct Prewritten {
@@ -690,41 +800,45 @@ struct emb_replay {
   ~emb_replay() {
     if (gate)
       while (gate->state.load(std::memory_order_acquire) != 0) sched_yield();
-    if (wrote) (void)hipEventDestroy(wrote);
-    if (read) (void)hipEventDestroy(read);
     if (dev_rows) (void)hipFree(dev_rows);
   }
 
-  void order_before(bool gather, hipStream_t stream) {
-    if (!multistream) return;
-    if (!wrote) {
-      HIP_OK(hipEventCreateWithFlags(&wrote, hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&read, hipEventDisableTiming));
-    }
-    // A read must see every earlier write; a write must not overtake a read
-    // of rows it may recycle, nor an earlier write on another stream.
-    if (has_wrote && wrote_on != stream) HIP_OK(hipStreamWaitEvent(stream, wrote, 0));
-    if (!gather && has_read && read_on != stream) HIP_OK(hipStreamWaitEvent(stream, read, 0));
+  void order_before(int kind, hipStream_t stream) {
+    if (multistream) order.before(kind, stream, index->chunks_opened());
+  }
+  void order_after(int kind, hipStream_t stream) {
+    if (multistream) order.after(kind, stream);
   }
 
-  void order_after(bool gather, hipStream_t stream) {
-    if (!multistream) return;
-    if (gather) {
-      HIP_OK(hipEventRecord(read, stream));
-      read_on = stream;
-      has_read = true;
-    } else {
-      HIP_OK(hipEventRecord(wrote, stream));
-      wrote_on = stream;
-      has_wrote = true;
+  // One argument ring per stream (a ring guards its slots with events on the
+  // stream that filled them: two streams taking turns on one ring would close a
+  // group -- an event record, ~4 us of host time -- at every change of hands).
+  ArgRing& args_for(hipStream_t stream) {
+    for (auto& entry : arg_rings)
+      if (entry.first == stream) return *entry.second;
+    if (arg_rings.size() < 4) {
+      arg_rings.emplace_back(stream, std::make_unique<ArgRing>());
+      return *arg_rings.back().second;
     }
+    return *arg_rings.back().second;      // more streams than rings: the last one is shared
   }
+  std::vector<std::pair<hipStream_t, std::unique_ptr<ArgRing>>> arg_rings;
 };
 
 extern "C" {
 
 const char* emb_last_error(void) { return g_error.c_str(); }
 int32_t emb_abi_version(void) { return EMB_ABI_VERSION; }
+
+int32_t emb_configure(const char* name, const char* value) {
+  return guarded([&] {
+    need(name && std::strncmp(name, "EMB_", 4) == 0, "configure: knob names start with EMB_");
+    if (emb::knob_set(name, value) != 0)
+      throw std::invalid_argument(std::string("configure: ") + name +
+                                  " is already in effect (knobs are read once: set them before the "
+                                  "first call that uses them)");
+  });
+}
 
 int32_t emb_device_count(int32_t* count) {
   return guarded([&] {
@@ -1112,7 +1226,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     for (int k = 0; k < plan.n_keys; ++k) bytes += plan.key[k].rowbytes * n_rows;
     // EMB_ARGS_DEVICE_MIN: smallest move (bytes) that gets a device copy of its arguments.
     static const int64_t device_min = [] {
-      const char* e = std::getenv("EMB_ARGS_DEVICE_MIN");
+      const char* e = emb::knob("EMB_ARGS_DEVICE_MIN");
       return e ? std::atoll(e) : int64_t{4} << 20;
     }();
     if (bytes >= device_min) {
@@ -1121,9 +1235,10 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
         rep->timer_other.enabled = rep->timer_other.discard = true;
         rep->timer_other.next(&none, &done);
       }
-      if (rep->arg_ring.usable()) {
+      ArgRing& arg_ring = rep->args_for(stream);
+      if (arg_ring.usable()) {
         // The CPU writes the block into device memory through the BAR.
-        device_args = rep->arg_ring.put(launch.args, emb::move_args_bytes(), stream);
+        device_args = arg_ring.put(launch.args, emb::move_args_bytes(), stream);
         args_in_bar = true;
         // A timed gather wants a predecessor that carries a completion stamp
         // (see stamp_predecessors): a one-lane marker kernel, only then.
@@ -1139,7 +1254,9 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     }
   }
   hp.lap(gather ? 12 : 17, gather ? "gather: args -> device (+marker)" : "scatter: args -> device");
-  rep->order_before(gather, stream);
+  const int access = gather ? StreamOrder::kRead
+                            : plan.fresh_rows ? StreamOrder::kWriteFresh : StreamOrder::kWriteLive;
+  rep->order_before(access, stream);
   hipEvent_t start = nullptr, stop = nullptr;
   if (stamp_this) {
     own.next(&start, &stop);
@@ -1153,10 +1270,10 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
     start = nullptr;                 // completion stamp only
   }
   HIP_OK(emb::launch_move(launch, gather, device_args, stream, start, stop));
-  rep->order_after(gather, stream);
+  rep->order_after(access, stream);
   hp.lap(gather ? (stamp_this ? 14 : 13) : 18,
          gather ? (stamp_this ? "gather: launch (stamped)" : "gather: launch") : "scatter: launch");
-  if (args_in_bar) rep->arg_ring.retire(stream);
+  if (args_in_bar) rep->args_for(stream).retire(stream);
   if (args_lease.slot >= 0) rep->ring.retire(args_lease, stream);
   if (lease.slot >= 0) rep->ring.retire(lease, stream);
   hp.lap(gather ? 15 : 19, gather ? "gather: retire" : "scatter: retire");
@@ -1171,6 +1288,7 @@ struct KeyList {
   int32_t group = 0;            // gather: destination groups (MovePlan::group)
   int64_t group_stride = 0;
   bool dst_read_soon = false;   // gather: MovePlan::dst_read_soon
+  bool fresh_rows = false;      // scatter: MovePlan::fresh_rows (an insert)
   // Masked insert: per key a DType code (-1 = plain copy) and the buffer that
   // also receives the masked value; mask_flags = is_last of the rows.
   std::vector<int8_t> mask_dtype;
@@ -1200,6 +1318,7 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
     plan.group = list.group;
     plan.group_stride = list.group_stride;
     plan.dst_read_soon = list.dst_read_soon;
+    plan.fresh_rows = list.fresh_rows;
     plan.is_first_pool = first_pool;
     for (int k = lo; k < hi; ++k) {
       if (list.mask_flags && list.mask_dtype[k] >= 0) {
@@ -1330,16 +1449,17 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     // All that is left is one small key (the action): the rows are in device
     // memory since the early insert, the launch needs 56 bytes of arguments.
     const bool masked = list.mask_flags && list.mask_dtype[0] >= 0;
-    rep->order_before(false, stream);
+    rep->order_before(StreamOrder::kWriteFresh, stream);
     HIP_OK(emb::launch_publish_one(list.key[0].batch, list.key[0].pool, masked ? list.mask_out[0] : nullptr,
                                    rep->dev_rows, masked ? list.mask_flags : nullptr, n,
                                    list.key[0].rowbytes, masked ? list.mask_dtype[0] : emb::kU8, stream,
                                    write_stamp(rep)));
-    rep->order_after(false, stream);
+    rep->order_after(StreamOrder::kWriteFresh, stream);
     hp.lap(2, "add: publish_one launch");
     return;
   }
   // (a deferred add never has the step ids in the list: the early insert wrote them)
+  list.fresh_rows = true;
   run_move_all(rep, list, rows, n, list.key_stepid >= 0 ? rep->ids.data() : nullptr, false, stream);
   hp.lap(3, "add: mover launch (run_move)");
 }
@@ -1451,8 +1571,9 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
     const uint8_t* ids = reinterpret_cast<const uint8_t*>(rep->ids.data());
     TableRing::Lease lease{-1, nullptr, nullptr};
     bool in_bar = false;
-    if (bytes <= ArgRing::kSlotBytes && rep->arg_ring.usable()) {
-      uint8_t* slot = rep->arg_ring.take(s);
+    ArgRing& arg_ring = rep->args_for(s);
+    if (bytes <= ArgRing::kSlotBytes && arg_ring.usable()) {
+      uint8_t* slot = arg_ring.take(s);
       emb::prewrite_fill_table(slot, plan, rep->rows.data(), ids);
       ArgRing::publish();
       plan.table_dev = slot;
@@ -1464,11 +1585,11 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
       plan.table_dev = lease.device;
     }
     hp.lap(6, "early insert: table -> device");
-    rep->order_before(false, s);
+    rep->order_before(StreamOrder::kWriteFresh, s);
     HIP_OK(emb::launch_obs_stack_insert(plan, s, write_stamp(rep)));
-    rep->order_after(false, s);
+    rep->order_after(StreamOrder::kWriteFresh, s);
     hp.lap(7, "early insert: launch");
-    if (in_bar) rep->arg_ring.retire(s);
+    if (in_bar) arg_ring.retire(s);
     if (lease.slot >= 0) rep->ring.retire(lease, s);
     pre.workers.assign(workers, workers + n);
     pre.rows = rep->rows;
@@ -1695,7 +1816,14 @@ int32_t emb_replay_profile_report(emb_replay_t* rep, int32_t which, int64_t* lau
   });
 }
 
-int32_t emb_replay_multistream(emb_replay_t* rep, int32_t enable) { REP_OP(rep->multistream = enable != 0); }
+int32_t emb_replay_multistream(emb_replay_t* rep, int32_t enable) {
+  REP_OP({
+    // Pool accesses issued before the switch were not counted: let them finish
+    // (once, when a second stream first appears).
+    if (enable && !rep->multistream) HIP_OK(hipDeviceSynchronize());
+    rep->multistream = enable != 0;
+  });
+}
 
 int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* total_ms, int32_t reset) {
   REP_OP({
@@ -1982,7 +2110,7 @@ const Rccl& rccl() {
     // other (a site's own RCCL build; the suite's loopback transport between
     // processes that share one GPU, tests/fake_rccl/).  No fallback: a path
     // that does not load is an error.
-    if (const char* chosen = std::getenv("EMB_RCCL_LIB"); chosen && *chosen) {
+    if (const char* chosen = emb::knob("EMB_RCCL_LIB"); chosen && *chosen) {
       lib = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
       if (!lib) throw std::runtime_error(std::string("EMB_RCCL_LIB: cannot load ") + chosen + ": " + dlerror());
     }

@@ -60,6 +60,10 @@ struct MovePlan {
   // tensors as source, Replay.update): leave it in L2 / Infinity Cache -- plain
   // stores instead of the span mover's non-temporal ones.
   bool dst_read_soon = false;
+  // Scatter only: the rows are rows of the workers' OPEN chunks (an insert), not
+  // rows of existing items (a write-back): what cross-stream ordering it needs
+  // (abi.cpp StreamOrder).
+  bool fresh_rows = false;
 };
 
 // True if this plan's tables fit the kernel-argument block (else the caller

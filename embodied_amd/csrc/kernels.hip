@@ -5,6 +5,7 @@
 // lane with consecutive lanes on consecutive addresses, several independent
 // loads in flight per lane, and far more than 256 workgroups per launch.
 #include "kernels.h"
+#include "knobs.h"
 
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
@@ -591,7 +592,7 @@ struct MoveVariant { int unroll; int nt; int remap; int threads; int persist; };
 const MoveVariant& move_variant() {
   static const MoveVariant variant = [] {
     MoveVariant v{2, 3, 0, 256, 0};
-    if (const char* s = std::getenv("EMB_MOVE_VARIANT"))
+    if (const char* s = emb::knob("EMB_MOVE_VARIANT"))
       std::sscanf(s, "%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.remap, &v.threads, &v.persist);
     if (v.persist < 0 || v.persist > 64) v.persist = 0;
     if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 2;
@@ -629,7 +630,7 @@ struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; in
 const SpanVariant& span_variant() {
   static const SpanVariant variant = [] {
     SpanVariant v{4, 3, 512, 2, 160, 3, false};
-    if (const char* s = std::getenv("EMB_SPAN_VARIANT"))
+    if (const char* s = emb::knob("EMB_SPAN_VARIANT"))
       v.nt_given = std::sscanf(s, "%d,%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb,
                                &v.nt_scatter) >= 2;
     if (v.unroll != 2 && v.unroll != 4) v.unroll = 4;
@@ -720,12 +721,12 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
     // dependent reads (84 MB write-back: 20.3 us flat-indirect, 17.6 us span) —
     // there the span mover takes every size.
     static const int64_t scatter_mb = [] {    // EMB_SPAN_SCATTER_MB: size limit of span write-backs
-      const char* e = std::getenv("EMB_SPAN_SCATTER_MB");
+      const char* e = emb::knob("EMB_SPAN_SCATTER_MB");
       return e ? std::atoll(e) : 40;
     }();
     const int64_t limit_mb = gather ? sv.max_mb : (sv.max_mb < scatter_mb ? sv.max_mb : scatter_mb);
     static const bool host_all = [] {       // EMB_SPAN_HOST_ALL=0: size limits in host mode too (A/B)
-      const char* e = std::getenv("EMB_SPAN_HOST_ALL");
+      const char* e = emb::knob("EMB_SPAN_HOST_ALL");
       return !(e && e[0] == '0');
     }();
     span_path = wide_bytes > 0 && wide_keys <= kSpanKeys &&
@@ -827,7 +828,7 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
     // walks the same number of tiles (896 tiles: 448 workers x 2 rounds instead
     // of 512 x 1.75); EMB_SPAN_BALANCE=0 keeps the untrimmed count.
     static const bool balance = [] {
-      const char* e = std::getenv("EMB_SPAN_BALANCE");
+      const char* e = emb::knob("EMB_SPAN_BALANCE");
       return !(e && e[0] == '0');
     }();
     int64_t workers = std::min<int64_t>(h.ntiles, int64_t(compute_units()) * sv.per_cu);
@@ -865,7 +866,7 @@ hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStr
   // measured -0.15 us on the gather and +3.2 us on this kernel (eight PCIe
   // readers), so one writer is the default.
   static const int writers = [] {
-    const char* e = std::getenv("EMB_ARGS_WRITERS");
+    const char* e = emb::knob("EMB_ARGS_WRITERS");
     const int n = e ? std::atoi(e) : 1;
     return n >= 1 && n <= 64 ? n : 1;
   }();
@@ -1708,7 +1709,7 @@ hipError_t launch_scan(const Op& op, hipStream_t stream) {
   }
   // EMB_SCAN_FORM=1: the one-element-per-lane kernel (A/B against rows4).
   static const bool one_per_lane = [] {
-    const char* e = std::getenv("EMB_SCAN_FORM");
+    const char* e = emb::knob("EMB_SCAN_FORM");
     return e && e[0] == '1';
   }();
   // Short rows in small batches (Dreamer's imagined returns, (1024, 16)) stay
@@ -2059,7 +2060,7 @@ hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, ui
   // A frame over a few workgroups: 64 envs x 4 = one workgroup per CU.
   const int64_t vecs = frame_bytes >> 4;
   static const int64_t per_env = [] {       // EMB_SYNTH_BLOCKS: workgroups per env (A/B)
-    const char* e = std::getenv("EMB_SYNTH_BLOCKS");
+    const char* e = emb::knob("EMB_SYNTH_BLOCKS");
     const int64_t v = e ? std::atoll(e) : 4;
     return v >= 1 && v <= 64 ? v : 4;
   }();

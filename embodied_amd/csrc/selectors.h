@@ -17,6 +17,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "knobs.h"
 #include "np_random.h"
 
 namespace emb {
@@ -993,7 +994,7 @@ class Prioritized : public Selector {
     if (where_stale_) return;
     where_pending_.push_back({id, st, pos, add});
     static const size_t limit = [] {        // EMB_WHERE_BACKLOG: entries kept before giving up (tests)
-      const char* e = std::getenv("EMB_WHERE_BACKLOG");
+      const char* e = emb::knob("EMB_WHERE_BACKLOG");
       const long v = e ? std::atol(e) : 0;
       return v > 0 ? static_cast<size_t>(v) : (size_t{1} << 16);
     }();

@@ -66,6 +66,15 @@ typedef struct emb_replay emb_replay_t;
 
 const char* emb_last_error(void);
 int32_t emb_abi_version(void);
+
+/* Tuning knobs (INTEGRATION.md lists them: EMB_SPAN_VARIANT, EMB_DEFER_INDEX,
+ * EMB_DEFER_MAX_GAP_US, EMB_ARGS_BAR, ...).  Each is read once, by the first
+ * call that needs it, from emb_configure's value or else from the environment
+ * variable of the same name.  emb_configure after that first use is refused
+ * (EMB_ERR_INVALID): a setting is never half in effect.  value NULL withdraws
+ * an earlier emb_configure.  The reference has no counterpart (its knobs are
+ * Python config fields); this replaces "export EMB_...=" for host programs. */
+int32_t emb_configure(const char* name, const char* value);
 int32_t emb_device_count(int32_t* count);
 
 /* ---- numpy-compatible PRNG ------------------------------------------------

@@ -174,3 +174,40 @@ def test_import_chooses_host_resident_kernel_arguments_unless_told_otherwise():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == want, (given, out.stdout)
+
+
+def test_knobs_are_set_before_their_first_use_or_not_at_all():
+  """emb_configure (include/embodied_hip.h): a knob is read once; the value a
+  host program gives beats the environment; a late setting is refused instead of
+  being half in effect.  Child process: knobs are process-wide."""
+  import os
+  import subprocess
+  import sys
+  code = '''
+import os
+os.environ["EMB_WHERE_BACKLOG"] = "65536"
+import embodied_amd as emb
+from embodied_amd import _lib
+emb.configure(EMB_WHERE_BACKLOG=7, EMB_SPAN_VARIANT="4,1")
+emb.configure(EMB_SPAN_VARIANT=None)                       # withdrawn again
+import numpy as np
+sel = emb.selectors.Prioritized(exponent=0.8, initial=1.0, seed=0)
+sel[0] = np.arange(60, dtype=np.uint8).reshape(3, 20)
+sel[1] = np.arange(60, 120, dtype=np.uint8).reshape(3, 20)
+del sel[0]                                                  # by now the selector has read EMB_WHERE_BACKLOG
+try:
+  emb.configure(EMB_WHERE_BACKLOG=9)
+  print("late: accepted")
+except ValueError as e:
+  print("late: refused", "already in effect" in str(e))
+try:
+  emb.configure(SOMETHING=1)
+  print("name: accepted")
+except ValueError as e:
+  print("name: refused")
+'''
+  out = subprocess.run([sys.executable, '-c', code], cwd=str(ROOT), capture_output=True, text=True,
+                       timeout=300)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = out.stdout.strip().splitlines()
+  assert lines[-2:] == ['late: refused True', 'name: refused'], out.stdout

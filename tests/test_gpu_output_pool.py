@@ -164,10 +164,11 @@ def test_private_torch_internals_mean_what_the_opt_in_pool_assumes():
   box = [object()]
   held = sys.getrefcount(box[0])
   tensors = [torch.empty(4, device='cuda')]
-  assert sys.getrefcount(tensors[0]) == held              # only the list holds it
-  extra = tensors[0]
-  assert sys.getrefcount(tensors[0]) == held + 1
+  alone = sys.getrefcount(tensors[0])                     # (outside `assert`: pytest's rewriting
+  extra = tensors[0]                                      # keeps sub-expressions alive in temporaries)
+  shared = sys.getrefcount(tensors[0])
   del extra
+  assert alone == held and shared == held + 1             # only the list holds it / one more holder
 
 
 def test_opt_in_pool_reuses_only_unreferenced_sets(emb, monkeypatch):
