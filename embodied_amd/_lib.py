@@ -264,6 +264,16 @@ def _load_fastcall():
     return None
 
 
+def _same_values(values, expected):
+  """len(values) == len(expected) and every value IS the expected object."""
+  if len(values) != len(expected):
+    return False
+  for value, want in zip(values.values(), expected):
+    if value is not want:
+      return False
+  return True
+
+
 class _FastApi:
   """`fast.emb_xxx(...)`: hot entry points through the call shim.  Arguments:
   Python ints (addresses, sizes, handles as `.value`), None, floats, ctypes
@@ -284,6 +294,7 @@ class _FastApi:
     self.module = module
     # Replay.add_batch's per-key checks in C (None: the Python loop is used).
     self.columns = getattr(module, 'columns', None)
+    self.same_values = getattr(module, 'same_values', None) or _same_values
     for name, shape in self.SHAPES.items():
       if module is None:
         setattr(self, name, getattr(api, name))

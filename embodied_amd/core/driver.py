@@ -389,7 +389,10 @@ class Driver:
           ring = self._mask_ring = (names, [{} for _ in range(4)], [0])
         ring[2][0] = turn = (ring[2][0] + 1) & 3
         mask = (names, is_last, ring[1][turn])
-      acts = sink.add_batch({**obs, **acts, **outs}, self._workers, mask=mask)
+      if len(mask) == 3:
+        acts = sink.add_step(obs, acts, outs, self._workers, is_last, mask[2])
+      else:
+        acts = sink.add_batch({**obs, **acts, **outs}, self._workers, mask=mask)
       self.acts = {**acts, 'reset': is_last}
     else:
       acts = {k: mask_actions(v, is_last) for k, v in acts.items()}

@@ -60,6 +60,17 @@ class Batch(dict):
   __slots__ = ('_emb_ptrs', '_emb_shape', '_emb_stream', '_emb_owner')
 
 
+class _StepRecord:
+  """What one vectorised step of a vector env looks like to the early insert and
+  the publish behind it, remembered on the step's frame tensor.  Vector envs
+  hand out the same few tensor objects step after step (an output ring): when
+  every observation tensor IS the object the record was made for, and the agent
+  stacks it the same way into the same staging tensor, all the per-key checks
+  and pointer look-ups of the general path have been done before."""
+  __slots__ = ('owner', 'values', 'workers', 'workers_ptr', 'n', 'frame_key', 'frames_ptr',
+               'early_ptrs', 'memo', 'spec', 'out_ptr', 'flags_at', 'flags_ptr', 'publishes')
+
+
 def _itemsize(dtype):
   return _ITEMSIZE.get(dtype) or torch.empty((), dtype=dtype).element_size()
 
@@ -181,6 +192,7 @@ class Replay:
     self._colspecs = {}
     self._early_ptrs = None
     self._pre_token = 0
+    self._cur_rec = None            # the step record the standing early insert went through
     self._token = C.c_uint64()
     self.early_inserts = 0          # steps whose observation keys went in with the obs stack
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
@@ -434,6 +446,7 @@ class Replay:
         keep.append(flags)
       # The early insert of this step (offer / _early_insert), if there was one.
       token, self._pre_token, self._offer_obs = self._pre_token, 0, None
+      self._cur_rec = None
       while True:
         try:
           if token:
@@ -482,6 +495,7 @@ class Replay:
     self._offer_obs = obs
     self._offer_workers = workers
     self._pre_token = 0
+    self._cur_rec = None
     order = tuple(obs)
     names = self._offer_names.get(order)
     if names is None:
@@ -494,12 +508,29 @@ class Replay:
       if getattr(frames, '_emb_offer', None) is not tag:
         frames._emb_offer = tag
 
-  def _early_insert(self, frames, pixels, channels, first, dtype, scale, offset, out):
+  def _early_insert(self, frames, pixels, channels, first, dtype, scale, offset, out, memo=None):
     """ops.obs_stack on an offered frame tensor.  True: the policy batch has
-    been written (with or without the early insert); False: not handled."""
+    been written (with or without the early insert); False: not handled.
+    `memo`: ops.obs_stack's note on the frame tensor (same object = same options
+    and staging tensor as when it was made)."""
     obs = self._offer_obs
     if obs is None or self._pre_token or self._keys is None:
       return False
+    rec = frames.__dict__.get('_emb_rec')
+    if (rec is not None and memo is not None and rec.memo is memo and rec.owner is self._offer_tag
+        and self._offer_workers is rec.workers and fast.same_values(obs, rec.values)):
+      # This step is, object for object, one that went through the general path
+      # below before: straight to the launch.
+      with self._lock:
+        if not self._staged:
+          fast.emb_replay_obs_stack_insert(
+              self._h, rec.n, rec.workers_ptr, rec.frame_key, rec.frames_ptr, rec.spec, rec.out_ptr,
+              rec.early_ptrs, self._stream(), self._token)
+          self._pre_token = self._token.value
+          if self._pre_token:
+            self.early_inserts += 1
+            self._cur_rec = rec
+          return True
     with self._lock:
       if self._staged:
         self._flush()
@@ -549,7 +580,73 @@ class Replay:
       self._pre_token = self._token.value
       if self._pre_token:
         self.early_inserts += 1
+        if memo is not None and self._workers_seen is self._offer_workers:
+          # Remember the step on its frame tensor (_StepRecord): the next time
+          # these very tensors come round, the checks above are skipped.
+          rec = _StepRecord()
+          rec.owner, rec.values = self._offer_tag, tuple(obs.values())
+          rec.workers, rec.workers_ptr, rec.n = self._offer_workers, workers_ptr, n
+          rec.frame_key, rec.frames_ptr = frame_key, frames.data_ptr()
+          rec.early_ptrs = (C.c_void_p * len(self._keys))(*self._early_ptrs)
+          rec.memo, rec.spec, rec.out_ptr = memo, spec[1], out.data_ptr()
+          rec.flags_at, rec.flags_ptr, rec.publishes = -1, None, {}
+          frames._emb_rec = rec
+          self._cur_rec = rec
     return True
+
+  def add_step(self, obs, acts, outs, workers, flags, masked):
+    """The Driver's insert of one vectorised step whose observations were
+    offered before the policy ran: the same as
+
+        add_batch({**obs, **acts, **outs}, workers, mask=(tuple(acts), flags, masked))
+
+    (driver.py:72-79: the actions are stored as `value * ~flags` and written to
+    `masked[name]`, which is returned).  When the step went in through a step
+    record (_StepRecord) and the action / output tensors are ready device
+    tensors, the observation keys need no second look: their pointers were
+    collected for the early insert."""
+    rec = self._cur_rec
+    if rec is not None and self._pre_token and obs is self._offer_obs and workers is rec.workers:
+      entry = rec.publishes.get(id(masked))
+      if entry is not None and entry[0] is masked and len(masked) == entry[5]:
+        _, plan, ptrs, mask_plan, flags_at, _ = entry
+        extra = {**acts, **outs} if outs else acts
+        if (len(extra) == len(plan) and rec.values[flags_at] is flags
+            and not fast.columns(extra, plan, ptrs, torch.Tensor, self.device.index)):
+          ids, codes, outs_ptr = mask_plan
+          with self._lock:
+            token, self._pre_token, self._offer_obs, self._cur_rec = self._pre_token, 0, None, None
+            while True:
+              try:
+                fast.emb_replay_publish(
+                    self._h, rec.n, rec.workers_ptr, ptrs, len(ids), ids, codes, outs_ptr,
+                    rec.flags_ptr, token, self._stream())
+                break
+              except _lib.PoolFull:
+                self._grow(2 * rec.n)
+            self._reraise()
+          return masked
+    names = tuple(acts)
+    token = self._pre_token
+    result = self.add_batch({**obs, **acts, **outs}, workers, mask=(names, flags, masked))
+    if (rec is not None and token and fast.columns is not None and result is masked
+        and len(masked) == len(names) and len(rec.publishes) < 16
+        and flags.dtype in (torch.bool, torch.uint8) and flags.is_contiguous()
+        and flags.device == self.device):
+      # What the general path just worked out, kept for the next time this record
+      # meets this set of mask outputs: the pointer table (observation keys in
+      # place, the actions' slots are refilled per step) and the mask plan.
+      flags_at = [i for i, v in enumerate(rec.values) if v is flags]
+      extra = {**acts, **outs} if outs else acts
+      if flags_at and all(name in self._keyid for name in extra):
+        plan = tuple(self._column(self._keyid[name], rec.n, name) for name in extra)
+        ptrs = (C.c_void_p * len(self._keys))(*self._batch_ptrs)
+        if not fast.columns(extra, plan, ptrs, torch.Tensor, self.device.index):    # every value ready
+          ids, codes, _ = self._mask_plans[names]
+          outs_ptr = (C.c_void_p * len(names))(*[masked[name].data_ptr() for name in names])
+          rec.flags_ptr = flags.data_ptr()
+          rec.publishes[id(masked)] = (masked, plan, ptrs, (ids, codes, outs_ptr), flags_at[0], len(masked))
+    return result
 
   def _collect(self, values, columns, ptrs):
     """data_ptr() of every ready value (a contiguous tensor of the column's dtype

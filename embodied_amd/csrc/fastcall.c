@@ -279,6 +279,23 @@ static PyObject* call_columns(PyObject* self, PyObject* const* args, Py_ssize_t 
   Py_RETURN_NONE;
 }
 
+/* same_values(d: dict, t: tuple) -> bool: len(d) == len(t) and the i-th value of
+ * d IS t[i] for every i.  A vector env hands out the same few tensor objects
+ * step after step: one call tells whether this step's observations are the
+ * objects a cached step record was made for. */
+static PyObject* call_same_values(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 2 || !PyDict_Check(args[0]) || !PyTuple_Check(args[1])) {
+    PyErr_SetString(PyExc_TypeError, "fastcall.same_values(dict, tuple)");
+    return NULL;
+  }
+  if (PyDict_GET_SIZE(args[0]) != PyTuple_GET_SIZE(args[1])) Py_RETURN_FALSE;
+  PyObject *name, *value;
+  Py_ssize_t pos = 0, i = 0;
+  while (PyDict_Next(args[0], &pos, &name, &value))
+    if (value != PyTuple_GET_ITEM(args[1], i++)) Py_RETURN_FALSE;
+  Py_RETURN_TRUE;
+}
+
 static PyMethodDef methods[] = {
     {"ints", (PyCFunction)(void (*)(void))call_ints, METH_FASTCALL,
      "ints(addr, *args) -> status: call an int32 f(pointers/integers...)"},
@@ -288,6 +305,8 @@ static PyMethodDef methods[] = {
      "scan(addr, *10 or 11 args) -> status"},
     {"columns", (PyCFunction)(void (*)(void))call_columns, METH_FASTCALL,
      "columns(steps, plan, out, tensor_type, device) -> None | positions for the slow path"},
+    {"same_values", (PyCFunction)(void (*)(void))call_same_values, METH_FASTCALL,
+     "same_values(dict, tuple) -> the dict's values are exactly these objects, in order"},
     {NULL, NULL, 0, NULL},
 };
 

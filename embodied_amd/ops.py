@@ -35,7 +35,7 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
       if tag is not None:
         replay = tag()
         if replay is not None and replay._early_insert(
-            frames, pixels, c, first, dtype, scale_f, offset_f, out):
+            frames, pixels, c, first, dtype, scale_f, offset_f, out, memo):
           return out
       fast.emb_obs_stack(
           frames.data_ptr(), None, n, pixels, c,
@@ -67,7 +67,8 @@ def obs_stack(frames, env_ids=None, layout='channels_first', dtype=torch.uint8,
     # into the step's pool rows, every frame is read once.
     replay = tag()
     if replay is not None and replay._early_insert(
-        frames, h * w, c, first, dtype, float(scale), float(offset), out):
+        frames, h * w, c, first, dtype, float(scale), float(offset), out,
+        frames.__dict__.get('_emb_stack')):
       return out
   fast.emb_obs_stack(
       frames.data_ptr(), _lib.ptr(ids), n, h * w, c,

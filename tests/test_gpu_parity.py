@@ -419,11 +419,12 @@ def test_callbacks_may_keep_the_tensors_of_a_step(emb):
           key: v.clone() for key, v in tran.items() if torch.is_tensor(v)})))
     driver.on_step(rep.add)
     driver.reset(lambda n: 0)
-    ptrs = []
+    ptrs, seen = [], []
 
     def policy(carry, obs):
       n = len(obs['is_first'])
       ptrs.append(obs['is_first'].data_ptr())
+      seen.append(obs)            # (kept alive: a freed buffer's address may come back from the allocator)
       act = {'act_disc': (np.arange(n) + carry).astype(np.int32),
              'act_cont': np.full((n, 3), carry, np.float32)}
       return carry + 1, act, {}
