@@ -167,12 +167,15 @@ def parse():
   p.add_argument('--selector', default='uniform', choices=['uniform', 'prioritized'],
                  help='prioritized = ppo/configs.yaml:42 (exponent .8, maxfrac .5, initial inf, '
                       'zero_on_sample) instead of the default fracs.uniform 1.0')
-  p.add_argument('--streams', type=int, default=2, choices=[1, 2],
-                 help='2 (default): the learner\'s work of a train step -- sample gather, return '
-                      'scans, write-back -- is issued on a HIP stream of its own (the actor / learner '
-                      'split of run/actor_learner.py; the reference dispatches its train step '
-                      'asynchronously as well), so the HBM-bound gathers run beside the '
-                      'latency-bound kernels of the env steps; 1: everything on one stream')
+  p.add_argument('--streams', type=int, default=0, choices=[0, 1, 2],
+                 help='2: the learner\'s work of a train step -- sample gather, return scans, '
+                      'write-back -- is issued on a HIP stream of its own (the actor / learner split '
+                      'of run/actor_learner.py; the reference dispatches its train step '
+                      'asynchronously as well); 1: everything on one stream; 0 (default): 2 for the '
+                      'dreamer workload (+6-7 %: the env steps\' small kernels run in the ramps of the '
+                      '144 MB gathers), 1 for ppo (measured 12 % SLOWER with 2: the persistent gather '
+                      'holds every CU\'s registers for its 11 us, the three dependent small kernels '
+                      'of the env step wait behind it instead of beside it)')
   p.add_argument('--host-envs', action='store_true',
                  help='step 64 numpy envs on the host and upload through the pinned slab '
                       '(PCIe-inclusive rate; never the headline value)')
@@ -275,6 +278,8 @@ def main():
   args = parse()
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     launch_ranks(args)
+  if args.streams == 0:
+    args.streams = 2 if args.workload == 'dreamer' else 1
   if args.workload == 'dreamer':      # dreamerv3/configs.yaml:11,15,40-42 (size overridden to 1e6)
     if args.capacity == 100_000:
       args.capacity = 1_000_000
