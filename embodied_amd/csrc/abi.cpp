@@ -455,6 +455,7 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
   // that cannot keep up (no CPU near the poster, an oversubscribed host) costs
   // more than it saves: deferral then pauses for a while.
   uint64_t wait_cycles = 0, jobs = 0, skip = 0;
+  uint64_t job_cycles = 0;               // written by the helper while a job runs, read after a drain
 
   // "0-7,128-135" -> set
   static bool read_cpu_list(const char* path, cpu_set_t* out) {
@@ -558,11 +559,13 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
       }
       void (*fn)(void*) = g.fn;
       g.fn = nullptr;
+      const uint64_t began = __builtin_ia32_rdtsc();
       try {
         fn(g.ctx);
       } catch (...) {
         g.error = std::current_exception();
       }
+      g.job_cycles += __builtin_ia32_rdtsc() - began;
       g.state.store(0, std::memory_order_release);
     }
   }
@@ -589,10 +592,13 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
     }
     place_helper();
     if (++jobs >= 4096) {
-      // more than ~2 us of waiting per job: the next 2^15 publishes do their
-      // bookkeeping themselves, then try again
-      if (wait_cycles / jobs > tsc_ticks(2.0)) skip = uint64_t{1} << 15;
-      wait_cycles = jobs = 0;
+      // The stepping thread waited more than ~2 us per job AND more than half of
+      // what the jobs took (a prioritized selector's 9 us job is worth a 3 us
+      // wait, a uniform one's 3 us job is not): the next 2^15 publishes do their
+      // bookkeeping themselves, then try again.  (This thread has drained: the
+      // helper is idle and job_cycles is complete.)
+      if (wait_cycles / jobs > tsc_ticks(2.0) && wait_cycles > job_cycles / 2) skip = uint64_t{1} << 15;
+      wait_cycles = jobs = job_cycles = 0;
     }
     ctx = c;
     fn = f;
