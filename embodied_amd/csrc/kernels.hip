@@ -606,7 +606,14 @@ const MoveVariant& move_variant() {
 // Span-mode mover (move_wide_spans): EMB_SPAN_VARIANT="U,NT,threads,W" = units
 // per lane per tile (2|4), non-temporal hints, workgroup size (256|512|1024)
 // and persistent workgroups per CU; W=0 turns the path off (flat mover for
-// everything).  Defaults from tools/gather_lab.hip on MI355X.
+// everything).  Defaults: round 2 from tools/gather_lab.hip (512 threads, 2 per
+// CU, tiles of 32 KB); round 4: 256 threads x 4 per CU, tiles of 16 KB, every
+// worker slot filled -- the same bytes in flight per CU from four independent
+// workgroups: B=16 10.07-10.28 us against 10.8-11.2 in a tight loop (three
+// repetitions each, profiles/r04_gather_shapes.txt), 10.25-10.42 against
+// 11.2-11.3 inside bench.py (three alternating runs, r04_ab_span_shape.txt),
+// B=12 9.2 against 10.4, level (+-1 %) at B <= 8 and B >= 24; the Dreamer keys'
+// 144 MB 25.3 against 26.2 us.
 //
 // The persistent mover wins clearly while the launch is ramp-dominated and stays
 // level with the flat mover's many short-lived workgroups far beyond that
@@ -629,7 +636,7 @@ const MoveVariant& move_variant() {
 struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; int nt_scatter; bool nt_given; };
 const SpanVariant& span_variant() {
   static const SpanVariant variant = [] {
-    SpanVariant v{4, 3, 512, 2, 160, 3, false};
+    SpanVariant v{4, 3, 256, 4, 160, 3, false};
     if (const char* s = emb::knob("EMB_SPAN_VARIANT"))
       v.nt_given = std::sscanf(s, "%d,%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb,
                                &v.nt_scatter) >= 2;
@@ -824,12 +831,14 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   t.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
   out->blocks = static_cast<uint32_t>(blocks);
   if (span_path) {
-    // As many workers as the chip takes at once, trimmed so that every worker
-    // walks the same number of tiles (896 tiles: 448 workers x 2 rounds instead
-    // of 512 x 1.75); EMB_SPAN_BALANCE=0 keeps the untrimmed count.
+    // As many workers as the chip takes at once.  EMB_SPAN_BALANCE=1 trims the
+    // count so that every worker walks the same number of tiles (round 2/3's
+    // default with 512-thread workgroups: 896 tiles = 448 workers x 2 rounds
+    // instead of 512 x 1.75); with four 256-thread workgroups per CU the full
+    // count is faster (B=16: 10.1 against 10.8 us).
     static const bool balance = [] {
       const char* e = emb::knob("EMB_SPAN_BALANCE");
-      return !(e && e[0] == '0');
+      return e && e[0] == '1';
     }();
     int64_t workers = std::min<int64_t>(h.ntiles, int64_t(compute_units()) * sv.per_cu);
     if (balance && workers > 0) {
