@@ -719,6 +719,12 @@ def main():
         'avg_launch_us': round(wb_s * 1e6, 2), 'launches': wb_launches,
         'achieved': round(wb_bytes / wb_s / 1e9, 1), 'unit': 'GB/s',
         'frac': round(wb_bytes / wb_s / 1e9 / HBM_PEAK_GBS, 4),
+        # r+w bytes over the launch time, like the gather's figure -- but the source of a
+        # write-back is the batch the gather of the same train step just stored with plain
+        # stores: most of its reads are served by L2 / Infinity Cache, only the writes must
+        # reach HBM (write-only fraction = half of `frac`)
+        'write_frac': round(wb_bytes / 2 / wb_s / 1e9 / HBM_PEAK_GBS, 4),
+        'source': 'the sampled batch, resident in L2 / Infinity Cache (plain-store gather)',
     }
 
   # Outside the timed region, measured context (no credit): SURVEY 8d's
