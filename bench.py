@@ -140,9 +140,15 @@ def parse():
   p.add_argument('--sustained-seconds', type=float, default=10.0,
                  help='after the headline region: the same loop for this long (SURVEY 8d asks for '
                       'wall-clock rates over >= 10 s windows); reported as `sustained`, 0 = skip')
-  p.add_argument('--stamp-every', type=int, default=4,
-                 help='dispatch stamps on one sample gather in this many (a stamped launch costs '
-                      'the host a few microseconds more than a plain one; 1 = every gather)')
+  p.add_argument('--stamp-every', type=int, default=0,
+                 help='dispatch stamps on one sample gather in this many (1 = every gather).  A '
+                      'stamped launch is not free: its start stamp puts ~10 us of idle time in front '
+                      'of the kernel on the GPU\'s timeline (rocprofv3 --kernel-trace of this script: '
+                      'marker, gap, gather) and costs the host a few microseconds: with one in 4 stamped '
+                      'the dreamer workload ran at 610 k env steps/s, one in 16: 651 k, one in 64: 661 k, '
+                      'none: 665 k (ppo: 4.40 / 4.52 / 4.55 / 4.56 M; the gather times themselves do '
+                      'not move).  0 (default): 32 when the timed region holds >= 8192 gathers, 16 from '
+                      '4096, 4 from 256, every second one in shorter regions')
   p.add_argument('--no-context', action='store_true',
                  help='skip the batches-per-launch sweep and the plain-copy reference after the '
                       'timed regions (counter passes: only the workload\'s own launches)')
@@ -495,8 +501,10 @@ def main():
   expected = args.steps * args.envs * args.train_ratio / (B * T)
   if args.consec != 1:
     stamp_every = 1
-  elif expected >= 256:
+  elif args.stamp_every > 0:
     stamp_every = args.stamp_every
+  elif expected >= 256:
+    stamp_every = 32 if expected >= 8192 else 16 if expected >= 4096 else 4
   else:
     # A handful of gathers in the region (the driver's --steps 20 has four):
     # every second one is stamped, beginning with the second (the stamp counter
