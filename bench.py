@@ -229,7 +229,8 @@ def build_path(args, rank, device):
     # The env owns a 4-deep ring of output buffers (transitions are copied into
     # the replay pool within the step, `reset` aliases the previous is_last).
     env = synthetic.SyntheticBatchEnv(
-        n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device, ring=4)
+        n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device, ring=4,
+        takes_unmasked_actions=True)
     driver = emb.Driver(batch_env=env, device=device)
   driver.on_step(replay.add)
   # 4096 pre-drawn action rows (the stub policy hands them out in turn).

@@ -179,6 +179,8 @@ SIGNATURES = {
     'emb_scan_gae_grouped': [p, p, p, p, i64, i64, f32, f32, p, p, i64, i64, p],
     'emb_scan_lambda': [p, p, p, p, i64, i64, f32, f32, p, p],
     'emb_scan_lambda_multi': [i32, p, p],
+    'emb_replay_carry_publish': [p, i32],
+    'emb_replay_settle': [p],
     'emb_scan_director': [p, p, p, i64, i64, f32, f32, p, p],
     'emb_abstract_traj': [p, p, i64, i64, i32, p, p, p],
     'emb_synth_env_step': [p, p, p, p, p, i64, i64, i64, i64, p, p, i32, p],

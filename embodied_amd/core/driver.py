@@ -44,6 +44,9 @@ from . import replay as replaylib
 # EMB_EARLY_INSERT=0: the Driver does not offer observations to its Replay ahead
 # of the policy (every key then goes in with the post-policy insert; the A/B).
 _EARLY_INSERT = os.environ.get('EMB_EARLY_INSERT', '1') != '0'
+# EMB_CARRY_PUBLISH=0: envs that take unmasked actions are served like all others
+# (masked copy of the actions, publish launch after the policy; the A/B).
+_CARRY = os.environ.get('EMB_CARRY_PUBLISH', '1') != '0'
 
 _DTYPE_CODE = {
     torch.uint8: _lib.U8, torch.int8: _lib.I8, torch.int16: _lib.I16,
@@ -122,6 +125,7 @@ class Driver:
     self._obs_names, self._obs_has_logs = None, False
     self._uploaded, self._upload_pending = None, False
     self._mask_ring = None
+    self._unmasked = None
     self._workers = np.arange(self.length, dtype=np.int64)
     self._workers.setflags(write=False)     # lets Replay.add_batch keep its converted copy
     self.reset()
@@ -381,6 +385,24 @@ class Driver:
       # env's own outputs: a set is overwritten four steps later.  The sink is the
       # step's only consumer; `fresh_obs=True` gives `driver.acts` fresh tensors.)
       names = tuple(acts)
+      if self._unmasked is None:
+        # An env that takes the policy's actions as they are, together with
+        # `reset` (it ignores the action of an env it resets, as the Env protocol
+        # asks: base.py:44-52), needs no masked copy of them: the Replay stores
+        # value * ~is_last in its pool rows and may carry that write into its
+        # next launch (Replay.carry_publish) -- one launch less per step.
+        self._unmasked = bool(
+            _CARRY and getattr(self.batch_env, 'takes_unmasked_actions', False)
+            and hasattr(sink, 'carry_publish') and hasattr(sink, 'add_step'))
+        if self._unmasked:
+          sink.carry_publish(True)
+      if self._unmasked:
+        sink.add_step(obs, acts, outs, self._workers, is_last, False)
+        self.acts = {**acts, 'reset': is_last}
+        step += self.length
+        if self._count_episodes:
+          episode += int(is_last.sum().item())
+        return step, episode
       if self._fresh_obs:
         mask = (names, is_last)
       else:

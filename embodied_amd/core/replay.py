@@ -193,6 +193,7 @@ class Replay:
     self._early_ptrs = None
     self._pre_token = 0
     self._cur_rec = None            # the step record the standing early insert went through
+    self._carrying, self._carry_keep = False, None
     self._token = C.c_uint64()
     self.early_inserts = 0          # steps whose observation keys went in with the obs stack
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
@@ -297,6 +298,8 @@ class Replay:
     if self._owners > 1:
       raise _lib.PoolFull(_lib.ERR_POOL_FULL, 'a sharded replay pool cannot grow: raise `slots`')
     new_slots = max(2 * self._slots, self._slots + at_least + 2)
+    if self._carrying:
+      api.emb_replay_settle(self._handle)      # a carried publish targets the OLD pool: write it before the copy
     if self._keys is not None:
       # The copy below runs on the caller's stream and the old pool goes back to
       # the allocator: with actor and learner on different streams, write-backs
@@ -397,7 +400,8 @@ class Replay:
     `mask=(names, is_last)` fuses the Driver's action mask into the insert
     (driver.py:72-74): the listed keys are stored as `value * ~is_last` in their
     own dtype and the masked tensors are returned (dict name -> tensor);
-    `mask=(names, is_last, outs)` writes them into the caller's `outs[name]`."""
+    `mask=(names, is_last, outs)` writes them into the caller's `outs[name]`;
+    `outs=False`: the masked values go to the pool rows only, None is returned."""
     workers, workers_ptr = self._workers_of(workers)
     n = len(workers)
     with self._lock:
@@ -434,13 +438,20 @@ class Replay:
           codes = (C.c_int32 * len(names))(*[_DTYPE_CODE[keys[keyid[name]].dtype] for name in names])
           plan = self._mask_plans[names] = (ids, codes, (C.c_void_p * len(names))())
         ids, codes, outs = plan
-        masked = given[0] if given and given[0] is not None else {}
-        for j, name in enumerate(names):
-          out = masked.get(name)
-          if out is None:
-            key = keys[ids[j]]
-            out = masked[name] = _lib.empty((n, *key.shape), key.dtype, device)
-          outs[j] = out.data_ptr()
+        if given and given[0] is False:
+          # nobody wants the masked values back (a Driver whose env takes the
+          # unmasked actions with `reset`): pool rows only
+          masked = None
+          for j in range(len(names)):
+            outs[j] = None
+        else:
+          masked = given[0] if given and given[0] is not None else {}
+          for j, name in enumerate(names):
+            out = masked.get(name)
+            if out is None:
+              key = keys[ids[j]]
+              out = masked[name] = _lib.empty((n, *key.shape), key.dtype, device)
+            outs[j] = out.data_ptr()
         if flags.device != device or not flags.is_contiguous():
           flags = flags.to(device).contiguous()
         keep.append(flags)
@@ -450,14 +461,14 @@ class Replay:
       while True:
         try:
           if token:
-            if masked is None:
+            if mask is None:
               fast.emb_replay_publish(
                   self._h, n, workers_ptr, ptrs, 0, None, None, None, None, token, self._stream())
             else:
               fast.emb_replay_publish(
                   self._h, n, workers_ptr, ptrs, len(ids), ids, codes, outs, flags.data_ptr(),
                   token, self._stream())
-          elif masked is None:
+          elif mask is None:
             fast.emb_replay_add(self._h, n, workers_ptr, ptrs, self._stream())
           else:
             fast.emb_replay_add_masked(
@@ -468,6 +479,17 @@ class Replay:
           self._grow(2 * n)
       self._reraise()
     return masked
+
+  def carry_publish(self, enable=True):
+    """Let a publish whose only remaining key is a small masked one, and whose
+    masked values nobody wants back (`add_step(..., masked=False)`), skip its
+    launch: the key is written by this replay's NEXT launch -- the following
+    step's early insert takes it along, anything else that touches the pool
+    settles it first (emb_replay_carry_publish, include/embodied_hip.h).  One
+    dependent launch less per env step.  The caller keeps the key's source
+    tensor and the flags unchanged until then (the Driver does)."""
+    api.emb_replay_carry_publish(self._handle, int(bool(enable)))
+    self._carrying = bool(enable)
 
   def _workers_of(self, workers):
     """(private int64 copy, its address) of a worker list."""
@@ -601,14 +623,21 @@ class Replay:
         add_batch({**obs, **acts, **outs}, workers, mask=(tuple(acts), flags, masked))
 
     (driver.py:72-79: the actions are stored as `value * ~flags` and written to
-    `masked[name]`, which is returned).  When the step went in through a step
+    `masked[name]`, which is returned; `masked=False`: pool rows only, see
+    `carry_publish`).  When the step went in through a step
     record (_StepRecord) and the action / output tensors are ready device
     tensors, the observation keys need no second look: their pointers were
     collected for the early insert."""
     rec = self._cur_rec
+    wanted = masked is not False
+    if not wanted:
+      # Carried publish: the library may leave the action's pool write to its
+      # next launch (emb_replay_carry_publish) -- the tensors stay referenced
+      # from here until this replay's next step replaces them.
+      self._carry_keep = (acts, outs, flags)
     if rec is not None and self._pre_token and obs is self._offer_obs and workers is rec.workers:
-      entry = rec.publishes.get(id(masked))
-      if entry is not None and entry[0] is masked and len(masked) == entry[5]:
+      entry = rec.publishes.get(id(masked) if wanted else 0)
+      if entry is not None and entry[0] is masked and (not wanted or len(masked) == entry[5]):
         _, plan, ptrs, mask_plan, flags_at, _ = entry
         extra = {**acts, **outs} if outs else acts
         if (len(extra) == len(plan) and rec.values[flags_at] is flags
@@ -625,12 +654,13 @@ class Replay:
               except _lib.PoolFull:
                 self._grow(2 * rec.n)
             self._reraise()
-          return masked
+          return masked if wanted else None
     names = tuple(acts)
     token = self._pre_token
     result = self.add_batch({**obs, **acts, **outs}, workers, mask=(names, flags, masked))
-    if (rec is not None and token and fast.columns is not None and result is masked
-        and len(masked) == len(names) and len(rec.publishes) < 16
+    if (rec is not None and token and fast.columns is not None
+        and (result is masked if wanted else result is None)
+        and (not wanted or len(masked) == len(names)) and len(rec.publishes) < 16
         and flags.dtype in (torch.bool, torch.uint8) and flags.is_contiguous()
         and flags.device == self.device):
       # What the general path just worked out, kept for the next time this record
@@ -643,9 +673,13 @@ class Replay:
         ptrs = (C.c_void_p * len(self._keys))(*self._batch_ptrs)
         if not fast.columns(extra, plan, ptrs, torch.Tensor, self.device.index):    # every value ready
           ids, codes, _ = self._mask_plans[names]
-          outs_ptr = (C.c_void_p * len(names))(*[masked[name].data_ptr() for name in names])
+          if wanted:
+            outs_ptr = (C.c_void_p * len(names))(*[masked[name].data_ptr() for name in names])
+          else:
+            outs_ptr = (C.c_void_p * len(names))()
           rec.flags_ptr = flags.data_ptr()
-          rec.publishes[id(masked)] = (masked, plan, ptrs, (ids, codes, outs_ptr), flags_at[0], len(masked))
+          rec.publishes[id(masked) if wanted else 0] = (
+              masked, plan, ptrs, (ids, codes, outs_ptr), flags_at[0], len(masked) if wanted else 0)
     return result
 
   def _collect(self, values, columns, ptrs):
@@ -1221,10 +1255,12 @@ class Replay:
   def profile_report(self, which='sample', reset=True):
     """(stamped launches, their total ms, kernel name) of the sample gathers or
     of the `update` write-backs since the last reset; 'deferred': how many
-    publishes handed their index bookkeeping to the library's helper thread."""
+    publishes handed their index bookkeeping to the library's helper thread;
+    'carried': (carried publishes that rode in the next early-insert launch, all
+    carried publishes -- in the `ms` position)."""
     launches, ms, name = C.c_int64(), C.c_double(), C.create_string_buffer(128)
     api.emb_replay_profile_report(
-        self._handle, {'sample': 0, 'update': 1, 'deferred': 2}[which], C.byref(launches), C.byref(ms),
+        self._handle, {'sample': 0, 'update': 1, 'deferred': 2, 'carried': 3}[which], C.byref(launches), C.byref(ms),
         int(reset), name, len(name))
     return launches.value, ms.value, name.value.decode()
 

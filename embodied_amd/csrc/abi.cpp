@@ -800,6 +800,22 @@ struct emb_replay {
     hipStream_t stream = nullptr;
   } pre;
   uint64_t pre_serial = 0, peek_mark = 0;
+  // Carried publish (emb_replay_carry_publish): the one small masked key a
+  // publish had left, not launched yet -- it rides in the next early-insert
+  // launch on the same stream, or is settled by a publish_one launch before
+  // anything else touches the pool.
+  struct Carried {
+    bool active = false;
+    const void* src = nullptr;
+    uint8_t* pool = nullptr;
+    const uint8_t* flags = nullptr;
+    int64_t rowbytes = 0, n = 0;
+    int dtype = 0;
+    std::vector<int32_t> rows;       // the carried step's pool rows (host copy)
+    hipStream_t stream = nullptr;
+  } carry;
+  bool carry_publish = false;
+  int64_t carried_total = 0, carried_inline = 0;
   int32_t* dev_rows = nullptr;       // the prewrite launch's rows, for the publish launch
   size_t dev_rows_cap = 0;
 
@@ -1055,6 +1071,8 @@ int32_t emb_replay_destroy(emb_replay_t* rep) {
   return EMB_OK;
 }
 
+static void settle_carry(emb_replay* rep);
+
 #define REP_OP(...)                                   \
   return guarded([&] {                                \
     need(rep, "replay handle is null");               \
@@ -1088,6 +1106,7 @@ int32_t emb_replay_set_keys(emb_replay_t* rep, int32_t n_keys, const char* const
 
 int32_t emb_replay_grow(emb_replay_t* rep, int64_t n_slots, void* const* pools) {
   REP_OP({
+    settle_carry(rep);            // (callers that move the pool settle BEFORE they copy it: emb_replay_settle)
     rep->index->grow(n_slots);
     if (pools)
       for (size_t k = 0; k < rep->keys.size(); ++k) rep->keys[k].pool = static_cast<uint8_t*>(pools[k]);
@@ -1353,6 +1372,20 @@ static hipEvent_t write_stamp(emb_replay* rep) {
   return stop;
 }
 
+// A carried publish that cannot ride in an early-insert launch (something else
+// touches the pool first): the publish_one launch it replaced, now.  The rows
+// are still in dev_rows -- only the next early insert overwrites them, and that
+// one takes the carry along itself.
+static void settle_carry(emb_replay* rep) {
+  emb_replay::Carried& c = rep->carry;
+  if (!c.active) return;
+  c.active = false;
+  rep->order_before(StreamOrder::kWriteFresh, c.stream);
+  HIP_OK(emb::launch_publish_one(c.src, c.pool, nullptr, rep->dev_rows, c.flags, c.n, c.rowbytes, c.dtype,
+                                 c.stream, write_stamp(rep)));
+  rep->order_after(StreamOrder::kWriteFresh, c.stream);
+}
+
 // The helper thread's job (DeferGate): the index bookkeeping of a publish whose
 // rows were fixed by the early insert.  `pre.workers` / `pre.rows` are not
 // written again before the next replay operation, which drains the gate first.
@@ -1374,6 +1407,7 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
   need(!rep->keys.empty(), "add: call emb_replay_set_keys first");
   need(n_masked == 0 || (masked_keys && masked_dtypes && is_last), "add: bad mask arguments");
   if (n == 0) return;
+  settle_carry(rep);            // (in a stepping loop the early insert in between has taken it along)
   for (size_t k = 0; k < rep->keys.size(); ++k) {
     need(rep->keys[k].pool, "add: key has no pool");
     need(static_cast<int>(k) == rep->key_stepid || src[k], "add: null source buffer");
@@ -1455,6 +1489,25 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     // All that is left is one small key (the action): the rows are in device
     // memory since the early insert, the launch needs 56 bytes of arguments.
     const bool masked = list.mask_flags && list.mask_dtype[0] >= 0;
+    if (rep->carry_publish && masked && !list.mask_out[0] && n <= INT32_MAX &&
+        emb::carry_supported(list.key[0].rowbytes, list.mask_dtype[0])) {
+      // Nobody wants the masked values back: no launch now.  Source and flags
+      // are read by the next launch on this replay (the caller's contract,
+      // emb_replay_carry_publish).
+      emb_replay::Carried& c = rep->carry;
+      c.active = true;
+      c.src = list.key[0].batch;
+      c.pool = list.key[0].pool;
+      c.flags = list.mask_flags;
+      c.rowbytes = list.key[0].rowbytes;
+      c.n = n;
+      c.dtype = list.mask_dtype[0];
+      c.rows.assign(rows, rows + n);
+      c.stream = stream;
+      rep->carried_total += 1;
+      hp.lap(2, "add: publish_one launch");
+      return;
+    }
     rep->order_before(StreamOrder::kWriteFresh, stream);
     HIP_OK(emb::launch_publish_one(list.key[0].batch, list.key[0].pool, masked ? list.mask_out[0] : nullptr,
                                    rep->dev_rows, masked ? list.mask_flags : nullptr, n,
@@ -1554,6 +1607,8 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
       }
       early = emb::prewrite_supported(plan);
     }
+    emb_replay::Carried& carried = rep->carry;
+    if (carried.active && !(early && carried.stream == s && carried.n == n)) settle_carry(rep);
     if (!early) {
       HIP_OK(emb::launch_obs_stack(static_cast<const uint8_t*>(frames), nullptr, dst, n, spec->pixels,
                                    spec->channels, spec->layout, spec->out_dtype, spec->scale,
@@ -1570,6 +1625,14 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
       rep->dev_rows_cap = cap;
     }
     plan.rows_out = rep->dev_rows;
+    if (carried.active) {            // the previous step's action rides in this launch
+      plan.carry_src = static_cast<const uint8_t*>(carried.src);
+      plan.carry_pool = carried.pool;
+      plan.carry_flags = carried.flags;
+      plan.carry_rowbytes = carried.rowbytes;
+      plan.carry_dtype = carried.dtype;
+      plan.carry_rows = carried.rows.data();
+    }
     hp.lap(5, "early insert: key plan");
     // The per-env table goes to device memory: written by the CPU through the
     // BAR when it fits a slot of the argument ring, else staged and copied.
@@ -1594,6 +1657,10 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
     rep->order_before(StreamOrder::kWriteFresh, s);
     HIP_OK(emb::launch_obs_stack_insert(plan, s, write_stamp(rep)));
     rep->order_after(StreamOrder::kWriteFresh, s);
+    if (carried.active) {
+      carried.active = false;
+      rep->carried_inline += 1;
+    }
     hp.lap(7, "early insert: launch");
     if (in_bar) arg_ring.retire(s);
     if (lease.slot >= 0) rep->ring.retire(lease, s);
@@ -1611,6 +1678,7 @@ static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* co
                           uint8_t* first_stepids_out, hipStream_t stream) {
   need(batch >= 0 && dst, "sample: bad arguments");
   need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
+  settle_carry(rep);
   need(group >= 0 && group_stride >= 0 && (group == 0 || group_stride % 16 == 0),
        "sample: bad destination groups");
   if (batch == 0) return;
@@ -1670,6 +1738,7 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
                           void* stream) {
   REP_OP({
     need(B >= 0 && T >= 1 && stepids, "update: bad arguments");
+    settle_carry(rep);
     if (B == 0) return;
     KeyList list = list_subset(rep, n_keys, key_ids, src);
     list.seq_len = static_cast<int32_t>(T);
@@ -1734,6 +1803,7 @@ int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n
                                int64_t seq_len, void* const* dst, void* stream) {
   REP_OP({
     need(rows && n_rows >= 0 && dst && seq_len >= 1, "gather_rows: bad arguments");
+    settle_carry(rep);
     if (n_rows == 0) return;
     KeyList list;
     for (size_t k = 0; k < rep->keys.size(); ++k) {
@@ -1776,6 +1846,7 @@ int32_t emb_replay_scatter_rows(emb_replay_t* rep, const int32_t* rows, int64_t 
                                 void* stream) {
   REP_OP({
     need(rows && n_rows >= 0, "scatter_rows: bad arguments");
+    settle_carry(rep);
     if (n_rows == 0) return;
     KeyList list = list_subset(rep, n_keys, key_ids, src);
     run_move_all(rep, list, rows, n_rows, nullptr, false, static_cast<hipStream_t>(stream));
@@ -1804,17 +1875,22 @@ int32_t emb_replay_profile(emb_replay_t* rep, int32_t enable) {
 int32_t emb_replay_profile_report(emb_replay_t* rep, int32_t which, int64_t* launches, double* total_ms,
                                   int32_t reset, char* kernel_out, int32_t kernel_cap) {
   REP_OP({
-    need(launches && total_ms && which >= 0 && which <= 2, "profile_report: bad arguments");
+    need(launches && total_ms && which >= 0 && which <= 3, "profile_report: bad arguments");
     static const std::string helper_name = "index bookkeeping on the helper thread";
+    static const std::string carried_name = "publishes carried into the next early-insert launch (total_ms: of how many carried)";
     if (which == 2) {                    // not a kernel: publishes deferred to the helper thread
       *launches = rep->deferred_adds;
       *total_ms = 0;
       if (reset) rep->deferred_adds = 0;
+    } else if (which == 3) {             // not a kernel either: carried publishes that rode along / all of them
+      *launches = rep->carried_inline;
+      *total_ms = static_cast<double>(rep->carried_total);
+      if (reset) rep->carried_inline = rep->carried_total = 0;
     } else {
       (which == 0 ? rep->timer : rep->timer_update).read(launches, total_ms, reset != 0);
     }
     if (kernel_out && kernel_cap > 0) {
-      const std::string& name = which == 2 ? helper_name : rep->timed_kernel[which];
+      const std::string& name = which == 2 ? helper_name : which == 3 ? carried_name : rep->timed_kernel[which];
       const size_t n = std::min<size_t>(name.size(), static_cast<size_t>(kernel_cap) - 1);
       std::memcpy(kernel_out, name.data(), n);
       kernel_out[n] = 0;
@@ -1826,6 +1902,7 @@ int32_t emb_replay_multistream(emb_replay_t* rep, int32_t enable) {
   REP_OP({
     // Pool accesses issued before the switch were not counted: let them finish
     // (once, when a second stream first appears).
+    settle_carry(rep);
     if (enable && !rep->multistream) HIP_OK(hipDeviceSynchronize());
     rep->multistream = enable != 0;
   });
@@ -1838,7 +1915,16 @@ int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* to
   });
 }
 
-int32_t emb_replay_complete_all(emb_replay_t* rep) { REP_OP(rep->index->complete_all()); }
+int32_t emb_replay_complete_all(emb_replay_t* rep) { REP_OP(settle_carry(rep); rep->index->complete_all()); }
+
+int32_t emb_replay_carry_publish(emb_replay_t* rep, int32_t enable) {
+  REP_OP({
+    if (!enable) settle_carry(rep);
+    rep->carry_publish = enable != 0;
+  });
+}
+
+int32_t emb_replay_settle(emb_replay_t* rep) { REP_OP(settle_carry(rep)); }
 int32_t emb_replay_open_chunks(emb_replay_t* rep, int64_t* n) { REP_OP(need(n, "open_chunks: null output"); *n = rep->index->open_chunks()); }
 int32_t emb_replay_reserve_uids(emb_replay_t* rep, uint64_t serial) { REP_OP(rep->index->reserve_uids(serial)); }
 
@@ -1846,6 +1932,7 @@ int32_t emb_replay_chunks(emb_replay_t* rep, int64_t cap, uint64_t* uid, uint64_
                           int64_t* fill, int64_t* slot, int64_t* time_ms, int64_t* n) {
   REP_OP({
     need(n, "chunks: n is null");
+    settle_carry(rep);
     int64_t i = 0;
     for (const auto& kv : rep->index->chunks()) {
       if (i < cap) {

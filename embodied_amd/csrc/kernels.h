@@ -195,7 +195,17 @@ struct PrewritePlan {
   uint8_t* stepid_pool = nullptr;
   const void* table_dev = nullptr;
   int32_t* rows_out = nullptr;       // device int32[n] for launch_publish_one (optional)
+  // Carried publish: the PREVIOUS step's masked key (value * !flags[e] in
+  // carry_dtype) written to rows carry_rows[e] of carry_pool by this launch.
+  const uint8_t* carry_src = nullptr;
+  uint8_t* carry_pool = nullptr;
+  const uint8_t* carry_flags = nullptr;
+  int64_t carry_rowbytes = 0;
+  int carry_dtype = kU8;
+  const int32_t* carry_rows = nullptr;   // host int32[n]
 };
+// A key the early-insert launch can carry: one element per lane of a workgroup.
+bool carry_supported(int64_t rowbytes, int dtype);
 bool prewrite_supported(const PrewritePlan& plan);
 size_t prewrite_table_bytes(int64_t n);
 void prewrite_fill_table(void* dst, const PrewritePlan& plan, const int32_t* rows, const uint8_t* stepids);

@@ -1125,11 +1125,20 @@ struct PreKey {
   uint8_t* pool;
   int64_t rowbytes;
 };
+// The action of the PREVIOUS step, carried into this launch (see "carried
+// publish" below): value * !flags[e] in `dtype` to row prev_rows[e] of `pool`.
+struct PreCarry {
+  const uint8_t* src;           // (n, rowbytes); null = nothing carried
+  uint8_t* pool;
+  const uint8_t* flags;         // the previous step's is_last, one byte per env
+  int32_t rowbytes, dtype, elem, pad;
+};
 struct alignas(16) PreTable {
   uint8_t* stepid_pool;
   int32_t* rows_out;            // device int32[n]: the rows again, for the publish launch (may be null)
   PreKey narrow[kPreNarrow];
-  uint32_t words[1];            // rows[n] | step ids, 5 words per row (6 * n words)
+  PreCarry carry;
+  uint32_t words[1];            // rows[n] | step ids, 5 words per row | the carried step's rows[n] (7 * n words)
 };
 struct PrewriteArgs {
   const uint8_t* frames;
@@ -1147,9 +1156,39 @@ static_assert(sizeof(PrewriteArgs) == 56, "obs_stack_insert_kernel's arguments (
 // dependent reads (table -> source bytes -> stores) runs beside the frame
 // workgroups instead of behind one of them.  All loads are issued before the
 // first store: three memory round trips, however many keys.
+//
+// Carried publish: when all that an insert has left after the policy is one
+// small masked key (the action) and nobody needs the masked values back, the
+// publish launch is not made at all -- the previous step's action rides in THIS
+// launch (one element per lane of the env's narrow workgroup, the same typed
+// multiply as publish_one_kernel), one dependent launch less per env step.
+__device__ __forceinline__ void prewrite_carry(const PreTable& t, const uint32_t* tab, int32_t n_envs,
+                                               int64_t n) {
+  const PreCarry c = t.carry;                    // uniform: scalar loads
+  if (!c.src) return;
+  const int64_t prev = static_cast<int32_t>(gload<uint32_t>(tab + 6 * static_cast<int64_t>(n_envs) + n));
+  const int64_t off = static_cast<int64_t>(threadIdx.x) * c.elem;
+  if (prev < 0 || off >= c.rowbytes) return;
+  const bool keep = gload<uint8_t>(c.flags + n) == 0;
+  const uint8_t* src = c.src + n * c.rowbytes + off;
+  uint8_t* pool = c.pool + prev * c.rowbytes + off;
+  switch (c.dtype) {
+    case kU8: case kBool: put_masked<uint8_t>(src, pool, nullptr, keep); break;
+    case kI8: put_masked<int8_t>(src, pool, nullptr, keep); break;
+    case kI16: put_masked<int16_t>(src, pool, nullptr, keep); break;
+    case kI32: put_masked<int32_t>(src, pool, nullptr, keep); break;
+    case kI64: put_masked<int64_t>(src, pool, nullptr, keep); break;
+    case kF16: put_masked<_Float16>(src, pool, nullptr, keep); break;
+    case kBF16: put_masked_bf16(src, pool, nullptr, keep); break;
+    case kF32: put_masked<float>(src, pool, nullptr, keep); break;
+    default: put_masked<double>(src, pool, nullptr, keep); break;
+  }
+}
+
 __device__ __forceinline__ void prewrite_narrow(const PrewriteArgs& a, int64_t n) {
   const PreTable& t = *a.table;
   const uint32_t* tab = t.words;
+  prewrite_carry(t, tab, a.n, n);
   const int64_t row = static_cast<int32_t>(gload<uint32_t>(tab + n));
   if (row < 0) return;
   uint32_t sid = 0;
@@ -2105,7 +2144,7 @@ bool prewrite_supported(const PrewritePlan& p) {
 }
 
 size_t prewrite_table_bytes(int64_t n) {
-  return offsetof(PreTable, words) + static_cast<size_t>(n) * 6 * sizeof(uint32_t);
+  return offsetof(PreTable, words) + static_cast<size_t>(n) * 7 * sizeof(uint32_t);
 }
 
 void prewrite_fill_table(void* dst, const PrewritePlan& p, const int32_t* rows, const uint8_t* stepids) {
@@ -2116,12 +2155,26 @@ void prewrite_fill_table(void* dst, const PrewritePlan& p, const int32_t* rows, 
   for (int k = 0; k < kPreNarrow; ++k)
     head.narrow[k] = k < p.n_narrow ? PreKey{p.narrow[k].src, p.narrow[k].pool, p.narrow[k].rowbytes}
                                     : PreKey{nullptr, nullptr, 0};
+  head.carry = PreCarry{nullptr, nullptr, nullptr, 0, 0, 1, 0};
+  if (p.carry_src && p.carry_rows) {
+    const int elem = dtype_size(p.carry_dtype);
+    head.carry = PreCarry{p.carry_src, p.carry_pool, p.carry_flags, static_cast<int32_t>(p.carry_rowbytes),
+                          p.carry_dtype, elem > 0 ? elem : 1, 0};
+  }
   uint8_t* out = static_cast<uint8_t*>(dst);
   std::memcpy(out, &head, offsetof(PreTable, words));
   out += offsetof(PreTable, words);
   std::memcpy(out, rows, static_cast<size_t>(p.n) * sizeof(int32_t));
-  std::memcpy(out + static_cast<size_t>(p.n) * sizeof(int32_t), stepids,
-              static_cast<size_t>(p.n) * kStepBytes);
+  out += static_cast<size_t>(p.n) * sizeof(int32_t);
+  std::memcpy(out, stepids, static_cast<size_t>(p.n) * kStepBytes);
+  out += static_cast<size_t>(p.n) * kStepBytes;
+  if (head.carry.src) std::memcpy(out, p.carry_rows, static_cast<size_t>(p.n) * sizeof(int32_t));
+}
+
+bool carry_supported(int64_t rowbytes, int dtype) {
+  const int elem = dtype_size(dtype);
+  return elem > 0 && rowbytes > 0 && rowbytes % elem == 0 && rowbytes / elem <= kThreads &&
+         rowbytes <= INT32_MAX;
 }
 
 hipError_t launch_obs_stack_insert(const PrewritePlan& p, hipStream_t stream, hipEvent_t stop) {

@@ -16,8 +16,12 @@ from .._lib import api, fast
 class SyntheticBatchEnv:
 
   def __init__(self, n, shape=(84, 84, 4), episode_len=1000, env0=0,
-               actions=6, device='cuda', ring=0):
+               actions=6, device='cuda', ring=0, takes_unmasked_actions=False):
     self.n = n
+    # True: the Driver may hand this env the policy's actions unmasked, with
+    # `reset` beside them (this generator never looks at the action of an env
+    # it restarts -- nor at any other): see Driver._step_device_env.
+    self.takes_unmasked_actions = bool(takes_unmasked_actions)
     self.shape = tuple(shape)
     self.frame_bytes = int(np.prod(shape))
     assert self.frame_bytes % 16 == 0

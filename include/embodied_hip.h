@@ -248,6 +248,24 @@ int32_t emb_replay_publish(emb_replay_t* rep, int64_t n, const int64_t* workers,
                            const void* const* src, int32_t n_masked, const int32_t* masked_keys,
                            const int32_t* masked_dtypes, void* const* masked_out,
                            const void* is_last, uint64_t token, void* stream);
+
+/* Carried publish (round 4).  With the early insert in use, what a publish has
+ * left is usually one small masked key (the action): a launch of its own whose
+ * only cost is its place in the chain of dependent launches of an env step.
+ * emb_replay_carry_publish(rep, 1) lets emb_replay_publish skip that launch when
+ * the caller passes a NULL masked_out for the key (nobody needs the masked
+ * values back -- Driver: the env takes unmasked actions together with `reset`,
+ * driver.py:72-75): the key is written, masked, by the NEXT
+ * emb_replay_obs_stack_insert launch on the same stream, or by a launch of its
+ * own before any other call reads or writes the pool (sample, update, add,
+ * gather / scatter rows, chunk bookkeeping, grow all settle it first).
+ * Contract while it is enabled: the key's source buffer and the is_last flags of
+ * a publish stay unchanged until the next call on this replay that launches
+ * (its early insert, or anything that settles).  emb_replay_settle(rep) settles
+ * explicitly (before the caller moves the pool, reads it directly or frees the
+ * source).  Results are identical to an immediate publish.                      */
+int32_t emb_replay_carry_publish(emb_replay_t* rep, int32_t enable);
+int32_t emb_replay_settle(emb_replay_t* rep);
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
                           uint8_t* online_out, uint8_t* first_stepids_out, void* stream);
 /* The same with the batch side cut into groups of `group` sequences whose

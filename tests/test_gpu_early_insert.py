@@ -28,13 +28,14 @@ def _host(batch):
 
 def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, out_dtype=torch.bfloat16,
               layout='channels_first', extra_out=False, sample_every=7, episode_len=5, on_replay=None,
-              block=1):
+              block=1, unmasked=False, act_dtype=np.int32):
   """Device Driver + Replay next to the oracle Driver + Replay on the same
   envs, policy and seeds; `stack` = the policy builds its batch with
   ops.obs_stack (which takes up the Driver's offer).  Returns the replay, the
   policy batches the agent saw and the number of early inserts."""
   from embodied_amd.envs import synthetic
-  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=episode_len, ring=4)
+  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=episode_len, ring=4,
+                                    takes_unmasked_actions=unmasked)
   rep = emb.Replay(length=length, capacity=capacity, chunksize=chunksize, online=online, seed=0)
   ref = np_oracle.Replay(length, capacity, chunksize, online, seed=0)
   if on_replay:
@@ -49,7 +50,7 @@ def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, 
 
   def acts_at(t):
     # negative values too: the mask is a multiply (-x -> -0 for floats)
-    return ((np.arange(n) * 3 + t * 5) % 7 - 3).astype(np.int32)
+    return ((np.arange(n) * 3 + t * 5) % 7 - 3).astype(act_dtype)
 
   def outs_at(t):
     return (np.arange(n * 6).reshape(n, 6) + t).astype(np.float32)
@@ -409,3 +410,97 @@ def test_blocks_of_steps_per_driver_call(emb, seed):
   got, want = rep.stats(), ref.stats()
   for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
     assert got[k] == want[k], (k, got[k], want[k])
+
+
+# ------------------------------------------------------------ carried publish --
+
+@pytest.mark.parametrize('online', [False, True])
+@pytest.mark.parametrize('sample_every', [1, 7])
+def test_carried_publish_matches_oracle(emb, online, sample_every):
+  """An env that takes unmasked actions (Driver: no masked copy, Replay.
+  carry_publish): the action's pool write rides in the NEXT step's early-insert
+  launch, or is settled by a launch of its own when a sample comes first.  Every
+  sampled batch equals the oracle's (which masks the stored action,
+  driver.py:72-74); with a sample every 7th step most publishes ride along."""
+  n, steps = 5, 90
+  rep, ref, _ = _run_pair(emb, n, (8, 8, 4), length=4, capacity=60, chunksize=8, steps=steps,
+                          online=online, stack=True, sample_every=sample_every, unmasked=True)
+  assert rep.early_inserts == steps - 1
+  inline, total = rep.profile_report('carried')[:2]
+  assert total >= steps - 2                       # every publish behind an early insert was carried
+  if sample_every == 1:
+    assert inline <= total // 2                   # a sample after every step settles them first
+  else:
+    assert inline >= total * 0.7
+  got, want = rep.stats(), ref.stats()
+  for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
+    assert got[k] == want[k], k
+  assert_same(_host(rep.sample(6)), ref.sample(6), 'final')
+
+
+@pytest.mark.parametrize('act_dtype', [np.float32, np.float16, np.int64, np.uint8])
+def test_carried_publish_masks_in_the_actions_own_dtype(emb, act_dtype):
+  """value * ~is_last in the key's dtype inside the carrying launch: -x -> -0.0
+  for floats, exactly as the publish launch and numpy do."""
+  rep, ref, _ = _run_pair(emb, 6, (8, 8, 4), length=3, capacity=200, chunksize=16, steps=60,
+                          online=False, stack=True, sample_every=11, unmasked=True, act_dtype=act_dtype)
+  assert rep.profile_report('carried')[0] > 40
+  for _ in range(4):
+    got, want = _host(rep.sample(9)), ref.sample(9)
+    assert got['action'].dtype == want['action'].dtype
+    assert np.array_equal(got['action'].view(np.uint8), want['action'].view(np.uint8))     # bit for bit (-0.0)
+    assert_same(got, want, 'dtype')
+
+
+def test_carried_publish_with_pool_growth_blocks_and_agent_outputs(emb):
+  """Pool growth between a carried publish and the launch that would have taken
+  it along (settled before the pool is copied), several steps per Driver call,
+  and agent outputs beside the action (more than one key left: nothing to
+  carry, same results)."""
+  rep, ref, _ = _run_pair(emb, 6, (8, 8, 4), length=4, capacity=None, chunksize=4, steps=120,
+                          online=False, stack=True, sample_every=9, unmasked=True)
+  assert_same(_host(rep.sample(8)), ref.sample(8), 'growth')
+  rep, ref, _ = _run_pair(emb, 4, (8, 8, 4), length=3, capacity=80, chunksize=8, steps=60, online=True,
+                          stack=True, sample_every=3, unmasked=True, block=3)
+  assert_same(_host(rep.sample(8)), ref.sample(8), 'blocks')
+  rep, ref, _ = _run_pair(emb, 4, (8, 8, 4), length=3, capacity=80, chunksize=8, steps=60, online=False,
+                          stack=True, sample_every=5, unmasked=True, extra_out=True)
+  assert rep.profile_report('carried')[1] == 0
+  assert_same(_host(rep.sample(8)), ref.sample(8), 'outs')
+
+
+def test_carried_publish_is_settled_before_checkpoints_and_on_request(emb, tmp_path):
+  """save() reads the pool through torch: the chunk bookkeeping call in front of
+  it settles a carried publish; carry_publish(False) settles too."""
+  from embodied_amd.envs import synthetic
+  n = 4
+  env = synthetic.SyntheticBatchEnv(n, shape=(8, 8, 4), episode_len=50, ring=4, takes_unmasked_actions=True)
+  rep = emb.Replay(length=2, capacity=400, chunksize=16, seed=0, directory=str(tmp_path), save_wait=True)
+  driver = emb.Driver(batch_env=env, device='cuda')
+  driver.on_step(rep.add)
+  tick = [0]
+
+  def policy(carry, obs, **kw):
+    emb.ops.obs_stack(obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+    tick[0] += 1
+    return carry, {'action': torch.full((n,), tick[0], dtype=torch.int32, device='cuda')}, {}
+
+  driver.reset()
+  driver(policy, steps=n)                         # the first step allocates the pool (uninitialised memory)
+  key = rep._keys[rep._keyid['action']]
+  torch.cuda.synchronize()
+  key.pool.zero_()
+  driver(policy, steps=n * 9)
+  assert rep.profile_report('carried', reset=False)[1] >= 8
+  rep.save()
+  torch.cuda.synchronize()
+  stored = key.pool.view(torch.int32).cpu().numpy()
+  assert sorted(set(stored[stored > 0].tolist())) == list(range(2, 11))      # the 10th step's action is in
+  driver(policy, steps=n * 3)
+  rep.carry_publish(False)
+  torch.cuda.synchronize()
+  stored = key.pool.view(torch.int32).cpu().numpy()
+  assert stored.max() == 13
+  again = emb.Replay(length=2, capacity=400, chunksize=16, seed=0, directory=str(tmp_path))
+  again.load()
+  assert len(again) >= 4 * 8
