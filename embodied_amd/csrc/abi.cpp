@@ -812,6 +812,7 @@ struct emb_replay {
     int64_t rowbytes = 0, n = 0;
     int dtype = 0;
     std::vector<int32_t> rows;       // the carried step's pool rows (host copy)
+    std::vector<int32_t> sorted;     // the same, sorted (does a sampled window end on one of them?)
     hipStream_t stream = nullptr;
   } carry;
   bool carry_publish = false;
@@ -1503,6 +1504,8 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
       c.n = n;
       c.dtype = list.mask_dtype[0];
       c.rows.assign(rows, rows + n);
+      c.sorted = c.rows;
+      std::sort(c.sorted.begin(), c.sorted.end());
       c.stream = stream;
       rep->carried_total += 1;
       hp.lap(2, "add: publish_one launch");
@@ -1678,7 +1681,6 @@ static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* co
                           uint8_t* first_stepids_out, hipStream_t stream) {
   need(batch >= 0 && dst, "sample: bad arguments");
   need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
-  settle_carry(rep);
   need(group >= 0 && group_stride >= 0 && (group == 0 || group_stride % 16 == 0),
        "sample: bad destination groups");
   if (batch == 0) return;
@@ -1702,6 +1704,16 @@ static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* co
   HostLap hp;
   rep->rows.resize(batch * L);
   sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
+  if (rep->carry.active) {
+    // A carried publish holds the NEWEST step of every worker stream: a sampled
+    // window reads one of its rows only as its own last row.  Settle the carry
+    // (a launch) only then; otherwise it stays for the next early insert.
+    const auto& newest = rep->carry.sorted;
+    bool hit = false;
+    for (int64_t b = 0; b < batch && !hit; ++b)
+      hit = std::binary_search(newest.begin(), newest.end(), rep->rows[b * L + L - 1]);
+    if (hit) settle_carry(rep);
+  }
   hp.lap(9, "sample: index draws + spans");
   run_move_all(rep, list, rep->rows.data(), batch * L, nullptr, true, stream, &rep->spans);
   hp.lap(10, "sample: run_move (all of it)");
