@@ -592,12 +592,15 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
     }
     place_helper();
     if (++jobs >= 4096) {
-      // The stepping thread waited more than ~2 us per job AND more than half of
-      // what the jobs took (a prioritized selector's 9 us job is worth a 3 us
-      // wait, a uniform one's 3 us job is not): the next 2^15 publishes do their
-      // bookkeeping themselves, then try again.  (This thread has drained: the
-      // helper is idle and job_cycles is complete.)
-      if (wait_cycles / jobs > tsc_ticks(2.0) && wait_cycles > job_cycles / 2) skip = uint64_t{1} << 15;
+      // Deferral pays while the stepping thread waits for less than the jobs
+      // take (it would have spent that time doing them): pause -- the next 2^15
+      // publishes do their bookkeeping themselves, then try again -- only when it
+      // waited more than ~2 us per job AND more than three quarters of the jobs'
+      // own time (a uniform selector's 3 us job waited for in full is a loss: the
+      // index then lives in two cores' caches; a prioritized selector's 9 us job
+      // with a 5 us wait still saves 4).  (This thread has drained: the helper is
+      // idle and job_cycles is complete.)
+      if (wait_cycles / jobs > tsc_ticks(2.0) && wait_cycles > job_cycles / 4 * 3) skip = uint64_t{1} << 15;
       wait_cycles = jobs = job_cycles = 0;
     }
     ctx = c;
