@@ -193,7 +193,7 @@ class Replay:
     self._early_ptrs = None
     self._pre_token = 0
     self._cur_rec = None            # the step record the standing early insert went through
-    self._carrying, self._carry_keep = False, None
+    self._carrying, self._carry_keep, self._carry_tmp = False, None, None
     self._token = C.c_uint64()
     self.early_inserts = 0          # steps whose observation keys went in with the obs stack
     self._savers = concurrent.futures.ThreadPoolExecutor(16, 'replay_saver')
@@ -440,8 +440,11 @@ class Replay:
         ids, codes, outs = plan
         if given and given[0] is False:
           # nobody wants the masked values back (a Driver whose env takes the
-          # unmasked actions with `reset`): pool rows only
+          # unmasked actions with `reset`): pool rows only.  The library may read
+          # the sources at its NEXT launch (carried publish): converted copies
+          # made above live until this replay's next such step.
           masked = None
+          self._carry_tmp = keep
           for j in range(len(names)):
             outs[j] = None
         else:

@@ -373,15 +373,18 @@ def test_env_processes_forked_while_the_helper_thread_is_running(emb):
     driver.close()
 
 
-def test_soak_stepping_loop_with_sampler_threads():
+@pytest.mark.parametrize('flags', [(), ('--unmasked',)])
+def test_soak_stepping_loop_with_sampler_threads(flags):
   """tools/soak_early_insert.py for a few seconds: the device Driver steps
   through the early insert and the helper thread while two sampler threads draw
-  on their own streams; every sampled window must follow the env's generator."""
+  on their own streams; every sampled window must follow the env's generator.
+  `--unmasked`: with the action's pool write carried into the next early insert
+  (settled by whichever thread's sample needs it first)."""
   import pathlib
   import subprocess
   import sys
   root = pathlib.Path(__file__).resolve().parent.parent
-  res = subprocess.run([sys.executable, str(root / 'tools' / 'soak_early_insert.py'), '--seconds', '4'],
+  res = subprocess.run([sys.executable, str(root / 'tools' / 'soak_early_insert.py'), '--seconds', '4', *flags],
                        cwd=root, capture_output=True, text=True, timeout=300)
   assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
   assert 'errors []' in res.stdout, res.stdout[-2000:]
@@ -506,3 +509,40 @@ def test_carried_publish_is_settled_before_checkpoints_and_on_request(emb, tmp_p
   again = emb.Replay(length=2, capacity=400, chunksize=16, seed=0, directory=str(tmp_path))
   again.load()
   assert len(again) >= 4 * 8
+
+
+def test_carried_publish_with_actions_that_need_a_contiguous_copy(emb):
+  """A policy that returns a broadcast view (stride 0): the insert works on a
+  contiguous copy, which has to outlive the call when the write is carried."""
+  from embodied_amd.envs import synthetic
+  n, shape = 6, (8, 8, 4)
+  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=4, ring=4, takes_unmasked_actions=True)
+  rep = emb.Replay(length=3, capacity=300, chunksize=16, seed=0)
+  ref = np_oracle.Replay(3, 300, 16, False, seed=0)
+  oracle = np_oracle.Driver([synthetic.HostSyntheticEnv(e, shape=shape, episode_len=4) for e in range(n)])
+  oracle.on_step(ref.add)
+  driver = emb.Driver(batch_env=env, device='cuda')
+  driver.on_step(rep.add)
+  ticks = torch.arange(1, 200, dtype=torch.int32, device='cuda')
+  tick = [0, 0]
+
+  def policy(carry, obs, **kw):
+    emb.ops.obs_stack(obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+    tick[0] += 1
+    junk = torch.full((n,), -1, dtype=torch.int32, device='cuda')      # allocator traffic around the copy
+    del junk
+    return carry, {'action': ticks[tick[0]].expand(n)}, {}
+
+  def host_policy(carry, obs):
+    tick[1] += 1
+    return carry, {'action': np.full(n, tick[1] + 1, np.int32)}, {}
+
+  driver.reset()
+  for t in range(60):
+    driver(policy, steps=n)
+    torch.full((n,), -7, dtype=torch.int32, device='cuda')              # reuses freed blocks, if any
+    oracle.step(host_policy)
+    if t % 13 == 12:
+      assert_same(_host(rep.sample(7)), ref.sample(7), f'step {t}')
+  assert rep.profile_report('carried')[0] > 40
+  assert_same(_host(rep.sample(12)), ref.sample(12), 'final')

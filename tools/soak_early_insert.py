@@ -23,10 +23,12 @@ p = argparse.ArgumentParser()
 p.add_argument('--seconds', type=float, default=30)
 p.add_argument('--samplers', type=int, default=2)
 p.add_argument('--envs', type=int, default=64)
+p.add_argument('--unmasked', action='store_true',
+               help='the env takes unmasked actions: the action write is carried into the next early insert')
 args = p.parse_args()
 
 n, L = args.envs, 16
-env = synthetic.SyntheticBatchEnv(n, episode_len=37, ring=4)
+env = synthetic.SyntheticBatchEnv(n, episode_len=37, ring=4, takes_unmasked_actions=args.unmasked)
 rep = emb.Replay(length=L, capacity=20000, chunksize=256, seed=0)
 driver = emb.Driver(batch_env=env, device='cuda')
 driver.on_step(rep.add)
@@ -96,5 +98,6 @@ running[0] = False
 [t.join() for t in threads]
 torch.cuda.synchronize()
 print('env steps', counts['steps'], 'windows checked', counts['windows'], 'early inserts', rep.early_inserts,
-      'deferred', rep.profile_report('deferred')[0], 'errors', errors[:5])
+      'deferred', rep.profile_report('deferred')[0], 'carried (inline, all)', rep.profile_report('carried')[:2],
+      'errors', errors[:5])
 sys.exit(1 if errors else 0)
