@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define EMB_ABI_VERSION 2
+/* 3 (round 4): + emb_configure, emb_scan_lambda_multi, emb_replay_carry_publish,
+ * emb_replay_settle; emb_replay_profile_report which = 3.  Additions only: a
+ * caller written against version 2 runs unchanged.                             */
+#define EMB_ABI_VERSION 3
 
 #define EMB_OK 0
 #define EMB_ERR_INVALID (-1)   /* bad argument / state                         */

@@ -29,7 +29,7 @@ def test_binding_covers_every_declared_symbol():
 
 def test_version_and_device_probe():
   from embodied_amd import _lib
-  assert _lib.lib.emb_abi_version() == 2
+  assert _lib.lib.emb_abi_version() == 3
   assert _lib.device_count() >= 0
 
 
