@@ -548,7 +548,7 @@ def main():
       if hi_s != -neg_lo_s or hi_t != -neg_lo_t:
         raise SystemExit(f'rank {rank}: ranks disagree on the exchange schedule '
                          f'(sliced {-neg_lo_s:.0f}..{hi_s:.0f}, train steps {-neg_lo_t:.0f}..{hi_t:.0f})')
-    torch.cuda.synchronize(device)
+      torch.cuda.synchronize(device)      # (the barrier's own kernels)
 
   fence()
   trace = os.environ.get('EMB_BENCH_TRACE_STEPS') == '1'     # per-step host times of a short region
