@@ -578,6 +578,10 @@ def main():
   # long as --steps says; this window is long whatever the caller chose).
   sustained = None
   if args.sustained_seconds > 0:
+    if stamp_every < 16 and args.consec == 1 and os.environ.get('EMB_BENCH_NO_TIMER') != '1':
+      # A short headline region stamps every second gather; the long window that
+      # follows holds thousands: one in 16 (a stamp costs the job time, see --stamp-every)
+      replay.profile(True, every=16)
     fence()
     s_start = time.perf_counter()
     s_steps = 0
