@@ -582,6 +582,9 @@ def main():
       # A short headline region stamps every second gather; the long window that
       # follows holds thousands: one in 16 (a stamp costs the job time, see --stamp-every)
       replay.profile(True, every=16)
+      sustained_stamp_every = 16
+    else:
+      sustained_stamp_every = stamp_every
     fence()
     s_start = time.perf_counter()
     s_steps = 0
@@ -613,7 +616,7 @@ def main():
             (counters['train_steps'] - headline['train_steps']) * world / s_elapsed, 2),
         'ms_per_step': round(s_elapsed / s_steps * 1e3, 5),
         'gather_avg_us': round(s_ms / s_launches * 1e3, 2) if s_launches else None,
-        'gather_launches': s_launches,
+        'gather_launches': s_launches, 'stamped_one_in': sustained_stamp_every,
         **({'writeback_avg_us': round(s_wb_ms / s_wb_launches * 1e3, 2)} if s_wb_launches else {}),
         # how far the GPU was behind the host when the last step had been issued:
         # a few steps' worth = the host sets the pace, milliseconds = the GPU does
