@@ -32,29 +32,47 @@ def lap(name, t0):
 iters = 3000
 acts = driver.acts
 workers = driver._workers
+unmasked = bool(getattr(env, 'takes_unmasked_actions', False)) and os.environ.get('EMB_CARRY_PUBLISH', '1') != '0'
+if unmasked:
+  replay.carry_publish(True)
 ring = [{} for _ in range(4)]
 for it in range(iters):
+  if it % 16 == 0:
+    # (bursts of 16 steps with the GPU drained in between: since round 4 the GPU
+    # sets the pace of a long loop, and a launch call that waits for a full queue
+    # would be counted as host time)
+    torch.cuda.synchronize()
   t = time.perf_counter()
   obs = env.step(acts); t = lap('env.step', t)
   if early:
     replay.offer(obs, workers); t = lap('offer', t)
   carry, a, outs = policy((), obs); t = lap('policy (obs stack [+ early insert])', t)
   is_last = obs['is_last']
-  trans = {**obs, **a, **outs}; t = lap('dicts', t)
-  a = replay.add_batch(trans, workers, mask=(tuple(a), is_last, ring[it & 3])); t = lap('add_batch(mask)', t)
-  acts = {**a, 'reset': is_last}
+  if unmasked:      # the Driver's sequence for an env that takes unmasked actions
+    replay.add_step(obs, a, outs, workers, is_last, False); t = lap('add_step (publish, carried)', t)
+    acts = {**a, 'reset': is_last}
+  else:
+    a = replay.add_step(obs, a, outs, workers, is_last, ring[it & 3]); t = lap('add_step (publish + mask)', t)
+    acts = {**a, 'reset': is_last}
+  t = lap('next acts dict', t)
 torch.cuda.synchronize()
+trans = {**obs, **a, **outs}
 total = sum(T.values())
 for k, v in T.items():
   print(f'{k:40s} {v / iters * 1e6:7.2f} us')
-print(f'{"total":40s} {total / iters * 1e6:7.2f} us   (early inserts: {replay.early_inserts})')
+print(f'{"total":40s} {total / iters * 1e6:7.2f} us   (early inserts: {replay.early_inserts}, '
+      f'carried: {replay.profile_report("carried")[:2]})')
 
 # The whole Driver step, and the pieces in isolation
-t0 = time.perf_counter()
-for _ in range(iters):
-  driver(policy, steps=args.envs)
+spent = 0.0
+for burst in range(iters // 16):
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(16):
+    driver(policy, steps=args.envs)
+  spent += time.perf_counter() - t0
 torch.cuda.synchronize()
-print(f'{"driver(policy, steps=N)":40s} {(time.perf_counter() - t0) / iters * 1e6:7.2f} us')
+print(f'{"driver(policy, steps=N), bursts of 16":40s} {spent / (iters // 16 * 16) * 1e6:7.2f} us')
 
 import ctypes as C
 import numpy as np
