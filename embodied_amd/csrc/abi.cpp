@@ -656,6 +656,16 @@ std::shared_ptr<DeferGate> make_gate() {
   return gate;
 }
 
+// EMB_PREDICT_ROWS=0: every early insert waits for the helper thread and reads
+// the cursors (the A/B of the predicted rows, emb_replay::Predicted).
+bool predict_rows() {
+  static const bool value = [] {
+    const char* e = emb::knob("EMB_PREDICT_ROWS");
+    return !(e && e[0] == '0');
+  }();
+  return value;
+}
+
 // EMB_DEFER_INDEX=0: emb_replay_publish does its index bookkeeping itself.
 // A process confined to one CPU keeps it too: the helper would only take turns
 // with the thread that waits for it.
@@ -820,6 +830,26 @@ struct emb_replay {
   } carry;
   bool carry_publish = false;
   int64_t carried_total = 0, carried_inline = 0;
+  // The helper thread's job reads ITS OWN copies of the workers and rows (the
+  // next early insert rewrites `pre` while the job may still run, see below).
+  std::vector<int64_t> job_workers;
+  std::vector<int32_t> job_rows;
+  // Rows and step ids of the NEXT step, known when a publish hands its
+  // bookkeeping to the helper thread and no worker fills its chunk's last row:
+  // every cursor moves on by one (same chunk, index + 1).  The next early insert
+  // of the same workers takes them from here WITHOUT waiting for the helper --
+  // it then touches neither the index nor the selector -- provided nothing else
+  // has been called on this handle in between (`epoch`).  The publish behind it
+  // drains as ever and finds the cursors where the prediction put them.
+  struct Predicted {
+    bool valid = false;
+    uint64_t epoch = 0;
+    std::vector<int64_t> workers;
+    std::vector<int32_t> rows;
+    std::vector<emb::StepId> ids;
+  } predict;
+  uint64_t epoch = 0;               // operations on this handle so far (REP_OP)
+  int64_t predicted_inserts = 0;
   int32_t* dev_rows = nullptr;       // the prewrite launch's rows, for the publish launch
   size_t dev_rows_cap = 0;
 
@@ -829,8 +859,10 @@ struct emb_replay {
     if (dev_rows) (void)hipFree(dev_rows);
   }
 
-  void order_before(int kind, hipStream_t stream) {
-    if (multistream) order.before(kind, stream, index->chunks_opened());
+  // index_busy: the helper thread may be at the index (an early insert on
+  // predicted rows): no chunk opens in such a job, the last count seen stands.
+  void order_before(int kind, hipStream_t stream, bool index_busy = false) {
+    if (multistream) order.before(kind, stream, index_busy ? order.opens_seen : index->chunks_opened());
   }
   void order_after(int kind, hipStream_t stream) {
     if (multistream) order.after(kind, stream);
@@ -1075,7 +1107,7 @@ int32_t emb_replay_destroy(emb_replay_t* rep) {
   return EMB_OK;
 }
 
-static void settle_carry(emb_replay* rep);
+static void settle_carry(emb_replay* rep, bool index_busy = false);
 
 #define REP_OP(...)                                   \
   return guarded([&] {                                \
@@ -1083,6 +1115,7 @@ static void settle_carry(emb_replay* rep);
     std::lock_guard<std::mutex> lock(rep->mu);        \
     std::lock_guard<std::mutex> sel_lock(*rep->selector_mu); \
     rep->gate->drain();                               \
+    ++rep->epoch;                                     \
     __VA_ARGS__;                                      \
   })
 
@@ -1380,11 +1413,11 @@ static hipEvent_t write_stamp(emb_replay* rep) {
 // touches the pool first): the publish_one launch it replaced, now.  The rows
 // are still in dev_rows -- only the next early insert overwrites them, and that
 // one takes the carry along itself.
-static void settle_carry(emb_replay* rep) {
+static void settle_carry(emb_replay* rep, bool index_busy) {
   emb_replay::Carried& c = rep->carry;
   if (!c.active) return;
   c.active = false;
-  rep->order_before(StreamOrder::kWriteFresh, c.stream);
+  rep->order_before(StreamOrder::kWriteFresh, c.stream, index_busy);
   HIP_OK(emb::launch_publish_one(c.src, c.pool, nullptr, rep->dev_rows, c.flags, c.n, c.rowbytes, c.dtype,
                                  c.stream, write_stamp(rep)));
   rep->order_after(StreamOrder::kWriteFresh, c.stream);
@@ -1395,11 +1428,11 @@ static void settle_carry(emb_replay* rep) {
 // written again before the next replay operation, which drains the gate first.
 static void deferred_add(void* ctx) {
   emb_replay* rep = static_cast<emb_replay*>(ctx);
-  const int64_t n = static_cast<int64_t>(rep->pre.workers.size());
+  const int64_t n = static_cast<int64_t>(rep->job_workers.size());
   rep->defer_rows.resize(n);
   rep->defer_ids.resize(n);
-  add_index_locked(rep, n, rep->pre.workers.data(), rep->defer_rows.data(), rep->defer_ids.data());
-  if (!std::equal(rep->defer_rows.begin(), rep->defer_rows.end(), rep->pre.rows.begin()))
+  add_index_locked(rep, n, rep->job_workers.data(), rep->defer_rows.data(), rep->defer_ids.data());
+  if (!std::equal(rep->defer_rows.begin(), rep->defer_rows.end(), rep->job_rows.begin()))
     throw std::logic_error("replay: a deferred add left the rows of its early insert");
 }
 
@@ -1444,19 +1477,39 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     const int64_t chunksize = rep->index->config().chunksize;
     int64_t rotations = 0;               // workers that fill their chunk's last row: one new slot each
     bool same = true;
+    emb_replay::Predicted& next = rep->predict;
+    next.valid = false;
+    next.ids.resize(n);
     for (int64_t i = 0; i < n && same; ++i) {
       int64_t row = 0;
-      emb::StepId sid;
-      same = rep->index->peek(workers[i], mark, &row, &sid) && row == pre.rows[i];
+      same = rep->index->peek(workers[i], mark, &row, &next.ids[i]) && row == pre.rows[i];
       rotations += (row % chunksize) + 1 >= chunksize;
     }
     // (PoolFull must be raised before anything changes: only a batch that cannot
     // run out of slots goes to the helper)
     if (same && rotations <= rep->index->free_slots()) {
+      rep->job_workers = pre.workers;
+      rep->job_rows = pre.rows;
       rep->gate->post(&deferred_add, rep);
       rep->deferred_adds += 1;
       rows = pre.rows.data();
       deferred = true;
+      if (rotations == 0 && predict_rows()) {
+        // where the next step of these workers goes: one row on, same chunk
+        next.workers = pre.workers;
+        next.rows.resize(n);
+        for (int64_t i = 0; i < n; ++i) {
+          next.rows[i] = pre.rows[i] + 1;
+          uint8_t* be = next.ids[i].b + 16;            // 4-byte big-endian row-in-chunk
+          const uint32_t index = (uint32_t{be[0]} << 24 | uint32_t{be[1]} << 16 | uint32_t{be[2]} << 8 | be[3]) + 1;
+          be[0] = static_cast<uint8_t>(index >> 24);
+          be[1] = static_cast<uint8_t>(index >> 16);
+          be[2] = static_cast<uint8_t>(index >> 8);
+          be[3] = static_cast<uint8_t>(index);
+        }
+        next.epoch = rep->epoch;
+        next.valid = true;
+      }
       hp.lap(22, "add: peek check + post");
     }
   }
@@ -1555,7 +1608,20 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
                                     int32_t frame_key, const void* frames, const emb_obs_spec_t* spec,
                                     void* dst, const void* const* src, void* stream,
                                     uint64_t* token_out) {
-  REP_OP({
+  return guarded([&] {
+    need(rep, "replay handle is null");
+    std::lock_guard<std::mutex> lock(rep->mu);
+    std::lock_guard<std::mutex> sel_lock(*rep->selector_mu);
+    // Rows predicted by the publish before this call (emb_replay::Predicted):
+    // nothing below touches the index or the selector then, so the helper
+    // thread's job may still be running.
+    emb_replay::Predicted& known = rep->predict;
+    const bool predicted = known.valid && known.epoch == rep->epoch && workers && n > 0 &&
+                           static_cast<int64_t>(known.workers.size()) == n &&
+                           std::equal(workers, workers + n, known.workers.begin());
+    known.valid = false;
+    if (!predicted) rep->gate->drain();
+    ++rep->epoch;
     need(n >= 0 && workers && frames && spec && dst && src && token_out, "obs_stack_insert: bad arguments");
     need(spec->pixels > 0 && spec->channels > 0, "obs_stack_insert: bad frame shape");
     need(spec->layout == EMB_LAYOUT_SAME || spec->layout == EMB_LAYOUT_CHANNELS_FIRST,
@@ -1580,7 +1646,12 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
     bool early = frame_key >= 0 && frame_key < n_keys && frame_key != rep->key_stepid &&
                  rep->keys[frame_key].pool && src[frame_key] == frames &&
                  rep->keys[frame_key].rowbytes == spec->pixels * spec->channels && n <= INT32_MAX;
-    if (early) {
+    if (early && predicted) {
+      rep->rows = known.rows;
+      rep->ids = known.ids;
+      rep->predicted_inserts += 1;
+    } else if (early) {
+      if (predicted) rep->gate->drain();       // (not reached: `early` only depends on the arguments)
       rep->rows.resize(n);
       rep->ids.resize(n);
       const uint64_t mark = ++rep->peek_mark;
@@ -1614,7 +1685,7 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
       early = emb::prewrite_supported(plan);
     }
     emb_replay::Carried& carried = rep->carry;
-    if (carried.active && !(early && carried.stream == s && carried.n == n)) settle_carry(rep);
+    if (carried.active && !(early && carried.stream == s && carried.n == n)) settle_carry(rep, predicted);
     if (!early) {
       HIP_OK(emb::launch_obs_stack(static_cast<const uint8_t*>(frames), nullptr, dst, n, spec->pixels,
                                    spec->channels, spec->layout, spec->out_dtype, spec->scale,
@@ -1660,7 +1731,7 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
       plan.table_dev = lease.device;
     }
     hp.lap(6, "early insert: table -> device");
-    rep->order_before(StreamOrder::kWriteFresh, s);
+    rep->order_before(StreamOrder::kWriteFresh, s, predicted);
     HIP_OK(emb::launch_obs_stack_insert(plan, s, write_stamp(rep)));
     rep->order_after(StreamOrder::kWriteFresh, s);
     if (carried.active) {
@@ -1895,8 +1966,8 @@ int32_t emb_replay_profile_report(emb_replay_t* rep, int32_t which, int64_t* lau
     static const std::string carried_name = "publishes carried into the next early-insert launch (total_ms: of how many carried)";
     if (which == 2) {                    // not a kernel: publishes deferred to the helper thread
       *launches = rep->deferred_adds;
-      *total_ms = 0;
-      if (reset) rep->deferred_adds = 0;
+      *total_ms = static_cast<double>(rep->predicted_inserts);   // early inserts that did not wait for it
+      if (reset) rep->deferred_adds = rep->predicted_inserts = 0;
     } else if (which == 3) {             // not a kernel either: carried publishes that rode along / all of them
       *launches = rep->carried_inline;
       *total_ms = static_cast<double>(rep->carried_total);

@@ -310,7 +310,9 @@ int32_t emb_replay_profile_read(emb_replay_t* rep, int64_t* launches, double* to
  * which = 0 the sample gathers, 1 the write-backs of emb_replay_update (stamped
  * at the same rate while profiling is on), 2 no kernel: `launches` = the
  * emb_replay_publish calls that handed their index bookkeeping to the library's
- * helper thread (total_ms 0).  kernel_out may be NULL.                          */
+ * helper thread (total_ms: how many early inserts took predicted rows instead of
+ * waiting for it); which = 3: carried publishes that rode in the next early
+ * insert (total_ms: all carried publishes).  kernel_out may be NULL.            */
 int32_t emb_replay_profile_report(emb_replay_t* rep, int32_t which, int64_t* launches,
                                   double* total_ms, int32_t reset, char* kernel_out,
                                   int32_t kernel_cap);

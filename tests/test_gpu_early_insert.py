@@ -546,3 +546,50 @@ def test_carried_publish_with_actions_that_need_a_contiguous_copy(emb):
       assert_same(_host(rep.sample(7)), ref.sample(7), f'step {t}')
   assert rep.profile_report('carried')[0] > 40
   assert_same(_host(rep.sample(12)), ref.sample(12), 'final')
+
+
+def test_early_inserts_on_predicted_rows(emb):
+  """A stepping loop that calls nothing else on the replay: the publish that
+  hands its bookkeeping to the helper thread also says where the next step goes
+  (every cursor one row on), and the next early insert does not wait for the
+  helper.  Chunks of 16 rows: a prediction is made on 15 steps of 16.  The
+  replay must equal the oracle's after 300 such steps, and after sampling in
+  between (which invalidates a prediction)."""
+  import os
+  if os.environ.get('EMB_DEFER_INDEX') == '0':
+    pytest.skip('no helper thread in this run')
+  from embodied_amd.envs import synthetic
+  n, shape = 6, (8, 8, 4)
+  for unmasked in (False, True):
+    env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=7, ring=4, takes_unmasked_actions=unmasked)
+    rep = emb.Replay(length=4, capacity=500, chunksize=16, online=True, seed=0)
+    ref = np_oracle.Replay(4, 500, 16, True, seed=0)
+    oracle = np_oracle.Driver([synthetic.HostSyntheticEnv(e, shape=shape, episode_len=7) for e in range(n)])
+    oracle.on_step(ref.add)
+    driver = emb.Driver(batch_env=env, device='cuda')
+    driver.on_step(rep.add)
+    tick = [0, 0]
+
+    def policy(carry, obs, **kw):
+      emb.ops.obs_stack(obs['image'], layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+      tick[0] += 1
+      return carry, {'action': torch.full((n,), tick[0] % 5 - 2, dtype=torch.int32, device='cuda')}, {}
+
+    def host_policy(carry, obs):
+      tick[1] += 1
+      return carry, {'action': np.full(n, tick[1] % 5 - 2, np.int32)}, {}
+
+    driver.reset()
+    driver(policy, steps=n * 300)
+    for _ in range(300):
+      oracle.step(host_policy)
+    deferred, predicted = rep.profile_report('deferred')[:2]
+    assert deferred >= 295 and predicted >= 270, (deferred, predicted)
+    assert len(rep) == len(ref)
+    for mode in ('train', 'report', 'train'):
+      assert_same(_host(rep.sample(8, mode)), ref.sample(8, mode), f'after 300 steps, {mode}')
+    for t in range(40):
+      driver(policy, steps=n)
+      oracle.step(host_policy)
+      if t % 3 == 0:
+        assert_same(_host(rep.sample(5)), ref.sample(5), f'step {t}')
