@@ -110,5 +110,11 @@ def train(make_agent, make_replay, make_env, make_stream, make_logger, args):
       checkpoint.save()
 
   episodes.flush()
+  # (The reference stops here and drops what was aggregated since the last
+  # wall-clock log; a run shorter than `log_every` would leave no train metrics.)
+  rest = learner.metrics.result()
+  if rest:
+    logger.add(rest)
+    logger.write()
   logger.close()
   driver.close()

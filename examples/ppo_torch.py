@@ -114,7 +114,7 @@ def main(argv=None):
   cfg = types.SimpleNamespace(device='cuda', lr=3e-4, horizon=200, lam=0.8, clip=0.2, entropy=1e-2)
   args = types.SimpleNamespace(
       logdir=flags.logdir, batch_size=16, batch_length=32, train_ratio=8.0,
-      log_every=5, report_every=1e9, save_every=1e9, envs=flags.envs, debug=True,
+      log_every=1, report_every=1e9, save_every=1e9, envs=flags.envs, debug=True,
       from_checkpoint='', steps=flags.steps, consec_report=1, report_batches=1,
       device='cuda')
   env0 = cartpole.CartPole()
