@@ -104,6 +104,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # same guide: what a plain device-to-device copy achieves (read + written bytes)
 
 
 def parse():
@@ -718,6 +719,8 @@ def main():
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
         'traffic_source': traffic_source,
         'read_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
+        # context: the same bytes against the chip's measured copy rate (a gather cannot beat a copy)
+        'frac_of_copy_rate': round(achieved / HBM_COPY_GBS, 4),
         'bytes_per_launch': algo_bytes, 'avg_launch_us': round(avg_s * 1e6, 2),
         'launches': launches, 'stamped_one_in': stamp_every, 'source': source,
         'headline_region': region,
