@@ -289,10 +289,13 @@ def test_deferred_bookkeeping_with_readers_on_other_threads(emb):
   import threading
   box, seen_lengths, stop = [], set(), threading.Event()
 
+  import time
+
   def reader(via_selector):
     while not stop.is_set():
       if box:
         seen_lengths.add(len(box[0].sampler) if via_selector else len(box[0]))
+      time.sleep(0)       # (a full replay answers len() without a library call: let go of the GIL)
 
   threads = [threading.Thread(target=reader, args=(flag,), daemon=True) for flag in (False, True)]
   [t.start() for t in threads]
