@@ -183,6 +183,13 @@ def parse():
                       '144 MB gathers), 1 for ppo (measured 12 % SLOWER with 2: the persistent gather '
                       'holds every CU\'s registers for its 11 us, the three dependent small kernels '
                       'of the env step wait behind it instead of beside it)')
+  p.add_argument('--mask-actions-for-env', action='store_true',
+                 help='the synthetic env asks for masked actions like an env that reads the action of '
+                      'an env it resets would: the Driver then makes the masked copy and the Replay '
+                      'its publish launch after the policy (three dependent launches per step instead '
+                      'of two; same as EMB_CARRY_PUBLISH=0).  Default: the env takes the policy\'s '
+                      'actions unmasked together with `reset` (Env protocol, base.py:44-52), the '
+                      'stored transition holds value * ~is_last either way')
   p.add_argument('--host-envs', action='store_true',
                  help='step 64 numpy envs on the host and upload through the pinned slab '
                       '(PCIe-inclusive rate; never the headline value)')
@@ -231,7 +238,7 @@ def build_path(args, rank, device):
     # the replay pool within the step, `reset` aliases the previous is_last).
     env = synthetic.SyntheticBatchEnv(
         n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device, ring=4,
-        takes_unmasked_actions=True)
+        takes_unmasked_actions=not args.mask_actions_for_env)
     driver = emb.Driver(batch_env=env, device=device)
   driver.on_step(replay.add)
   # 4096 pre-drawn action rows (the stub policy hands them out in turn).
@@ -833,6 +840,13 @@ def main():
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
             # 2: the train step's gather / scans / write-back on the learner's own HIP stream
             'streams': args.streams,
+            # how the policy's actions reach the env: 'unmasked + reset' = the env declared that it
+            # ignores the action of an env it resets, the Driver skips the masked copy and the
+            # Replay carries the masked pool write into its next launch (carried
+            # publish); 'masked' = the reference's form, one more dependent launch per step
+            'env_actions': ('masked' if (args.mask_actions_for_env or args.host_envs
+                                         or os.environ.get('EMB_CARRY_PUBLISH') == '0')
+                            else 'unmasked + reset'),
             'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
             'cpus': PINNED,         # CPUs this process was pinned to (pin_cpus), None = scheduler's choice
             # the per-step Python of Driver / Replay / streams: Cython-compiled copies of the
