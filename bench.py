@@ -630,6 +630,36 @@ def main():
         # a few steps' worth = the host sets the pace, milliseconds = the GPU does
         'closing_fence_us': round((s_start + s_elapsed - s_issued) * 1e6, 1),
     }
+  # Context (single GPU, device envs, no part of `value`): the same loop for two
+  # more seconds with the env asking for MASKED actions, i.e. the reference's form
+  # of the env's input (driver.py:72-75) -- the Driver makes the masked copy, the
+  # Replay its publish launch after the policy: three dependent launches per step
+  # instead of two.  The stored transitions are the same either way.
+  masked_env_actions = None
+  if (not use_dist and env is not None and args.sustained_seconds > 0 and not args.no_context
+      and getattr(env, 'takes_unmasked_actions', False) and driver._unmasked):
+    fence()
+    env.takes_unmasked_actions = False
+    driver._unmasked = None
+    replay.carry_publish(False)
+    for _ in range(64):
+      one_step()
+    fence()
+    m_start, m_steps = time.perf_counter(), 0
+    while time.perf_counter() - m_start < 2.0:
+      for _ in range(256):
+        one_step()
+      m_steps += 256
+    fence()
+    m_elapsed = time.perf_counter() - m_start
+    masked_env_actions = {
+        'env_steps_per_s': round(m_steps * args.envs / m_elapsed, 1), 'steps': m_steps,
+        'ms_per_step': round(m_elapsed / m_steps * 1e3, 5),
+        'what': 'same loop, the env handed masked actions (--mask-actions-for-env): a masked copy and a '
+                'publish launch after the policy, three dependent launches per step'}
+    env.takes_unmasked_actions = True
+    driver._unmasked = None
+    replay.profile_read(reset=True)
   # Ranks only, context: the same loop with the collectives switched off (N
   # independent replicas: no exchange, no gradient all-reduce) -- what the path
   # itself does on N GPUs, next to what the links allow with them.
@@ -868,6 +898,7 @@ def main():
         **({'link_bound': native['per_train_step']['link_bound']}
            if native is not None and 'per_train_step' in native else {}),
         **({'replicas_only': replicas_only} if replicas_only is not None else {}),
+        **({'masked_env_actions': masked_env_actions} if masked_env_actions is not None else {}),
         **({'expected': expected} if expected is not None else {}),
     }), flush=True)
   if native_stuck:       # a collective of the check never returned: leave without the teardown
