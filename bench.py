@@ -579,6 +579,8 @@ def main():
     elapsed = float(t.item())
 
   launches, gather_ms, gather_kernel = replay.profile_report('sample', reset=True)
+  h_deferred, h_predicted, _ = replay.profile_report('deferred', reset=True)
+  h_inline, h_carried, _ = replay.profile_report('carried', reset=True)
   wb_launches, wb_ms, wb_kernel = replay.profile_report('update', reset=True)
   headline = dict(counters)
 
@@ -616,6 +618,8 @@ def main():
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
       s_elapsed = float(t.item())
     s_launches, s_ms, _ = replay.profile_report('sample', reset=True)
+    s_deferred, s_predicted, _ = replay.profile_report('deferred', reset=True)
+    s_inline, s_carried, _ = replay.profile_report('carried', reset=True)
     s_wb_launches, s_wb_ms, _ = replay.profile_report('update', reset=True)
     sustained = {
         'seconds': round(s_elapsed, 3), 'steps': s_steps,
@@ -625,6 +629,10 @@ def main():
         'ms_per_step': round(s_elapsed / s_steps * 1e3, 5),
         'gather_avg_us': round(s_ms / s_launches * 1e3, 2) if s_launches else None,
         'gather_launches': s_launches, 'stamped_one_in': sustained_stamp_every,
+        # of the window's publishes: bookkeeping on the helper thread / next early insert on
+        # predicted rows / action write carried into the next launch (all) / (rode along)
+        'publishes': {'deferred': s_deferred, 'predicted': int(s_predicted), 'carried': int(s_carried),
+                      'carried_inline': s_inline},
         **({'writeback_avg_us': round(s_wb_ms / s_wb_launches * 1e3, 2)} if s_wb_launches else {}),
         # how far the GPU was behind the host when the last step had been issued:
         # a few steps' worth = the host sets the pace, milliseconds = the GPU does
@@ -890,6 +898,8 @@ def main():
                             f'{"emb_comm_exchange" if use_native else "torch.distributed"})')
                            if use_dist else 'single',
         },
+        'publishes': {'deferred': h_deferred, 'predicted': int(h_predicted), 'carried': int(h_carried),
+                      'carried_inline': h_inline},
         'sustained': sustained,
         'roofline': roofline, 'cpu_baseline': cpu,
         **({'writeback': writeback} if writeback is not None else {}),
