@@ -1584,10 +1584,25 @@ struct LambdaOp {   // dreamerv3/agent.py:482-490
     const int64_t i = b * T + t0 + 1;
     float r[4], bt[4];
     uint8_t tm[4], ls[4];
-    load4(rew + i, valid, r);
-    load4(boot + i, valid, bt);
-    load4(term + i, valid, tm);
-    load4(last + i, valid, ls);
+    if (valid >= 4) {
+      // the usual lane: all four loads issued back to back, one wait (as GaeOp)
+      const F4 r4 = gload<F4>(rew + i);
+      const F4 b4 = gload<F4>(boot + i);
+      const B4 t4 = gload<B4>(term + i);
+      const B4 l4 = gload<B4>(last + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        r[k] = r4[k];
+        bt[k] = b4[k];
+        tm[k] = t4[k];
+        ls[k] = l4[k];
+      }
+    } else {
+      load4(rew + i, valid, r);
+      load4(boot + i, valid, bt);
+      load4(term + i, valid, tm);
+      load4(last + i, valid, ls);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float live = (1.f - static_cast<float>(tm[k] != 0)) * disc;
