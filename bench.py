@@ -195,6 +195,9 @@ def parse():
                       '(PCIe-inclusive rate; never the headline value)')
   p.add_argument('--parallel-envs', action='store_true',
                  help='with --host-envs: one process per env writing into the shared slab')
+  p.add_argument('--envs-per-worker', type=int, default=1,
+                 help='with --parallel-envs: this many envs per worker process (Driver(envs_per_worker=K)); '
+                      'for hosts whose CPU budget is smaller than the env count')
   return p.parse_args()
 
 
@@ -231,7 +234,8 @@ def build_path(args, rank, device):
   n = args.envs
   if args.host_envs:
     fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]
-    driver = emb.Driver(fns, parallel=args.parallel_envs, device=device)
+    driver = emb.Driver(fns, parallel=args.parallel_envs, device=device,
+                        **({'envs_per_worker': args.envs_per_worker} if args.parallel_envs else {}))
     env = None
   else:
     # The env owns a 4-deep ring of output buffers (transitions are copied into

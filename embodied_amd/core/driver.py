@@ -80,7 +80,7 @@ def mask_actions(value, is_last):
 class Driver:
 
   def __init__(self, make_env_fns=None, parallel=True, device=None,
-               batch_env=None, shared_obs=True, fresh_obs=None, **kwargs):
+               batch_env=None, shared_obs=True, fresh_obs=None, envs_per_worker=1, **kwargs):
     self.kwargs = kwargs
     if fresh_obs is None and os.environ.get('EMB_FRESH_OBS') == '1':
       fresh_obs = True
@@ -100,19 +100,34 @@ class Driver:
       assert len(make_env_fns) >= 1
       self.length = len(make_env_fns)
       if self.parallel:
+        # envs_per_worker = K > 1 (an addition; the reference starts one process
+        # per env, driver.py:17-25): worker w steps envs [w*K, (w+1)*K) one after
+        # the other.  For hosts whose CPU budget is smaller than the env count (a
+        # container quota): N processes that all become runnable at once then
+        # cost more in wake-ups and time slices than their env steps take.
+        # Needs the shared-memory step protocol (`shared_obs`).
+        self._per_worker = K = max(1, int(envs_per_worker))
+        if K > 1 and not shared_obs:
+          raise ValueError('envs_per_worker > 1 needs shared_obs=True')
         context = mp.get_context()
-        self.pipes, pipes = zip(*[context.Pipe() for _ in range(self.length)])
+        n_workers = -(-self.length // K)
+        self.pipes, pipes = zip(*[context.Pipe() for _ in range(n_workers)])
         fns = [cloudpickle.dumps(fn) for fn in make_env_fns]
-        self._wake = [context.Semaphore(0) for _ in range(self.length)]
+        self._wake = [context.Semaphore(0) for _ in range(n_workers)]
         self.procs = [
-            context.Process(target=_env_server, args=(i, pipe, fn, self._wake), daemon=True)
-            for i, (fn, pipe) in enumerate(zip(fns, pipes))]
+            context.Process(target=_env_server, args=(w * K, pipe, fns[w * K: (w + 1) * K], self._wake, w),
+                            daemon=True)
+            for w, pipe in enumerate(pipes)]
         [proc.start() for proc in self.procs]
         self.pipes[0].send(('act_space',))
         self.act_space = self._receive(self.pipes[0])
         self._shared, self._act_slab, self._fast = {}, {}, False
         if shared_obs:
           self._attach_shared_slab()
+        if K > 1 and not self._fast:
+          self.close()
+          raise RuntimeError('envs_per_worker > 1: the shared-memory step protocol could not be set up '
+                             '(the envs must expose obs_space)')
       else:
         self.envs = [fn() for fn in make_env_fns]
         self.act_space = self.envs[0].act_space
@@ -466,7 +481,7 @@ class Driver:
     results = []
     for i in range(self.length):
       if done[i] < 0 or self._extra[i]:
-        results.append(self._receive(self.pipes[i]))    # raises on ('error', e)
+        results.append(self._receive(self.pipes[i // self._per_worker]))    # raises on ('error', e)
       else:
         results.append({})
     return results
@@ -563,13 +578,18 @@ def _wake_children(envid, wakes):
     wakes[child].release()
 
 
-def _env_server(envid, pipe, ctor, wakes=None):
+def _env_server(envid, pipe, ctor, wakes=None, worker=None):
   """Worker process.  Pipe protocol as the reference's (driver.py:101-137):
   ('step', act) -> ('result', obs), 'obs_space', 'act_space'.  After
   ('attach', obs layout, n, act layout, ctrl name) it switches to the shared
   memory protocol: wait on `wake`, read its action row, step, write the
-  observation row, publish `done[envid] = seq`."""
+  observation row, publish `done[envid] = seq`.  `ctor` may be a LIST of pickled
+  constructors (Driver(envs_per_worker=K)): envs envid .. envid + K - 1, stepped
+  one after the other per wake-up; the pipe protocol then speaks for the first."""
   env = None
+  envs = []
+  ctors = ctor if isinstance(ctor, (list, tuple)) else [ctor]
+  worker = envid if worker is None else worker
   blocks, slabs = [], {}
 
   def open_block(name):
@@ -595,14 +615,15 @@ def _env_server(envid, pipe, ctor, wakes=None):
                             offset=where[0] if where else 0)
     return out
 
-  def put(obs):
+  def put(obs, row=None):
+    row = envid if row is None else row
     rest = {}
     for key, value in obs.items():
       slab = slabs.get(key)
       if slab is None:
         rest[key] = value
       else:
-        slab[envid] = value
+        slab[row] = value
     return rest
 
   def serve_shared(layout, n, act_layout=None, ctrl_name=None):
@@ -617,21 +638,23 @@ def _env_server(envid, pipe, ctor, wakes=None):
     ctrl = np.ndarray(2 + 2 * n, np.int64, buffer=ctrl_block.buf)
     done, extra = ctrl[2: 2 + n], ctrl[2 + n:]
     pipe.send(('result', True))
-    wake = wakes[envid]
+    wake = wakes[worker]
     while True:
       wake.acquire()
-      _wake_children(envid, wakes)        # first: they are woken even if this env then fails
+      _wake_children(worker, wakes)       # first: they are woken even if an env then fails
       seq = int(ctrl[0])
-      try:
-        rest = put(env.step({k: v[envid].copy() for k, v in acts.items()}))
-        if rest:
-          pipe.send(('result', rest))
-        extra[envid] = 1 if rest else 0
-        done[envid] = seq
-      except Exception as e:
-        pipe.send(('error', e))
-        done[envid] = -1
-        raise
+      for j, one in enumerate(envs):
+        row = envid + j
+        try:
+          rest = put(one.step({k: v[row].copy() for k, v in acts.items()}), row)
+          if rest:
+            pipe.send(('result', rest))
+          extra[row] = 1 if rest else 0
+          done[row] = seq
+        except Exception as e:
+          pipe.send(('error', e))
+          done[row] = -1
+          raise
 
   def step(action):
     obs = env.step(action)
@@ -644,7 +667,8 @@ def _env_server(envid, pipe, ctor, wakes=None):
       'act_space': lambda: pipe.send(('result', env.act_space)),
   }
   try:
-    env = cloudpickle.loads(ctor)()
+    envs = [cloudpickle.loads(c)() for c in ctors]
+    env = envs[0]
     while True:
       if not pipe.poll(0.1):                    # also notices a vanished parent
         continue
@@ -665,10 +689,11 @@ def _env_server(envid, pipe, ctor, wakes=None):
       pass
     raise
   finally:
-    try:
-      env and env.close()
-    except Exception:
-      pass
+    for one in envs:
+      try:
+        one.close()
+      except Exception:
+        pass
     slabs.clear()
     for block in blocks:
       try:

@@ -192,6 +192,54 @@ def test_parallel_workers_match_serial(shared_obs):
       assert np.array_equal(t0[k], t1[k]) and t0[k].dtype == t1[k].dtype, k
 
 
+@pytest.mark.parametrize('per_worker', [2, 3, 5])
+def test_several_envs_per_worker_process_match_serial(per_worker):
+  """Driver(envs_per_worker=K): worker w steps envs [w*K, (w+1)*K) one after the
+  other (for hosts whose CPU budget is smaller than the env count); the
+  transitions are the in-process loop's, also when N is no multiple of K."""
+  from tests import scenarios
+
+  def run(**kw):
+    fns = [bind(scenarios.ScriptEnv, i, 3 + i) for i in range(7)]
+    driver = emb.Driver(fns, **kw)
+    log = []
+    driver.on_step(lambda tran, w: log.append((w, {k: np.array(v) for k, v in tran.items()})))
+    driver.reset(lambda n: 0)
+    def policy(carry, obs):
+      n = len(obs['is_first'])
+      act = {'act_disc': (np.arange(n) + carry).astype(np.int32),
+             'act_cont': np.full((n, 3), carry, np.float32)}
+      return carry + 1, act, {}
+    driver(policy, steps=70)
+    procs = len(getattr(driver, 'procs', []))
+    driver.close()
+    return log, procs
+
+  serial, _ = run(parallel=False)
+  par, procs = run(parallel=True, envs_per_worker=per_worker)
+  assert procs == -(-7 // per_worker)
+  assert len(serial) == len(par) == 70
+  for (w0, t0), (w1, t1) in zip(serial, par):
+    assert w0 == w1 and set(t0) == set(t1)
+    for k in t0:
+      assert np.array_equal(t0[k], t1[k]) and t0[k].dtype == t1[k].dtype, k
+  with pytest.raises(ValueError):
+    emb.Driver([bind(scenarios.ScriptEnv, 0, 3)] * 2, parallel=True, envs_per_worker=2, shared_obs=False)
+
+
+def test_errors_and_extras_with_several_envs_per_worker():
+  agent = make_agent()
+  driver = emb.Driver([lambda: _Flaky('disc', length=10)] * 4, parallel=True, envs_per_worker=2)
+  assert driver._fast and len(driver.procs) == 2
+  driver.reset(agent.init_policy)
+  seen = []
+  driver.on_step(lambda tran, w: seen.append(float(tran['log/steps'])))
+  with pytest.raises(RuntimeError, match='simulator crashed'):
+    driver(agent.policy, steps=40)
+  driver.close()
+  assert seen[:8] == [0.0] * 4 + [1.0] * 4
+
+
 class _Flaky(dummy.Dummy):
   def step(self, action):
     obs = super().step(action)
