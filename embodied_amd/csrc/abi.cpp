@@ -701,7 +701,7 @@ struct emb_selector {
 //   write to live rows (update,      after every earlier write AND read on another
 //     scatter_rows)                    stream;
 //   write to fresh rows (add: rows   after the other streams' work only when a chunk
-//     of the workers' open chunks)     slot has been opened since the last look --
+//     of the workers' open chunks)     slot has been opened since THIS stream's last look --
 //                                      rows of an open chunk belong to no item, so no
 //                                      gather reads them and no write-back targets
 //                                      them, unless the slot was recycled.
@@ -720,7 +720,7 @@ struct StreamOrder {
   Entry e[kMax];
   uint64_t seen_w[kMax][kMax] = {}, seen_r[kMax][kMax] = {};    // [waiter][other]
   int n = 0;
-  int64_t opens_seen = -1;
+  int64_t opens_seen[kMax] = {-1, -1, -1, -1, -1, -1};           // per inserting stream
 
   ~StreamOrder() {
     for (int i = 0; i < n; ++i)
@@ -739,6 +739,7 @@ struct StreamOrder {
       }
       std::memset(seen_w, 0, sizeof(seen_w));
       std::memset(seen_r, 0, sizeof(seen_r));
+      std::fill(opens_seen, opens_seen + kMax, int64_t{-1});
       n = 0;
     }
     e[n].stream = stream;
@@ -760,8 +761,8 @@ struct StreamOrder {
     const int i = entry(stream);
     bool reads_too = kind == kWriteLive;
     if (kind == kWriteFresh) {
-      if (chunks_opened == opens_seen) return;
-      opens_seen = chunks_opened;
+      if (chunks_opened == opens_seen[i]) return;
+      opens_seen[i] = chunks_opened;
       reads_too = true;
     }
     for (int j = 0; j < n; ++j) {
@@ -859,10 +860,17 @@ struct emb_replay {
     if (dev_rows) (void)hipFree(dev_rows);
   }
 
-  // index_busy: the helper thread may be at the index (an early insert on
-  // predicted rows): no chunk opens in such a job, the last count seen stands.
+  // While the helper thread may be at the index (from the post of a job to the
+  // next drain: the publish's own launch, an early insert on predicted rows) the
+  // count of opened chunks is not read: the one seen before the post stands.  A
+  // launch in that window writes rows of chunks that were open before the job; a
+  // chunk the job opens is first written after the next drain.
+  bool index_posted = false;
+  int64_t opens_known = -1;
   void order_before(int kind, hipStream_t stream, bool index_busy = false) {
-    if (multistream) order.before(kind, stream, index_busy ? order.opens_seen : index->chunks_opened());
+    if (!multistream) return;
+    if (!index_busy && !index_posted) opens_known = index->chunks_opened();
+    order.before(kind, stream, opens_known);
   }
   void order_after(int kind, hipStream_t stream) {
     if (multistream) order.after(kind, stream);
@@ -1115,6 +1123,7 @@ static void settle_carry(emb_replay* rep, bool index_busy = false);
     std::lock_guard<std::mutex> lock(rep->mu);        \
     std::lock_guard<std::mutex> sel_lock(*rep->selector_mu); \
     rep->gate->drain();                               \
+    rep->index_posted = false;                        \
     ++rep->epoch;                                     \
     __VA_ARGS__;                                      \
   })
@@ -1490,6 +1499,8 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     if (same && rotations <= rep->index->free_slots()) {
       rep->job_workers = pre.workers;
       rep->job_rows = pre.rows;
+      if (rep->multistream) rep->opens_known = rep->index->chunks_opened();
+      rep->index_posted = true;
       rep->gate->post(&deferred_add, rep);
       rep->deferred_adds += 1;
       rows = pre.rows.data();
@@ -1620,7 +1631,10 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
                            static_cast<int64_t>(known.workers.size()) == n &&
                            std::equal(workers, workers + n, known.workers.begin());
     known.valid = false;
-    if (!predicted) rep->gate->drain();
+    if (!predicted) {
+      rep->gate->drain();
+      rep->index_posted = false;
+    }
     ++rep->epoch;
     need(n >= 0 && workers && frames && spec && dst && src && token_out, "obs_stack_insert: bad arguments");
     need(spec->pixels > 0 && spec->channels > 0, "obs_stack_insert: bad frame shape");

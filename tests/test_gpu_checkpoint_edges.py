@@ -179,3 +179,35 @@ def test_growth_with_actor_and_learner_on_two_streams(emb):
           assert float(got['deter'][b, j, 0]) == -7.0
           hits += 1
   assert hits > 0
+
+
+def test_recycled_slots_with_inserts_on_two_streams_and_a_busy_sampler(emb):
+  """A gather queued behind a busy learner stream must read its rows before
+  inserts -- of ONE worker, issued from two other streams in turn -- recycle the
+  chunk slots under it.  (Fresh-row writes wait for the other streams only when
+  a chunk was opened since THAT stream's last look.)"""
+  make = lambda: emb.Replay(length=4, capacity=64, chunksize=8, seed=3)
+  rep, twin = make(), make()
+  step = lambda t: {'x': np.full(4096, t, np.float32), 'is_first': t == 0, 'is_last': False}
+  a, b, learner = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+  for t in range(64):
+    with torch.cuda.stream(a if t % 2 else b):
+      rep.add(step(t), 0)
+    twin.add(step(t), 0)
+  torch.cuda.synchronize()
+  t = 64
+  for round_ in range(6):
+    with torch.cuda.stream(learner):
+      big = torch.randn(1 << 26, device='cuda')
+      for _ in range(6):
+        big = big * 1.0001                   # the gather below queues up behind this
+      got = rep.sample(8)
+    want = twin.sample(8)
+    for _ in range(96):                      # every slot is recycled at least once
+      with torch.cuda.stream(a if t % 2 else b):
+        rep.add(step(t), 0)
+      twin.add(step(t), 0)
+      t += 1
+    torch.cuda.synchronize()
+    for k in want:
+      assert torch.equal(got[k], want[k]), (round_, k)
