@@ -458,7 +458,8 @@ def main():
 
   # The learner's stream (--streams 2): the Replay orders its pool accesses across
   # the two streams itself (emb_replay_multistream; abi.cpp StreamOrder).
-  learner = torch.cuda.Stream(device) if args.streams == 2 else None
+  learner = (torch.cuda.Stream(device, priority=int(os.environ.get('EMB_BENCH_LEARNER_PRIORITY', '0')))
+             if args.streams == 2 else None)
   if learner is not None:
     main_stream = torch.cuda.current_stream(device)
     set_stream = torch._C._cuda_setStream

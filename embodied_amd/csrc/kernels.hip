@@ -1144,7 +1144,7 @@ struct PrewriteArgs {
   const uint8_t* frames;
   void* dst;
   uint8_t* frame_pool;
-  int64_t pixels;
+  int32_t pixels, frame_blocks;
   float scale, offset;
   int32_t n, n_narrow;
   const PreTable* table;        // device memory
@@ -1152,7 +1152,7 @@ struct PrewriteArgs {
 static_assert(sizeof(PrewriteArgs) == 56, "obs_stack_insert_kernel's arguments (passed one by one) fit the 14 preloaded dwords");
 
 // The narrow keys, the step id and the row for the publish launch of env n: one
-// extra workgroup per env (blockIdx.x == gridDim.x - 1), so that this chain of
+// extra workgroup per env (the first n of the grid), so that this chain of
 // dependent reads (table -> source bytes -> stores) runs beside the frame
 // workgroups instead of behind one of them.  All loads are issued before the
 // first store: three memory round trips, however many keys.
@@ -1219,23 +1219,31 @@ static_assert(kThreads >= 256, "a narrow key (<= 256 bytes per step) is one byte
 // s_load by every wave, `.amdhsa_user_sgpr_kernarg_preload_length 0`.)
 template <typename Out, int C, bool kChannelsFirst>
 // (The preload covers 14 dwords = 56 bytes: exactly these.)
+// ONE-dimensional grid: workgroups [0, n) are the narrow ones (their chain is the
+// longest: first out), [n, n + n * frame_blocks) the frame blocks, env by env.
+// The hardware hands consecutive workgroup ids to the 8 XCDs in turn: as a
+// (frame_blocks + 1, n) grid with 7 + 1 blocks per env (84 x 84 x 4) every
+// narrow workgroup landed on one XCD, which then took no frame block at all
+// (tools/insert_lab.hip: 0.24 us of the launch).
 __global__ __launch_bounds__(kThreads) void obs_stack_insert_kernel(
     const uint8_t* frames, const PreTable* table, uint8_t* frame_pool, void* dst,
-    int64_t pixels_, int32_t n_envs, int32_t n_narrow, float scale, float offset) {
-  const PrewriteArgs a{frames, dst, frame_pool, pixels_, scale, offset, n_envs, n_narrow, table};
-  const int64_t n = blockIdx.y;
-  if (blockIdx.x == gridDim.x - 1) {
-    prewrite_narrow(a, n);
+    int32_t pixels_, int32_t frame_blocks, int32_t n_envs, int32_t n_narrow, float scale, float offset) {
+  const PrewriteArgs a{frames, dst, frame_pool, pixels_, frame_blocks, scale, offset, n_envs, n_narrow, table};
+  if (blockIdx.x < static_cast<uint32_t>(n_envs)) {
+    prewrite_narrow(a, blockIdx.x);
     return;
   }
+  const uint32_t id = blockIdx.x - static_cast<uint32_t>(n_envs);
+  const int64_t n = id / static_cast<uint32_t>(frame_blocks);
+  const uint32_t block = id - static_cast<uint32_t>(n) * static_cast<uint32_t>(frame_blocks);
   const int64_t pixels = a.pixels;
   const int64_t quads = pixels >> 2;
   const uint32_t* frame = reinterpret_cast<const uint32_t*>(a.frames + n * pixels * C);
   Out* out = static_cast<Out*>(a.dst) + n * pixels * C;
   const int64_t row = static_cast<int32_t>(gload<uint32_t>(a.table->words + n));
   uint32_t* pool = reinterpret_cast<uint32_t*>(a.frame_pool + row * pixels * C);
-  const int64_t stride = static_cast<int64_t>(gridDim.x - 1) * kThreads;
-  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; q < quads; q += stride) {
+  const int64_t stride = static_cast<int64_t>(frame_blocks) * kThreads;
+  for (int64_t q = static_cast<int64_t>(block) * kThreads + threadIdx.x; q < quads; q += stride) {
     uint32_t w[C];
     if constexpr (C == 4) {
       const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(frame) + q);
@@ -1321,14 +1329,12 @@ __global__ __launch_bounds__(kThreads) void publish_one_kernel(
 template <typename Out>
 hipError_t obs_stack_insert_typed(const PrewriteArgs& a, int64_t channels, int layout,
                                   hipStream_t stream, hipEvent_t stop) {
-  const int64_t quads = a.pixels / 4;
-  // frame workgroups + one workgroup per env for the narrow keys
-  dim3 grid(static_cast<uint32_t>(std::min<int64_t>((quads + kThreads - 1) / kThreads, 32)) + 1,
-            static_cast<uint32_t>(a.n));
+  // one workgroup per env for the narrow keys + frame_blocks per env for its frames
+  dim3 grid(static_cast<uint32_t>(a.n) * static_cast<uint32_t>(a.frame_blocks + 1));
   const bool cf = layout == kLayoutChannelsFirst && channels > 1;
   // (hipExtLaunchKernelGGL only when a completion stamp is wanted: the plain
   // launch is the cheaper call.)
-#define EMB_PRE_ARGS a.frames, a.table, a.frame_pool, a.dst, a.pixels, a.n, a.n_narrow, a.scale, a.offset
+#define EMB_PRE_ARGS a.frames, a.table, a.frame_pool, a.dst, a.pixels, a.frame_blocks, a.n, a.n_narrow, a.scale, a.offset
 #define EMB_PRE(C)                                                                                \
   if (cf && stop) hipExtLaunchKernelGGL((obs_stack_insert_kernel<Out, C, true>), grid,            \
                                         dim3(kThreads), 0, stream, nullptr, stop, 0, EMB_PRE_ARGS); \
@@ -2150,7 +2156,9 @@ hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, ui
 }
 
 bool prewrite_supported(const PrewritePlan& p) {
-  return p.n > 0 && p.pixels > 0 && p.pixels % 4 == 0 && p.channels >= 1 && p.channels <= 4 &&
+  // (one-dimensional grid of n * (frame blocks + 1) workgroups, 32-bit pixel count)
+  return p.n > 0 && p.n <= (1 << 24) && p.pixels > 0 && p.pixels <= INT32_MAX && p.pixels % 4 == 0 &&
+         p.channels >= 1 && p.channels <= 4 &&
          reinterpret_cast<uint64_t>(p.frames) % 16 == 0 &&
          reinterpret_cast<uint64_t>(p.frame_pool) % 16 == 0 &&
          (p.pixels * p.channels) % 16 == 0 &&
@@ -2198,7 +2206,8 @@ hipError_t launch_obs_stack_insert(const PrewritePlan& p, hipStream_t stream, hi
   a.frames = p.frames;
   a.dst = p.dst;
   a.frame_pool = p.frame_pool;
-  a.pixels = p.pixels;
+  a.pixels = static_cast<int32_t>(p.pixels);
+  a.frame_blocks = static_cast<int32_t>(std::min<int64_t>((p.pixels / 4 + kThreads - 1) / kThreads, 32));
   a.scale = p.scale;
   a.offset = p.offset;
   a.n = p.n;

@@ -1,0 +1,256 @@
+// Shapes of the obs-stack + early-insert launch (kernels.hip obs_stack_insert_kernel,
+// bf16 channels-first, C = 4) inside the chain it runs in: producer (frames of the
+// step, like the synthetic env) -> insert -> producer -> ...  on one stream, every
+// launch dependent on the one before.  Prints the chain's period per pair and the
+// period with an empty kernel of the same grid in the insert's place (the
+// dependent-dispatch floor for that grid).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/build/insert_lab tools/insert_lab.hip
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bf16_of(uint32_t byte, float scale, float offset) {
+  const float f = static_cast<float>(byte) * scale + offset;
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);           // round to nearest even
+  return u >> 16;
+}
+
+__global__ void producer(uint8_t* image, int frame_bytes, uint32_t salt0) {
+  const int64_t e = blockIdx.y;
+  u32x4* out = reinterpret_cast<u32x4*>(image + e * frame_bytes);
+  const int64_t vecs = frame_bytes >> 4;
+  const uint32_t salt = salt0 + e * 131;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < vecs;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const uint32_t x = salt + static_cast<uint32_t>(i * 16);
+    __builtin_nontemporal_store(u32x4{x, x + 4, x + 8, x + 12}, out + i);
+  }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void empty_kernel(const uint8_t* frames, const int32_t* rows) {
+  if (frames == nullptr && rows[0] == 12345) __builtin_trap();
+}
+
+// Q quads per lane (issued back to back), NTB: policy batch with non-temporal
+// stores, NTL: frames with non-temporal loads, NARROW: one extra workgroup per env
+// doing a little dependent work (the narrow keys' stand-in).
+template <int THREADS, int Q, bool NTB, bool NTL, bool NARROW>
+__global__ __launch_bounds__(THREADS) void insert_kernel(
+    const uint8_t* frames, const int32_t* rows, uint8_t* frame_pool, uint16_t* dst, int64_t pixels,
+    float scale, float offset, uint8_t* narrow_pool) {
+  const int64_t n = blockIdx.y;
+  const int frame_blocks = NARROW ? gridDim.x - 1 : gridDim.x;
+  if (NARROW && blockIdx.x == gridDim.x - 1) {
+    const int64_t row = rows[n];
+    if (threadIdx.x < 24) narrow_pool[row * 24 + threadIdx.x] = static_cast<uint8_t>(threadIdx.x + n);
+    return;
+  }
+  const int64_t quads = pixels >> 2;
+  const u32x4* frame = reinterpret_cast<const u32x4*>(frames + n * pixels * 4);
+  uint16_t* out = dst + n * pixels * 4;
+  const int64_t row = rows[n];
+  u32x4* pool = reinterpret_cast<u32x4*>(frame_pool + row * pixels * 4);
+  const int64_t stride = static_cast<int64_t>(frame_blocks) * THREADS;
+  for (int64_t q0 = static_cast<int64_t>(blockIdx.x) * THREADS + threadIdx.x; q0 < quads; q0 += stride * Q) {
+    u32x4 v[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int64_t q = q0 + j * stride;
+      if (q < quads) v[j] = NTL ? __builtin_nontemporal_load(frame + q) : frame[q];
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int64_t q = q0 + j * stride;
+      if (q >= quads) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t h[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int idx = p * 4 + c;
+          h[p] = bf16_of((v[j][idx >> 2] >> ((idx & 3) * 8)) & 0xFFu, scale, offset);
+        }
+        const u32x2 o{h[0] | h[1] << 16, h[2] | h[3] << 16};
+        u32x2* at = reinterpret_cast<u32x2*>(out + c * pixels + q * 4);
+        if (NTB) __builtin_nontemporal_store(o, at); else *at = o;
+      }
+      __builtin_nontemporal_store(v[j], pool + q);
+    }
+  }
+}
+
+// The same work on a ONE-dimensional grid: workgroups [0, n * fb) are the frame
+// blocks (env = id / fb), [n * fb, n * fb + n) the narrow ones.  (Hardware hands
+// consecutive workgroup ids to the 8 XCDs in turn: with a (fb + 1, n) grid and
+// fb + 1 == 8 every narrow workgroup lands on one XCD, which then takes no frame
+// block at all.)
+template <int THREADS, int Q, int NG>
+__global__ __launch_bounds__(THREADS) void insert_flat_kernel(
+    const uint8_t* frames, const int32_t* rows, uint8_t* frame_pool, uint16_t* dst, int64_t pixels,
+    float scale, float offset, uint8_t* narrow_pool, int n_envs, int fb) {
+  const int id = blockIdx.x;
+  if (NG > 0 && id >= n_envs * fb) {
+    // NG envs per narrow workgroup, one env per group of THREADS / NG lanes
+    const int lanes = THREADS / NG, lane = threadIdx.x % lanes;
+    const int64_t n = static_cast<int64_t>(id - n_envs * fb) * NG + threadIdx.x / lanes;
+    if (n >= n_envs) return;
+    const int64_t row = rows[n];
+    if (lane < 24) narrow_pool[row * 24 + lane] = static_cast<uint8_t>(lane + n);
+    return;
+  }
+  const int64_t n = id / fb;
+  const int block = id - static_cast<int>(n) * fb;
+  const int64_t quads = pixels >> 2;
+  const u32x4* frame = reinterpret_cast<const u32x4*>(frames + n * pixels * 4);
+  uint16_t* out = dst + n * pixels * 4;
+  const int64_t row = rows[n];
+  u32x4* pool = reinterpret_cast<u32x4*>(frame_pool + row * pixels * 4);
+  const int64_t stride = static_cast<int64_t>(fb) * THREADS;
+  for (int64_t q0 = static_cast<int64_t>(block) * THREADS + threadIdx.x; q0 < quads; q0 += stride * Q) {
+    u32x4 v[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int64_t q = q0 + j * stride;
+      if (q < quads) v[j] = __builtin_nontemporal_load(frame + q);
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int64_t q = q0 + j * stride;
+      if (q >= quads) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t h[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int idx = p * 4 + c;
+          h[p] = bf16_of((v[j][idx >> 2] >> ((idx & 3) * 8)) & 0xFFu, scale, offset);
+        }
+        *reinterpret_cast<u32x2*>(out + c * pixels + q * 4) = u32x2{h[0] | h[1] << 16, h[2] | h[3] << 16};
+      }
+      __builtin_nontemporal_store(v[j], pool + q);
+    }
+  }
+}
+
+struct Bufs {
+  uint8_t *frames, *pool, *narrow;
+  uint16_t* dst;
+  int32_t* rows;
+  int64_t pixels;
+  int n;
+};
+
+template <typename F>
+double chain_us(hipStream_t s, const Bufs& b, F&& launch_insert, int iters = 4000) {
+  const dim3 pgrid(7, b.n);
+  auto pair = [&](int i) {
+    hipLaunchKernelGGL(producer, pgrid, dim3(256), 0, s, b.frames, static_cast<int>(b.pixels * 4),
+                       static_cast<uint32_t>(i));
+    launch_insert();
+  };
+  for (int i = 0; i < 300; ++i) pair(i);
+  CHECK(hipStreamSynchronize(s));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) pair(i);
+  CHECK(hipStreamSynchronize(s));
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
+}
+
+template <int THREADS, int Q, bool NTB, bool NTL, bool NARROW>
+void run(hipStream_t s, const Bufs& b, const char* name) {
+  const int64_t quads = b.pixels / 4;
+  const int blocks = static_cast<int>((quads + THREADS * Q - 1) / (THREADS * Q));
+  const dim3 grid(blocks + (NARROW ? 1 : 0), b.n);
+  double best = 1e9, best_empty = 1e9;
+  for (int rep = 0; rep < 3; ++rep) {
+    best = std::min(best, chain_us(s, b, [&] {
+      hipLaunchKernelGGL((insert_kernel<THREADS, Q, NTB, NTL, NARROW>), grid, dim3(THREADS), 0, s, b.frames,
+                         b.rows, b.pool, b.dst, b.pixels, 1.f / 255, 0.f, b.narrow);
+    }));
+    best_empty = std::min(best_empty, chain_us(s, b, [&] {
+      hipLaunchKernelGGL(empty_kernel<THREADS>, grid, dim3(THREADS), 0, s, b.frames, b.rows);
+    }));
+  }
+  std::printf("%-44s grid %2d x %d x %4d : pair %6.2f us   (empty kernel in its place %6.2f)\n", name, grid.x,
+              b.n, THREADS, best, best_empty);
+  std::fflush(stdout);
+}
+
+template <int THREADS, int Q, int NG>
+void run_flat(hipStream_t s, const Bufs& b, const char* name) {
+  const int64_t quads = b.pixels / 4;
+  const int fb = static_cast<int>((quads + THREADS * Q - 1) / (THREADS * Q));
+  const dim3 grid(b.n * fb + (NG ? (b.n + NG - 1) / NG : 0));
+  double best = 1e9, best_empty = 1e9;
+  for (int rep = 0; rep < 3; ++rep) {
+    best = std::min(best, chain_us(s, b, [&] {
+      hipLaunchKernelGGL((insert_flat_kernel<THREADS, Q, NG>), grid, dim3(THREADS), 0, s, b.frames,
+                         b.rows, b.pool, b.dst, b.pixels, 1.f / 255, 0.f, b.narrow, b.n, fb);
+    }));
+    best_empty = std::min(best_empty, chain_us(s, b, [&] {
+      hipLaunchKernelGGL(empty_kernel<THREADS>, grid, dim3(THREADS), 0, s, b.frames, b.rows);
+    }));
+  }
+  std::printf("%-44s grid %4d x %4d      : pair %6.2f us   (empty kernel in its place %6.2f)\n", name, grid.x,
+              THREADS, best, best_empty);
+  std::fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  Bufs b{};
+  b.n = argc > 1 ? std::atoi(argv[1]) : 64;
+  b.pixels = 84 * 84;
+  const int64_t frame_bytes = b.pixels * 4, pool_rows = 200000;
+  CHECK(hipMalloc(&b.frames, b.n * frame_bytes));
+  CHECK(hipMalloc(&b.pool, pool_rows * frame_bytes));
+  CHECK(hipMalloc(&b.narrow, pool_rows * 24));
+  CHECK(hipMalloc(&b.dst, b.n * frame_bytes * 2));
+  CHECK(hipMalloc(&b.rows, b.n * 4));
+  std::vector<int32_t> rows(b.n);
+  for (int i = 0; i < b.n; ++i) rows[i] = (i * 3001 + 17) % pool_rows;     // one row per worker's open chunk
+  CHECK(hipMemcpy(b.rows, rows.data(), b.n * 4, hipMemcpyHostToDevice));
+  hipStream_t s;
+  CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  std::printf("HIP_FORCE_DEV_KERNARG=%s, %d envs, %lld B per frame stack\n",
+              std::getenv("HIP_FORCE_DEV_KERNARG") ? std::getenv("HIP_FORCE_DEV_KERNARG") : "(unset)", b.n,
+              static_cast<long long>(frame_bytes));
+  {
+    double best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) best = std::min(best, chain_us(s, b, [] {}));
+    std::printf("producer alone                                                        : %6.2f us\n", best);
+  }
+  if (argc > 2) {
+  run<256, 1, false, true, true>(s, b, "256 thr, 1 quad/lane, nt load (shipped)");
+  run<256, 1, false, false, true>(s, b, "256 thr, 1 quad/lane, plain load");
+  run<256, 1, true, true, true>(s, b, "256 thr, 1 quad/lane, nt load, nt batch");
+  run<256, 1, false, true, false>(s, b, "256 thr, 1 quad/lane, no narrow workgroup");
+  run<256, 2, false, true, true>(s, b, "256 thr, 2 quads/lane");
+  run<256, 2, true, true, true>(s, b, "256 thr, 2 quads/lane, nt batch");
+  run<256, 4, false, true, true>(s, b, "256 thr, 4 quads/lane");
+  run<512, 1, false, true, true>(s, b, "512 thr, 1 quad/lane");
+  run<512, 2, false, true, true>(s, b, "512 thr, 2 quads/lane");
+  run<1024, 1, false, true, true>(s, b, "1024 thr, 1 quad/lane");
+  run<1024, 2, false, true, true>(s, b, "1024 thr, 2 quads/lane");
+  run<1024, 2, true, true, true>(s, b, "1024 thr, 2 quads/lane, nt batch");
+  }
+  for (int round = 0; round < 3; ++round) {
+    run<256, 1, false, true, true>(s, b, "256 thr, 1 quad/lane (shipped)");
+    run_flat<256, 1, 1>(s, b, "flat grid, a narrow workgroup per env");
+    run_flat<256, 1, 4>(s, b, "flat grid, a narrow workgroup per 4 envs");
+    run_flat<256, 1, 8>(s, b, "flat grid, a narrow workgroup per 8 envs");
+    run_flat<256, 1, 0>(s, b, "flat grid, no narrow work");
+  }
+  return 0;
+}

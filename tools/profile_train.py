@@ -35,9 +35,29 @@ timeit('replay.sample(16)', lambda: replay.sample(16))
 timeit('next(Consec(sample))', lambda: next(stream))
 b = next(stream)
 timeit('scans.gae', lambda: emb.scans.gae(b['reward'], value, b['is_last'], b['is_terminal']))
+# as bench.py's train step does it: batches lent for one draw, GAE into agent-owned pairs
+lend = iter(emb.streams.Consec(emb.streams.Stateless(replay.sample, 16, 'train', recycle=1),
+                               length=64, consec=1, prefix=1, strict=True, contiguous=True))
+pairs = [tuple(torch.empty(16, 64, device=device) for _ in range(2)) for _ in range(2)]
+turn = [0]
+def bench_train_step():
+  batch = next(lend)
+  turn[0] += 1
+  return emb.scans.gae(batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8,
+                       out=pairs[turn[0] & 1])
+timeit('next(Consec(sample, recycle=1))', lambda: next(lend))
+held = replay.sample(16)
+def sample_recycled():
+  replay.recycle(held)
+  return replay.sample(16)
+timeit('recycle + replay.sample(16)', sample_recycled)
+timeit('replay.sample(16, out=held)', lambda: replay.sample(16, out=held))
+timeit('scans.gae(out=)', lambda: emb.scans.gae(b['reward'], value, b['is_last'], b['is_terminal'], hor=200,
+                                              lam=0.8, out=pairs[0]))
+timeit('train step as in bench.py', bench_train_step)
 timeit('_alloc_batch', lambda: replay._alloc_batch(16, 65))
 timeit('torch.full consec', lambda: torch.full((16, 65), 0, dtype=torch.int32, device=device))
 import cProfile, pstats
 prof = cProfile.Profile(); prof.enable()
-for _ in range(2000): next(stream)
-prof.disable(); pstats.Stats(prof).sort_stats('tottime').print_stats(10)
+for _ in range(2000): bench_train_step()
+prof.disable(); pstats.Stats(prof).sort_stats('tottime').print_stats(14)
