@@ -119,6 +119,20 @@ def test_early_insert_other_policy_layouts(emb, out_dtype, layout):
     assert torch.equal(batch, want)
 
 
+@pytest.mark.parametrize('shape', [(200, 200, 3), (256, 160, 4), (84, 84, 4)])
+def test_early_insert_frames_of_many_blocks(emb, shape):
+  """Frames wider than the launch's 32 frame blocks per env (the blocks loop),
+  and BASELINE's 84 x 84 x 4 (7 blocks + the narrow workgroup per env on the
+  one-dimensional grid): every sampled batch equals the oracle's, the policy
+  batch equals the plain obs stack."""
+  rep, ref, seen = _run_pair(emb, 3, shape, length=3, capacity=40, chunksize=8, steps=30,
+                             online=True, stack=True, out_dtype=torch.bfloat16, layout='channels_first')
+  assert rep.early_inserts == 29
+  for batch, frames in seen[::5]:
+    want = emb.ops.obs_stack(frames, layout='channels_first', dtype=torch.bfloat16, scale=1 / 255)
+    assert torch.equal(batch, want)
+
+
 def test_early_insert_with_agent_outputs(emb):
   """A policy that also returns replay outputs (wider keys: the general insert
   launch carries action + outputs, the observation keys are already in place)."""
