@@ -282,12 +282,17 @@ class Uniform : public Selector {
 // draw at each level indexes them and float sums run left to right.
 class SampleTree {
  public:
+  // A node keeps its children's masses next to each other (`kid_mass[i]` ==
+  // `kids[i]->mass`, always): re-summing a node and drawing among its children
+  // read one short array instead of following sixteen pointers.
   struct Node {
     Node* up = nullptr;
     bool leaf = false;
+    int32_t slot = 0;           // position among `up`'s children
     int64_t key = 0;
     double mass = 0.0;
     std::vector<Node*> kids;
+    std::vector<double> kid_mass;
   };
 
   SampleTree(int branching, uint64_t seed) : branching_(branching), rng_(seed) {
@@ -364,7 +369,7 @@ class SampleTree {
   void update(int64_t key, double mass) {
     Node** found = leaves_.find(key);
     if (!found) throw std::out_of_range("SampleTree: unknown key");
-    (*found)->mass = mass;
+    set_mass(*found, mass);
     resum((*found)->up);
   }
 
@@ -383,7 +388,7 @@ class SampleTree {
   void update_leaves(Node* const* leaves, const double* masses, int64_t n) {
     dirty_.clear();
     for (int64_t i = 0; i < n; ++i) {
-      leaves[i]->mass = masses[i];
+      set_mass(leaves[i], masses[i]);
       if (leaves[i]->up) dirty_.push_back(leaves[i]->up);
     }
     while (!dirty_.empty()) {
@@ -392,9 +397,9 @@ class SampleTree {
       next_.clear();
       for (Node* node : dirty_) {
         double total = 0.0;
-        for (Node* kid : node->kids) total += kid->mass;
+        for (double m : node->kid_mass) total += m;
         if (same_bits(total, node->mass)) continue;      // ancestors stay as they are
-        node->mass = total;
+        set_mass(node, total);
         if (node->up) next_.push_back(node->up);
       }
       dirty_.swap(next_);
@@ -406,11 +411,10 @@ class SampleTree {
     Node* node = root_;
     while (!node->leaf) {
       const int k = static_cast<int>(node->kids.size());
-      mass_.resize(k);
       prob_.resize(k);
       cdf_.resize(k);
-      for (int i = 0; i < k; ++i) mass_[i] = node->kids[i]->mass;
-      const double total = np_pairwise_sum(mass_.data(), k);
+      const double* mass_ = node->kid_mass.data();
+      const double total = np_pairwise_sum(mass_, k);
       if (!std::isfinite(total)) {
         int hot = 0;
         for (int i = 0; i < k; ++i) hot += std::isinf(mass_[i]) ? 1 : 0;
@@ -437,25 +441,34 @@ class SampleTree {
     std::memcpy(&y, &b, 8);
     return x == y;
   }
+  static void set_mass(Node* node, double mass) {
+    node->mass = mass;
+    if (node->up) node->up->kid_mass[static_cast<size_t>(node->slot)] = mass;
+  }
   static void resum(Node* node) {
     while (node) {
       double total = 0.0;
-      for (Node* kid : node->kids) total += kid->mass;
+      for (double m : node->kid_mass) total += m;
       if (same_bits(total, node->mass)) return;
-      node->mass = total;
+      set_mass(node, total);
       node = node->up;
     }
   }
   static void detach(Node* parent, Node* child) {
     child->up = nullptr;
     auto& kids = parent->kids;
-    kids.erase(std::find(kids.begin(), kids.end(), child));
+    const auto at = static_cast<std::ptrdiff_t>(child->slot);
+    kids.erase(kids.begin() + at);
+    parent->kid_mass.erase(parent->kid_mass.begin() + at);
+    for (size_t i = static_cast<size_t>(at); i < kids.size(); ++i) kids[i]->slot = static_cast<int32_t>(i);
     resum(parent);
   }
   static void attach(Node* parent, Node* child) {
     if (child->up) detach(child->up, child);
     child->up = parent;
+    child->slot = static_cast<int32_t>(parent->kids.size());
     parent->kids.push_back(child);
+    parent->kid_mass.push_back(child->mass);
     resum(parent);
   }
   static void destroy(Node* node) {
@@ -468,7 +481,7 @@ class SampleTree {
   Node* root_;
   Node* tail_ = nullptr;
   SlidingMap<Node*> leaves_;
-  std::vector<double> mass_, prob_, cdf_;
+  std::vector<double> prob_, cdf_;
   std::vector<Node*> dirty_, next_, handles_;
 };
 
@@ -513,11 +526,16 @@ class Prioritized : public Selector {
     if (!own) throw std::out_of_range("Prioritized: unknown key");
     Stream* st = own->first;
     const int64_t start = own->second;
+    // The n steps of the drawn item are contiguous in the stream's arrays, and
+    // the items that contain one of them are ONE range of start positions (the
+    // union of touch_range over the n steps; the drawn item is in it).
+    const double zero_powered = powered(0.0);
+    double* prio = &st->prio[start - st->step0];
+    double* pw = &st->powered[start - st->step0];
+    for (int i = 0; i < st->n; ++i) prio[i] = 0.0, pw[i] = zero_powered;
+    const int64_t last = st->item0 + static_cast<int64_t>(st->items.size()) - 1;
     ranges_.clear();
-    for (int64_t pos = start; pos < start + st->n; ++pos) {
-      set_slot(*st, pos, 0.0);
-      touch_range(st, pos);
-    }
+    ranges_.push_back({st, std::max(st->item0, start - st->n + 1), std::min(last, start + st->n - 1)});
     refresh_ranges();
     return key;
   }
@@ -706,31 +724,42 @@ class Prioritized : public Selector {
     }
     return finish(total, top, st.n);
   }
-  // Masses of the `count` items starting at start, start+1, ...: eight items at
-  // a time, each lane doing its own left-to-right sum (independent add chains
-  // instead of one 65-long dependent chain per item).
+  // Masses of the `count` items starting at start, start+1, ...  One pass over
+  // the region's steps (running counts) sorts the windows: a window that holds a
+  // +inf step and nothing NaN or negative sums to +inf with maximum +inf whatever
+  // else it holds; a window of zeros only sums to +0 with maximum 0 (-0 steps
+  // included: 0 + -0 = +0, and finish() adds a +0 mean to the maximum).  With
+  // `initial: inf` and zero_on_sample that is nearly every window; only the
+  // others are summed -- eight at a time, each lane its own left-to-right sum
+  // (independent add chains instead of one 65-long dependent chain per item),
+  // when no window of the range is decided by the counts.
   void stream_masses(const Stream& st, int64_t start, int64_t count, std::vector<double>* out) const {
     constexpr int kLanes = 8;
     const double* base = &st.powered[start - st.step0];
+    out->resize(static_cast<size_t>(count));
+    double* o = out->data();
     int64_t done = 0;
-    // Windows that hold a +inf step (and nothing that is NaN or negative) sum to
-    // +inf with maximum +inf whatever else they hold: one pass over the region
-    // finds them (running counts), only the others are summed.  With `initial:
-    // inf` that is nearly every window.
     const int64_t span = count + st.n - 1;
     if (span <= kRegion) {
-      int32_t hot[kRegion + 1], odd[kRegion + 1];
-      hot[0] = odd[0] = 0;
+      int32_t hot[kRegion + 1], odd[kRegion + 1], some[kRegion + 1];
+      hot[0] = odd[0] = some[0] = 0;
       for (int64_t i = 0; i < span; ++i) {
         const double v = base[i];
         hot[i + 1] = hot[i] + (v == INFINITY ? 1 : 0);
         odd[i + 1] = odd[i] + ((v >= 0.0) ? 0 : 1);           // NaN or negative
+        some[i + 1] = some[i] + ((v == 0.0) ? 0 : 1);
       }
-      if (hot[span] > 0 && odd[span] == 0) {
+      int64_t decided = 0;
+      if (odd[span] == 0 && (hot[span] > 0 || some[span] < span))
+        for (int64_t j = 0; j < count; ++j)
+          decided += (hot[j + st.n] > hot[j] || some[j + st.n] == some[j]) ? 1 : 0;
+      if (decided > 0) {
         const double all_inf = finish(INFINITY, INFINITY, st.n);
+        const double all_zero = finish(0.0, 0.0, st.n);
         for (int64_t j = 0; j < count; ++j) {
-          if (hot[j + st.n] - hot[j] > 0) out->push_back(all_inf);
-          else out->push_back(stream_mass(st, start + j));
+          if (hot[j + st.n] > hot[j]) o[j] = all_inf;
+          else if (some[j + st.n] == some[j]) o[j] = all_zero;
+          else o[j] = stream_mass(st, start + j);
         }
         return;
       }
@@ -746,9 +775,9 @@ class Prioritized : public Selector {
           top[j] = (v > top[j]) ? v : top[j];
         }
       }
-      for (int j = 0; j < kLanes; ++j) out->push_back(finish(total[j], top[j], st.n));
+      for (int j = 0; j < kLanes; ++j) o[done + j] = finish(total[j], top[j], st.n);
     }
-    for (; done < count; ++done) out->push_back(stream_mass(st, start + done));
+    for (; done < count; ++done) o[done] = stream_mass(st, start + done);
   }
   // Items of `st` that contain the step at `pos`.
   void touch_range(Stream* st, int64_t pos) {
@@ -777,7 +806,6 @@ class Prioritized : public Selector {
       }
       const int64_t from = std::max(done, r.lo);
       if (from <= r.hi) {
-        fresh_.clear();
         stream_masses(*st, from, r.hi - from + 1, &fresh_);
         // A leaf whose freshly aggregated mass is bit for bit what it holds
         // already needs no update: every ancestor is the left-to-right sum of its
