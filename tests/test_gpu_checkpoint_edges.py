@@ -211,3 +211,39 @@ def test_recycled_slots_with_inserts_on_two_streams_and_a_busy_sampler(emb):
     torch.cuda.synchronize()
     for k in want:
       assert torch.equal(got[k], want[k]), (round_, k)
+
+
+def test_more_streams_than_the_ordering_table_holds(emb):
+  """Inserts, samples and write-backs issued from eight streams in turn (the
+  cross-stream ordering table holds six: it drains the device and starts over):
+  the same batches as a twin that stays on one stream."""
+  make = lambda: emb.Replay(length=3, capacity=48, chunksize=8, seed=5)
+  rep, twin = make(), make()
+  streams = [torch.cuda.Stream() for _ in range(8)]
+  step = lambda t: {'x': np.full(512, t, np.float32), 'is_first': t == 0, 'is_last': False}
+  turn = 0
+  for t in range(200):
+    with torch.cuda.stream(streams[turn % 8]):
+      rep.add(step(t), 0)
+    twin.add(step(t), 0)
+    turn += 1
+    if t >= 20 and t % 3 == 0:
+      with torch.cuda.stream(streams[turn % 8]):
+        got = rep.sample(4)
+      turn += 1
+      want = twin.sample(4)
+      new = torch.full((4, 3, 512), float(-t), device='cuda')
+      with torch.cuda.stream(streams[turn % 8]):
+        new_there = new.clone()            # (made on the stream that uses it)
+        rep.update({'stepid': got['stepid'], 'x': new_there})
+      turn += 1
+      twin.update({'stepid': want['stepid'], 'x': new})
+      torch.cuda.synchronize()
+      for k in want:
+        assert torch.equal(got[k], want[k]), (t, k)
+  torch.cuda.synchronize()
+  for _ in range(10):
+    a, b = rep.sample(6), twin.sample(6)
+    torch.cuda.synchronize()
+    for k in b:
+      assert torch.equal(a[k], b[k]), k
