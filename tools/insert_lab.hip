@@ -43,6 +43,14 @@ __global__ __launch_bounds__(THREADS) void empty_kernel(const uint8_t* frames, c
   if (frames == nullptr && rows[0] == 12345) __builtin_trap();
 }
 
+__global__ __launch_bounds__(256) void empty_noargs_kernel() {}
+
+__device__ int g_sink;
+__global__ __launch_bounds__(256) void empty_7args_kernel(const uint8_t* a, const int32_t* b, uint8_t* c, void* d,
+                                                          int64_t e, int32_t f, int32_t g, float h, float i) {
+  if (a == nullptr && f == 12345) g_sink = g;
+}
+
 // Q quads per lane (issued back to back), NTB: policy batch with non-temporal
 // stores, NTL: frames with non-temporal loads, NARROW: one extra workgroup per env
 // doing a little dependent work (the narrow keys' stand-in).
@@ -245,7 +253,36 @@ int main(int argc, char** argv) {
   run<1024, 2, false, true, true>(s, b, "1024 thr, 2 quads/lane");
   run<1024, 2, true, true, true>(s, b, "1024 thr, 2 quads/lane, nt batch");
   }
-  for (int round = 0; round < 3; ++round) {
+  {
+    // What a dependent launch costs by the size of its kernel-argument segment
+    // (host-resident with HIP_FORCE_DEV_KERNARG=0: the command processor fetches it
+    // over PCIe before the waves start).  Chains of ONE kernel, 8 x 64 workgroups.
+    auto chain1 = [&](auto&& launch) {
+      double best = 1e9;
+      for (int rep = 0; rep < 3; ++rep) {
+        for (int i = 0; i < 300; ++i) launch();
+        CHECK(hipStreamSynchronize(s));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 8000; ++i) launch();
+        CHECK(hipStreamSynchronize(s));
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 8000);
+      }
+      return best;
+    };
+    const dim3 grid(8, b.n);
+    std::printf("chain of empty kernels, 512 workgroups: no arguments %.2f us, 16 B %.2f us, 56 B %.2f us per launch\n",
+                chain1([&] { hipLaunchKernelGGL(empty_noargs_kernel, grid, dim3(256), 0, s); }),
+                chain1([&] { hipLaunchKernelGGL(empty_kernel<256>, grid, dim3(256), 0, s, b.frames, b.rows); }),
+                chain1([&] { hipLaunchKernelGGL(empty_7args_kernel, grid, dim3(256), 0, s, b.frames, b.rows, b.pool,
+                                                static_cast<void*>(b.dst), b.pixels, 1, 2, 1.f, 0.f); }));
+    const dim3 one(1);
+    std::printf("chain of empty kernels, 1 workgroup: no arguments %.2f us, 16 B %.2f us, 56 B %.2f us per launch\n",
+                chain1([&] { hipLaunchKernelGGL(empty_noargs_kernel, one, dim3(256), 0, s); }),
+                chain1([&] { hipLaunchKernelGGL(empty_kernel<256>, one, dim3(256), 0, s, b.frames, b.rows); }),
+                chain1([&] { hipLaunchKernelGGL(empty_7args_kernel, one, dim3(256), 0, s, b.frames, b.rows, b.pool,
+                                                static_cast<void*>(b.dst), b.pixels, 1, 2, 1.f, 0.f); }));
+  }
+  for (int round = 0; round < 1; ++round) {
     run<256, 1, false, true, true>(s, b, "256 thr, 1 quad/lane (shipped)");
     run_flat<256, 1, 1>(s, b, "flat grid, a narrow workgroup per env");
     run_flat<256, 1, 4>(s, b, "flat grid, a narrow workgroup per 4 envs");
