@@ -526,32 +526,3 @@ def test_prioritized_with_a_tiny_step_id_backlog():
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
 
-
-@pytest.mark.parametrize('seed', range(8))
-def test_sample_tree_random_histories_against_oracle(seed):
-  """Inserts, removals (a sibling's position shifts, the tail moves into the
-  hole), updates and draws in random order with zero, +inf and finite masses:
-  the native tree (child masses in one array per node, `slot` = a child's
-  position) draws what the oracle's pointer tree draws."""
-  import embodied_amd as emb
-  from oracle import np_oracle
-  rng = np.random.default_rng(100 + seed)
-  branching = int(rng.choice([2, 3, 4, 5, 16]))
-  want, got = np_oracle.SampleTree(branching, seed=seed), emb.selectors.SampleTree(branching, seed=seed)
-  live, key = [], 0
-  for it in range(700):
-    op = rng.integers(0, 5)
-    if op <= 1 or len(live) < 2:
-      mass = float(rng.choice([0.0, np.inf, rng.random() * 3, 1.0]))
-      want.insert(key, mass), got.insert(key, mass)
-      live.append(key)
-      key += 1
-    elif op == 2:
-      victim = live.pop(int(rng.integers(0, len(live))))
-      want.remove(victim), got.remove(victim)
-    elif op == 3:
-      target = live[int(rng.integers(0, len(live)))]
-      mass = float(rng.choice([0.0, np.inf, rng.random(), 2.0]))
-      want.update(target, mass), got.update(target, mass)
-    if live:
-      assert want.sample() == got.sample(), (seed, it)
