@@ -108,6 +108,16 @@ def window_batch(batch, start, count):
   return dict(zip(names, outs))
 
 
+_BATCH_TYPE = []
+
+
+def _batch_type():
+  if not _BATCH_TYPE:
+    from . import replay as replaylib
+    _BATCH_TYPE.append(replaylib.Batch)
+  return _BATCH_TYPE[0]
+
+
 class Consec(base.Stream):
   """Sequence windowing (streams.py:89-150): a source batch of
   `consec * length + prefix` steps is served as `consec` windows
@@ -163,6 +173,13 @@ class Consec(base.Stream):
             f'{"exactly" if self.strict else "at least"} {need} steps per sequence, got {have}')
     start, count = number * self.length, self.length + self.prefix
     batch = self.current
+    if (self.consec == 1 and type(batch) is _batch_type()
+        and getattr(batch, '_emb_shape', (0, 0))[1] == count):
+      # The whole of a batch this package's Replay.sample made (contiguous device
+      # tensors by construction): the window is the batch itself.
+      chunk = dict(batch)
+      chunk['consec'] = self._number(chunk['is_first'], 0)
+      return chunk
     if torch.is_tensor(batch['is_first']):
       # Device batches are always materialised contiguously (one kernel for all
       # keys); `contiguous` only matters for numpy views.

@@ -145,9 +145,14 @@ def gae(rew, val, last, term, hor=200, lam=0.8, out=None):
   if out is not None:
     adv, tar = out
     for result in (adv, tar):
+      # (a tensor object that passed for this shape and device keeps a mark, like
+      # the inputs: an agent hands the same few result tensors in again)
+      if result.__dict__.get('_emb_gae_out') == (B, T, dev):
+        continue
       if (result.dtype != torch.float32 or tuple(result.shape) != (B, T - 1) or result.device != dev
           or not result.is_contiguous()):
         raise ValueError(f'gae(out=): needs contiguous float32 {(B, T - 1)} tensors on {dev}')
+      result._emb_gae_out = (B, T, dev)
   elif B * T <= 1 << 20:
     adv, tar = _pair(B, T - 1, dev)                         # one allocation, two views
   else:       # bandwidth-bound sizes: two write streams a power-of-two-ish distance apart
