@@ -391,15 +391,22 @@ class Driver:
     sink = self._sinks[0] if len(self._sinks) == 1 and not logs else None
     if sink is not None and _EARLY_INSERT:
       sink.offer(obs, self._workers)
-    self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
-    assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
+    if self.kwargs:
+      self.carry, acts, outs = policy(self.carry, obs, **self.kwargs)
+    else:
+      self.carry, acts, outs = policy(self.carry, obs)
+    if outs:
+      assert all(k not in acts for k in outs), (list(outs.keys()), list(acts.keys()))
     is_last = obs['is_last']
-    acts = {k: self._to_device(v) for k, v in acts.items()}
+    device, Tensor = self.device, torch.Tensor
+    for v in acts.values():
+      if type(v) is not Tensor or v.device != device:
+        acts = {k: self._to_device(v) for k, v in acts.items()}
+        break
     if sink is not None:
       # (The masked actions rotate through four sets of buffers, like a vector
       # env's own outputs: a set is overwritten four steps later.  The sink is the
       # step's only consumer; `fresh_obs=True` gives `driver.acts` fresh tensors.)
-      names = tuple(acts)
       if self._unmasked is None:
         # An env that takes the policy's actions as they are, together with
         # `reset` (it ignores the action of an env it resets, as the Env protocol
@@ -418,6 +425,7 @@ class Driver:
         if self._count_episodes:
           episode += int(is_last.sum().item())
         return step, episode
+      names = tuple(acts)
       if self._fresh_obs:
         mask = (names, is_last)
       else:
