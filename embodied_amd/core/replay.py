@@ -115,6 +115,7 @@ class Replay:
       selector = selectorlib.Uniform(seed)
     self.sampler = selector
     self._native = selectorlib._as_native(selector)
+    self._foreign_selector = isinstance(self._native, selectorlib.Foreign)   # Python callbacks: errors to re-raise
     if slots is None:
       slots = 64
       if self.capacity:
@@ -656,7 +657,8 @@ class Replay:
                 break
               except _lib.PoolFull:
                 self._grow(2 * rec.n)
-            self._reraise()
+            if self._foreign_selector:
+              self._native.reraise()
           return masked if wanted else None
     names = tuple(acts)
     token = self._pre_token
@@ -777,7 +779,8 @@ class Replay:
         first = sid._emb_first = (C.c_uint8 * (batch * _lib.STEPID_BYTES))()
       fast.emb_replay_sample(
           self._h, batch, _lib.MODES[mode], ptrs, None, first, stream)
-      self._reraise()
+      if self._foreign_selector:
+        self._native.reraise()
     return self._finish(out)
 
   def recycle(self, batch):
@@ -1043,7 +1046,7 @@ class Replay:
       self._updates += steps
 
   def _reraise(self):
-    if isinstance(self._native, selectorlib.Foreign):
+    if self._foreign_selector:
       self._native.reraise()
 
   # ------------------------------------------------------------ save / load --
