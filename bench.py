@@ -458,6 +458,8 @@ def main():
 
   # The learner's stream (--streams 2): the Replay orders its pool accesses across
   # the two streams itself (emb_replay_multistream; abi.cpp StreamOrder).
+  # (EMB_BENCH_LEARNER_PRIORITY=1: a low-priority learner stream -- the A/B of
+  # DESIGN.md 3, which measured level for PPO, tools/exp_r04q.sh.)
   learner = (torch.cuda.Stream(device, priority=int(os.environ.get('EMB_BENCH_LEARNER_PRIORITY', '0')))
              if args.streams == 2 else None)
   if learner is not None:
