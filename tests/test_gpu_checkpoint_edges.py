@@ -232,12 +232,12 @@ def test_more_streams_than_the_ordering_table_holds(emb):
         got = rep.sample(4)
       turn += 1
       want = twin.sample(4)
-      new = torch.full((4, 3, 512), float(-t), device='cuda')
       with torch.cuda.stream(streams[turn % 8]):
-        new_there = new.clone()            # (made on the stream that uses it)
-        rep.update({'stepid': got['stepid'], 'x': new_there})
+        # (made on the stream that uses it: torch's side streams do not wait for
+        # the default stream)
+        rep.update({'stepid': got['stepid'], 'x': torch.full((4, 3, 512), float(-t), device='cuda')})
       turn += 1
-      twin.update({'stepid': want['stepid'], 'x': new})
+      twin.update({'stepid': want['stepid'], 'x': torch.full((4, 3, 512), float(-t), device='cuda')})
       torch.cuda.synchronize()
       for k in want:
         assert torch.equal(got[k], want[k]), (t, k)
