@@ -528,6 +528,15 @@ def main():
     # a GPU that the fence has just drained).
     stamp_every = 2 if expected >= 2 else 1
   replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1', every=stamp_every)
+  # Like `timeit`: no pass of the interpreter's cyclic collector over its whole
+  # heap (tens of ms: the GPU idles, the first steps after it measure 130 + 100 us
+  # instead of 17 + 34) between the warm-up and the end of a timed region that
+  # may be 300 us long.  A full collection runs HERE, before the warm-up; the
+  # collector is switched on again behind the region's closing fence and stays
+  # on for the sustained window (whose rate shows what it costs: nothing).
+  import gc
+  gc.collect()
+  gc.disable()
   # The fill runs no train step: warm the train path (allocator, online queue,
   # caches) whatever --warmup says, then the caller's warmup steps.
   if learner is not None:
@@ -576,6 +585,7 @@ def main():
   before_fence = time.perf_counter()
   fence()
   elapsed = time.perf_counter() - start
+  gc.enable()
   if trace and rank == 0:
     steps_us = [round((b - a) * 1e6) for a, b in zip([start] + stamps, stamps)]
     print('per-step us:', steps_us[:40], 'final fence us:',
@@ -850,7 +860,6 @@ def main():
       and args.consec == 1 and args.prefetch == 1):
     del driver, env, stream, policy
     replay = None
-    import gc
     gc.collect()
     torch.cuda.empty_cache()
     workloads = {'dreamer': dreamer_leg(args)}
