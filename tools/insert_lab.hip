@@ -282,6 +282,28 @@ int main(int argc, char** argv) {
                 chain1([&] { hipLaunchKernelGGL(empty_7args_kernel, one, dim3(256), 0, s, b.frames, b.rows, b.pool,
                                                 static_cast<void*>(b.dst), b.pixels, 1, 2, 1.f, 0.f); }));
   }
+  {
+    // Host time of each launch call of a chain that starts on a drained stream
+    // (what the first steps after a fence pay): producer, insert, producer, ...
+    const int64_t quads = b.pixels / 4;
+    const int fb = static_cast<int>((quads + 255) / 256);
+    const dim3 grid(b.n * fb + b.n), pgrid(7, b.n);
+    double lap[12] = {};
+    const int reps = 200;
+    for (int rep = 0; rep < reps; ++rep) {
+      CHECK(hipStreamSynchronize(s));
+      for (int i = 0; i < 12; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (i % 2 == 0) hipLaunchKernelGGL(producer, pgrid, dim3(256), 0, s, b.frames, static_cast<int>(b.pixels * 4), 1u);
+        else hipLaunchKernelGGL((insert_flat_kernel<256, 1, 1>), grid, dim3(256), 0, s, b.frames, b.rows, b.pool, b.dst,
+                                b.pixels, 1.f / 255, 0.f, b.narrow, b.n, fb);
+        lap[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      }
+    }
+    std::printf("host us per launch call after a stream sync, launches 1..12:");
+    for (int i = 0; i < 12; ++i) std::printf(" %.2f", lap[i] / reps);
+    std::printf("\n");
+  }
   for (int round = 0; round < 1; ++round) {
     run<256, 1, false, true, true>(s, b, "256 thr, 1 quad/lane (shipped)");
     run_flat<256, 1, 1>(s, b, "flat grid, a narrow workgroup per env");
