@@ -545,7 +545,7 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
       int spins = 0;
       while (g.state.load(std::memory_order_acquire) != 1 || g.fn == nullptr) {
         if (self.use_count() == 1) return nullptr;      // every replay / selector handle is gone
-        if (++spins < 40000) {           // ~100 us of polling, then sleep
+        if (++spins < 40000) {           // 0.1 - 1 ms of polling (a `pause` is 10 - 65 cycles by core), then sleep
           __builtin_ia32_pause();
           continue;
         }
