@@ -138,6 +138,24 @@ def test_load_of_a_reference_written_directory(emb):
   assert seen == {tuple(x.reshape(-1).tolist()) for x in want}
 
 
+def test_written_directory_equals_the_committed_product_chunks(emb, tmp_path):
+  """tests/golden/product_chunks (the directory the real reference loads in
+  tests/test_product_chunks_host.py) is what `save()` writes today: same
+  files but for the time stamp, same arrays."""
+  import pathlib
+  from tools import write_product_chunks as scenario
+  golden = pathlib.Path(__file__).parent / 'golden' / 'product_chunks'
+  names = scenario.write(tmp_path / 'out', emb)
+  tail = lambda name: name.split('-', 1)[1]
+  committed = {tail(p.name): p for p in golden.glob('*.npz')}
+  assert sorted(committed) == sorted(tail(n) for n in names)
+  for name in names:
+    with np.load(tmp_path / 'out' / name) as got, np.load(committed[tail(name)]) as want:
+      assert sorted(got.keys()) == sorted(want.keys())
+      for key in want.keys():
+        assert got[key].dtype == want[key].dtype and (got[key] == want[key]).all(), (name, key)
+
+
 def test_sharded_pool_refuses_checkpoints(emb, tmp_path):
   rep = emb.Replay(length=2, capacity=40, directory=tmp_path, chunksize=4, slots=16,
                    owners=2, owner=0, workers_per_owner=1)
