@@ -30,6 +30,9 @@ from .._lib import api, fast
 from . import limiters
 from . import selectors as selectorlib
 
+# csrc/fastcall.c: Replay.add of a host step dict as one C call (None: Python path).
+_add_step = getattr(fast.module, 'add_step', None)
+
 _TORCH_OF = {
     np.dtype(np.uint8): torch.uint8, np.dtype(np.int8): torch.int8,
     np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32,
@@ -76,7 +79,7 @@ def _itemsize(dtype):
 
 
 class _Key:
-  __slots__ = ('name', 'dtype', 'shape', 'rowbytes', 'pool', 'stage', 'stage_np')
+  __slots__ = ('name', 'dtype', 'shape', 'rowbytes', 'pool', 'stage', 'stage_np', 'stages')
 
   def __init__(self, name, dtype, shape):
     self.name = name
@@ -145,6 +148,10 @@ class Replay:
     # ndarray.ctypes.data costs ~1.2 us per access: addresses of the persistent
     # buffers are taken once.
     self._one_ptrs = (_lib.ptr(self._one_worker), _lib.ptr(self._one_row), _lib.ptr(self._one_sid))
+    self._stage_plan = None
+    self._many_row = np.zeros(self._stage_rows, np.int32)
+    self._many_sid = np.zeros((self._stage_rows, _lib.STEPID_BYTES), np.uint8)
+    self._many_ptrs = (self._many_row.ctypes.data, self._many_sid.ctypes.data)
     self._new_chunks = C.c_int32()
     self._new_chunks_ref = C.byref(self._new_chunks)
     self._pending_count = C.c_int64()
@@ -166,6 +173,7 @@ class Replay:
     self._mask_plans = {}
     self._add_plan = None
     self._stage_busy, self._stage_pending = None, False
+    self._stage_events, self._stage_set = [None, None], 0
     self._rowbytes_total = None
     # Output sets handed back with `recycle` (explicit) and, opt-in, the pool that
     # finds unreferenced sets itself (EMB_SAMPLE_POOL=1, see _alloc_batch).
@@ -275,13 +283,42 @@ class Replay:
     rows = self._slots // self._owners * self.chunksize
     for key in keys:
       key.pool = torch.empty(rows * key.rowbytes, dtype=torch.uint8, device=self.device)
-      key.stage = torch.empty(
-          (self._stage_rows, key.rowbytes), dtype=torch.uint8).pin_memory()
-      key.stage_np = key.stage.numpy()
+      # Two pinned sets used in turn: the adds after a flush fill the other set
+      # while the flush's H2D copies still read this one.
+      both = torch.empty((2, self._stage_rows, key.rowbytes), dtype=torch.uint8).pin_memory()
+      key.stages = [(both[i], both[i].numpy()) for i in range(2)]
+      key.stage, key.stage_np = key.stages[0]
     self._keys = keys
     self._keyid = {k.name: i for i, k in enumerate(keys)}
     self._batch_ptrs = (C.c_void_p * len(keys))()
     self._push_keys()
+    self._stage_set = 0
+    self._stage_plans = [self._make_stage_plan(i) for i in range(2)]
+    self._stage_plan = self._stage_plans[0]
+
+  def _make_stage_plan(self, which):
+    """`add`'s per-step work as one C call (fastcall.c stage_plan / add_step):
+    None without the call shim, for more than 64 keys or for a dtype numpy
+    cannot hand over as it is (bfloat16)."""
+    if _add_step is None or len(self._keys) > 65:
+      return None
+    entries = []
+    for key in self._keys[:-1]:
+      try:
+        dtype = np.dtype(_numpy_of(key.dtype))
+      except Exception:
+        return None
+      kind = {'b': 'b', 'i': 'i', 'u': 'u', 'f': 'f'}.get(dtype.kind)
+      if kind is None or key.dtype == torch.bfloat16:
+        return None
+      entries.append((sys.intern(key.name), key.stages[which][0].data_ptr(), key.rowbytes, kind,
+                      dtype.itemsize, tuple(int(d) for d in key.shape)))
+    sid = self._keys[-1]
+    self._add_step_args = (
+        C.cast(_lib.lib.emb_replay_add_index, C.c_void_p).value, self._h,
+        *self._one_ptrs, C.addressof(self._new_chunks))
+    return _lib.fast.module.stage_plan(
+        tuple(entries), sid.stages[which][0].data_ptr(), sid.rowbytes, self._stage_dst.ctypes.data)
 
   def _push_keys(self):
     n = len(self._keys)
@@ -328,6 +365,32 @@ class Replay:
     staged in pinned memory and written to HBM by one scatter launch per
     `stage_rows` steps (or at the next sample/update); device tensors go through
     `add_batch`."""
+    plan = self._stage_plan
+    if plan is not None:
+      # The whole step in one C call (csrc/fastcall.c add_step): values checked
+      # against the schema, index bookkeeping, copies into the pinned stage
+      # rows.  -1: a value the C side does not take as it is (no buffer, another
+      # dtype, a device tensor, a key or shape mismatch) -- nothing was touched,
+      # the Python path below converts or raises.
+      with self._lock:
+        self._one_worker[0] = worker
+        while True:
+          if self._stage_pending:             # a flush still reads this set's pinned rows
+            self._stage_busy.synchronize()
+            self._stage_pending = False
+          status = _add_step(self._stage_plan, step, self._staged, *self._add_step_args)
+          if status != _lib.ERR_POOL_FULL:
+            break
+          self._flush()                       # (moves on to the other stage set)
+          self._grow()
+        if status == 0:
+          self._reraise()
+          self._staged += 1
+          if self._staged == self._stage_rows or self._new_chunks.value:
+            self._flush()
+          return
+        if status > 0:
+          _lib.check(status)
     step = {k: v for k, v in step.items() if not k.startswith('log/')}
     if any(torch.is_tensor(v) and v.is_cuda for v in step.values()):
       batch = {k: (v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v)))[None]
@@ -386,12 +449,20 @@ class Replay:
     rows = self._stage_dst[:n].copy()
     api.emb_replay_scatter_rows(
         self._handle, _lib.ptr(rows), n, len(self._keys), ids, ptrs, self._stream())
-    # The pinned rows are reused by the next staged add: that add waits for the
-    # H2D copies (an event, not a stream drain — the host goes on stepping envs).
-    if self._stage_busy is None:
-      self._stage_busy = torch.cuda.Event()
-    self._stage_busy.record()
-    self._stage_pending = True
+    # The pinned rows of this set are reused after the NEXT flush: the first add
+    # into a set waits for the H2D copies that last read it (an event, not a
+    # stream drain -- the host goes on stepping envs), which by then are one
+    # whole stage of adds old.
+    turn = self._stage_set
+    if self._stage_events[turn] is None:
+      self._stage_events[turn] = torch.cuda.Event()
+    self._stage_events[turn].record()
+    turn = self._stage_set = 1 - turn
+    for key in self._keys:
+      key.stage, key.stage_np = key.stages[turn]
+    self._stage_plan = self._stage_plans[turn]
+    self._stage_busy = self._stage_events[turn]
+    self._stage_pending = self._stage_busy is not None
     self._staged = 0
 
   def add_batch(self, steps, workers, mask=None):
@@ -410,6 +481,31 @@ class Replay:
         self._init_keys({
             k: (v[0] if torch.is_tensor(v) else np.asarray(v)[0])
             for k, v in steps.items() if not k.startswith('log/')})
+      if (mask is None and self._stage_plan is not None and not self._pre_token
+          and n <= self._stage_rows and _all_host_arrays(steps)):
+        # Host arrays take the staging of `add` (n rows at once, one C call, the
+        # payload leaves with the next flush) instead of one H2D copy per key.
+        if self._staged + n > self._stage_rows:
+          self._flush()
+        fn, handle, _, _, _, new_chunks = self._add_step_args
+        while True:
+          if self._stage_pending:
+            self._stage_busy.synchronize()
+            self._stage_pending = False
+          status = _add_step(self._stage_plan, steps, self._staged, fn, handle, workers_ptr,
+                             *self._many_ptrs, new_chunks, n)
+          if status != _lib.ERR_POOL_FULL:
+            break
+          self._flush()
+          self._grow(2 * n)
+        if status == 0:
+          self._reraise()
+          self._staged += n
+          if self._staged == self._stage_rows or self._new_chunks.value:
+            self._flush()
+          return None
+        if status > 0:
+          _lib.check(status)
       if self._staged:
         self._flush()
       keyid, keys, device = self._keyid, self._keys, self.device
@@ -1269,6 +1365,14 @@ class Replay:
         self._handle, {'sample': 0, 'update': 1, 'deferred': 2, 'carried': 3}[which], C.byref(launches), C.byref(ms),
         int(reset), name, len(name))
     return launches.value, ms.value, name.value.decode()
+
+
+def _all_host_arrays(steps):
+  ndarray = np.ndarray
+  for value in steps.values():
+    if type(value) is not ndarray:
+      return False
+  return True
 
 
 def _numpy_of(dtype):

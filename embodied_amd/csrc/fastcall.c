@@ -21,6 +21,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <string.h>
 
 typedef uint64_t u64;
 
@@ -296,6 +297,216 @@ static PyObject* call_same_values(PyObject* self, PyObject* const* args, Py_ssiz
   Py_RETURN_TRUE;
 }
 
+/* ---- Replay.add of one host step dict (replay.py:77-118), staged in C --------
+ *
+ * stage_plan(keys, sid_base, sid_bytes, dst) -> capsule.  `keys` lists the
+ * schema's columns but the step id: (name, stage base address, row bytes,
+ * kind, item size, shape) with kind one of 'b' bool, 'i' signed, 'u' unsigned,
+ * 'f' float.  `sid_base` / `dst`: the pinned step-id rows and the int32 pool
+ * rows of the staged steps.
+ *
+ * add_step(plan, step, slot, fn, handle, workers, rows, sids, new_chunks[, n]) -> int
+ *   checks every value of the dict against the plan (same key set but `log/*`,
+ *   buffer protocol, C-contiguous, same kind / item size / shape) BEFORE the
+ *   index is touched, calls emb_replay_add_index(handle, 1, workers, rows, sids,
+ *   new_chunks) by address and, on status 0, copies the values, the step id and
+ *   the pool row into stage row `slot`.  Returns 0, the library's status (> 0:
+ *   nothing was staged), or -1 when the step needs the Python path (a value
+ *   without a buffer, another dtype, a shape or key mismatch -- which that path
+ *   converts or reports exactly as before); nothing has been touched then.
+ *   With n > 0 the dict holds n steps, one per workers[i] (Replay.add_batch of
+ *   host arrays): every value has a leading dimension n, the index is called
+ *   for n steps and stage rows [slot, slot + n) are filled. */
+#define STAGE_MAX_KEYS 64
+#define STAGE_MAX_DIMS 8
+
+typedef struct {
+  PyObject* name;
+  char* base;
+  int64_t rowbytes;
+  int itemsize, ndim;
+  char kind;
+  Py_ssize_t shape[STAGE_MAX_DIMS];
+} StageKey;
+
+typedef struct {
+  int n;
+  StageKey keys[STAGE_MAX_KEYS];
+  char* sid_base;
+  int64_t sid_bytes;
+  int32_t* dst;
+} StagePlan;
+
+static void stage_plan_free(PyObject* capsule) {
+  StagePlan* plan = (StagePlan*)PyCapsule_GetPointer(capsule, "emb.stage_plan");
+  if (!plan) return;
+  for (int i = 0; i < plan->n; ++i) Py_XDECREF(plan->keys[i].name);
+  PyMem_Free(plan);
+}
+
+static PyObject* call_stage_plan(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 4 || !PyTuple_Check(args[0])) {
+    PyErr_SetString(PyExc_TypeError, "fastcall.stage_plan(keys tuple, sid_base, sid_bytes, dst)");
+    return NULL;
+  }
+  const Py_ssize_t n = PyTuple_GET_SIZE(args[0]);
+  if (n < 1 || n > STAGE_MAX_KEYS) {
+    PyErr_SetString(PyExc_ValueError, "fastcall.stage_plan: 1 .. 64 keys");
+    return NULL;
+  }
+  u64 sid_base, sid_bytes, dst;
+  if (as_u64(args[1], &sid_base) < 0 || as_u64(args[2], &sid_bytes) < 0 || as_u64(args[3], &dst) < 0)
+    return NULL;
+  StagePlan* plan = (StagePlan*)PyMem_Calloc(1, sizeof(StagePlan));
+  if (!plan) return PyErr_NoMemory();
+  plan->sid_base = (char*)(uintptr_t)sid_base;
+  plan->sid_bytes = (int64_t)sid_bytes;
+  plan->dst = (int32_t*)(uintptr_t)dst;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject* item = PyTuple_GET_ITEM(args[0], i);
+    const char* kind;
+    PyObject *name, *shape;
+    unsigned long long base;
+    long long rowbytes;
+    int itemsize;
+    if (!PyTuple_Check(item) ||
+        !PyArg_ParseTuple(item, "UKLsiO!", &name, &base, &rowbytes, &kind, &itemsize, &PyTuple_Type, &shape) ||
+        PyTuple_GET_SIZE(shape) > STAGE_MAX_DIMS || !kind[0]) {
+      if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "fastcall.stage_plan: bad key entry");
+      goto fail;
+    }
+    StageKey* key = &plan->keys[i];
+    key->base = (char*)(uintptr_t)base;
+    key->rowbytes = rowbytes;
+    key->itemsize = itemsize;
+    key->kind = kind[0];
+    key->ndim = (int)PyTuple_GET_SIZE(shape);
+    int64_t count = 1;
+    for (int d = 0; d < key->ndim; ++d) {
+      key->shape[d] = PyLong_AsSsize_t(PyTuple_GET_ITEM(shape, d));
+      if (key->shape[d] < 0) {
+        if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "fastcall.stage_plan: bad shape");
+        goto fail;
+      }
+      count *= key->shape[d];
+    }
+    if (count * itemsize != rowbytes) {
+      PyErr_SetString(PyExc_ValueError, "fastcall.stage_plan: row bytes != items x item size");
+      goto fail;
+    }
+    Py_INCREF(name);
+    key->name = name;
+    plan->n = (int)i + 1;
+  }
+  {
+    PyObject* capsule = PyCapsule_New(plan, "emb.stage_plan", stage_plan_free);
+    if (capsule) return capsule;
+  }
+fail:
+  for (int i = 0; i < plan->n; ++i) Py_XDECREF(plan->keys[i].name);
+  PyMem_Free(plan);
+  return NULL;
+}
+
+/* struct-module format of a buffer -> kind; 0: not a native fixed-size scalar. */
+static char format_kind(const char* format) {
+  if (!format) return 'u';                          /* PyBUF_SIMPLE exporters: bytes */
+  if (*format == '@' || *format == '=' || *format == '<' || *format == '|') ++format;
+  if (!format[0] || format[1]) return 0;
+  switch (format[0]) {
+    case '?': return 'b';
+    case 'b': case 'h': case 'i': case 'l': case 'q': case 'n': return 'i';
+    case 'B': case 'H': case 'I': case 'L': case 'Q': case 'N': return 'u';
+    case 'e': case 'f': case 'd': return 'f';
+    default: return 0;
+  }
+}
+
+static PyObject* call_add_step(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 9 && nargs != 10) {
+    PyErr_SetString(PyExc_TypeError,
+                    "fastcall.add_step(plan, step, slot, fn, handle, workers, rows, sids, new_chunks[, n])");
+    return NULL;
+  }
+  u64 batch = 0;
+  if (nargs == 10 && as_u64(args[9], &batch) < 0) return NULL;
+  const int lead = batch > 0;                       /* values carry a leading dimension n */
+  const int64_t steps = lead ? (int64_t)batch : 1;
+  StagePlan* plan = (StagePlan*)PyCapsule_GetPointer(args[0], "emb.stage_plan");
+  if (!plan) return NULL;
+  PyObject* step = args[1];
+  if (!PyDict_Check(step)) return PyLong_FromLong(-1);
+  u64 a[7];
+  for (int i = 0; i < 7; ++i)
+    if (as_u64(args[2 + i], &a[i]) < 0) return NULL;
+  const int64_t slot = (int64_t)a[0];
+  Py_buffer views[STAGE_MAX_KEYS];
+  int column[STAGE_MAX_KEYS];
+  int held = 0, slow = 0;
+  u64 seen = 0;
+  PyObject *name, *value;
+  Py_ssize_t pos = 0;
+  int guess = 0;                                    /* dicts keep the schema's order as a rule */
+  while (PyDict_Next(step, &pos, &name, &value)) {
+    if (!PyUnicode_Check(name)) { slow = 1; break; }
+    int found = -1;
+    if (guess < plan->n && plan->keys[guess].name == name) {
+      found = guess;
+    } else {
+      for (int j = 0; j < plan->n && found < 0; ++j)
+        if (plan->keys[j].name == name) found = j;
+      for (int j = 0; j < plan->n && found < 0; ++j)
+        if (PyUnicode_Compare(plan->keys[j].name, name) == 0) found = j;
+      if (found < 0) {
+        if (PyErr_Occurred()) PyErr_Clear();
+        const Py_ssize_t len = PyUnicode_GET_LENGTH(name);
+        if (len >= 4 && PyUnicode_READ_CHAR(name, 0) == 'l' && PyUnicode_READ_CHAR(name, 1) == 'o' &&
+            PyUnicode_READ_CHAR(name, 2) == 'g' && PyUnicode_READ_CHAR(name, 3) == '/')
+          continue;                                 /* log/* keys are not stored (replay.py:78) */
+        slow = 1;                                   /* unknown key: the Python path raises */
+        break;
+      }
+    }
+    guess = found + 1;
+    if (seen >> found & 1) { slow = 1; break; }
+    seen |= (u64)1 << found;
+    const StageKey* key = &plan->keys[found];
+    if (!PyObject_CheckBuffer(value)) { slow = 1; break; }
+    Py_buffer* view = &views[held];
+    if (PyObject_GetBuffer(value, view, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) < 0) {
+      PyErr_Clear();
+      slow = 1;
+      break;
+    }
+    column[held++] = found;
+    if (view->ndim != key->ndim + lead || view->itemsize != key->itemsize ||
+        view->len != steps * key->rowbytes || format_kind(view->format) != key->kind) { slow = 1; break; }
+    if (lead && view->shape[0] != steps) { slow = 1; break; }
+    for (int d = 0; d < key->ndim; ++d)
+      if (view->shape[d + lead] != key->shape[d]) slow = 1;
+    if (slow) break;
+  }
+  if (!slow && held != plan->n) slow = 1;           /* a key is missing: the Python path raises */
+  int32_t status = -1;
+  if (!slow) {
+    void* fn = (void*)(uintptr_t)a[1];
+    Py_BEGIN_ALLOW_THREADS
+    status = ((int32_t(*)(u64, u64, u64, u64, u64, u64))fn)(a[2], (u64)steps, a[3], a[4], a[5], a[6]);
+    if (status == 0) {
+      for (int i = 0; i < held; ++i) {
+        const StageKey* key = &plan->keys[column[i]];
+        memcpy(key->base + slot * key->rowbytes, views[i].buf, (size_t)(steps * key->rowbytes));
+      }
+      memcpy(plan->sid_base + slot * plan->sid_bytes, (const void*)(uintptr_t)a[5],
+             (size_t)(steps * plan->sid_bytes));
+      memcpy(plan->dst + slot, (const void*)(uintptr_t)a[4], (size_t)steps * sizeof(int32_t));
+    }
+    Py_END_ALLOW_THREADS
+  }
+  for (int i = 0; i < held; ++i) PyBuffer_Release(&views[i]);
+  return PyLong_FromLong(status);
+}
+
 static PyMethodDef methods[] = {
     {"ints", (PyCFunction)(void (*)(void))call_ints, METH_FASTCALL,
      "ints(addr, *args) -> status: call an int32 f(pointers/integers...)"},
@@ -305,6 +516,10 @@ static PyMethodDef methods[] = {
      "scan(addr, *10 or 11 args) -> status"},
     {"columns", (PyCFunction)(void (*)(void))call_columns, METH_FASTCALL,
      "columns(steps, plan, out, tensor_type, device) -> None | positions for the slow path"},
+    {"stage_plan", (PyCFunction)(void (*)(void))call_stage_plan, METH_FASTCALL,
+     "stage_plan(keys, sid_base, sid_bytes, dst) -> capsule for add_step"},
+    {"add_step", (PyCFunction)(void (*)(void))call_add_step, METH_FASTCALL,
+     "add_step(plan, step, slot, fn, handle, workers, rows, sids, new_chunks) -> 0 | status | -1 (Python path)"},
     {"same_values", (PyCFunction)(void (*)(void))call_same_values, METH_FASTCALL,
      "same_values(dict, tuple) -> the dict's values are exactly these objects, in order"},
     {NULL, NULL, 0, NULL},

@@ -64,3 +64,104 @@ def test_columns_rejects_bad_calls(columns):
     pass
   sub = torch.zeros(3).as_subclass(Sub)
   assert columns({'a': sub}, ((0, torch.float32, (3,), 'a'),), (C.c_void_p * 1)(), torch.Tensor, -1) == [0]
+
+
+class _FakeIndex:
+  """Stands in for emb_replay_add_index (include/embodied_hip.h): hands out
+  rows 78, 79, ... and step ids (call, call + 1, ...); `fail_at` = the call
+  that returns status 5."""
+
+  def __init__(self, fail_at=0):
+    self.calls = []
+    proto = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                        C.POINTER(C.c_uint8), C.POINTER(C.c_int32))
+
+    def fake(handle, n, workers, rows, sids, new_chunks):
+      self.calls.append((handle, n, workers[0]))
+      if len(self.calls) == fail_at:
+        return 5
+      rows[0] = 77 + len(self.calls)
+      for i in range(20):
+        sids[i] = i + len(self.calls)
+      new_chunks[0] = 0
+      return 0
+    self.keep = proto(fake)
+    self.addr = C.cast(self.keep, C.c_void_p).value
+    self.worker = np.array([9], np.int64)
+    self.row = np.zeros(1, np.int32)
+    self.sid = np.zeros(20, np.uint8)
+    self.new = C.c_int32()
+
+  def args(self):
+    return (self.addr, 1234, self.worker.ctypes.data, self.row.ctypes.data, self.sid.ctypes.data,
+            C.addressof(self.new))
+
+
+@pytest.fixture()
+def stage():
+  module = _lib.fast.module
+  if module is None or not hasattr(module, 'add_step'):
+    pytest.skip('call shim not built (ctypes binding only)')
+  rows = 4
+  bufs = {
+      'image': np.zeros((rows, 12), np.uint8), 'vec': np.zeros((rows, 12), np.uint8),
+      'is_first': np.zeros((rows, 1), np.uint8), 'sid': np.zeros((rows, 20), np.uint8),
+      'dst': np.zeros(rows, np.int32)}
+  plan = module.stage_plan(
+      (('image', bufs['image'].ctypes.data, 12, 'u', 1, (2, 2, 3)),
+       ('vec', bufs['vec'].ctypes.data, 12, 'f', 4, (3,)),
+       ('is_first', bufs['is_first'].ctypes.data, 1, 'b', 1, ())),
+      bufs['sid'].ctypes.data, 20, bufs['dst'].ctypes.data)
+  return module.add_step, plan, bufs
+
+
+def _step(**over):
+  step = {'image': np.arange(12, dtype=np.uint8).reshape(2, 2, 3),
+          'vec': np.array([1, 2, 3], np.float32), 'is_first': np.bool_(True), 'log/x': 5}
+  step.update(over)
+  return step
+
+
+def test_add_step_stages_a_host_step_in_one_call(stage):
+  """Replay.add's per-step work (replay.py:77-118) in C: values checked, index
+  called once, payload + step id + pool row land in the stage row `slot`."""
+  add_step, plan, bufs = stage
+  index = _FakeIndex()
+  assert add_step(plan, _step(), 1, *index.args()) == 0
+  assert index.calls == [(1234, 1, 9)]
+  assert bufs['image'][1].tolist() == list(range(12))
+  assert bufs['vec'][1].view(np.float32).tolist() == [1, 2, 3]
+  assert bufs['is_first'][1, 0] == 1
+  assert bufs['sid'][1].tolist() == list(range(1, 21)) and bufs['dst'].tolist() == [0, 78, 0, 0]
+  # any key order, 0-d arrays for the flags
+  again = {'is_first': np.array(False), 'vec': np.array([4, 5, 6], np.float32),
+           'image': np.full((2, 2, 3), 9, np.uint8)}
+  assert add_step(plan, again, 2, *index.args()) == 0
+  assert bufs['image'][2].tolist() == [9] * 12 and bufs['dst'].tolist() == [0, 78, 79, 0]
+  assert bufs['vec'][2].view(np.float32).tolist() == [4, 5, 6] and bufs['is_first'][2, 0] == 0
+
+
+@pytest.mark.parametrize('bad', [
+    dict(vec=np.array([1, 2, 3], np.float64)),             # another dtype: the Python path casts
+    dict(vec=np.array([1, 2, 3], np.int32)),               # same size, another kind
+    dict(vec=[1.0, 2.0, 3.0]),                             # no buffer
+    dict(vec=np.zeros(4, np.float32)),                     # shape
+    dict(image=np.zeros((4, 4, 3), np.uint8)[::2, ::2]),   # not contiguous
+    dict(image=torch.zeros((2, 2, 3), dtype=torch.uint8)), # a tensor
+    dict(extra=np.float32(1)),                             # a key the schema lacks
+])
+def test_add_step_leaves_other_steps_to_python_untouched(stage, bad):
+  add_step, plan, bufs = stage
+  index = _FakeIndex()
+  assert add_step(plan, _step(**bad), 3, *index.args()) == -1
+  assert index.calls == [] and not bufs['image'].any() and not bufs['dst'].any()
+  missing = _step()
+  del missing['vec']
+  assert add_step(plan, missing, 3, *index.args()) == -1 and index.calls == []
+
+
+def test_add_step_returns_the_library_status_without_staging(stage):
+  add_step, plan, bufs = stage
+  index = _FakeIndex(fail_at=1)
+  assert add_step(plan, _step(), 0, *index.args()) == 5
+  assert len(index.calls) == 1 and not bufs['image'].any() and not bufs['sid'].any()

@@ -69,6 +69,43 @@ def test_random_histories_against_oracle(emb, seed):
     assert got[k] == want[k], k
 
 
+def test_host_steps_through_the_c_call_the_python_path_and_add_batch_agree(emb):
+  """`add` of a host step dict takes one C call (fastcall.c add_step) when every
+  value can be copied as it is, the Python conversion otherwise (lists, other
+  dtypes, strided arrays, `log/*` extras), and `add_batch` of host arrays stages
+  n rows at once: three replays fed the same steps those three ways hold the
+  same bytes as the oracle, across many flushes of the two pinned stage sets."""
+  from embodied_amd.core import replay as replaylib
+  L, workers, steps = 4, 3, 150
+  make = lambda: emb.Replay(L, 90, chunksize=8, seed=5, stage_rows=7, slots=4)
+  fast, slow, batched = make(), make(), make()
+  ref = np_oracle.Replay(L, 90, 8, seed=5)
+  for t in range(steps):
+    rows = [scenarios.synth_step(t, w) for w in range(workers)]
+    for w, step in enumerate(rows):
+      ref.add(step, w)
+      fast.add({**step, 'log/extra': 1.0}, w)
+      awkward = dict(step)
+      awkward['vec'] = step['vec'].astype(np.float64) if t % 2 else step['vec'].tolist()
+      awkward['image'] = np.repeat(step['image'], 2, axis=1)[:, ::2]      # strided view, same values
+      awkward['reward'] = float(step['reward'])
+      slow.add(awkward if t or w else step, w)      # (the first step fixes the schema: chunk.py:43-47)
+    batched.add_batch({k: np.stack([r[k] for r in rows]) for k in rows[0]}, list(range(workers)))
+    if t % 9 == 8:
+      want = ref.sample(5)
+      for name, rep in (('fast', fast), ('slow', slow), ('batched', batched)):
+        assert len(rep) == len(ref)
+        got = {k: v.cpu().numpy() for k, v in rep.sample(5).items()}
+        assert_same(got, want, f'{name} t{t}')
+  if replaylib._add_step is not None:
+    assert fast._stage_plan is not None     # the C call was there to be taken
+  with pytest.raises(KeyError):
+    fast.add({k: v for k, v in scenarios.synth_step(0, 0).items() if k != 'vec'}, 0)
+  with pytest.raises(ValueError):
+    fast.add({**scenarios.synth_step(0, 0), 'vec': np.zeros(6, np.float32)}, 0)
+  assert len(fast) == len(ref)               # a rejected step left no trace
+
+
 def test_full_size_sample_matches_generator(emb):
   """BASELINE shapes: 64 envs, 84x84x4 uint8, B=16, L=65, chunksize 1024.
   Every gathered byte must equal the counter-hash generator's value for the

@@ -112,13 +112,38 @@ def driver_dummy(emb, label, seconds, parallel, envs=32):
   driver = emb.Driver(fns, parallel)
   driver.reset(agent.init_policy)
   driver(agent.policy, steps=100)
-  steps, start = 0, time.perf_counter()
+  # The script credits every call with 100 * envs steps (test_driver.py:24); a
+  # call of `steps=100` runs ceil(100 / envs) vectorised steps (driver.py:55-59,
+  # 84: the count advances by the number of envs), so both figures are printed.
+  calls, start = 0, time.perf_counter()
   while time.perf_counter() - start < seconds:
     driver(agent.policy, steps=100)
-    steps += 100 * envs
+    calls += 1
   dt = time.perf_counter() - start
   driver.close()
-  print(f'{label:<34} FPS {steps / dt:>10.0f} ({envs} Dummy envs, parallel={parallel})', flush=True)
+  true_steps = calls * -(-100 // envs) * envs
+  print(f'{label:<34} FPS as the script counts {calls * 100 * envs / dt:>10.0f}   env steps/sec '
+        f'{true_steps / dt:>9.0f} ({envs} Dummy envs, parallel={parallel})', flush=True)
+
+
+def oracle_driver_dummy(np_oracle, label, seconds, envs=32):
+  """The same loop over the oracle's serial Driver (driver.py:11-87), with the
+  package's Dummy env and RandomAgent classes (host Python either way)."""
+  from embodied_amd.envs import dummy
+  from embodied_amd.core.agents import RandomAgent
+  made = [dummy.Dummy('disc') for _ in range(envs)]
+  agent = RandomAgent(made[0].obs_space, made[0].act_space)
+  driver = np_oracle.Driver(made)
+  driver.reset(agent.init_policy)
+  driver(agent.policy, steps=100)
+  calls, start = 0, time.perf_counter()
+  while time.perf_counter() - start < seconds:
+    driver(agent.policy, steps=100)
+    calls += 1
+  dt = time.perf_counter() - start
+  true_steps = calls * -(-100 // envs) * envs
+  print(f'{label:<34} FPS as the script counts {calls * 100 * envs / dt:>10.0f}   env steps/sec '
+        f'{true_steps / dt:>9.0f} ({envs} Dummy envs, serial)', flush=True)
 
 
 def main():
@@ -155,6 +180,7 @@ def main():
       speed(make, f'oracle test_chunk_size {chunksize}', args.seconds, False, length=64, capacity=None,
             chunksize=chunksize)
     removal(make, 'oracle test_removal', args.seconds, False)
+    oracle_driver_dummy(np_oracle, 'oracle throughput_dummy', args.seconds)
 
 
 if __name__ == '__main__':
