@@ -266,8 +266,9 @@ class Driver:
     """fn(tran, worker, **kwargs) per env (driver.py:47-48).  A bound
     `embodied_amd.Replay.add` is recognised and served in batched form."""
     owner = getattr(callback, '__self__', None)
-    if (self.device is not None and isinstance(owner, replaylib.Replay)
+    if (isinstance(owner, replaylib.Replay)
         and getattr(callback, '__func__', None) is replaylib.Replay.add):
+      # (host mode too: the stacked host arrays of a step are staged by one call)
       self.batch_callbacks.append(
           lambda trans, workers, **kw: owner.add_batch(trans, workers))
       self._sinks.append(owner)

@@ -436,6 +436,39 @@ def test_parallel_env_workers_upload_from_shared_slab(emb):
     assert_same(b, a, 'parallel-device')
 
 
+@pytest.mark.parametrize('parallel', [False, True])
+def test_host_mode_driver_with_a_replay_sink_matches_the_oracle_pair(emb, parallel):
+  """The unchanged reference program: `Driver(fns, parallel)` in host mode with
+  `driver.on_step(replay.add)` (run/train.py:56-61).  The sink is served in
+  batched form (the step's stacked host arrays are staged by one call); the
+  replay must hold what the oracle's Driver + per-env `add` hold."""
+  from functools import partial
+  fns = [partial(scenarios.ScriptEnv, i, 3 + i) for i in range(4)]
+  driver = emb.Driver(fns, parallel=parallel)
+  rep = emb.Replay(length=3, capacity=60, chunksize=8, seed=2, stage_rows=16)
+  driver.on_step(rep.add)
+  assert driver._sinks == [rep] and not driver.callbacks
+  oracle = np_oracle.Driver([scenarios.ScriptEnv(i, 3 + i) for i in range(4)])
+  ref = np_oracle.Replay(3, 60, 8, seed=2)
+  oracle.on_step(ref.add)
+
+  def policy(carry, obs):
+    n = len(obs['is_first'])
+    act = {'act_disc': (np.arange(n) + carry).astype(np.int32),
+           'act_cont': np.full((n, 3), carry, np.float32)}
+    return carry + 1, act, {'value': np.full(n, 0.5 * carry, np.float32)}
+
+  driver.reset(lambda n: 0)
+  oracle.reset(lambda n: 0)
+  for _ in range(12):
+    driver(policy, steps=20)
+    oracle(policy, steps=20)
+    assert len(rep) == len(ref)
+    got = {k: v.cpu().numpy() for k, v in rep.sample(6).items()}
+    assert_same(got, ref.sample(6), 'host-driver-sink')
+  driver.close()
+
+
 def test_callbacks_may_keep_the_tensors_of_a_step(emb):
   """The reference stacks fresh arrays per step (driver.py:65): a callback that
   keeps a step's tensors (episode / video accumulators) must find them unchanged

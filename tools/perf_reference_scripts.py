@@ -102,7 +102,7 @@ def removal(make, label, seconds, device):
         f'{len(replay)} items held after {n0} to fill)', flush=True)
 
 
-def driver_dummy(emb, label, seconds, parallel, envs=32):
+def driver_dummy(emb, label, seconds, parallel, envs=32, sink=False):
   from functools import partial as bind
   from embodied_amd.envs import dummy
   fns = [bind(dummy.Dummy, 'disc') for _ in range(envs)]
@@ -110,6 +110,9 @@ def driver_dummy(emb, label, seconds, parallel, envs=32):
   agent = emb.RandomAgent(example.obs_space, example.act_space)
   example.close()
   driver = emb.Driver(fns, parallel)
+  if sink:      # run/train.py:56-61: every transition goes into the replay
+    replay = emb.Replay(length=32, capacity=int(1e5), chunksize=1024, seed=0)
+    driver.on_step(replay.add)
   driver.reset(agent.init_policy)
   driver(agent.policy, steps=100)
   # The script credits every call with 100 * envs steps (test_driver.py:24); a
@@ -126,7 +129,7 @@ def driver_dummy(emb, label, seconds, parallel, envs=32):
         f'{true_steps / dt:>9.0f} ({envs} Dummy envs, parallel={parallel})', flush=True)
 
 
-def oracle_driver_dummy(np_oracle, label, seconds, envs=32):
+def oracle_driver_dummy(np_oracle, label, seconds, envs=32, sink=False):
   """The same loop over the oracle's serial Driver (driver.py:11-87), with the
   package's Dummy env and RandomAgent classes (host Python either way)."""
   from embodied_amd.envs import dummy
@@ -134,6 +137,9 @@ def oracle_driver_dummy(np_oracle, label, seconds, envs=32):
   made = [dummy.Dummy('disc') for _ in range(envs)]
   agent = RandomAgent(made[0].obs_space, made[0].act_space)
   driver = np_oracle.Driver(made)
+  if sink:
+    replay = np_oracle.Replay(length=32, capacity=int(1e5), chunksize=1024, selector=np_oracle.Uniform(0))
+    driver.on_step(replay.add)
   driver.reset(agent.init_policy)
   driver(agent.policy, steps=100)
   calls, start = 0, time.perf_counter()
@@ -160,6 +166,13 @@ def main():
     print(f'# product: embodied_amd on {torch.cuda.get_device_name(0)}, host modules '
           f'{"compiled" if emb.compiled else "plain"}; one add(step, worker) per host step dict', flush=True)
     make = lambda **kw: emb.Replay(seed=0, **kw)
+    # Once per process, outside the timed loops: the first launches load the
+    # library's code objects (~0.2 s), which the first loop would otherwise carry.
+    warm = make(length=2, capacity=64, chunksize=8)
+    for t in range(40):
+      warm.add(STEP, 0)
+    warm.sample(1)
+    sync(True)
     speed(make, 'product test_speed', args.seconds, True)
     replay = make(length=32, capacity=int(1e5), chunksize=1024)
     n, dt = timed_batched_inserts(replay, int(2e5), 8, args.seconds, True)
@@ -170,6 +183,8 @@ def main():
     removal(make, 'product test_removal', args.seconds, True)
     driver_dummy(emb, 'product throughput_dummy', args.seconds, False)
     driver_dummy(emb, 'product throughput_dummy', args.seconds, True)
+    driver_dummy(emb, 'product dummy + on_step(add)', args.seconds, False, sink=True)
+    driver_dummy(emb, 'product dummy + on_step(add)', args.seconds, True, sink=True)
   if not args.no_oracle:
     from oracle import np_oracle
     print(f'# cpu baseline: oracle/np_oracle.py (numpy restatement of the reference), 1 core of '
@@ -181,6 +196,7 @@ def main():
             chunksize=chunksize)
     removal(make, 'oracle test_removal', args.seconds, False)
     oracle_driver_dummy(np_oracle, 'oracle throughput_dummy', args.seconds)
+    oracle_driver_dummy(np_oracle, 'oracle dummy + on_step(add)', args.seconds, sink=True)
 
 
 if __name__ == '__main__':
