@@ -112,6 +112,53 @@ def test_train_loop_counts_and_resume(tmp_path):
   assert int(logger2.step) >= 700
 
 
+def test_pretrain_from_the_replay_directory_of_a_run(tmp_path):
+  """embodied/run/pretrain.py:8-96 on the path: `run.train` leaves its replay
+  directory behind (chunk files); `run.pretrain` builds its three streams over a
+  Replay loaded from that directory (`make_stream(None, mode)`) and takes
+  train / report / eval batches from it -- the checking agent asserts count
+  continuity along every window -- then resumes from its own checkpoint."""
+  import embodied_amd as emb
+  box = []
+  run(tmp_path / 'collect', box)                  # 600 env steps, checkpoints on a 50 ms clock
+  directory = tmp_path / 'collect' / 'replay'
+  assert list(directory.glob('*.npz'))
+  args = types.SimpleNamespace(
+      logdir=str(tmp_path / 'pretrain'), steps=40, batch_size=4, batch_length=8, log_every=-1,
+      report_every=-1, save_every=-1, consec_report=1, report_batches=2, replica=0,
+      from_checkpoint='', from_checkpoint_regex=None)
+  replays = []
+
+  def make_stream(replay, mode):
+    assert replay is None
+    loaded = emb.Replay(length=args.batch_length + 1, capacity=500, chunksize=64, directory=directory,
+                        seed={'train': 1, 'report': 2, 'eval': 3}[mode])
+    loaded.load()
+    assert len(loaded) > 0
+    replays.append(loaded)
+    return emb.streams.Consec(
+        emb.streams.Stateless(loaded.sample, args.batch_size, mode),
+        length=args.batch_length, consec=1, prefix=1, strict=True, contiguous=True)
+
+  def make_model():
+    from embodied_amd.envs import dummy
+    env0 = dummy.Dummy('disc', size=(8, 8), length=17)
+    box.append(CheckingAgent(env0.obs_space, env0.act_space))
+    return box[-1]
+
+  logger = emb.utils.Logger()
+  emb.run.pretrain(make_model, make_stream, lambda: logger, args)
+  model = box[-1]
+  assert model.trains == 40 and int(logger.step) == 40 and model.loads == 0
+  assert model.reports == 40 * 4                              # report + eval, two batches each, every step
+  assert len(replays) == 3 and model.saves >= 40
+  assert any('train/loss' in r for r in logger.history)
+  logger2 = emb.utils.Logger()
+  args.steps = 50
+  emb.run.pretrain(make_model, make_stream, lambda: logger2, args)
+  assert box[-1].loads == 1 and int(logger2.step) == 50
+
+
 def test_actor_learner_split_respects_samples_per_insert(tmp_path):
   """Actor and learner threads on separate HIP streams, coupled by the
   SamplesPerInsert limiter: the realised sample/insert ratio stays near

@@ -123,3 +123,129 @@ def test_eval_only_steps_envs_in_eval_mode_and_logs_episodes(tmp_path):
   assert {'episode/score', 'episode/length', 'fps/policy'} <= keys
   lengths = [r['episode/length'] for r in logger.history if 'episode/length' in r]
   assert lengths and all(9 <= int(x) <= 12 for x in lengths)     # Dummy: `length` steps + the reset step
+
+
+class _CountingStream:
+  """A restorable stream of batches {'count': [k, k + 1, ...]}."""
+
+  def __init__(self, mode):
+    self.mode, self.k = mode, 0
+
+  def __iter__(self):
+    return self
+
+  def __next__(self):
+    self.k += 1
+    return {'count': np.arange(self.k, self.k + 4), 'mode': self.mode}
+
+  def save(self):
+    return self.k
+
+  def load(self, k):
+    self.k = k
+
+
+class _CountingModel:
+  """The learner side of the reference's self-checking TestAgent
+  (embodied/tests/utils.py:8-104): counts calls, checks what it is fed."""
+
+  def __init__(self):
+    self.trains, self.reports, self.loaded, self.seen = 0, {'report': 0, 'eval': 0}, None, []
+
+  def stream(self, st):
+    return st
+
+  def init_train(self, batch_size):
+    return ('train', batch_size)
+
+  def init_report(self, batch_size):
+    return ('report', batch_size)
+
+  def train(self, carry, batch):
+    assert carry == ('train', 4) and batch['mode'] == 'train'
+    self.seen.append(int(batch['count'][0]))
+    self.trains += 1
+    return carry, {}, {'loss': 1.0 / self.trains}
+
+  def report(self, carry, batch):
+    assert carry == ('report', 4) and batch['mode'] in ('report', 'eval')
+    self.reports[batch['mode']] += 1
+    return carry, {'score': float(batch['count'][0])}
+
+  def save(self):
+    return {'trains': self.trains}
+
+  def load(self, data, regex=None):
+    self.loaded = (data, regex)
+    self.trains = data['trains']
+
+
+def _pretrain_args(tmp_path, **over):
+  base = dict(
+      logdir=str(tmp_path), steps=25, batch_size=4, batch_length=8, log_every=-1, report_every=-1,
+      save_every=-1, consec_report=2, report_batches=3, replica=0, from_checkpoint='',
+      from_checkpoint_regex=None)
+  base.update(over)
+  return types.SimpleNamespace(**base)
+
+
+def test_pretrain_trains_reports_evaluates_and_checkpoints(tmp_path):
+  """embodied/run/pretrain.py:8-96: `steps` train steps from the train stream,
+  consec_report * report_batches report and eval batches per report, train
+  metrics / fps on the log schedule, a checkpoint holding step, model and the
+  three streams; a second call resumes from it."""
+  model = _CountingModel()
+  made = {}
+
+  def make_stream(replay, mode):
+    assert replay is None
+    made[mode] = _CountingStream(mode)
+    return made[mode]
+
+  logger = emb.utils.Logger()
+  emb.run.pretrain(lambda: model, make_stream, lambda: logger, _pretrain_args(tmp_path))
+  assert model.trains == 25 and model.seen == list(range(1, 26)) and int(logger.step) == 25
+  assert model.reports == {'report': 25 * 6, 'eval': 25 * 6}      # every step is due with -1
+  rows = logger.history
+  assert any('train/loss' in r for r in rows) and any('report/score' in r for r in rows)
+  assert any('eval/score' in r for r in rows) and any('fps' in r for r in rows)
+  assert (tmp_path / 'checkpoint.pkl').exists()
+  # resume: the counter, the model and the stream positions come back
+  again, streams2 = _CountingModel(), {}
+
+  def make_stream2(replay, mode):
+    streams2[mode] = _CountingStream(mode)
+    return streams2[mode]
+
+  logger2 = emb.utils.Logger()
+  emb.run.pretrain(lambda: again, make_stream2, lambda: logger2, _pretrain_args(tmp_path, steps=30))
+  assert again.loaded[0] == {'trains': 25} and again.trains == 30 and int(logger2.step) == 30
+  assert again.seen == list(range(26, 31))
+
+
+def test_pretrain_starts_from_another_checkpoint(tmp_path):
+  import pickle
+  source = tmp_path / 'other.pkl'
+  source.write_bytes(pickle.dumps({'model': {'trains': 100}}))
+  model = _CountingModel()
+  emb.run.pretrain(
+      lambda: model, lambda replay, mode: _CountingStream(mode), lambda: emb.utils.Logger(),
+      _pretrain_args(tmp_path / 'run', steps=3, from_checkpoint=str(source), from_checkpoint_regex='enc/.*',
+                     report_every=0))
+  assert model.loaded == ({'trains': 100}, 'enc/.*') and model.trains == 103
+  assert model.reports == {'report': 0, 'eval': 0}
+
+
+def test_clock_namespace_like_the_reference():
+  """`embodied.clock` / `embodied.GlobalClock` by name (core/__init__.py:3-4,10):
+  one process: GlobalClock is a LocalClock; setup() with one replica does
+  nothing, with more it wants the process group."""
+  import pytest
+  assert emb.clock.LocalClock is emb.LocalClock
+  always, never = emb.GlobalClock(-1), emb.clock.GlobalClock(0)
+  assert always() and always(skip=False) and not always(skip=True) and not never()
+  timed = emb.GlobalClock(1000.0, first=True)
+  assert timed() and not timed()
+  emb.clock.setup(is_server=True, replica=0, replicas=1, port=1234, addr='localhost')
+  with pytest.raises(RuntimeError):
+    emb.clock.setup(is_server=True, replica=0, replicas=2, port=1234, addr='localhost')
