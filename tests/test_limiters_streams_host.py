@@ -166,3 +166,84 @@ def test_recency_selector_prefers_recent_items():
   for key in range(5):
     small[key] = None
   assert set(small() for _ in range(200)) <= set(range(5))
+
+
+class _Numbered:
+  """A restorable stream of {'x': [[k, tag]] * rows} batches."""
+
+  def __init__(self, tag, rows=2):
+    self.tag, self.rows, self.k = tag, rows, 0
+
+  def __iter__(self):
+    return self
+
+  def __next__(self):
+    self.k += 1
+    return {'x': np.full((self.rows, 2), (self.k, self.tag)), 'nest': {'y': np.full(self.rows, self.k)}}
+
+  def save(self):
+    return self.k
+
+  def load(self, k):
+    self.k = k
+
+
+def test_zip_and_map_against_the_reference_classes():
+  """streams.py:153-201.  Zip concatenates one batch per source leaf by leaf;
+  Map applies a function; both checkpoint through their sources.  Build
+  container: the same sequence through the reference's own classes."""
+  def build(ns):
+    zipped = iter(ns.Zip([_Numbered(10), _Numbered(20, rows=3)]))
+    mapped = iter(ns.Map(_Numbered(30), lambda batch, k, scale=1: {'x': batch['x'] * scale + k}, 5, scale=2))
+    out = [next(zipped) for _ in range(3)]
+    state = zipped.save()
+    out += [next(zipped) for _ in range(2)]
+    zipped.load(state)
+    out.append(next(zipped))
+    out += [next(mapped), next(mapped)]
+    held = mapped.save()
+    next(mapped)
+    mapped.load(held)
+    out.append(next(mapped))
+    return out, state, held
+
+  got, state, held = build(streams)
+  assert state == [3, 3] and held == 2
+  assert got[0]['x'].tolist() == [[1, 10]] * 2 + [[1, 20]] * 3 and got[0]['nest']['y'].tolist() == [1] * 5
+  assert got[5]['x'][0].tolist() == [4, 10]                       # after load: the 4th batch again
+  assert got[6]['x'].tolist() == [[7, 65]] * 2 and got[8]['x'][0].tolist() == [11, 65]
+  if refload.available():
+    ref = refload.load()
+    import importlib
+    want, wstate, wheld = build(importlib.import_module('embodied.core.streams'))
+    assert wstate == state and wheld == held
+    for a, b in zip(got, want):
+      assert (a['x'] == b['x']).all()
+  # torch batches are concatenated as tensors
+  import torch
+  class _Tensors(_Numbered):
+    def __next__(self):
+      return {k: (torch.from_numpy(v) if not isinstance(v, dict) else v) for k, v in super().__next__().items()}
+  both = next(iter(streams.Zip([_Tensors(1), _Tensors(2)])))
+  assert torch.is_tensor(both['x']) and both['x'].shape == (4, 2)
+  with pytest.raises(ValueError):
+    streams.Zip([_Numbered(1)])
+
+
+def test_mixer_draws_sources_by_weight_and_restores():
+  """streams.py:204-243 (cannot run upstream: see the class docstring): the
+  source of step s is `default_rng([seed, s]).choice(p=weights / sum)` over the
+  sorted keys; save / load restore the step and every source."""
+  weights = {'b': 3.0, 'a': 1.0}
+  mixer = streams.Mixer({'a': _Numbered(1), 'b': _Numbered(2)}, weights, seed=7)
+  tags = [int(next(mixer)['x'][0, 1]) for _ in range(200)]
+  want = [1 + int(np.random.default_rng(seed=[7, s]).choice(2, p=np.array([0.25, 0.75], np.float32)))
+          for s in range(200)]
+  assert tags == want and 120 < tags.count(2) < 180
+  state = mixer.save()
+  assert state['step'] == 200 and state['sources'] == {'a': tags.count(1), 'b': tags.count(2)}
+  ahead = [next(mixer)['x'][0].tolist() for _ in range(5)]
+  mixer.load(state)
+  assert [next(mixer)['x'][0].tolist() for _ in range(5)] == ahead
+  with pytest.raises(ValueError):
+    streams.Mixer({'a': _Numbered(1)}, {'b': 1.0})
