@@ -29,6 +29,7 @@ from .. import _lib
 from .._lib import api, fast
 from . import limiters
 from . import selectors as selectorlib
+from . import selectors     # `embodied.replay.selectors`, as ppo/main.py:202 spells it
 
 # csrc/fastcall.c: Replay.add of a host step dict as one C call (None: Python path).
 _add_step = getattr(fast.module, 'add_step', None)
@@ -111,7 +112,7 @@ class Replay:
           f'HIP kernels; device={device!r} is not a GPU (no CPU fallback).')
     self.numpy = numpy
     self.save_wait = save_wait
-    self.directory = directory
+    directory = self.directory = _as_path(directory)
     # `selector or Uniform(seed)` in the reference (replay.py:26) silently drops
     # an empty selector that defines __len__; test for None instead.
     if selector is None:
@@ -1240,7 +1241,7 @@ class Replay:
     """Restore the newest chunks from disk until `amount` items are back
     (replay.py:311-359): file order, per-chunk item counts and reference
     counting as the reference; payload goes up with one copy per key per chunk."""
-    directory = directory or self.directory
+    directory = _as_path(directory) or self.directory
     amount = amount or self.capacity or np.inf
     if not directory:
       return
@@ -1365,6 +1366,14 @@ class Replay:
         self._handle, {'sample': 0, 'update': 1, 'deferred': 2, 'carried': 3}[which], C.byref(launches), C.byref(ms),
         int(reset), name, len(name))
     return launches.value, ms.value, name.value.decode()
+
+
+def _as_path(directory):
+  """None / '' stay falsy; str, os.PathLike or anything whose str() is the path
+  (elements.Path, ppo/main.py:190) -> pathlib.Path."""
+  if not directory:
+    return None
+  return pathlib.Path(directory if isinstance(directory, (str, os.PathLike)) else str(directory))
 
 
 def _all_host_arrays(steps):

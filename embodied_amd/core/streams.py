@@ -7,6 +7,7 @@ tensors the window copy is one `emb_window_keys` launch for all keys, and over
 this package's `Replay.sample` the sampling and the windowing are one gather.
 """
 import collections
+import functools
 import threading
 
 import numpy as np
@@ -35,6 +36,11 @@ class Stateless(base.Stream):
       if not hasattr(fn, '__next__'):
         raise TypeError(f'Stateless needs a callable or an iterator, got {type(fn).__name__}')
       fn = fn.__next__
+    if type(fn) is functools.partial:
+      # `Stateless(bind(replay.sample, batch, mode))` (ppo/main.py:262-263) is
+      # `Stateless(replay.sample, batch, mode)`: unwrapped, so that `recycle` and
+      # Consec's fused route see the Replay behind it.
+      fn, args, kwargs = fn.func, (*fn.args, *args), {**fn.keywords, **kwargs}
     self.fn, self.args, self.kwargs = fn, args, kwargs
     self.recycle = int(recycle)
     self._lent = collections.deque()

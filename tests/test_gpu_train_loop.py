@@ -112,6 +112,99 @@ def test_train_loop_counts_and_resume(tmp_path):
   assert int(logger2.step) >= 700
 
 
+class _PathLikeElements:
+  """Stands in for `elements.Path` (ppo/main.py:190): not an os.PathLike, its
+  str() is the path, `/` joins."""
+
+  def __init__(self, path):
+    self._path = str(path)
+
+  def __truediv__(self, part):
+    return _PathLikeElements(f'{self._path}/{part}')
+
+  def __str__(self):
+    return self._path
+
+
+def test_train_with_factories_spelled_like_the_shipped_mains(tmp_path):
+  """`make_replay` / `make_stream` / `wrap_env` as ppo/main.py:183-272 writes
+  them, with `embodied` = this package: `embodied.replay.Replay(**kwargs)` over
+  an elements-style directory, the three-way `embodied.replay.selectors.Mixture`
+  with a recency table, `Stateless(bind(replay.sample, batch, mode))` under
+  `Consec(..., contiguous=True)`, the wrapper chain of `wrap_env`."""
+  from functools import partial as bind
+  import embodied_amd as embodied
+  from embodied_amd.envs import dummy
+  config = types.SimpleNamespace(
+      batch_size=4, batch_length=8, report_length=8, consec_train=1, consec_report=1, replay_context=1,
+      logdir=str(tmp_path), replicas=1, replica=0,
+      replay=types.SimpleNamespace(
+          size=400, online=True, chunksize=64, recexp=1.0,
+          fracs={'uniform': 0.5, 'priority': 0.3, 'recency': 0.2},
+          prio=dict(exponent=0.8, maxfrac=0.5, initial=np.inf, zero_on_sample=True)))
+
+  def make_replay(config, folder, mode='train'):
+    batlen = config.batch_length if mode == 'train' else config.report_length
+    consec = config.consec_train if mode == 'train' else config.consec_report
+    capacity = config.replay.size if mode == 'train' else config.replay.size / 10
+    length = consec * batlen + config.replay_context
+    assert config.batch_size * length <= capacity
+    directory = _PathLikeElements(config.logdir) / folder
+    kwargs = dict(
+        length=length, capacity=int(capacity), online=config.replay.online,
+        chunksize=config.replay.chunksize, directory=directory)
+    if config.replay.fracs['uniform'] < 1 and mode == 'train':
+      recency = 1.0 / np.arange(1, capacity + 1) ** config.replay.recexp
+      selectors = embodied.replay.selectors
+      kwargs['selector'] = selectors.Mixture(dict(
+          uniform=selectors.Uniform(),
+          priority=selectors.Prioritized(**config.replay.prio),
+          recency=selectors.Recency(recency),
+      ), dict(config.replay.fracs))
+    return embodied.replay.Replay(**kwargs)
+
+  def wrap_env(env, config):
+    for name, space in env.act_space.items():
+      if not space.discrete:
+        env = embodied.wrappers.NormalizeAction(env, name)
+    env = embodied.wrappers.UnifyDtypes(env)
+    env = embodied.wrappers.CheckSpaces(env)
+    for name, space in env.act_space.items():
+      if not space.discrete:
+        env = embodied.wrappers.ClipAction(env, name)
+    return env
+
+  def make_stream(config, replay, mode):
+    fn = bind(replay.sample, config.batch_size, mode)
+    stream = embodied.streams.Stateless(fn)
+    return embodied.streams.Consec(
+        stream, length=config.batch_length if mode == 'train' else config.report_length,
+        consec=config.consec_train if mode == 'train' else config.consec_report,
+        prefix=config.replay_context, strict=(mode == 'train'), contiguous=True)
+
+  box, replays = [], []
+  env0 = wrap_env(dummy.Dummy('disc', size=(8, 8), length=17), config)
+
+  def make_agent():
+    box.append(CheckingAgent(env0.obs_space, env0.act_space))
+    return box[-1]
+
+  def replay_factory():
+    replays.append(make_replay(config, 'replay'))
+    return replays[-1]
+
+  args = make_args(tmp_path, steps=500)
+  logger = embodied.utils.Logger()
+  embodied.run.train(
+      make_agent, replay_factory, lambda i: wrap_env(dummy.Dummy('disc', size=(8, 8), length=17 + i), config),
+      bind(make_stream, config), lambda: logger, args)
+  agent = box[-1]
+  assert int(logger.step) >= 500 and agent.trains > 50 and agent.reports >= 1
+  assert list((tmp_path / 'replay').glob('*.npz'))            # the elements-style directory was used
+  stream = make_stream(config, replays[-1], 'train')
+  assert type(stream.source.fn).__name__ == 'method' and stream.source.args == (4, 'train')
+
+
 def test_pretrain_from_the_replay_directory_of_a_run(tmp_path):
   """embodied/run/pretrain.py:8-96 on the path: `run.train` leaves its replay
   directory behind (chunk files); `run.pretrain` builds its three streams over a

@@ -143,6 +143,15 @@ def test_stateless_takes_functions_and_iterators():
   assert list(zip(range(3), streams.Stateless(iter('abc')))) == [(0, 'a'), (1, 'b'), (2, 'c')]
   with pytest.raises(TypeError):
     streams.Stateless(3)
+  # the shipped mains bind the arguments first (ppo/main.py:262-263): same stream
+  import functools
+  import embodied_amd
+  bound = streams.Stateless(functools.partial(draw, 8, mode='eval'))
+  assert bound.fn is draw and bound.args == (8,) and bound.kwargs == {'mode': 'eval'}
+  assert next(bound) == 3 and calls[-1] == (8, 'eval')
+  # ... and reach the selectors through the replay module (ppo/main.py:202)
+  assert embodied_amd.replay.selectors is embodied_amd.selectors
+  assert embodied_amd.replay.Replay is embodied_amd.Replay
 
 
 def test_recency_selector_prefers_recent_items():
