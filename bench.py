@@ -365,6 +365,7 @@ def main():
   use_native = False
   link = None               # who carries a train step's collectives (set after the self-check)
   collectives = {'on': True, 'sliced': 0}
+  fresh = {'on': False, 'stream': None}
 
   def train_step():
     if args.workload == 'dreamer':
@@ -390,6 +391,12 @@ def main():
       if use_dist and grads is not None and collectives['on']:
         link.wait()
         link.exchange(grads=grads)
+    elif fresh['on']:
+      # (context leg `fresh_batches`: the learner as the reference writes it --
+      # every batch and every scan result a fresh allocation, ppo/main.py:262-272)
+      batch = next(fresh['stream'])
+      adv, tar = emb.scans.gae(
+          batch['reward'], value, batch['is_last'], batch['is_terminal'], hor=200, lam=0.8)
     elif not use_dist or not collectives['on']:
       batch = next(stream)
       adv, tar = emb.scans.gae(
@@ -685,6 +692,37 @@ def main():
     env.takes_unmasked_actions = True
     driver._unmasked = None
     replay.profile_read(reset=True)
+  # Context (single GPU, ppo, no part of `value`): the same loop for two more
+  # seconds with the learner written as the shipped mains write it -- the stream
+  # built from `bind(replay.sample, batch, mode)` without `recycle`, GAE without
+  # `out=`: seven fresh batch tensors and two fresh results per train step, as
+  # the reference's fresh arrays.
+  fresh_batches = None
+  if (not use_dist and args.workload == 'ppo' and args.sustained_seconds > 0 and not args.no_context
+      and args.prefetch == 1):
+    import functools
+    fence()
+    fresh['stream'] = iter(emb.streams.Consec(
+        emb.streams.Stateless(functools.partial(replay.sample, B, 'train')),
+        length=T, consec=args.consec, prefix=args.context, strict=True, contiguous=True))
+    fresh['on'] = True
+    for _ in range(64):
+      one_step()
+    fence()
+    f_start, f_steps, f_trains = time.perf_counter(), 0, counters['train_steps']
+    while time.perf_counter() - f_start < 2.0:
+      for _ in range(256):
+        one_step()
+      f_steps += 256
+    fence()
+    f_elapsed = time.perf_counter() - f_start
+    fresh['on'] = False
+    fresh_batches = {
+        'env_steps_per_s': round(f_steps * args.envs / f_elapsed, 1), 'steps': f_steps,
+        'train_steps_per_s': round((counters['train_steps'] - f_trains) / f_elapsed, 2),
+        'ms_per_step': round(f_elapsed / f_steps * 1e3, 5),
+        'what': 'same loop, the learner as ppo/main.py:262-272 spells it: Stateless(bind(replay.sample, '
+                'batch, mode)) without recycle, GAE without out= (fresh tensors per train step)'}
   # Ranks only, context: the same loop with the collectives switched off (N
   # independent replicas: no exchange, no gradient all-reduce) -- what the path
   # itself does on N GPUs, next to what the links allow with them.
@@ -925,6 +963,7 @@ def main():
            if native is not None and 'per_train_step' in native else {}),
         **({'replicas_only': replicas_only} if replicas_only is not None else {}),
         **({'masked_env_actions': masked_env_actions} if masked_env_actions is not None else {}),
+        **({'fresh_batches': fresh_batches} if fresh_batches is not None else {}),
         **({'expected': expected} if expected is not None else {}),
     }), flush=True)
   if native_stuck:       # a collective of the check never returned: leave without the teardown
