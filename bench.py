@@ -878,6 +878,7 @@ def main():
           sweep[str(per_launch)] = {
               'sequences': big, 'avg_launch_us': round(us, 2), 'achieved': round(gbs, 1),
               'frac': round(gbs / HBM_PEAK_GBS, 4), 'read_frac': round(gbs / 2 / HBM_PEAK_GBS, 4)}
+      sweep['how'] = 'context: per size, the quietest of three rounds of 20 back-to-back launches'
       roofline['batches_per_launch_sweep'] = sweep
       roofline['plain_copy_same_bytes'] = plain_copy_reference(replay, B * L, device)
     except Exception as e:     # context only: never lose the headline over it

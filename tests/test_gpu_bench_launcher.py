@@ -130,8 +130,9 @@ def test_bench_short_run_keeps_its_shape():
   roof = rec['roofline']
   assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and 0 < roof['frac'] < 1
   assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
-  assert set(roof['batches_per_launch_sweep']) == {'1', '4', '8', '16', '64'}
+  assert set(roof['batches_per_launch_sweep']) == {'1', '4', '8', '16', '64', 'how'}
   assert rec['sustained']['seconds'] >= 2.0 and rec['sustained']['gather_launches'] > 100
+  assert rec['fresh_batches']['env_steps_per_s'] > 0 and rec['fresh_batches']['train_steps_per_s'] > 0
   assert rec['cpu_baseline']['kind'] == 'port' and rec['cpu_baseline']['cores'] == 1
   assert rec['config']['kernargs'] in ('host', 'device')
   assert rec['config']['host_modules'] in ('compiled', 'python')
