@@ -39,6 +39,37 @@ STEP = {
 }
 
 
+# BASELINE.md 2 (the survey's indicative reference timings): the benchmark's own step
+BASELINE_STEP = {
+    'image': np.zeros((84, 84, 4), np.uint8),
+    'reward': np.float32(0),
+    'is_first': np.array(False),
+    'is_last': np.array(False),
+    'is_terminal': np.array(False),
+    'action': np.int32(0),
+}
+
+
+def baseline_shape(make, label, seconds, device):
+  """`Replay.add` (length 65, chunksize 1024, 64 workers, 84x84x4 u8 frames) and
+  `sample(16)` -> (16, 65, 84, 84, 4): BASELINE.md 2's two replay rows."""
+  global STEP
+  keep, STEP = STEP, BASELINE_STEP
+  try:
+    replay = make(length=65, capacity=int(1e5), chunksize=1024)
+    n, dt = timed_inserts(replay, int(3e5), 64, seconds, device)
+  finally:
+    STEP = keep
+  done, start = 0, time.perf_counter()
+  while time.perf_counter() - start < seconds:
+    replay.sample(16)
+    done += 1
+  sync(device)
+  ds = time.perf_counter() - start
+  print(f'{label:<34} add steps/sec {n / dt:>9.0f} ({n} in {dt:.2f} s)   sample(16) batches/sec {done / ds:>8.0f} '
+        f'= {done * 16 * 65 / ds:>9.0f} steps/sec ({len(replay)} items)', flush=True)
+
+
 def sync(device):
   if device:
     import torch
@@ -181,6 +212,7 @@ def main():
       speed(make, f'product test_chunk_size {chunksize}', args.seconds, True, length=64, capacity=None,
             chunksize=chunksize)
     removal(make, 'product test_removal', args.seconds, True)
+    baseline_shape(make, 'product BASELINE.md 2 shapes', args.seconds, True)
     driver_dummy(emb, 'product throughput_dummy', args.seconds, False)
     driver_dummy(emb, 'product throughput_dummy', args.seconds, True)
     driver_dummy(emb, 'product dummy + on_step(add)', args.seconds, False, sink=True)
@@ -195,6 +227,7 @@ def main():
       speed(make, f'oracle test_chunk_size {chunksize}', args.seconds, False, length=64, capacity=None,
             chunksize=chunksize)
     removal(make, 'oracle test_removal', args.seconds, False)
+    baseline_shape(make, 'oracle BASELINE.md 2 shapes', args.seconds, False)
     oracle_driver_dummy(np_oracle, 'oracle throughput_dummy', args.seconds)
     oracle_driver_dummy(np_oracle, 'oracle dummy + on_step(add)', args.seconds, sink=True)
 
