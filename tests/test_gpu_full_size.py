@@ -83,6 +83,33 @@ def test_ppo_config_full_size_online(emb):
   assert stats['items'] == cap and stats['inserts'] == total * n_env - n_env * (L - 1)
 
 
+def test_ppo_shapes_through_the_per_step_host_path(emb):
+  """The unchanged caller at BASELINE's shapes: one `add(step, worker)` per host
+  step dict (64 workers, 84x84x4 uint8 frames from the host generator, length
+  65) -- the C staging call, both pinned stage sets, many flushes and FIFO
+  eviction -- then `sample(16)`: every gathered byte is the generator's."""
+  from embodied_amd.envs import synthetic
+  n_env, L, capacity, ticks = 64, 65, 2000, 140
+  rep = emb.Replay(length=L, capacity=capacity, chunksize=1024, seed=3)
+  envs = [synthetic.HostSyntheticEnv(e, episode_len=50) for e in range(n_env)]
+  reset = [True] * n_env
+  count = [0] * n_env
+  for tick in range(ticks):
+    for e, env in enumerate(envs):
+      obs = env.step({'reset': reset[e]})
+      count[e] = 0 if obs['is_first'] else count[e] + 1
+      reset[e] = bool(obs['is_last'])
+      rep.add({
+          'image': obs['image'], 'reward': obs['reward'], 'is_first': np.bool_(obs['is_first']),
+          'is_last': np.bool_(obs['is_last']), 'is_terminal': np.bool_(obs['is_terminal']),
+          'action': np.int32(tick % 6), 'env': np.int32(e), 'count': np.int32(count[e]),
+          'tick': np.int32(tick)}, e)
+  assert rep._stage_plan is not None or emb.core.replay._add_step is None
+  assert len(rep) == capacity
+  for _ in range(6):
+    _check_batch(rep.sample(16), L, ticks, capacity, n_env)
+
+
 def test_dreamer_config_full_size_uniform_with_write_back(emb):
   """configs[2]: 10^6-step uniform replay, L=65, 40 KB of latents per step
   written back over sampled windows (dreamerv3/agent.py:144-150)."""
