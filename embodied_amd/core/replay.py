@@ -386,8 +386,10 @@ class Replay:
           self._grow()
         if status == 0:
           self._reraise()
+          if self._new_chunks.value and self._staged:
+            self._flush_ahead_of(1)
           self._staged += 1
-          if self._staged == self._stage_rows or self._new_chunks.value:
+          if self._staged == self._stage_rows:
             self._flush()
           return
         if status > 0:
@@ -425,6 +427,8 @@ class Replay:
           self._flush()
           self._grow()
       self._reraise()
+      if self._new_chunks.value and self._staged:
+        self._flush()                         # a recycled slot: what waited goes out ahead of this row
       slot = self._staged
       if self._stage_pending:                 # the last flush still reads the pinned rows
         self._stage_busy.synchronize()
@@ -434,8 +438,25 @@ class Replay:
       self._keys[-1].stage_np[slot] = self._one_sid[0]
       self._stage_dst[slot] = self._one_row[0]
       self._staged += 1
-      if self._staged == self._stage_rows or self._new_chunks.value:
+      if self._staged == self._stage_rows:
         self._flush()
+
+  def _flush_ahead_of(self, count):
+    """Rows [staged, staged + count) have just been written into the stage by a
+    call that opened a chunk in a RECYCLED slot: the `staged` rows before them
+    may still hold rows of the chunk that had the slot, and one scatter must not
+    carry two writers of a pool row.  Flush the earlier rows by themselves and
+    carry the new ones over to the front of the other stage set."""
+    first = self._staged
+    old = [key.stage_np for key in self._keys]
+    dst = self._stage_dst[first: first + count].copy()
+    self._flush()                             # rows [0, first); moves on to the other set
+    if self._stage_pending:
+      self._stage_busy.synchronize()
+      self._stage_pending = False
+    for key, rows in zip(self._keys, old):
+      key.stage_np[:count] = rows[first: first + count]
+    self._stage_dst[:count] = dst
 
   def _flush(self):
     """Pinned staging -> HBM: one H2D copy per key, one scatter launch."""
@@ -501,8 +522,10 @@ class Replay:
           self._grow(2 * n)
         if status == 0:
           self._reraise()
+          if self._new_chunks.value and self._staged:
+            self._flush_ahead_of(n)
           self._staged += n
-          if self._staged == self._stage_rows or self._new_chunks.value:
+          if self._staged == self._stage_rows:
             self._flush()
           return None
         if status > 0:

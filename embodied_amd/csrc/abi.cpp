@@ -1194,10 +1194,10 @@ int32_t emb_replay_add_index(emb_replay_t* rep, int64_t n, const int64_t* worker
   REP_OP({
     need(n >= 0 && workers && rows_out, "add_index: bad arguments");
     rep->ids.resize(n);
-    const int64_t before = rep->index->chunks_opened();
+    const int64_t before = rep->index->recycled_opens();
     add_index_locked(rep, n, workers, rows_out, rep->ids.data());
     if (stepids_out) std::memcpy(stepids_out, rep->ids.data(), n * EMB_STEPID_BYTES);
-    if (new_chunks_out) *new_chunks_out = static_cast<int32_t>(rep->index->chunks_opened() - before);
+    if (new_chunks_out) *new_chunks_out = static_cast<int32_t>(rep->index->recycled_opens() - before);
   });
 }
 

@@ -66,6 +66,7 @@ class ReplayIndex {
     free_.resize(cfg_.owners);
     const int64_t per = cfg_.n_slots / cfg_.owners;
     for (int64_t s = 0; s < cfg_.n_slots; ++s) free_[s / per].push_back(s);
+    used_.assign(static_cast<size_t>(cfg_.n_slots), 0);
   }
 
   const ReplayConfig& config() const { return cfg_; }
@@ -87,6 +88,11 @@ class ReplayIndex {
   // Chunks opened so far: a caller that batches payload writes flushes them
   // whenever this moves, so a recycled slot never sees two writers in one launch.
   int64_t chunks_opened() const { return static_cast<int64_t>(next_uid_) - 1 + loaded_; }
+  // Of those, the ones that took a slot an earlier chunk had held: only such an
+  // opening can make a caller's batched payload writes meet on a pool row (rows
+  // still waiting for the old chunk, rows of the new one); a slot that was never
+  // handed out has no rows waiting.
+  int64_t recycled_opens() const { return recycled_opens_; }
 
   void grow(int64_t n_slots) {
     if (n_slots < cfg_.n_slots) throw std::invalid_argument("replay: pool cannot shrink");
@@ -94,6 +100,7 @@ class ReplayIndex {
     if (n_slots * cfg_.chunksize > INT32_MAX)
       throw std::invalid_argument("replay: more than 2^31 rows in the pool");
     for (int64_t s = cfg_.n_slots; s < n_slots; ++s) free_[0].push_back(s);
+    used_.resize(static_cast<size_t>(n_slots), 0);
     cfg_.n_slots = n_slots;
   }
 
@@ -338,6 +345,8 @@ class ReplayIndex {
     c.time_ms = time_ms;
     c.slot = free_[0].front();
     free_[0].pop_front();
+    if (used_[c.slot]) ++recycled_opens_;
+    used_[c.slot] = 1;
     chunks_[uid] = c;
     ++loaded_;
     if (uid >= next_uid_) next_uid_ = uid + 1;
@@ -365,6 +374,8 @@ class ReplayIndex {
         std::chrono::system_clock::now().time_since_epoch()).count();
     c.slot = free.front();
     free.pop_front();
+    if (used_[c.slot]) ++recycled_opens_;
+    used_[c.slot] = 1;
     c.worker = worker;
     return chunks_[c.uid] = c;
   }
@@ -467,6 +478,8 @@ class ReplayIndex {
   std::shared_ptr<Selector> selector_;
   std::unordered_map<uint64_t, Chunk> chunks_;
   std::vector<std::deque<int64_t>> free_;   // per owner, FIFO: a freed slot is recycled as late as possible
+  std::vector<uint8_t> used_;               // per slot: some chunk has held it
+  int64_t recycled_opens_ = 0;
   Ring<Pos> items_;
   int64_t first_item_ = 0;
   int64_t next_item_ = 0;

@@ -168,10 +168,12 @@ int32_t emb_replay_grow(emb_replay_t* rep, int64_t n_slots, void* const* pools);
 /* Host-only index steps (no GPU needed; bit-exact with the reference):
  * add_index    = bookkeeping of Replay.add for n steps, one per workers[i], in
  *                order (replay.py:77-118); rows_out[i] = pool row to write,
- *                stepids_out = n x 20 bytes; new_chunks_out = chunks opened by
- *                this call (a caller that batches the payload writes must
- *                flush them whenever it is non-zero: the new chunk may sit in
- *                a recycled slot).
+ *                stepids_out = n x 20 bytes; new_chunks_out = chunks this call
+ *                opened in RECYCLED slots (slots an evicted chunk had held).  A
+ *                caller that batches the payload writes must, whenever it is
+ *                non-zero, write out what it had batched BEFORE this call ahead
+ *                of this call's rows: rows still waiting for the old chunk and
+ *                rows of the new one would otherwise meet in one launch.
  * sample_index = `batch` sequence draws (replay.py:121-127,151-169,193-214):
  *                rows_out[batch*length] pool rows, online_out[batch] flags,
  *                workers_out[batch] the worker stream of each sequence.

@@ -526,3 +526,23 @@ def test_prioritized_with_a_tiny_step_id_backlog():
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout
 
+
+
+def test_add_index_reports_openings_in_recycled_slots_only():
+  """include/embodied_hip.h: `new_chunks_out` counts the chunks a call opened in
+  slots an evicted chunk had held (what makes a caller that batches payload
+  writes send the waiting rows first); a slot that was never handed out is not
+  reported.  One worker, chunksize 4, 6 slots, capacity 5 items of length 2: a
+  chunk's successor is opened by the call that fills it (replay.py:100-104); the
+  first five successors take fresh slots 1..5, from the sixth on (call 23, back
+  in slot 0) every opening recycles."""
+  rep = HostReplay(length=2, capacity=5, chunksize=4, n_slots=6)
+  workers, rows, sid = np.zeros(1, np.int64), np.zeros(1, np.int32), np.zeros((1, 20), np.uint8)
+  opened = C.c_int32()
+  reported, slots = [], []
+  for t in range(48):
+    api.emb_replay_add_index(rep.h, 1, _lib.ptr(workers), _lib.ptr(rows), _lib.ptr(sid), C.byref(opened))
+    reported.append(opened.value)
+    slots.append(int(rows[0]) // 4)
+  assert slots == [(t // 4) % 6 for t in range(48)]
+  assert reported == [1 if t >= 23 and t % 4 == 3 else 0 for t in range(48)]

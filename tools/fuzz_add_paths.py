@@ -47,7 +47,7 @@ def one(seed, steps):
   online = bool(gen.integers(0, 2))
   workers = int(gen.integers(1, 7))
   ours = emb.Replay(length, capacity, chunksize=chunksize, online=online, seed=seed,
-                    stage_rows=int(gen.integers(1, 24)), slots=int(gen.integers(6, 12)))
+                    stage_rows=int(gen.integers(1, 65)), slots=int(gen.integers(6, 12)))
   ref = np_oracle.Replay(length, capacity, chunksize, online, seed=seed)
   clock = [0] * workers
   ways = [0, 0, 0, 0]
