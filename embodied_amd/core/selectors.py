@@ -239,11 +239,13 @@ class Recency:
   """Age-biased sampling: the item inserted `age` inserts ago is drawn with
   probability proportional to `uprobs[age]` (reference: selectors.py:60-125).
 
-  The reference implementation cannot draw (`_sample` reads an unbound
-  `segment`, selectors.py:98-105), so nothing pins its stream; this class
-  implements the evident intent — a b-ary table of normalised block masses, one
-  `choice` per level — on the host in numpy.  It plugs into `Replay` / `Mixture`
-  through the callback ABI like any other Python selector.
+  The reference implementation cannot draw as written (`_sample` reads an
+  unbound `segment`, selectors.py:98-105); with that one token repaired
+  (`len(p)`) its draws are the ones this class makes, bit for bit (golden
+  `sel_recency`, tests/adapters.py builds the repaired class from the reference's
+  own source): a b-ary table of normalised block masses, one `choice` per level,
+  on the host in numpy.  It plugs into `Replay` / `Mixture` through the callback
+  ABI like any other Python selector.
   """
 
   def __init__(self, uprobs, seed=0, bfactor=16):

@@ -57,6 +57,7 @@ def reference_ns():
       return True
 
   ns.Prioritized = TruthyPrioritized
+  ns.Recency = _repaired_recency(emb.selectors.Recency)
   ns.Mixture = emb.selectors.Mixture
   ns.SampleTree = emb.selectors.SampleTree
   ns.Driver = lambda envs: emb.Driver(
@@ -73,6 +74,23 @@ def reference_ns():
   return ns
 
 
+def _repaired_recency(Recency):
+  """The reference's Recency with ONE token of `_sample` repaired, made from its
+  own source at run time (nothing of it is stored here).  selectors.py:98-105
+  draws `rng.choice(len(segment), p=p)`: `segment` is unbound at the first level
+  (UnboundLocalError on the first draw) and an int at the
+  next; `p` -- the probability row the line already passes -- is what has a
+  length.  Everything else (the table of `_build`, the age scaling, the item
+  bookkeeping, the order of the generator's draws) is the reference's code."""
+  import inspect
+  import textwrap
+  source = textwrap.dedent(inspect.getsource(Recency._sample))
+  assert source.count('len(segment)') == 1, 'the reference changed: look at Recency._sample again'
+  scope = {}
+  exec(source.replace('len(segment)', 'len(p)'), {'np': np}, scope)
+  return type('RepairedRecency', (Recency,), {'_sample': scope['_sample']})
+
+
 def product_ns(device='cuda'):
   """The product: embodied_amd on its HIP library (needs a GPU)."""
   import torch
@@ -82,6 +100,7 @@ def product_ns(device='cuda'):
   ns.Replay = lambda **kw: emb.Replay(device=device, **kw)
   ns.Uniform = emb.selectors.Uniform
   ns.Prioritized = emb.selectors.Prioritized
+  ns.Recency = emb.selectors.Recency
   ns.Mixture = emb.selectors.Mixture
   ns.SampleTree = emb.selectors.SampleTree
   from embodied_amd.core import wrappers

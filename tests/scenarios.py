@@ -591,6 +591,52 @@ def wrappers_chain(ns):
   return out
 
 
+def sel_recency(ns):
+  """Recency (selectors.py:60-125) through its public surface: the draws of a
+  filling buffer (fewer items than table entries: the age is scaled), of a full
+  one under FIFO eviction, a three-level table, and a flat prefix of zeros at
+  the old end.  Reference side: its own class with the one-token repair of
+  `_sample` (tests/adapters.py)."""
+  out = {}
+  # two levels (40 -> 16^2), the table of ppo/main.py:199 with recexp 1
+  r = ns.Recency(1.0 / np.arange(1, 41) ** 1.0, seed=3)
+  draws = []
+  for k in range(12):
+    r[k] = None
+    draws += [r(), r()]
+  out['filling'] = np.array(draws)
+  live, draws = list(range(12)), []
+  for k in range(12, 150):
+    if len(live) >= 40:
+      del r[live.pop(0)]
+    r[k] = None
+    live.append(k)
+    draws.append(r())
+  out['churn'] = np.array(draws)
+  # three levels (300 -> 16^3), steeper table, full from the start
+  r = ns.Recency(1.0 / np.arange(1, 301) ** 1.7, seed=11)
+  for k in range(300):
+    r[1000 + k] = None
+  out['deep'] = np.array([r() for _ in range(200)])
+  live = list(range(1000, 1300))
+  draws = []
+  for k in range(1300, 1500):
+    del r[live.pop(0)]
+    r[k] = None
+    live.append(k)
+    draws.append(r())
+  out['deep_churn'] = np.array(draws)
+  # a table whose old end is zero: those ages are never drawn
+  table = np.concatenate([np.linspace(1.0, 0.1, 20), np.zeros(12)])
+  r = ns.Recency(table, seed=5)
+  for k in range(32):
+    r[k] = None
+  out['zero_tail'] = np.array([r() for _ in range(120)])
+  out['lens'] = np.array([len(r)])
+  return out
+
+
 HOST_SCENARIOS = {
     'wrappers_chain': wrappers_chain,
+    'sel_recency': sel_recency,
 }

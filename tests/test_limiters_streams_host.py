@@ -155,7 +155,7 @@ def test_stateless_takes_functions_and_iterators():
 
 
 def test_recency_selector_prefers_recent_items():
-  """Not pinned by the reference (its Recency cannot draw); checks the intent:
+  """(The exact draws are pinned by golden `sel_recency`.)  The intent:
   draw frequency follows uprobs over age, deleted items are never returned."""
   from embodied_amd import selectors
   n = 300
