@@ -423,8 +423,9 @@ class Mixer(base.Stream):
   """Every step draws ONE of the named sources with probability proportional to
   its weight, from `default_rng([seed, step])`, and returns that source's next
   batch (streams.py:204-243).  Upstream cannot run as written (`np.ranodm`, an
-  assert on a flag that is never set, `load` indexing a list by key); this is
-  its evident intent, so no golden pins it -- like `selectors.Recency`."""
+  assert on a flag that is never set, `load` indexing a list by key); with the
+  one misspelt token repaired and the flag set its draws are these, source for
+  source (tests/test_limiters_streams_host.py, build container)."""
 
   def __init__(self, sources, weights, seed=0):
     if sources.keys() != weights.keys():

@@ -256,3 +256,21 @@ def test_mixer_draws_sources_by_weight_and_restores():
   assert [next(mixer)['x'][0].tolist() for _ in range(5)] == ahead
   with pytest.raises(ValueError):
     streams.Mixer({'a': _Numbered(1)}, {'b': 1.0})
+  if refload.available():
+    # Build container: the reference's own Mixer with ONE token of `__next__`
+    # repaired (`np.ranodm` -> `np.random`, from its source at run time) and the
+    # `started` flag it asserts on but never sets switched on: the same sources
+    # in the same order.
+    import importlib
+    import inspect
+    import textwrap
+    refload.load()
+    ref_streams = importlib.import_module('embodied.core.streams')
+    source = textwrap.dedent(inspect.getsource(ref_streams.Mixer.__next__))
+    assert source.count('np.ranodm') == 1
+    scope = {}
+    exec(source.replace('np.ranodm', 'np.random'), {'np': np}, scope)
+    Repaired = type('RepairedMixer', (ref_streams.Mixer,), {'__next__': scope['__next__']})
+    theirs = Repaired({'a': _Numbered(1), 'b': _Numbered(2)}, dict(weights), seed=7)
+    theirs.started = True
+    assert [int(next(theirs)['x'][0, 1]) for _ in range(200)] == tags
