@@ -130,6 +130,7 @@ SIGNATURES = {
     'emb_selector_create_uniform': [u64, pp],
     'emb_selector_create_prioritized': [f64, f64, i32, f64, i32, u64, pp],
     'emb_selector_create_mixture': [p, p, i32, u64, pp],
+    'emb_selector_create_recency': [p, i64, i32, i32, i64, u64, pp],
     'emb_selector_create_callback': [p, pp],
     'emb_selector_insert': [p, i64, p, i32],
     'emb_selector_remove': [p, i64],

@@ -235,7 +235,7 @@ class SampleTree:
     return depths[:leaves.value], nodes.value
 
 
-class Recency:
+class Recency(_Native):
   """Age-biased sampling: the item inserted `age` inserts ago is drawn with
   probability proportional to `uprobs[age]` (reference: selectors.py:60-125).
 
@@ -243,9 +243,10 @@ class Recency:
   unbound `segment`, selectors.py:98-105); with that one token repaired
   (`len(p)`) its draws are the ones this class makes, bit for bit (golden
   `sel_recency`, tests/adapters.py builds the repaired class from the reference's
-  own source): a b-ary table of normalised block masses, one `choice` per level,
-  on the host in numpy.  It plugs into `Replay` / `Mixture` through the callback
-  ABI like any other Python selector.
+  own source).  The b-ary table of normalised block masses is built here with
+  the reference's numpy arithmetic (`_build`, :107-125) and handed to the host
+  index core, which draws one `choice` per level (csrc/selectors.h Recency) --
+  native like the other members of a Mixture, no callbacks.
   """
 
   def __init__(self, uprobs, seed=0, bfactor=16):
@@ -253,40 +254,14 @@ class Recency:
     assert uprobs[0] >= uprobs[-1], uprobs
     assert np.isfinite(uprobs).all() and (uprobs >= 0).all(), uprobs
     self.uprobs = uprobs
-    self.bfactor = bfactor
-    self.levels = self._build(uprobs, bfactor)
-    self.rng = np.random.default_rng(seed)
-    self.step = 0
-    self.steps = {}
-    self.items = {}
-
-  def __len__(self):
-    return len(self.items)
-
-  def __call__(self):
-    for _ in range(1000):
-      age = self._draw_age()
-      if len(self.items) < len(self.uprobs):
-        age = int(age / len(self.uprobs) * len(self.items))
-      key = self.items.get(self.step - 1 - age)
-      if key is not None:       # deleted slots (evicted items) are redrawn
-        return key
-    raise KeyError('Recency: no live item found')
-
-  def __setitem__(self, key, stepids):
-    self.steps[key] = self.step
-    self.items[self.step] = key
-    self.step += 1
-
-  def __delitem__(self, key):
-    del self.items[self.steps.pop(key)]
-
-  def _draw_age(self):
-    index = 0
-    for level in self.levels:
-      probs = level[index]
-      index = index * self.bfactor + int(self.rng.choice(len(probs), p=probs))
-    return index
+    self.bfactor = int(bfactor)
+    self.levels = self._build(uprobs, self.bfactor)
+    table = np.ascontiguousarray(np.concatenate([level.reshape(-1) for level in self.levels]), np.float64)
+    handle = C.c_void_p()
+    api.emb_selector_create_recency(
+        _lib.ptr(table), table.size, len(self.levels), self.bfactor, len(uprobs), int(seed),
+        C.byref(handle))
+    self._adopt(handle)
 
   @staticmethod
   def _build(uprobs, bfactor):

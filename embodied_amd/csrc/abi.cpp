@@ -1051,6 +1051,16 @@ int32_t emb_selector_create_mixture(emb_selector_t* const* members, const float*
   });
 }
 
+int32_t emb_selector_create_recency(const double* table, int64_t table_len, int32_t depth,
+                                    int32_t bfactor, int64_t entries, uint64_t seed,
+                                    emb_selector_t** out) {
+  return guarded([&] {
+    need(table && table_len > 0 && out, "recency: bad arguments");
+    make_selector(out, std::make_shared<emb::Recency>(
+                           std::vector<double>(table, table + table_len), depth, bfactor, entries, seed));
+  });
+}
+
 int32_t emb_selector_create_callback(const emb_selector_callbacks_t* cb, emb_selector_t** out) {
   return guarded([&] {
     need(cb && cb->sample && cb->size && cb->insert && cb->remove && out, "callback selector: bad arguments");

@@ -1106,6 +1106,69 @@ class Mixture : public Selector {
   NpRandom rng_;
 };
 
+// Age-biased sampling (selectors.py:60-125): the item inserted `age` inserts ago
+// is drawn with probability proportional to uprobs[age].  The b-ary table of
+// normalised block masses is built by the caller (numpy arithmetic, the
+// reference's `_build`) and handed over level by level: level l has b^l rows of
+// b probabilities.  A draw is one `choice` per level; while fewer items than
+// table entries are held the age is scaled by items / entries; an age whose
+// item is gone is drawn again (the reference sleeps 10 ms and retries).  The
+// reference's `_sample` cannot run as written (an unbound `segment`); with that
+// one token repaired its draws are these (golden sel_recency).
+class Recency : public Selector {
+ public:
+  Recency(std::vector<double> table, int depth, int bfactor, int64_t entries, uint64_t seed)
+      : table_(std::move(table)), depth_(depth), b_(bfactor), entries_(entries), rng_(seed) {
+    if (depth_ < 1 || b_ < 2 || entries_ < 1) throw std::invalid_argument("Recency: bad table shape");
+    int64_t rows = 1, need = 0;
+    for (int l = 0; l < depth_; ++l) {
+      offset_.push_back(need);
+      need += rows * b_;
+      rows *= b_;
+    }
+    if (static_cast<int64_t>(table_.size()) != need || entries_ > rows)
+      throw std::invalid_argument("Recency: table size does not match depth / branching");
+    cdf_.resize(b_);
+  }
+  int64_t sample() override {
+    for (int attempt = 0; attempt < 1000; ++attempt) {
+      int64_t age = 0;
+      for (int l = 0; l < depth_; ++l)
+        age = age * b_ + rng_.choice(table_.data() + offset_[l] + age * b_, b_, cdf_.data());
+      const int64_t held = static_cast<int64_t>(key_of_.size());
+      if (held < entries_)
+        age = static_cast<int64_t>(static_cast<double>(age) / static_cast<double>(entries_) *
+                                   static_cast<double>(held));
+      auto it = key_of_.find(step_ - 1 - age);
+      if (it != key_of_.end()) return it->second;
+    }
+    throw std::out_of_range("Recency: no live item found");
+  }
+  int64_t size() const override { return static_cast<int64_t>(key_of_.size()); }
+  bool needs_stepids() const override { return false; }
+  void insert(int64_t key, const StepId*, int) override {
+    step_of_[key] = step_;
+    key_of_[step_] = key;
+    ++step_;
+  }
+  void remove(int64_t key) override {
+    auto it = step_of_.find(key);
+    if (it == step_of_.end()) throw std::runtime_error("Recency: unknown key");
+    key_of_.erase(it->second);
+    step_of_.erase(it);
+  }
+
+ private:
+  std::vector<double> table_;
+  std::vector<int64_t> offset_;
+  int depth_, b_;
+  int64_t entries_;
+  int64_t step_ = 0;
+  std::unordered_map<int64_t, int64_t> step_of_, key_of_;
+  std::vector<double> cdf_;
+  NpRandom rng_;
+};
+
 // A selector implemented by the caller (the duck-typed Python protocol of
 // selectors.py: __call__/__len__/__setitem__/__delitem__/prioritize) reached
 // through C function pointers.

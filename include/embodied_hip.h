@@ -118,6 +118,16 @@ int32_t emb_selector_create_prioritized(double exponent, double initial, int32_t
  * the mixture shares the members, which stay valid handles of their own.     */
 int32_t emb_selector_create_mixture(emb_selector_t* const* members, const float* fractions,
                                     int32_t n, uint64_t seed, emb_selector_t** out);
+/* Recency (embodied/core/selectors.py:60-125): age-biased draws from a b-ary
+ * table of normalised block masses.  `table` = the levels of the reference's
+ * `_build(uprobs)` (:107-125) one after the other, level l as bfactor^l rows of
+ * bfactor probabilities (table_len = sum over levels); `entries` = len(uprobs).
+ * One Generator.choice per level and draw (:98-105, with the one-token repair
+ * DESIGN.md 6 describes), age scaled while fewer than `entries` items are held
+ * (:77-79), a vanished age drawn again (:75-88 sleeps and retries).            */
+int32_t emb_selector_create_recency(const double* table, int64_t table_len, int32_t depth,
+                                    int32_t bfactor, int64_t entries, uint64_t seed,
+                                    emb_selector_t** out);
 /* a caller-implemented selector (any Python object with the protocol).       */
 typedef struct {
   void* user;
