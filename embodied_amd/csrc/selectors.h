@@ -1085,6 +1085,24 @@ class Mixture : public Selector {
   void insert(int64_t key, const StepId* steps, int n) override {
     for (auto& m : members_) m->insert(key, steps, n);
   }
+  // The next window of a stream: handed on when exactly one member wants step
+  // ids (the usual uniform / priority / recency mix) -- that member is asked
+  // first, and only if it takes the step do the others get their plain insert;
+  // otherwise nothing has changed and the caller inserts the full step list.
+  // (Members are independent: the order of their inserts changes no draw.)
+  bool insert_successor(int64_t key, int64_t prev_key, const StepId& newest) override {
+    Selector* picky = nullptr;
+    int count = 0;
+    for (auto& m : members_)
+      if (m->needs_stepids()) {
+        picky = m.get();
+        ++count;
+      }
+    if (count != 1 || !picky->insert_successor(key, prev_key, newest)) return false;
+    for (auto& m : members_)
+      if (m.get() != picky) m->insert(key, nullptr, 0);
+    return true;
+  }
   void remove(int64_t key) override {
     for (auto& m : members_) m->remove(key);
   }
@@ -1139,23 +1157,26 @@ class Recency : public Selector {
       if (held < entries_)
         age = static_cast<int64_t>(static_cast<double>(age) / static_cast<double>(entries_) *
                                    static_cast<double>(held));
-      auto it = key_of_.find(step_ - 1 - age);
-      if (it != key_of_.end()) return it->second;
+      const int64_t* key = key_of_.find(step_ - 1 - age);
+      if (key) return *key - 1;
     }
     throw std::out_of_range("Recency: no live item found");
   }
   int64_t size() const override { return static_cast<int64_t>(key_of_.size()); }
   bool needs_stepids() const override { return false; }
+  // (Both maps hold value + 1: SlidingMap reads a zero as "absent".  A Replay's
+  // item ids and the insert counter both arrive in order and leave oldest first,
+  // so neither map hashes.)
   void insert(int64_t key, const StepId*, int) override {
-    step_of_[key] = step_;
-    key_of_[step_] = key;
+    step_of_.put(key, step_ + 1);
+    key_of_.put(step_, key + 1);
     ++step_;
   }
   void remove(int64_t key) override {
-    auto it = step_of_.find(key);
-    if (it == step_of_.end()) throw std::runtime_error("Recency: unknown key");
-    key_of_.erase(it->second);
-    step_of_.erase(it);
+    const int64_t* step = step_of_.find(key);
+    if (!step) throw std::runtime_error("Recency: unknown key");
+    key_of_.erase(*step - 1);
+    step_of_.erase(key);
   }
 
  private:
@@ -1164,7 +1185,7 @@ class Recency : public Selector {
   int depth_, b_;
   int64_t entries_;
   int64_t step_ = 0;
-  std::unordered_map<int64_t, int64_t> step_of_, key_of_;
+  SlidingMap<int64_t> step_of_, key_of_;
   std::vector<double> cdf_;
   NpRandom rng_;
 };

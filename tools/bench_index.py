@@ -12,6 +12,7 @@ from embodied_amd import _lib
 from embodied_amd._lib import api
 
 n, L, cap = 64, 65, 100_000
+keep = []
 
 
 def run(kind, iters=3000):
@@ -19,6 +20,15 @@ def run(kind, iters=3000):
   h, sel = C.c_void_p(), C.c_void_p()
   if kind == 'prioritized':        # ppo/configs.yaml:42: exponent .8, maxfrac .5, initial inf, zero_on_sample
     api.emb_selector_create_prioritized(0.8, float('inf'), 1, 0.5, 16, 0, C.byref(sel))
+  if kind == 'mixture':            # ppo/main.py:197-207 with all three fractions on
+    from embodied_amd import selectors
+    mix = selectors.Mixture(dict(
+        uniform=selectors.Uniform(),
+        priority=selectors.Prioritized(exponent=0.8, maxfrac=0.5, initial=float('inf'), zero_on_sample=True),
+        recency=selectors.Recency(1.0 / np.arange(1, cap + 1) ** 1.0),
+    ), dict(uniform=0.5, priority=0.25, recency=0.25))
+    keep.append(mix)
+    sel = mix._handle
   api.emb_replay_create(C.byref(cfg), sel if kind != 'uniform' else None, 0, C.byref(h))
   workers = np.arange(n, dtype=np.int64)
   rows = np.zeros(n, np.int32)
@@ -54,3 +64,4 @@ def run(kind, iters=3000):
 if __name__ == '__main__':
   run('uniform')
   run('prioritized')
+  run('mixture')
