@@ -358,3 +358,61 @@ def test_normalize_stats_before_any_update():
   assert float(lo) == 0.0 and float(scale) == float(np.float32(1e-8))       # zero statistics, the limit as scale
   mean, std = D.Normalize('meanstd', debias=False).stats(torch.zeros(()))
   assert float(mean) == 0.0 and float(std) == float(np.float32(1e-8))
+
+
+def _pretrain_job(rank, world, D):
+  """`run.pretrain` on every rank of a job (embodied/run/pretrain.py:8-96 with
+  `replicas` > 1): the report / log / save decisions come from GlobalClocks, so
+  every rank takes them at the same steps; only replica 0 writes checkpoints."""
+  import tempfile
+  import time
+  import types
+  import embodied_amd as emb
+  emb.clock.setup(is_server=(rank == 0), replica=rank, replicas=world, port=0, addr='127.0.0.1')
+  logdir = os.path.join(tempfile.gettempdir(), f'emb_pretrain_{os.environ["MASTER_PORT"]}_{rank}')
+
+  class Stream:
+    def __init__(self):
+      self.k = 0
+    def __iter__(self):
+      return self
+    def __next__(self):
+      self.k += 1
+      return {'count': np.arange(self.k, self.k + 2)}
+
+  class Model:
+    def __init__(self):
+      self.trains, self.report_steps, self.saves = 0, [], 0
+    def stream(self, st):
+      return st
+    def init_train(self, n):
+      return ()
+    init_report = init_train
+    def train(self, carry, batch):
+      self.trains += 1
+      time.sleep(0.002 * (1 + rank))            # ranks of different speed: rank 0's clock decides
+      return carry, {}, {'loss': 1.0}
+    def report(self, carry, batch):
+      self.report_steps.append(self.trains)
+      return carry, {'m': 1.0}
+    def save(self):
+      self.saves += 1
+      return {}
+    def load(self, data):
+      pass
+
+  model = Model()
+  args = types.SimpleNamespace(
+      logdir=logdir, steps=60, batch_size=2, batch_length=4, log_every=0.03, report_every=0.05,
+      save_every=0.04, consec_report=1, report_batches=1, replica=rank, from_checkpoint='')
+  emb.run.pretrain(lambda: model, lambda replay, mode: Stream(), lambda: emb.utils.Logger(), args)
+  wrote = os.path.exists(os.path.join(logdir, 'checkpoint.pkl'))
+  return model.trains, sorted(set(model.report_steps)), model.saves, wrote
+
+
+def test_pretrain_takes_its_decisions_in_lockstep_world2():
+  out = run2(_pretrain_job)
+  (trains0, reports0, saves0, wrote0), (trains1, reports1, saves1, wrote1) = out[0], out[1]
+  assert trains0 == trains1 == 60
+  assert reports0 == reports1 and len(reports0) >= 1      # the same train steps on both ranks
+  assert wrote0 and not wrote1 and saves0 >= 1 and saves1 == 0
