@@ -149,6 +149,9 @@ def test_add_step_stages_a_host_step_in_one_call(stage):
     dict(image=np.zeros((4, 4, 3), np.uint8)[::2, ::2]),   # not contiguous
     dict(image=torch.zeros((2, 2, 3), dtype=torch.uint8)), # a tensor
     dict(extra=np.float32(1)),                             # a key the schema lacks
+    dict(vec=np.array([1, 2, 3], '>f4')),                  # not the machine's byte order
+    dict(vec=np.zeros(3, [('a', 'f4')])),                  # a structured dtype of the same size
+    dict(image=bytes(12)),                                 # right byte count, no shape
 ])
 def test_add_step_leaves_other_steps_to_python_untouched(stage, bad):
   add_step, plan, bufs = stage
