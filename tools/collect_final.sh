@@ -10,6 +10,9 @@ for i in 1 2 3; do python $R/bench.py --steps 20 --warmup 5 2>/dev/null | grep '
 python $R/bench.py --selector prioritized --no-cpu-baseline --no-dreamer-leg 2>/dev/null | grep '^{' > $O/bench_selectorprioritized.json
 python $R/bench.py --host-envs --parallel-envs --no-cpu-baseline --no-dreamer-leg 2>/dev/null | grep '^{' > $O/bench_hostenvsparallelenvs.json
 python $R/tools/bench_index.py > $O/bench_index.txt 2>&1
+# the reference's own perf loops (per-step add, sample(1), Driver over Dummy envs) and the insert-route fuzz
+python $R/tools/perf_reference_scripts.py --seconds 3 > $O/perf_reference_scripts.txt 2>/dev/null
+timeout 300 python $R/tools/fuzz_add_paths.py --seeds 1000 --steps 600 2>&1 | tail -1 > $O/fuzz_add_paths.txt
 HIP_FORCE_DEV_KERNARG=0 python $R/tools/profile_host_step.py > $O/profile_host_step.txt 2>&1
 # timelines (queues, overlap, the sequence of a window) of both workloads
 for w in ppo dreamer; do
