@@ -780,9 +780,12 @@ def scan_closed_form(a, b, seed):
 
 # ----------------------------------------------------------------------------
 # Normaliser statistics over data-parallel ranks (embodied/jax/utils.py:16-88).
-# Restated, not executed: the class is a ninjax module (JAX absent) and the
-# reference has no test for it -- parity of this restatement is UNPINNED; it
-# serves as the single-process statement of what the ranks must agree on.
+# The class is a ninjax module (JAX absent) and the reference has no test for
+# it.  Pinned since round 4 by EXECUTING the reference's class under numpy
+# stand-ins (oracle/gen_normalize_golden.py -> tests/golden/normalize.npz): this
+# restatement returns bit-identical statistics over five configurations x 40
+# steps (tests/test_normalize_golden.py).  It also serves as the single-process
+# statement of what the ranks must agree on.
 # ----------------------------------------------------------------------------
 
 
