@@ -249,3 +249,68 @@ def test_clock_namespace_like_the_reference():
   emb.clock.setup(is_server=True, replica=0, replicas=1, port=1234, addr='localhost')
   with pytest.raises(RuntimeError):
     emb.clock.setup(is_server=True, replica=0, replicas=2, port=1234, addr='localhost')
+
+
+def _reference_logfn(logger, epstats):
+  """The reference's own per-env `logfn` (the function nested in
+  embodied/run/train.py:31-54), taken out of the file's syntax tree at run time
+  and compiled with the names it closes over: `episodes` / `epstats` are this
+  package's `utils.Agg` (the stand-in for the un-vendored elements.Agg, SURVEY
+  Appendix A), `logger` the test's sink."""
+  import ast
+  import collections
+  from oracle import refload
+  path = refload.REFERENCE / 'embodied' / 'run' / 'train.py'
+  tree = ast.parse(path.read_text(), filename=str(path))
+  train = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'train')
+  node = next(n for n in ast.walk(train) if isinstance(n, ast.FunctionDef) and n.name == 'logfn')
+  node.decorator_list = []                      # (@elements.timer.section: timing only)
+  namespace = {
+      'np': np, 'episodes': collections.defaultdict(emb.utils.Agg), 'logger': logger, 'epstats': epstats}
+  exec(compile(ast.Module(body=[node], type_ignores=[]), str(path), 'exec'), namespace)
+  return namespace['logfn']
+
+
+def test_episode_stats_equal_the_references_own_logfn():
+  """Build container only: the vectorised `EpisodeStats` against the reference's
+  `logfn` itself, executed from its source (not a restatement), on random
+  episodes with images, rewards and scalar `log/*` values."""
+  import pytest
+  from oracle import refload
+  if not refload.available():
+    pytest.skip('no /root/reference here')
+  n, steps = 5, 400
+  gen = np.random.default_rng(1)
+
+  class ScalarSink(Sink):
+    # the reference keeps worker 0's image stacks in the episode result (its
+    # video logging, `policy_*`): not a statistic, not kept
+    def add(self, mapping, prefix=None):
+      super().add({k: v for k, v in mapping.items() if np.ndim(v) == 0}, prefix)
+
+  ours_log, ours_ep = Sink(), Sink()
+  want_log, want_ep = ScalarSink(), ScalarSink()
+  stats = EpisodeStats(ours_log, ours_ep)
+  logfn = _reference_logfn(want_log, want_ep)
+  is_last = np.zeros(n, bool)
+  for t in range(steps):
+    is_first = is_last.copy() if t else np.ones(n, bool)
+    is_last = gen.random(n) < 0.07
+    reward = np.where(gen.random(n) < 0.5, 0.0, gen.standard_normal(n)).astype(np.float32)
+    trans = {
+        'reward': reward, 'is_first': is_first, 'is_last': is_last,
+        'image': gen.integers(0, 255, (n, 4, 4, 3), dtype=np.uint8),
+        'log/height': gen.standard_normal(n).astype(np.float32),
+        'log/coins': gen.integers(0, 3, n).astype(np.float32)}
+    stats.on_batch(trans, np.arange(n))
+    for i in range(n):
+      logfn({k: v[i] for k, v in trans.items()}, i)
+  stats.flush()
+  assert len(want_log.rows) > 20 and len(want_ep.rows) == len(want_log.rows)
+  key = lambda row: sorted(row.items())
+  for ours, want in ((ours_log, want_log), (ours_ep, want_ep)):
+    a, b = sorted(map(key, ours.rows)), sorted(map(key, want.rows))
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+      assert [k for k, _ in x] == [k for k, _ in y]
+      np.testing.assert_allclose([v for _, v in x], [v for _, v in y], rtol=1e-6, atol=1e-6)
