@@ -29,6 +29,17 @@ import time
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
 
 
+def _flag_value(name, default):
+  """`--name value` / `--name=value` from sys.argv (needed before argparse runs:
+  the pinning happens ahead of the first import of torch)."""
+  for i, arg in enumerate(sys.argv):
+    if arg == name and i + 1 < len(sys.argv):
+      return sys.argv[i + 1]
+    if arg.startswith(name + '='):
+      return arg[len(name) + 1:]
+  return default
+
+
 def pin_cpus(width=4):
   """Keep the stepping thread (and the runtime's helper threads, which inherit
   the mask) on a few adjacent, currently idle CPUs.  The GPU boxes are shared
@@ -37,8 +48,8 @@ def pin_cpus(width=4):
   2.96-3.15 M.  Picks the `width` adjacent CPUs of the allowed set that were
   least busy over 100 ms of /proc/stat, one window per local rank (rank r takes
   the r-th least busy window that does not overlap a better one).
-  EMB_BENCH_PIN=0 leaves the affinity alone, EMB_BENCH_PIN=a-b sets it."""
-  knob = os.environ.get('EMB_BENCH_PIN', 'auto')
+  `--pin 0` leaves the affinity alone, `--pin a-b` sets it."""
+  knob = _flag_value('--pin', 'auto')
   if knob == '0' or not hasattr(os, 'sched_setaffinity'):
     return None
   try:
@@ -88,12 +99,8 @@ def _is_launcher():
   under torch.distributed.run: the ranks pin themselves, not this process."""
   if 'WORLD_SIZE' in os.environ:
     return False
-  for i, arg in enumerate(sys.argv):
-    if arg == '--gpus' and i + 1 < len(sys.argv):
-      return sys.argv[i + 1].isdigit() and int(sys.argv[i + 1]) > 1
-    if arg.startswith('--gpus='):
-      return arg[7:].isdigit() and int(arg[7:]) > 1
-  return False
+  gpus = _flag_value('--gpus', '1')
+  return gpus.isdigit() and int(gpus) > 1
 
 
 # (Env worker processes would inherit the mask: the host-env workloads stay unpinned.)
@@ -190,6 +197,21 @@ def parse():
                       'of two; same as EMB_CARRY_PUBLISH=0).  Default: the env takes the policy\'s '
                       'actions unmasked together with `reset` (Env protocol, base.py:44-52), the '
                       'stored transition holds value * ~is_last either way')
+  p.add_argument('--context-only', action='store_true',
+                 help='dreamer workload: Replay(heads={"dyn/": context}) -- the replay-context latents come '
+                      'back (B, K, ...) instead of (B, L, ...), which is all the shipped agent reads of them '
+                      '(dreamerv3/agent.py:322-331, lhs = x[:, :K]); the write-back still covers every step')
+  p.add_argument('--regions', type=int, default=0,
+                 help='how many fenced regions of exactly --steps steps are timed back to back; `value` is '
+                      'their median.  0 (default) = 16 when --steps < 256 (a 20-step region lasts 0.3 ms and '
+                      'reads +-30 %% from run to run by itself), else 1')
+  p.add_argument('--pin', default='auto', help='CPUs of the stepping thread: auto (default), 0 = leave alone, a-b')
+  p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                 help='N>1: process-group backend (gloo: the control flow on fewer GPUs than ranks)')
+  p.add_argument('--force-dist', action='store_true', help='run the RCCL code path with one rank')
+  p.add_argument('--no-timer', action='store_true',
+                 help='no dispatch stamps (roofline is then null): for a rocprofv3 run that sees the gather '
+                      'without the timed-dispatch perturbation')
   p.add_argument('--host-envs', action='store_true',
                  help='step 64 numpy envs on the host and upload through the pinned slab '
                       '(PCIe-inclusive rate; never the headline value)')
@@ -230,7 +252,8 @@ def build_path(args, rank, device):
         exponent=0.8, maxfrac=0.5, initial=float('inf'), zero_on_sample=True, seed=0)
   replay = emb.Replay(
       length=L, capacity=args.capacity, chunksize=1024, online=not dreamer, seed=0,
-      selector=selector, device=device, replica=rank, reuse_outputs=args.reuse_outputs)
+      selector=selector, device=device, replica=rank, reuse_outputs=args.reuse_outputs,
+      heads={'dyn/': args.context} if (dreamer and args.context_only) else None)
   n = args.envs
   if args.host_envs:
     fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]
@@ -278,11 +301,11 @@ def launch_ranks(args):
   GPU, under torch.distributed.run and become that process (rank 0 prints the
   JSON line).  Reference shape: embodied/jax/internal.py:96-105."""
   import socket
-  backend = os.environ.get('EMB_BENCH_BACKEND', 'nccl')
+  backend = args.backend
   have = torch.cuda.device_count()
   if backend == 'nccl' and have < args.gpus:
     raise SystemExit(f'bench.py --gpus {args.gpus}: this node has {have} GPU(s); RCCL needs one '
-                     'GPU per rank (EMB_BENCH_BACKEND=gloo runs the control flow on fewer)')
+                     'GPU per rank (--backend gloo runs the control flow on fewer)')
   with socket.socket() as sock:
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
@@ -308,7 +331,7 @@ def main():
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
   # (LOCAL_RANK wraps so that the multi-rank control flow can be exercised on a
-  # box with fewer GPUs: EMB_BENCH_BACKEND=gloo, several ranks on one device.)
+  # box with fewer GPUs: --backend gloo, several ranks on one device.)
   if rank != 0:
     # stdout carries exactly one JSON line (rank 0's); whatever other ranks or
     # their libraries print (RCCL's NCCL_DEBUG=VERSION banner) goes to stderr.
@@ -316,14 +339,13 @@ def main():
   local %= max(torch.cuda.device_count(), 1)
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
-  # EMB_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank.
-  use_dist = world > 1 or os.environ.get('EMB_BENCH_FORCE_DIST') == '1'
+  use_dist = world > 1 or args.force_dist
   if use_dist:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29517')
     import datetime
-    backend = os.environ.get('EMB_BENCH_BACKEND', 'nccl')
+    backend = args.backend
     dist.init_process_group(
         backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
         **({'device_id': device} if backend == 'nccl' else {}))
@@ -339,7 +361,6 @@ def main():
   stream = iter(emb.streams.Consec(
       emb.streams.Stateless(replay.sample, B * args.prefetch, 'train', recycle=1),
       length=T, consec=args.consec, prefix=args.context, strict=True, contiguous=True))
-  lambda_pair = os.environ.get('EMB_BENCH_LAMBDA_PAIR', '1') != '0'
   lambda_out = [[torch.empty(B * args.prefetch, T + args.context - 1, device=device),
                  torch.empty(B * T, 15, device=device)] for _ in range(2)]
   gae_out = [tuple(torch.empty(B * args.prefetch, T + args.context - 1, device=device) for _ in range(2))
@@ -348,6 +369,10 @@ def main():
   value = torch.randn(B * args.prefetch, T + args.context, device=device)
   imag_rew = torch.randn(B * T, 16, device=device)
   imag_flags = torch.zeros(B * T, 16, dtype=torch.bool, device=device)
+  entries = None
+  if args.workload == 'dreamer':      # two sets of model outputs used in turn (agent-owned)
+    entries = [(torch.zeros((B * args.prefetch, L, 8192), device=device),
+                torch.zeros((B * args.prefetch, L, 32, 64), device=device)) for _ in range(2)]
   grad_dtype = torch.bfloat16 if args.grad_dtype == 'bf16' else torch.float32
   grads = (torch.zeros(args.grad_numel, dtype=grad_dtype, device=device)
            if use_dist and args.grad_numel else None)
@@ -357,11 +382,7 @@ def main():
   native, native_stuck, native_comm = None, False, None
   if use_dist:
     from embodied_amd import distributed as D
-    if os.environ.get('EMB_BENCH_COMM') == 'thread':
-      comm = D.CommThread(device)
-      issue = comm.submit
-    else:
-      issue = D.Done
+    issue = D.Done
   use_native = False
   link = None               # who carries a train step's collectives (set after the self-check)
   collectives = {'on': True, 'sliced': 0}
@@ -376,18 +397,16 @@ def main():
       # train step later.
       batch = next(stream)
       # (both return scans of the train step -- replay (B,T) and imagination
-      # (B*K,H+1), agent.py:401-405,464-466 -- in one launch; EMB_BENCH_LAMBDA_PAIR=0: two)
-      if lambda_pair:
-        adv, _ = emb.scans.lambda_returns(
-            [(batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95),
-             (imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)],
-            out=lambda_out[counters['train_steps'] & 1])
-      else:
-        adv = emb.scans.lambda_return(
-            batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95)
-        emb.scans.lambda_return(imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)
-      replay.update({'stepid': batch['stepid'], 'dyn/deter': batch['dyn/deter'],
-                     'dyn/stoch': batch['dyn/stoch']})
+      # (B*K,H+1), agent.py:401-405,464-466 -- in one launch)
+      adv, _ = emb.scans.lambda_returns(
+          [(batch['is_last'], batch['is_terminal'], batch['reward'], None, value, 1 - 1 / 333, 0.95),
+           (imag_flags, imag_flags, imag_rew, None, imag_rew, 1 - 1 / 333, 0.95)],
+          out=lambda_out[counters['train_steps'] & 1])
+      # The train step's new latents (`entries`, agent.py:139-150): outputs of the
+      # model, i.e. the agent's own tensors -- not the sampled batch, of whose
+      # latents the agent has read [:, :K] only.
+      new = entries[counters['train_steps'] & 1]
+      replay.update({'stepid': batch['stepid'], 'dyn/deter': new[0], 'dyn/stoch': new[1]})
       if use_dist and grads is not None and collectives['on']:
         link.wait()
         link.exchange(grads=grads)
@@ -465,10 +484,8 @@ def main():
 
   # The learner's stream (--streams 2): the Replay orders its pool accesses across
   # the two streams itself (emb_replay_multistream; abi.cpp StreamOrder).
-  # (EMB_BENCH_LEARNER_PRIORITY=1: a low-priority learner stream -- the A/B of
-  # DESIGN.md 3, which measured level for PPO, tools/exp_r04q.sh.)
-  learner = (torch.cuda.Stream(device, priority=int(os.environ.get('EMB_BENCH_LEARNER_PRIORITY', '0')))
-             if args.streams == 2 else None)
+  # (a low-priority learner stream measured level for PPO)
+  learner = torch.cuda.Stream(device) if args.streams == 2 else None
   if learner is not None:
     main_stream = torch.cuda.current_stream(device)
     set_stream = torch._C._cuda_setStream
@@ -515,9 +532,8 @@ def main():
     native['timed_path'] = 'native' if use_native else 'c10d'
   if use_dist:
     link = native_comm if use_native else D.GroupComm()
-  # EMB_BENCH_NO_TIMER=1: no dispatch stamps (roofline is then null) -- for a
-  # rocprofv3 run that sees the gather without the timed-dispatch perturbation.
-  # Switched on before the warm-up so that the stamps' events exist by then.
+  # --no-timer: no dispatch stamps (roofline is then null).  Stamps are
+  # switched on before the warm-up so that the stamps' events exist by then.
   # One gather in --stamp-every carries stamps, unless the timed region is too
   # short for that to leave a usable sample (the driver's --steps 20 has three
   # or four gathers: every second one then).
@@ -534,7 +550,7 @@ def main():
     # restarts right before the timed region; the region's first gather runs on
     # a GPU that the fence has just drained).
     stamp_every = 2 if expected >= 2 else 1
-  replay.profile(os.environ.get('EMB_BENCH_NO_TIMER') != '1', every=stamp_every)
+  replay.profile(not args.no_timer, every=stamp_every)
   # Like `timeit`: no pass of the interpreter's cyclic collector over its whole
   # heap (tens of ms: the GPU idles, the first steps after it measure 130 + 100 us
   # instead of 17 + 34) between the warm-up and the end of a timed region that
@@ -555,7 +571,7 @@ def main():
   for _ in range(args.warmup):
     one_step()
   replay.profile_read(reset=True)
-  if os.environ.get('EMB_BENCH_NO_TIMER') != '1':
+  if not args.no_timer:
     replay.profile(True, every=stamp_every)       # restart the stamp counter (first stamped gather: the stamp_every-th)
   base = dict(counters)
 
@@ -581,38 +597,45 @@ def main():
                          f'(sliced {-neg_lo_s:.0f}..{hi_s:.0f}, train steps {-neg_lo_t:.0f}..{hi_t:.0f})')
       torch.cuda.synchronize(device)      # (the barrier's own kernels)
 
+  # The timed region: EXACTLY --steps steps between two fences (barrier +
+  # synchronize), the maximum over ranks.  A region of a few hundred microseconds
+  # (the driver's --steps 20) is dominated by the first launch after a fence and
+  # by where its handful of train steps fall: it is then timed --regions times
+  # back to back and `value` is the MEDIAN region (all of them in `regions`).
+  n_regions = args.regions if args.regions > 0 else (16 if args.steps < 256 else 1)
   fence()
-  trace = os.environ.get('EMB_BENCH_TRACE_STEPS') == '1'     # per-step host times of a short region
-  stamps = []
-  start = time.perf_counter()
-  for _ in range(args.steps):
-    one_step()
-    if trace:
-      stamps.append(time.perf_counter())
-  before_fence = time.perf_counter()
-  fence()
-  elapsed = time.perf_counter() - start
+  region_times, region_counts = [], []
+  for _ in range(n_regions):
+    before = dict(counters)
+    start = time.perf_counter()
+    for _ in range(args.steps):
+      one_step()
+    fence()
+    took = time.perf_counter() - start
+    if use_dist:
+      t = torch.tensor([took], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      took = float(t.item())
+    region_times.append(took)
+    region_counts.append({k: counters[k] - before[k] for k in counters})
   gc.enable()
-  if trace and rank == 0:
-    steps_us = [round((b - a) * 1e6) for a, b in zip([start] + stamps, stamps)]
-    print('per-step us:', steps_us[:40], 'final fence us:',
-          round((start + elapsed - before_fence) * 1e6), file=sys.stderr)
-  if use_dist:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  order = sorted(range(n_regions), key=lambda i: region_times[i])
+  median_at = order[(n_regions - 1) // 2]         # (the lower median: a region that was measured)
+  elapsed = region_times[median_at]
+  total_elapsed = sum(region_times)
 
   launches, gather_ms, gather_kernel = replay.profile_report('sample', reset=True)
   h_deferred, h_predicted, _ = replay.profile_report('deferred', reset=True)
   h_inline, h_carried, _ = replay.profile_report('carried', reset=True)
   wb_launches, wb_ms, wb_kernel = replay.profile_report('update', reset=True)
   headline = dict(counters)
+  was_unmasked = bool(getattr(driver, '_unmasked', False))     # how the timed regions handed actions to the env
 
   # The same loop for >= --sustained-seconds more (the headline region is as
   # long as --steps says; this window is long whatever the caller chose).
   sustained = None
   if args.sustained_seconds > 0:
-    if stamp_every < 16 and args.consec == 1 and os.environ.get('EMB_BENCH_NO_TIMER') != '1':
+    if stamp_every < 16 and args.consec == 1 and not args.no_timer:
       # A short headline region stamps every second gather; the long window that
       # follows holds thousands: one in 16 (a stamp costs the job time, see --stamp-every)
       replay.profile(True, every=16)
@@ -758,7 +781,7 @@ def main():
     native['per_train_step'] = {
         'collectives_us': round(calls['native_all_reduce']['total_us']
                                 + share * calls['native_all_to_all']['total_us'], 1),
-        'issue_period_us': round(elapsed / done * 1e6, 1),
+        'issue_period_us': round(total_elapsed / done * 1e6, 1),
         'sliced_share': round(share, 3),
     }
     # links bound the job when RCCL needs longer for one train step's collectives
@@ -776,18 +799,21 @@ def main():
     # the same two readings, measured: speed-up over ONE rank of the replicas_only loop
     per_rank = replicas_only['env_steps_per_s'] / world
     expected['measured_x'] = {
-        'value': round((headline['env_steps'] - base['env_steps']) * world / elapsed / per_rank, 2),
+        'value': round(args.steps * args.envs * world / elapsed / per_rank, 2),
         **({'sustained': round(sustained['env_steps_per_s'] / per_rank, 2)} if sustained else {}),
         'replicas_only': float(world),
         'unit': 'x one rank of this run with the collectives off'}
   counters.update(headline)
-  env_steps = (counters['env_steps'] - base['env_steps']) * world
-  train_steps = (counters['train_steps'] - base['train_steps']) * world
+  env_steps = args.steps * args.envs * world                     # of ONE region (the median one is `value`)
+  train_steps = (counters['train_steps'] - base['train_steps']) * world     # of all regions together
   S = sum(k.rowbytes for k in replay._keys)
+  # a key of `Replay(heads=)` moves key_len steps per sequence, the others L
+  seq_bytes = sum(k.rowbytes * (replay._key_lens[i] if replay._key_lens is not None else L)
+                  for i, k in enumerate(replay._keys))
   # read B*L*S + write B*L*S per sampled batch; with consec > 1 the windows are
   # gathered directly (prefix rows read once per window) and the 1-byte flag
   # keys take a second, tiny launch: normalise per sample, not per launch.
-  algo_bytes = 2 * B * args.prefetch * args.consec * (T + args.context) * S
+  algo_bytes = 2 * B * args.prefetch * (args.consec * (T + args.context) * S if args.consec != 1 else seq_bytes)
   samples = max(1, (counters['train_steps'] - base['train_steps']) // (args.prefetch * args.consec))
   roofline = None
   traffic, traffic_source = pmc_traffic(algo_bytes)
@@ -843,7 +869,7 @@ def main():
         # stores: most of its reads are served by L2 / Infinity Cache, only the writes must
         # reach HBM (write-only fraction = half of `frac`)
         'write_frac': round(wb_bytes / 2 / wb_s / 1e9 / HBM_PEAK_GBS, 4),
-        'source': 'the sampled batch, resident in L2 / Infinity Cache (plain-store gather)',
+        'source': 'the agent\'s own (B, L, ...) output tensors, two sets used in turn (170 MB: partly cache-resident)',
     }
 
   # Outside the timed region, measured context (no credit): SURVEY 8d's
@@ -903,6 +929,8 @@ def main():
     torch.cuda.empty_cache()
     workloads = {'dreamer': dreamer_leg(args)}
 
+  env_actions = ('unmasked + reset (Env protocol, base.py:44-52)' if was_unmasked
+                 else 'masked (driver.py:72-75)')
   if rank == 0:
     # Libraries that wrote to C stdio (RCCL's version banner) come out first, so
     # that the JSON line is the last line on stdout.
@@ -913,11 +941,20 @@ def main():
         'metric': 'env steps/sec + learner train-steps/sec, 64 envs 84x84x4 obs, 1/2/4/8 GPU',
         'value': round(env_steps / elapsed, 1),
         'unit': 'env_steps/s',
-        'train_steps_per_s': round(train_steps / elapsed, 2),
+        'train_steps_per_s': round(train_steps / total_elapsed, 2),
         'n_gpus': world, 'rccl_ranks': rccl_ranks,
         'backend': (dist.get_backend() if use_dist else None),
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 5),
+        # every timed region: exactly `steps` steps between two fences; `value` and
+        # `ms_per_step` are the median region's, `train_steps_per_s` is over all of them
+        'regions': {'n': n_regions,
+                    'env_steps_per_s': {
+                        'min': round(env_steps / max(region_times), 1),
+                        'median': round(env_steps / elapsed, 1),
+                        'max': round(env_steps / min(region_times), 1)},
+                    'ms': [round(t * 1e3, 4) for t in region_times],
+                    'train_steps': [c['train_steps'] for c in region_counts]},
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'u8', 'data': 'synthetic',
         'config': {
@@ -937,9 +974,12 @@ def main():
             # ignores the action of an env it resets, the Driver skips the masked copy and the
             # Replay carries the masked pool write into its next launch (carried
             # publish); 'masked' = the reference's form, one more dependent launch per step
-            'env_actions': ('masked' if (args.mask_actions_for_env or args.host_envs
-                                         or os.environ.get('EMB_CARRY_PUBLISH') == '0')
-                            else 'unmasked + reset'),
+            'env_actions': {
+                'value_measured_with': env_actions,
+                **({'env_steps_per_s': {
+                    'unmasked + reset (Env protocol, base.py:44-52)': sustained['env_steps_per_s'],
+                    'masked (driver.py:72-75)': masked_env_actions['env_steps_per_s']}}
+                   if (masked_env_actions is not None and sustained is not None) else {})},
             'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
             'cpus': PINNED,         # CPUs this process was pinned to (pin_cpus), None = scheduler's choice
             # the per-step Python of Driver / Replay / streams: Cython-compiled copies of the
@@ -1137,34 +1177,49 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
 
 def dreamer_leg(args):
   """`python bench.py --workload dreamer` for a few seconds in a process of its
-  own (HIP state, allocator and CPU placement as in a stand-alone run); returns
-  the part of its line that a reader of the PPO record needs."""
+  own (HIP state, allocator and CPU placement as in a stand-alone run), twice:
+  with the replay-context latents sampled as the shipped agent consumes them
+  (`--context-only`: (B, K, ...), dreamerv3/agent.py:322-331) and with all L steps
+  of them gathered (`full_gather`, what the reference's Replay.sample returns and
+  rounds 1-4 measured).  Returns the part of the lines that a reader of the PPO
+  record needs."""
   import subprocess
-  cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'dreamer', '--no-dreamer-leg',
-         '--steps', str(args.dreamer_leg_steps), '--warmup', '200', '--sustained-seconds', '3',
-         '--no-cpu-baseline', '--no-context']
-  began = time.perf_counter()
-  try:
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
-    if res.returncode or not lines:
-      return {'error': (res.stderr or res.stdout)[-300:], 'returncode': res.returncode}
-    line = json.loads(lines[-1])
-  except Exception as e:
-    return {'error': f'{type(e).__name__}: {e}'[:300]}
-  roof, wb = line.get('roofline') or {}, line.get('writeback') or {}
-  return {
-      'workload': line['config']['workload'],
-      'command': ' '.join(['python', 'bench.py'] + cmd[2:]),
-      'env_steps_per_s': line['value'], 'train_steps_per_s': line['train_steps_per_s'],
-      'ms_per_step': line['ms_per_step'], 'steps': line['steps'],
-      'sustained': line.get('sustained'),
-      'gather': {k: roof.get(k) for k in (
-          'kernel', 'avg_launch_us', 'bytes_per_launch', 'achieved', 'frac', 'read_frac', 'launches')},
-      'writeback': {k: wb.get(k) for k in (
-          'kernel', 'avg_launch_us', 'bytes_per_launch', 'achieved', 'frac', 'launches')},
-      'wall_s': round(time.perf_counter() - began, 1),
-  }
+
+  def run(*extra):
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'dreamer', '--no-dreamer-leg',
+           '--steps', str(args.dreamer_leg_steps), '--warmup', '200', '--sustained-seconds', '3',
+           '--no-cpu-baseline', '--no-context', *extra]
+    began = time.perf_counter()
+    try:
+      res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+      lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+      if res.returncode or not lines:
+        return {'error': (res.stderr or res.stdout)[-300:], 'returncode': res.returncode}
+      line = json.loads(lines[-1])
+    except Exception as e:
+      return {'error': f'{type(e).__name__}: {e}'[:300]}
+    roof, wb = line.get('roofline') or {}, line.get('writeback') or {}
+    return {
+        'workload': line['config']['workload'],
+        'command': ' '.join(['python', 'bench.py'] + cmd[2:]),
+        'env_steps_per_s': line['value'], 'train_steps_per_s': line['train_steps_per_s'],
+        'ms_per_step': line['ms_per_step'], 'steps': line['steps'],
+        'sustained': line.get('sustained'),
+        'gather': {k: roof.get(k) for k in (
+            'kernel', 'avg_launch_us', 'bytes_per_launch', 'achieved', 'frac', 'read_frac', 'launches')},
+        'writeback': {k: wb.get(k) for k in (
+            'kernel', 'avg_launch_us', 'bytes_per_launch', 'achieved', 'frac', 'launches')},
+        'wall_s': round(time.perf_counter() - began, 1),
+    }
+
+  leg = run('--context-only')
+  if 'error' in leg:
+    return leg
+  leg['latents_sampled'] = f'context only: (B, K={args.context}, ...) of dyn/ (dreamerv3/agent.py:322-331)'
+  full = run()
+  full['latents_sampled'] = 'all L steps (the reference\'s Replay.sample)'
+  leg['full_gather'] = full
+  return leg
 
 
 def plain_copy_reference(replay, rows, device, iters=200):

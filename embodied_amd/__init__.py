@@ -2,14 +2,10 @@
 the reference's Python interfaces."""
 __version__ = '0.1.0'
 
-import os as _os
-# Kernel arguments stay in host memory unless the process says otherwise: a
-# launch is ~2 us cheaper on the host (three per vectorised step) and the library
-# hands its big movers a device copy of their argument block itself (DESIGN.md 4).
-# The HIP runtime reads the variable at its first API call, so this takes effect
-# when the package is imported before the process touches the GPU; later it is
-# harmless (the runtime keeps its own placement, results are the same).
-_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')
+# (Importing this package changes nothing about the process: no environment
+# variables, no CPU affinity.  A host program that wants the cheaper launches of
+# host-resident kernel arguments sets HIP_FORCE_DEV_KERNARG=0 itself before HIP
+# starts, as bench.py does -- INTEGRATION.md; the library serves both placements.)
 
 from . import _compiled_finder
 compiled = _compiled_finder.install()   # compiled copies of the hot host modules, if built and fresh

@@ -157,6 +157,7 @@ SIGNATURES = {
     'emb_replay_publish': [p, i64, p, p, i32, p, p, p, p, u64, p],
     'emb_replay_sample': [p, i64, i32, p, p, p, p],
     'emb_replay_sample_grouped': [p, i64, i32, p, i32, i64, p, p, p],
+    'emb_replay_sample_heads': [p, i64, i32, p, p, p, p, p],
     'emb_replay_update': [p, i64, i64, p, i32, p, p, p],
     'emb_replay_gather_rows': [p, p, i64, i64, p, p],
     'emb_replay_scatter_rows': [p, p, i64, i32, p, p, p],
@@ -287,6 +288,7 @@ class _FastApi:
       'emb_replay_add': 'ints', 'emb_replay_add_masked': 'ints',
       'emb_replay_obs_stack_insert': 'ints', 'emb_replay_publish': 'ints',
       'emb_replay_sample': 'ints', 'emb_replay_sample_grouped': 'ints', 'emb_replay_update': 'ints',
+      'emb_replay_sample_heads': 'ints',
       'emb_replay_gather_rows': 'ints', 'emb_replay_scatter_rows': 'ints',
       'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',
       'emb_scan_gae_grouped': 'scan', 'emb_scan_lambda_multi': 'ints',
@@ -350,11 +352,37 @@ def ptr(array):
   return None if array is None else array.ctypes.data
 
 
+# Knobs that the Python layer reads (the rest belong to the C library): same
+# rules as emb_configure -- one name, read once by the first code that needs it,
+# `configure` beats the environment and is refused once the knob is in effect.
+PY_KNOBS = ('EMB_EARLY_INSERT', 'EMB_CARRY_PUBLISH')
+_py_given, _py_read = {}, set()
+
+
+def knob(name):
+  """Value of a Python-level knob (None = not set); marks it as in effect."""
+  assert name in PY_KNOBS, name
+  _py_read.add(name)
+  if name in _py_given:
+    return _py_given[name]
+  return os.environ.get(name)
+
+
 def configure(**knobs):
-  """`configure(EMB_DEFER_INDEX=0, EMB_SPAN_VARIANT='4,1')`: the library's tuning
-  knobs from the host program instead of the environment (emb_configure).  Each
-  knob is read once by the first call that needs it; setting it later raises."""
+  """`configure(EMB_DEFER_INDEX=0, EMB_GATHER_STORES='plain')`: the tuning knobs
+  (INTEGRATION.md lists them) from the host program instead of the environment.
+  Each knob is read once by the first call that needs it; setting it later
+  raises, as does a name that is not a knob of this package."""
   for name, value in knobs.items():
+    if name in PY_KNOBS:
+      if name in _py_read:
+        raise ValueError(f'libembodied_hip: configure: {name} is already in effect (knobs are read '
+                         'once: set them before the first Driver is made)')
+      if value is None:
+        _py_given.pop(name, None)
+      else:
+        _py_given[name] = str(value)
+      continue
     api.emb_configure(name.encode(), None if value is None else str(value).encode())
 
 

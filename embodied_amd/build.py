@@ -103,7 +103,7 @@ def build(force=False, verbose=True):
       # unless EMB_STRICT_SCRATCH=1 (what this repo's own builds use).
       listing = '\n'.join(f'  {kernel}: {nbytes} bytes/lane' for kernel, nbytes in spills)
       movers = [k for k, _ in spills if any(
-          tag in (k or '') for tag in ('gather_kernel', 'scatter_kernel', 'span_move_kernel',
+          tag in (k or '') for tag in ('flat_move_kernel', 'span_move_kernel',
                                        'obs_stack_insert_kernel'))]
       if movers or os.environ.get('EMB_STRICT_SCRATCH') == '1':
         raise RuntimeError('kernels that use scratch memory:\n' + listing)

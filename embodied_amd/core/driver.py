@@ -25,7 +25,7 @@ this package's `Replay.add` (which copies the step into its pool before the next
 one) do observations of env processes and masked actions rotate through FOUR
 sets of device buffers: a policy that keeps `obs` (or a reader of
 `driver.acts`) then sees them overwritten four steps later.
-`Driver(..., fresh_obs=True)` (or EMB_FRESH_OBS=1) switches the rotation off;
+`Driver(..., fresh_obs=True)` switches the rotation off;
 a device vector env (`batch_env=`) owns its outputs and states its own rule.
 """
 import multiprocessing as mp
@@ -42,11 +42,19 @@ from .._lib import api, fast
 from . import replay as replaylib
 
 # EMB_EARLY_INSERT=0: the Driver does not offer observations to its Replay ahead
-# of the policy (every key then goes in with the post-policy insert; the A/B).
-_EARLY_INSERT = os.environ.get('EMB_EARLY_INSERT', '1') != '0'
+# of the policy (every key then goes in with the post-policy insert: the fallback).
 # EMB_CARRY_PUBLISH=0: envs that take unmasked actions are served like all others
-# (masked copy of the actions, publish launch after the policy; the A/B).
-_CARRY = os.environ.get('EMB_CARRY_PUBLISH', '1') != '0'
+# (masked copy of the actions, publish launch after the policy: the fallback).
+# Both are knobs (`embodied_amd.configure` or the environment), read when the
+# first Driver is made.
+_EARLY_INSERT = _CARRY = None
+
+
+def _read_knobs():
+  global _EARLY_INSERT, _CARRY
+  if _EARLY_INSERT is None:
+    _EARLY_INSERT = (_lib.knob('EMB_EARLY_INSERT') or '1') != '0'
+    _CARRY = (_lib.knob('EMB_CARRY_PUBLISH') or '1') != '0'
 
 _DTYPE_CODE = {
     torch.uint8: _lib.U8, torch.int8: _lib.I8, torch.int16: _lib.I16,
@@ -82,8 +90,7 @@ class Driver:
   def __init__(self, make_env_fns=None, parallel=True, device=None,
                batch_env=None, shared_obs=True, fresh_obs=None, envs_per_worker=1, **kwargs):
     self.kwargs = kwargs
-    if fresh_obs is None and os.environ.get('EMB_FRESH_OBS') == '1':
-      fresh_obs = True
+    _read_knobs()
     self._fresh_obs = fresh_obs
     self.device = torch.device(device) if device is not None else None
     if self.device is not None and self.device.type == 'cuda' and self.device.index is None:

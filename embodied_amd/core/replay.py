@@ -50,12 +50,6 @@ _DTYPE_CODE = {
 }
 
 
-# Holders of a tensor's storage (tensors, views, storage handles): with
-# EMB_SAMPLE_POOL=1 `sample` uses them to prove that nobody can see an output set
-# any more before it is used again (opt-in; the explicit form is `recycle`).
-_STORAGE_USE_COUNT = getattr(torch._C, '_storage_Use_Count', None)
-
-
 class Batch(dict):
   """A sampled batch: a dict name -> (batch, length, ...) tensor that remembers
   the addresses, shape and stream it was gathered with, so that
@@ -72,7 +66,7 @@ class _StepRecord:
   stacks it the same way into the same staging tensor, all the per-key checks
   and pointer look-ups of the general path have been done before."""
   __slots__ = ('owner', 'values', 'workers', 'workers_ptr', 'n', 'frame_key', 'frames_ptr',
-               'early_ptrs', 'memo', 'spec', 'out_ptr', 'flags_at', 'flags_ptr', 'publishes')
+               'early_ptrs', 'memo', 'spec', 'out_ptr', 'publishes')
 
 
 def _itemsize(dtype):
@@ -97,8 +91,18 @@ class Replay:
       self, length, capacity=None, directory=None, chunksize=1024,
       online=False, selector=None, save_wait=False, name='unnamed', seed=0,
       device='cuda', numpy=False, slots=None, stage_rows=256, replica=0,
-      owners=1, owner=0, workers_per_owner=0, reuse_outputs=0):
+      owners=1, owner=0, workers_per_owner=0, reuse_outputs=0, heads=None):
     self.length = int(length)
+    # heads = {name or 'prefix/': K}: `sample` returns only the first K steps of
+    # those keys, (batch, K, ...) -- for keys whose consumer reads nothing else
+    # (DreamerV3's replay context: dreamerv3/agent.py:322-331 takes x[:, :K] of the
+    # sampled enc/ dyn/ dec/ entries, K = replay_context).  Every returned key
+    # equals the full sample's [:, :K]; `update` still writes all T steps back.
+    self._heads = {str(k): int(v) for k, v in (heads or {}).items()}
+    for name, k in self._heads.items():
+      if not 1 <= k <= self.length:
+        raise ValueError(f'Replay(heads=): {name!r}: {k} is not in 1..length ({self.length})')
+    self._key_lens = None           # ctypes int32[n_keys] once the keys are known (None: no key is cut)
     self.capacity = capacity and int(capacity)
     self.chunksize = int(chunksize)
     self.name = name
@@ -176,24 +180,12 @@ class Replay:
     self._stage_busy, self._stage_pending = None, False
     self._stage_events, self._stage_set = [None, None], 0
     self._rowbytes_total = None
-    # Output sets handed back with `recycle` (explicit) and, opt-in, the pool that
-    # finds unreferenced sets itself (EMB_SAMPLE_POOL=1, see _alloc_batch).
+    # Output sets handed back with `recycle`.
     self._free = {}
-    self._out_pool = None
-    if os.environ.get('EMB_SAMPLE_POOL') == '1':
-      if _STORAGE_USE_COUNT is None or not hasattr(torch.Tensor, '_use_count'):
-        raise RuntimeError(
-            'EMB_SAMPLE_POOL=1 needs torch._C._storage_Use_Count and Tensor._use_count, which this '
-            f'torch ({torch.__version__}) does not have: use Replay.recycle / streams.Stateless('
-            'recycle=K) instead')
-      self._out_pool = {}
     self._nonempty = False
     self._full = False
     self._len_out = C.c_int64()
     self._len_ref = C.byref(self._len_out)
-    self._pool_bytes = 0
-    probe = [object()]
-    self._ref_base = sys.getrefcount(probe[0])
     # Early insert (offer / _early_insert): the Driver's offer of the current
     # step, the token of the launch that took it up, cached plans.
     self._offer_tag = weakref.ref(self)
@@ -291,11 +283,25 @@ class Replay:
       key.stage, key.stage_np = key.stages[0]
     self._keys = keys
     self._keyid = {k.name: i for i, k in enumerate(keys)}
+    lens = [self._head_of(k.name) for k in keys]
+    if any(n != self.length for n in lens):
+      self._key_lens = (C.c_int32 * len(keys))(*lens)
     self._batch_ptrs = (C.c_void_p * len(keys))()
     self._push_keys()
     self._stage_set = 0
     self._stage_plans = [self._make_stage_plan(i) for i in range(2)]
     self._stage_plan = self._stage_plans[0]
+
+  def _head_of(self, name):
+    """Steps of a sampled sequence that `sample` returns for key `name`."""
+    if name in ('stepid', 'is_first', 'is_last'):
+      return self.length            # bookkeeping keys (update, the annotation's consumers) stay whole
+    best, steps = -1, self.length
+    for pattern, k in self._heads.items():
+      hit = name == pattern or (pattern.endswith('/') and name.startswith(pattern))
+      if hit and len(pattern) > best:
+        best, steps = len(pattern), k
+    return steps
 
   def _make_stage_plan(self, which):
     """`add`'s per-step work as one C call (fastcall.c stage_plan / add_step):
@@ -735,7 +741,7 @@ class Replay:
           rec.frame_key, rec.frames_ptr = frame_key, frames.data_ptr()
           rec.early_ptrs = (C.c_void_p * len(self._keys))(*self._early_ptrs)
           rec.memo, rec.spec, rec.out_ptr = memo, spec[1], out.data_ptr()
-          rec.flags_at, rec.flags_ptr, rec.publishes = -1, None, {}
+          rec.publishes = {}
           frames._emb_rec = rec
           self._cur_rec = rec
     return True
@@ -761,8 +767,10 @@ class Replay:
       self._carry_keep = (acts, outs, flags)
     if rec is not None and self._pre_token and obs is self._offer_obs and workers is rec.workers:
       entry = rec.publishes.get(id(masked) if wanted else 0)
-      if entry is not None and entry[0] is masked and (not wanted or len(masked) == entry[5]):
-        _, plan, ptrs, mask_plan, flags_at, _ = entry
+      # (the mask outputs are looked at tensor by tensor: a tensor replaced inside
+      # the same dict has another address)
+      if entry is not None and entry[0] is masked and (not wanted or fast.same_values(masked, entry[5])):
+        _, plan, ptrs, mask_plan, flags_at, _, flags_ptr = entry
         extra = {**acts, **outs} if outs else acts
         if (len(extra) == len(plan) and rec.values[flags_at] is flags
             and not fast.columns(extra, plan, ptrs, torch.Tensor, self.device.index)):
@@ -773,7 +781,7 @@ class Replay:
               try:
                 fast.emb_replay_publish(
                     self._h, rec.n, rec.workers_ptr, ptrs, len(ids), ids, codes, outs_ptr,
-                    rec.flags_ptr, token, self._stream())
+                    flags_ptr, token, self._stream())
                 break
               except _lib.PoolFull:
                 self._grow(2 * rec.n)
@@ -802,9 +810,11 @@ class Replay:
             outs_ptr = (C.c_void_p * len(names))(*[masked[name].data_ptr() for name in names])
           else:
             outs_ptr = (C.c_void_p * len(names))()
-          rec.flags_ptr = flags.data_ptr()
+          # (every entry keeps its own flag address: entries of one record may have
+          # been made with different flag tensors)
           rec.publishes[id(masked) if wanted else 0] = (
-              masked, plan, ptrs, (ids, codes, outs_ptr), flags_at[0], len(masked) if wanted else 0)
+              masked, plan, ptrs, (ids, codes, outs_ptr), flags_at[0],
+              tuple(masked.values()) if wanted else (), flags.data_ptr())
     return result
 
   def _collect(self, values, columns, ptrs):
@@ -886,10 +896,11 @@ class Replay:
     with self._lock:
       self._flush()
       stream = self._stream()
+      lens = self._key_lens
       if out is None:
-        out, ptrs = self._alloc_batch(batch, self.length)
+        out, ptrs = self._alloc_batch(batch, self.length, lens is not None)
       else:
-        out, ptrs = self._adopt(out, batch, self.length)
+        out, ptrs = self._adopt(out, batch, self.length, lens is not None)
       # Host copy of stepid[:, 0] rides on the tensor object so `update` with
       # the same tensor needs no device read-back (a sync).  A set that is used
       # again (recycled, `out=`) brings its buffer along.
@@ -897,8 +908,12 @@ class Replay:
       first = sid.__dict__.get('_emb_first')
       if first is None or len(first) != batch * _lib.STEPID_BYTES:
         first = sid._emb_first = (C.c_uint8 * (batch * _lib.STEPID_BYTES))()
-      fast.emb_replay_sample(
-          self._h, batch, _lib.MODES[mode], ptrs, None, first, stream)
+      if lens is None:
+        fast.emb_replay_sample(
+            self._h, batch, _lib.MODES[mode], ptrs, None, first, stream)
+      else:
+        fast.emb_replay_sample_heads(
+            self._h, batch, _lib.MODES[mode], ptrs, lens, None, first, stream)
       if self._foreign_selector:
         self._native.reraise()
     return self._finish(out)
@@ -919,10 +934,11 @@ class Replay:
     if len(sets) < 8 and all(b is not batch for b in sets):
       sets.append(batch)
 
-  def _adopt(self, out, batch, length):
+  def _adopt(self, out, batch, length, heads=False):
     """`out=`: a Batch of this replay with the right shape is taken as is;
     anything else is checked key by key."""
-    if type(out) is Batch and out._emb_owner is self._offer_tag and out._emb_shape == (batch, length):
+    shape = (batch, length, 'heads') if heads else (batch, length)
+    if type(out) is Batch and out._emb_owner is self._offer_tag and out._emb_shape == shape:
       out._emb_stream = self._last_stream
       return out, out._emb_ptrs
     if self._keys is None or set(out) != {k.name for k in self._keys}:
@@ -930,102 +946,71 @@ class Replay:
     ptrs = (C.c_void_p * len(self._keys))()
     for i, key in enumerate(self._keys):
       tensor = out[key.name]
-      want = (batch, length, *key.shape)
+      want = (batch, self._key_lens[i] if heads else length, *key.shape)
       if (not torch.is_tensor(tensor) or tensor.dtype != key.dtype or tuple(tensor.shape) != want
           or tensor.device != self.device or not tensor.is_contiguous()):
         raise ValueError(f'sample(out=): {key.name!r} must be a contiguous {key.dtype} tensor of shape '
                          f'{want} on {self.device}')
       ptrs[i] = tensor.data_ptr()
     adopted = Batch((k.name, out[k.name]) for k in self._keys)
-    adopted._emb_ptrs, adopted._emb_shape = ptrs, (batch, length)
+    adopted._emb_ptrs, adopted._emb_shape = ptrs, shape
     adopted._emb_stream, adopted._emb_owner = self._last_stream, self._offer_tag
     return adopted, ptrs
 
-  def _alloc_batch(self, batch, length):
+  def _alloc_batch(self, batch, length, heads=False):
     """Output tensors for one sampled batch: (Batch name -> tensor, ctypes array
     of their addresses).  `sample` returns tensors the caller owns, like the
     reference's fresh arrays (replay.py:255-275): fresh allocations, unless
 
     * the caller handed sets back (`recycle`) -- taken first, same stream only;
-    * `Replay(reuse_outputs=K)` rotates K sets;
-    * EMB_SAMPLE_POOL=1 (opt-in): sets whose tensors NOBODY references any more
-      are found by their Python reference counts, storage use counts and
-      `Tensor._use_count()` (private torch internals, checked by
-      tests/test_gpu_output_pool.py) and used again -- indistinguishable from a
-      fresh allocation for a caller that stays on one stream, but
-      `Tensor.record_stream` defers only the allocator's reuse of a block, not
-      this pool's: a consumer that reads a batch on a side stream and drops it
-      before that work is ordered after the sampling stream must not use it."""
+    * `Replay(reuse_outputs=K)` rotates K sets (a batch is overwritten by the
+      K-th sample after it: whoever holds batches longer -- a Prefetch of
+      `amount` batches needs K >= amount + 2 -- must not use it)."""
+    shape = (batch, length, 'heads') if heads else (batch, length)
     if self._reuse:
-      return self._alloc_batch_now(batch, length)
+      return self._alloc_batch_now(shape)
     stream = self._last_stream
-    sets = self._free.get((batch, length))
+    sets = self._free.get(shape)
     if sets:
       for i in range(len(sets) - 1, -1, -1):
         if sets[i]._emb_stream == stream:
           out = sets.pop(i)
           return out, out._emb_ptrs
-    pool = self._out_pool
-    if pool is None or self._multistream:
-      return self._new_batch(batch, length)
-    sets = pool.get((batch, length))
-    if sets is None:
-      sets = pool[(batch, length)] = []
-    refs, uses, held = sys.getrefcount, _STORAGE_USE_COUNT, self._ref_base
-    for tensors, cdata, ptrs, owner, _ in sets:
-      if owner != stream:
-        continue
-      for i in range(len(tensors)):
-        # `held` = what getrefcount reports for an object only a list holds;
-        # 2 = the tensor and the storage handle this pool keeps; 1 = nothing in
-        # C++ (a DLPack consumer, an autograd node) owns the tensor itself.
-        # (no local alias of the tensor here: it would count as a reference)
-        if refs(tensors[i]) != held or uses(cdata[i]) != 2 or tensors[i]._use_count() != 1:
-          break
-      else:
-        return self._as_batch(tensors, ptrs, batch, length), ptrs
-    out, ptrs = self._new_batch(batch, length)
-    if self._rowbytes_total is None:
-      self._rowbytes_total = sum(k.rowbytes for k in self._keys)
-    nbytes = batch * length * self._rowbytes_total
-    if len(sets) < 4 and self._pool_bytes + nbytes <= 2 << 30:
-      tensors = list(out.values())
-      stores = [t.untyped_storage() for t in tensors]
-      cdata = [s._cdata for s in stores]
-      if all(uses(c) == 2 for c in cdata):
-        self._pool_bytes += nbytes
-        sets.append((tensors, cdata, ptrs, stream, stores))
-    return out, ptrs
+    return self._new_batch(shape)
 
-  def _as_batch(self, tensors, ptrs, batch, length):
+  def _as_batch(self, tensors, ptrs, shape):
     out = Batch(zip(self._key_names, tensors))
-    out._emb_ptrs, out._emb_shape = ptrs, (batch, length)
+    out._emb_ptrs, out._emb_shape = ptrs, shape
     out._emb_stream, out._emb_owner = self._last_stream, self._offer_tag
     return out
 
-  def _alloc_batch_now(self, batch, length):
-    ring = self._out_ring.setdefault((batch, length), [[], 0])
+  def _alloc_batch_now(self, shape):
+    ring = self._out_ring.setdefault(shape, [[], 0])
     if len(ring[0]) < self._reuse:
-      ring[0].append(self._new_batch(batch, length))
+      ring[0].append(self._new_batch(shape))
     out, ptrs = ring[0][ring[1] % len(ring[0])]
     ring[1] += 1
-    return self._as_batch(list(out.values()), ptrs, batch, length), ptrs
+    return self._as_batch(list(out.values()), ptrs, shape), ptrs
 
-  def _new_batch(self, batch, length):
+  def _new_batch(self, shape):
+    """shape = (batch, length) or (batch, length, 'heads'): the latter gives the
+    keys of `Replay(heads=)` their own, shorter, time axis."""
     # torch.empty_like on a zero-stride, one-element template is about twice as
     # cheap on the host as torch.empty(shape, dtype, device) and yields the same
     # contiguous tensor.
-    templates = self._templates.get((batch, length))
+    templates = self._templates.get(shape)
     if templates is None:
-      templates = self._templates[(batch, length)] = [
+      batch, length = shape[:2]
+      lens = self._key_lens if len(shape) == 3 else [length] * len(self._keys)
+      templates = self._templates[shape] = [
           torch.empty(1, dtype=key.dtype, device=self.device).expand(
-              batch, length, *key.shape) for key in self._keys]
+              batch, lens[i], *key.shape) for i, key in enumerate(self._keys)]
       self._key_names = [k.name for k in self._keys]
     out, ptrs = Batch(), (C.c_void_p * len(self._keys))()
     for i, key in enumerate(self._keys):
       tensor = out[key.name] = torch.empty_like(templates[i])
       ptrs[i] = tensor.data_ptr()
-    out._emb_ptrs, out._emb_shape = ptrs, (batch, length)
+    out._emb_ptrs, out._emb_shape = ptrs, shape
     out._emb_stream, out._emb_owner = self._last_stream, self._offer_tag
     return out, ptrs
 

@@ -29,7 +29,9 @@ class Stateless(base.Stream):
   drawn and is then handed back to the replay (`Replay.recycle`), which gathers
   a later batch into the same tensors instead of allocating seven new ones.  The
   consumer of such a stream keeps no batch (and no view of one) for longer than
-  K draws, and reads it on the stream it was sampled on."""
+  K draws, and reads it on the stream it was sampled on.  (`Consec(consec > 1)`
+  over such a stream samples through `Replay.sample_windows` and lends nothing:
+  `recycle` only concerns whole-batch draws.)"""
 
   def __init__(self, fn, *args, recycle=0, **kwargs):
     if not callable(fn):
@@ -50,6 +52,9 @@ class Stateless(base.Stream):
       self._give_back = getattr(owner, 'recycle', None)
       if self.recycle < 0 or self._give_back is None or getattr(fn, '__name__', '') != 'sample':
         raise TypeError('Stateless(recycle=K) needs K >= 1 and a Replay.sample of this package as `fn`')
+      if getattr(owner, 'numpy', False):
+        raise TypeError('Stateless(recycle=K): Replay(numpy=True) returns host copies, there is nothing '
+                        'to hand back')
 
   def __iter__(self):
     return self
@@ -177,12 +182,21 @@ class Consec(base.Stream):
         raise AssertionError(
             f'Consec(length={self.length}, consec={self.consec}, prefix={self.prefix}) needs '
             f'{"exactly" if self.strict else "at least"} {need} steps per sequence, got {have}')
+      if self.consec > 1:
+        short = [k for k, v in self.current.items() if v.shape[1] != have]
+        if short:       # `Replay(heads=)` keys hold the head of the WHOLE sequence, not of each window
+          raise AssertionError(f'Consec(consec={self.consec}): keys {short} do not span the {have} steps '
+                               'of the source batch (context-only keys cannot be windowed)')
     start, count = number * self.length, self.length + self.prefix
     batch = self.current
     if (self.consec == 1 and type(batch) is _batch_type()
         and getattr(batch, '_emb_shape', (0, 0))[1] == count):
       # The whole of a batch this package's Replay.sample made (contiguous device
-      # tensors by construction): the window is the batch itself.
+      # tensors by construction): the window is the batch itself -- the same
+      # tensors, as the general route below also returns for a whole-batch window.
+      # They are the caller's unless the replay rotates its outputs
+      # (`Replay(reuse_outputs=K)`, whose contract Prefetch checks) or the source
+      # lends them (`Stateless(recycle=K)`).
       chunk = dict(batch)
       chunk['consec'] = self._number(chunk['is_first'], 0)
       return chunk
@@ -278,6 +292,13 @@ class Prefetch(base.Stream):
     if inner is not None and 0 < inner.recycle < self.amount + 2:
       raise ValueError(f'Prefetch(amount={self.amount}) over Stateless(recycle={inner.recycle}): '
                        f'needs recycle >= amount + 2 = {self.amount + 2}')
+    # The same for a replay that rotates K output sets itself: the batches of
+    # such a replay alias one of the K sets all the way through Consec.
+    reuse = getattr(getattr(getattr(inner, 'fn', None), '__self__', None), '_reuse', 0)
+    if 0 < reuse < self.amount + 2:
+      raise ValueError(f'Prefetch(amount={self.amount}) over Replay(reuse_outputs={reuse}): a batch is '
+                       f'overwritten {reuse} samples later; needs reuse_outputs >= amount + 2 = '
+                       f'{self.amount + 2}')
     self.source = iter(source) if hasattr(source, '__iter__') else source()
     self._transform = transform
     self._state = self._snapshot()

@@ -795,7 +795,6 @@ struct emb_replay {
   LaunchTimer timer, timer_other, timer_update;   // gathers, unread predecessor stamps, write-backs
   std::string timed_kernel[2];                    // the kernel the last stamped gather / write-back ran
   bool timing_update = false;                     // set by emb_replay_update around its launches
-  bool writes_back = false;                       // emb_replay_update has moved payload on this replay
   std::vector<int32_t> rows, spans;
   std::vector<std::pair<int32_t, int32_t>> runs;   // update: [first, last) pool rows per run
   std::vector<uint32_t> stamp;                     // update: last-writer-wins marks per pool row
@@ -822,7 +821,7 @@ struct emb_replay {
     bool active = false;
     const void* src = nullptr;
     uint8_t* pool = nullptr;
-    const uint8_t* flags = nullptr;
+    const uint8_t* flags = nullptr;  // the is_last POOL: a step's flag is read at its own row
     int64_t rowbytes = 0, n = 0;
     int dtype = 0;
     std::vector<int32_t> rows;       // the carried step's pool rows (host copy)
@@ -1374,22 +1373,25 @@ struct KeyList {
   int32_t seq_len = 1;
   int32_t group = 0;            // gather: destination groups (MovePlan::group)
   int64_t group_stride = 0;
-  bool dst_read_soon = false;   // gather: MovePlan::dst_read_soon
   bool fresh_rows = false;      // scatter: MovePlan::fresh_rows (an insert)
   // Masked insert: per key a DType code (-1 = plain copy) and the buffer that
   // also receives the masked value; mask_flags = is_last of the rows.
   std::vector<int8_t> mask_dtype;
   std::vector<uint8_t*> mask_out;
   const uint8_t* mask_flags = nullptr;
+  // Gather: steps of a sequence that key k receives (MovePlan::key_len; 0 = all).
+  std::vector<int32_t> key_len;
   KeyList() {           // one allocation each instead of a doubling series per call
     key.reserve(16);
     mask_dtype.reserve(16);
     mask_out.reserve(16);
+    key_len.reserve(16);
   }
-  void push(uint8_t* pool, const void* batch, int64_t rowbytes) {
+  void push(uint8_t* pool, const void* batch, int64_t rowbytes, int32_t len = 0) {
     key.push_back({pool, const_cast<uint8_t*>(static_cast<const uint8_t*>(batch)), rowbytes});
     mask_dtype.push_back(-1);
     mask_out.push_back(nullptr);
+    key_len.push_back(len);
   }
 };
 
@@ -1404,7 +1406,6 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
     plan.seq_len = list.seq_len;
     plan.group = list.group;
     plan.group_stride = list.group_stride;
-    plan.dst_read_soon = list.dst_read_soon;
     plan.fresh_rows = list.fresh_rows;
     plan.is_first_pool = first_pool;
     for (int k = lo; k < hi; ++k) {
@@ -1414,6 +1415,7 @@ static void run_move_all(emb_replay* rep, KeyList& list, const int32_t* rows, in
         plan.mask_out[plan.n_keys] = list.mask_out[k];
         plan.mask_flags = list.mask_flags;
       }
+      plan.key_len[plan.n_keys] = list.key_len[k];
       plan.key[plan.n_keys++] = list.key[k];
     }
     if (list.key_is_first >= lo && list.key_is_first < hi) plan.key_is_first = list.key_is_first - lo;
@@ -1444,7 +1446,7 @@ static void settle_carry(emb_replay* rep, bool index_busy) {
   c.active = false;
   rep->order_before(StreamOrder::kWriteFresh, c.stream, index_busy);
   HIP_OK(emb::launch_publish_one(c.src, c.pool, nullptr, rep->dev_rows, c.flags, c.n, c.rowbytes, c.dtype,
-                                 c.stream, write_stamp(rep)));
+                                 c.stream, write_stamp(rep), /*flags_by_row=*/true));
   rep->order_after(StreamOrder::kWriteFresh, c.stream);
 }
 
@@ -1573,16 +1575,21 @@ static void add_locked(emb_replay* rep, int64_t n, const int64_t* workers, const
     // All that is left is one small key (the action): the rows are in device
     // memory since the early insert, the launch needs 56 bytes of arguments.
     const bool masked = list.mask_flags && list.mask_dtype[0] >= 0;
-    if (rep->carry_publish && masked && !list.mask_out[0] && n <= INT32_MAX &&
+    // (the flags the mask uses are this step's is_last, and the early insert has
+    // put exactly that buffer into the is_last pool rows of this step)
+    const bool flags_stored = rep->key_is_last >= 0 && rep->keys[rep->key_is_last].pool &&
+                              pre.src[rep->key_is_last] == static_cast<const void*>(list.mask_flags);
+    if (rep->carry_publish && masked && !list.mask_out[0] && n <= INT32_MAX && flags_stored &&
         emb::carry_supported(list.key[0].rowbytes, list.mask_dtype[0])) {
-      // Nobody wants the masked values back: no launch now.  Source and flags
-      // are read by the next launch on this replay (the caller's contract,
-      // emb_replay_carry_publish).
+      // Nobody wants the masked values back: no launch now.  The source is read
+      // by the next launch on this replay (the caller's contract,
+      // emb_replay_carry_publish); the flags are read from the replay's own
+      // is_last rows of this step, so the env may reuse its flag buffer at once.
       emb_replay::Carried& c = rep->carry;
       c.active = true;
       c.src = list.key[0].batch;
       c.pool = list.key[0].pool;
-      c.flags = list.mask_flags;
+      c.flags = rep->keys[rep->key_is_last].pool;
       c.rowbytes = list.key[0].rowbytes;
       c.n = n;
       c.dtype = list.mask_dtype[0];
@@ -1782,7 +1789,8 @@ int32_t emb_replay_obs_stack_insert(emb_replay_t* rep, int64_t n, const int64_t*
 
 static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* const* dst,
                           int32_t group, int64_t group_stride, uint8_t* online_out,
-                          uint8_t* first_stepids_out, hipStream_t stream) {
+                          uint8_t* first_stepids_out, hipStream_t stream,
+                          const int32_t* key_len = nullptr) {
   need(batch >= 0 && dst, "sample: bad arguments");
   need(!rep->keys.empty(), "sample: call emb_replay_set_keys first");
   need(group >= 0 && group_stride >= 0 && (group == 0 || group_stride % 16 == 0),
@@ -1794,17 +1802,12 @@ static void sample_locked(emb_replay* rep, int64_t batch, int32_t mode, void* co
     need(dst[k] && rep->keys[k].pool, "sample: null buffer");
     if (static_cast<int>(k) == rep->key_is_first) list.key_is_first = static_cast<int>(list.key.size());
     if (static_cast<int>(k) == rep->key_is_last) list.key_is_last = static_cast<int>(list.key.size());
-    list.push(rep->keys[k].pool, dst[k], rep->keys[k].rowbytes);
+    need(!key_len || (key_len[k] >= 0 && key_len[k] <= L), "sample: a key's head is longer than the sequence");
+    list.push(rep->keys[k].pool, dst[k], rep->keys[k].rowbytes, key_len ? key_len[k] : 0);
   }
   list.seq_len = static_cast<int32_t>(L);
   list.group = group;
   list.group_stride = group_stride;
-  // A replay whose sampled batches come back through emb_replay_update (agent
-  // outputs written over the sampled steps, dreamerv3/agent.py:144-150): the
-  // write-back reads the batch tensors right after the learner -- sampled with
-  // plain stores it finds them in cache (84 MB: 13.0-13.4 us instead of
-  // 16.6-18.3 behind non-temporal stores; the gather itself costs the same).
-  list.dst_read_soon = rep->writes_back;
   HostLap hp;
   rep->rows.resize(batch * L);
   sample_index_locked(rep, batch, mode, rep->rows.data(), online_out, &rep->spans, first_stepids_out);
@@ -1834,6 +1837,13 @@ int32_t emb_replay_sample_grouped(emb_replay_t* rep, int64_t batch, int32_t mode
                                   uint8_t* first_stepids_out, void* stream) {
   REP_OP(sample_locked(rep, batch, mode, dst, group, group_stride, online_out, first_stepids_out,
                        static_cast<hipStream_t>(stream)));
+}
+
+int32_t emb_replay_sample_heads(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
+                                const int32_t* key_len, uint8_t* online_out,
+                                uint8_t* first_stepids_out, void* stream) {
+  REP_OP(sample_locked(rep, batch, mode, dst, 0, 0, online_out, first_stepids_out,
+                       static_cast<hipStream_t>(stream), key_len));
 }
 
 static KeyList list_subset(emb_replay* rep, int32_t n_keys, const int32_t* key_ids,
@@ -1903,7 +1913,6 @@ int32_t emb_replay_update(emb_replay_t* rep, int64_t B, int64_t T, const uint8_t
       }
     }
     rep->timing_update = rep->timer_update.enabled;
-    rep->writes_back = true;
     try {
       run_move_all(rep, list, rep->rows.data(), B * T, nullptr, false, static_cast<hipStream_t>(stream),
                    &rep->spans);

@@ -22,6 +22,11 @@ struct MovePlan {
   KeyDesc key[kMaxKeys];
   int32_t n_rows = 0;        // rows moved per key
   int32_t seq_len = 1;       // rows per sequence (annotate uses t = r % seq_len)
+  // Gather only: key k's batch side is (n_rows / seq_len, key_len[k], rowbytes)
+  // and receives the first key_len[k] steps of every sequence -- a key whose
+  // consumer reads only the head of the sampled window (DreamerV3's replay
+  // context, dreamerv3/agent.py:322-331).  0 = the whole sequence.
+  int32_t key_len[kMaxKeys] = {};
   int32_t key_is_first = -1; // gather only: fuse replay.py:277-292
   int32_t key_is_last = -1;
   const uint8_t* is_first_pool = nullptr;  // pool of the is_first key (may be in another launch)
@@ -55,11 +60,6 @@ struct MovePlan {
   int8_t mask_dtype[kMaxKeys] = {};
   uint8_t* mask_out[kMaxKeys] = {};
   const uint8_t* mask_flags = nullptr;
-  // Gather only: the batch is read again right away by a kernel that matters
-  // (the learner writes agent outputs back over the sampled steps with the same
-  // tensors as source, Replay.update): leave it in L2 / Infinity Cache -- plain
-  // stores instead of the span mover's non-temporal ones.
-  bool dst_read_soon = false;
   // Scatter only: the rows are rows of the workers' OPEN chunks (an insert), not
   // rows of existing items (a write-back): what cross-stream ordering it needs
   // (abi.cpp StreamOrder).
@@ -195,8 +195,10 @@ struct PrewritePlan {
   uint8_t* stepid_pool = nullptr;
   const void* table_dev = nullptr;
   int32_t* rows_out = nullptr;       // device int32[n] for launch_publish_one (optional)
-  // Carried publish: the PREVIOUS step's masked key (value * !flags[e] in
+  // Carried publish: the PREVIOUS step's masked key (value * !flag in
   // carry_dtype) written to rows carry_rows[e] of carry_pool by this launch.
+  // carry_flags = the replay's is_last pool (1-byte rows): env e's flag is read at
+  // carry_rows[e], where that step's own early insert stored it.
   const uint8_t* carry_src = nullptr;
   uint8_t* carry_pool = nullptr;
   const uint8_t* carry_flags = nullptr;
@@ -212,9 +214,10 @@ void prewrite_fill_table(void* dst, const PrewritePlan& plan, const int32_t* row
 hipError_t launch_obs_stack_insert(const PrewritePlan& plan, hipStream_t stream, hipEvent_t stop = nullptr);
 // One key of n rows to the pool rows `rows_dev` (device int32[n], -1 = skip):
 // value * !flags[r] in `dtype` when flags is set (and to `out` as well), a plain
-// copy otherwise.
+// copy otherwise.  flags_by_row: `flags` is a pool of 1-byte rows and row r's
+// flag is flags[rows_dev[r]].
 hipError_t launch_publish_one(const void* src, void* pool, void* out, const int32_t* rows_dev,
                               const uint8_t* flags, int64_t n, int64_t rowbytes, int dtype,
-                              hipStream_t stream, hipEvent_t stop = nullptr);
+                              hipStream_t stream, hipEvent_t stop = nullptr, bool flags_by_row = false);
 
 }  // namespace emb

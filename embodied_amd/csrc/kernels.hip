@@ -57,9 +57,13 @@ struct alignas(16) SpanHead {
   uint32_t ntiles, pad_;
   uint32_t tile0[kSpanKeys];          // first tile of wide key k; 0xFFFFFFFF beyond n_wide
   uint32_t tiles_per_seq[kSpanKeys];
+  // 16-byte units of one sequence of wide key k on the batch side: its head
+  // length (MovePlan::key_len, seq_len unless the key is a context-only one)
+  // times rowbytes / 16.
+  uint32_t units_per_seq[kSpanKeys];
   KeyDesc key[kSpanKeys];
 };
-static_assert(sizeof(SpanHead) == 160, "SpanHead is loaded as 40 dwords");
+static_assert(sizeof(SpanHead) == 176, "SpanHead is loaded as 44 dwords");
 
 // Per-launch plan in kernel-argument memory (< 4 KiB).
 // Everything of a launch plan except the head and the inline words: which key
@@ -70,8 +74,12 @@ struct alignas(16) MoveTables {
   KeyDesc key[kMaxKeys];
   int32_t first_block[kMaxKeys + 1];
   int32_t unit[kMaxKeys];           // 0: 16-byte flat path; else bytes per lane
+  // Steps of a sequence that key k moves (its head: seq_len, or fewer for a
+  // context-only key of a gather) and its batch rows in this launch
+  // (n_seq * key_len[k]; n_rows when every key moves whole sequences).
+  int32_t key_len[kMaxKeys];
+  int32_t key_rows[kMaxKeys];
   int32_t n_keys, n_rows, seq_len, key_is_first, key_is_last;
-  int32_t xcd_remap;
   int32_t rows_mode;                // 0 device table, 1 inline rows, 2 inline spans
   int32_t inline_key, inline_key_word0;
   const uint8_t* is_first_pool;
@@ -105,10 +113,11 @@ static_assert(sizeof(MoveArgs) <= 4096, "kernel arguments are limited to 4 KiB")
 
 // What the span mover stages through LDS before anything else: the head and the
 // first spans, contiguous in the arguments.
-constexpr int kStagedSeqs = 72;      // (160 + 72 * 12) / 16 = 64 lanes: one wave, one load each
+constexpr int kStagedSeqs = 70;      // (176 + 70 * 12 + 8) / 16 = 64 lanes: one wave, one load each
 struct StagedSpans {
   SpanHead head;
   uint32_t spans[3 * kStagedSeqs];
+  uint32_t tail_[2];                  // (two words of span 70: never read from here)
 };
 static_assert(sizeof(StagedSpans) == 64 * 16, "one 16-byte load per lane of one wave");
 static_assert(offsetof(MoveArgs, inline_words) == sizeof(SpanHead), "spans follow the head");
@@ -120,25 +129,27 @@ __device__ __forceinline__ int find_key(const MoveTables& tb, int block) {
   return k;
 }
 
-// Pool row of batch row r.
-__device__ __forceinline__ int32_t row_of(const MoveArgs& a, const MoveTables& tb, uint32_t r) {
+// Pool row of step t of sequence seq.  (A launch's row table is n_seq
+// sequences of tb.seq_len steps; a key's batch side holds the first klen of
+// them, so batch row r of that key is (seq, t) = (r / klen, r % klen).)
+__device__ __forceinline__ int32_t row_at(const MoveArgs& a, const MoveTables& tb, uint32_t seq, uint32_t t) {
   if (tb.rows_mode == 2) {
-    const uint32_t seq = r / static_cast<uint32_t>(tb.seq_len);
-    const uint32_t t = r - seq * static_cast<uint32_t>(tb.seq_len);
     const uint32_t row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
     return static_cast<int32_t>(t < n0 ? row0 + t : a.inline_words[3 * seq + 2] + (t - n0));
   }
+  const uint32_t r = seq * static_cast<uint32_t>(tb.seq_len) + t;
   if (tb.rows_mode == 1) return static_cast<int32_t>(a.inline_words[r]);
   return tb.rows[r];
 }
 
-// Byte offset of batch row r of `key` on the batch side (see MoveArgs::group).
-__device__ __forceinline__ int64_t batch_offset(const MoveTables& tb, const KeyDesc& key, uint32_t r) {
-  if (tb.group == 0) return static_cast<int64_t>(r) * key.rowbytes;
-  const uint32_t L = static_cast<uint32_t>(tb.seq_len), g = static_cast<uint32_t>(tb.group);
-  const uint32_t seq = r / L, t = r - seq * L;
+// Byte offset of step t of sequence seq of `key` on the batch side (klen steps
+// per sequence there; see MoveArgs::group).
+__device__ __forceinline__ int64_t batch_offset(const MoveTables& tb, const KeyDesc& key, uint32_t klen,
+                                                uint32_t seq, uint32_t t) {
+  if (tb.group == 0) return static_cast<int64_t>(seq * klen + t) * key.rowbytes;
+  const uint32_t g = static_cast<uint32_t>(tb.group);
   const uint32_t grp = seq / g, j = seq - grp * g;
-  return static_cast<int64_t>(grp) * tb.group_stride + static_cast<int64_t>(j * L + t) * key.rowbytes;
+  return static_cast<int64_t>(grp) * tb.group_stride + static_cast<int64_t>(j * klen + t) * key.rowbytes;
 }
 
 template <typename T>
@@ -174,25 +185,21 @@ __device__ __forceinline__ void copy_bytes(const uint8_t* s, uint8_t* d, int uni
 // independent loads in flight before its first store, and no lane waits on a
 // per-workgroup scalar dependency chain.
 template <bool kGather, int U, int NT>
-__device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& tb, const KeyDesc& key, int local,
-                                          int nblocks) {
+__device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& tb, const KeyDesc& key, int k,
+                                          int local) {
   const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
-  const uint32_t total = upr * static_cast<uint32_t>(tb.n_rows);
-  // Optional (EMB_MOVE_VARIANT's third field = 1; off by default): workgroup b
-  // runs on XCD b % 8, so this gives every XCD one contiguous eighth of the
-  // batch.  Measured on MI355X it is 0.2-0.3 us SLOWER at batch 16 inside the
-  // benchmark and 2-3 % slower at batch 256: the plain order already spreads
-  // each frame over all XCDs' memory channels, which a streaming copy prefers.
-  int vlocal = local;
-  const int per_xcd = nblocks >> 3;
-  if (tb.xcd_remap && local < (per_xcd << 3)) vlocal = (local & 7) * per_xcd + (local >> 3);
+  const uint32_t klen = static_cast<uint32_t>(tb.key_len[k]);
+  const uint32_t nrows = static_cast<uint32_t>(tb.key_rows[k]);
+  const uint32_t total = upr * nrows;
+  // (Workgroup b runs on XCD b % 8 and takes tile b: every frame is spread over
+  // all XCDs' memory channels, which a streaming copy prefers -- giving each XCD
+  // one contiguous eighth of the batch instead measured 2-3 % slower.)
   // One division per wave for the workgroup's first unit; lanes step from it
   // with adds and compares (a 32-bit divide costs ~40 VALU instructions).
-  const uint32_t base = static_cast<uint32_t>(vlocal) * (blockDim.x * U);
+  const uint32_t base = static_cast<uint32_t>(local) * (blockDim.x * U);
   const uint32_t r0 = base / upr;
   const uint32_t off0 = base - r0 * upr;
-  const uint32_t L = static_cast<uint32_t>(tb.seq_len);
-  const uint32_t seq0 = r0 / L, t0 = r0 - seq0 * L;
+  const uint32_t seq0 = r0 / klen, t0 = r0 - seq0 * klen;
   // The workgroup's units span at most kRows consecutive batch rows when rows
   // are long (the usual case: one 28 KB frame = 1764 units): resolve those rows
   // ONCE per wave with wave-uniform (scalar) reads of the inline span table and
@@ -205,34 +212,36 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& t
     uint32_t seq = seq0, t = t0;
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
-      if (r0 + i < static_cast<uint32_t>(tb.n_rows)) {
+      // (rows_mode 2 spelled out, not row_at: its other modes read through
+      // tb.rows, and a wave-uniform choice between that pointer and one into the
+      // by-value argument block makes the compiler copy the whole block -- 3.8 KB
+      // per lane -- to scratch)
+      if (r0 + i < nrows) {
         const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
         row_tab[i] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
       } else {
         row_tab[i] = -1;
       }
-      if (++t >= L) { t = 0; ++seq; }
+      if (++t >= klen) { t = 0; ++seq; }
     }
   }
-  uint32_t r[U], off[U];
+  uint32_t sq[U], tt[U], off[U];
   int32_t row[U];
 #pragma unroll
   for (int j = 0; j < U; ++j) {
     uint32_t x = off0 + j * blockDim.x + threadIdx.x, dr = 0;
     while (x >= upr) { x -= upr; ++dr; }
-    r[j] = r0 + dr;
+    uint32_t seq = seq0, t = t0 + dr;
+    while (t >= klen) { t -= klen; ++seq; }
+    sq[j] = seq;
+    tt[j] = t;
     off[j] = x;
     if (base + j * blockDim.x + threadIdx.x >= total) {
       row[j] = -1;
     } else if (few_rows) {
       row[j] = dr == 0 ? row_tab[0] : dr == 1 ? row_tab[1] : row_tab[2];
-    } else if (tb.rows_mode == 2) {
-      uint32_t seq = seq0, t = t0 + dr;
-      while (t >= L) { t -= L; ++seq; }
-      const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
-      row[j] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
     } else {
-      row[j] = row_of(a, tb, r[j]);
+      row[j] = row_at(a, tb, seq, t);
     }
   }
   u32x4 buf[U];
@@ -240,7 +249,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& t
   for (int j = 0; j < U; ++j) {
     if (row[j] < 0) continue;
     const uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
-    const uint8_t* batch = key.batch + batch_offset(tb, key, r[j]);
+    const uint8_t* batch = key.batch + batch_offset(tb, key, klen, sq[j], tt[j]);
     const u32x4* src = reinterpret_cast<const u32x4*>(kGather ? pool : batch) + off[j];
     buf[j] = load16<(NT & 1) != 0>(src);
   }
@@ -248,7 +257,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& t
   for (int j = 0; j < U; ++j) {
     if (row[j] < 0) continue;
     uint8_t* pool = key.pool + static_cast<int64_t>(row[j]) * key.rowbytes;
-    uint8_t* batch = key.batch + batch_offset(tb, key, r[j]);
+    uint8_t* batch = key.batch + batch_offset(tb, key, klen, sq[j], tt[j]);
     u32x4* dst = reinterpret_cast<u32x4*>(kGather ? batch : pool) + off[j];
     store16<(NT & 2) != 0>(dst, buf[j]);
   }
@@ -269,7 +278,6 @@ template <bool kGather, int U, int NT>
 __device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const StagedSpans& staged) {
   const SpanHead& h = staged.head;
   const uint32_t tile = blockDim.x * U;
-  const uint32_t L = static_cast<uint32_t>(h.seq_len);
   const uint32_t ntiles = h.ntiles;
   const uint32_t stride = static_cast<uint32_t>(h.wide_workers);
   struct Where {
@@ -297,7 +305,7 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const StagedS
     }
     Where w;
     w.split = n0 * upr;
-    w.total = L * upr;
+    w.total = h.units_per_seq[k];     // (a context-only key: fewer than L * upr, all of them maybe left of the split)
     w.u0 = piece * tile + threadIdx.x;
     w.p0 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row0) * upr;
     w.p1 = reinterpret_cast<const u32x4*>(key.pool) + static_cast<uint64_t>(row1) * upr - w.split;
@@ -360,25 +368,28 @@ __device__ __forceinline__ void gather_block(const MoveArgs& a, const MoveTables
   const int local = block - tb.first_block[k];
   const int unit = tb.unit[k];
   if (unit == 0) {
-    move_wide<true, U, NT>(a, tb, key, local, tb.first_block[k + 1] - tb.first_block[k]);
+    move_wide<true, U, NT>(a, tb, key, k, local);
     return;
   }
+  const uint32_t klen = static_cast<uint32_t>(tb.key_len[k]);
   const int64_t upr = key.rowbytes / unit;
   const int64_t u = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
-  if (u >= upr * tb.n_rows) return;
+  if (u >= upr * tb.key_rows[k]) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
-  const int64_t row = row_of(a, tb, static_cast<uint32_t>(r));
+  const uint32_t seq = static_cast<uint32_t>(r) / klen, t = static_cast<uint32_t>(r) - seq * klen;
+  const int64_t row = row_at(a, tb, seq, t);
   if (row < 0) return;   // not this rank's sequence (sharded pools): leave as is
   const uint8_t* src = key.pool + row * key.rowbytes + off;
-  uint8_t* dst = key.batch + batch_offset(tb, key, static_cast<uint32_t>(r)) + off;
+  uint8_t* dst = key.batch + batch_offset(tb, key, klen, seq, t) + off;
   if (key.rowbytes == 1 && (k == tb.key_is_first || k == tb.key_is_last)) {
-    const int t = static_cast<int>(r % tb.seq_len);
+    // (annotated over the FULL sequence, then cut to the key's head: what
+    // slicing the reference's annotated batch gives)
     uint8_t v = gload<uint8_t>(src);
     if (k == tb.key_is_first) {
       if (t == 0) v = 1;
-    } else if (tb.is_first_pool && t + 1 < tb.seq_len) {
-      v |= gload<uint8_t>(tb.is_first_pool + row_of(a, tb, static_cast<uint32_t>(r + 1)));
+    } else if (tb.is_first_pool && t + 1 < static_cast<uint32_t>(tb.seq_len)) {
+      v |= gload<uint8_t>(tb.is_first_pool + row_at(a, tb, seq, t + 1));
     }
     gstore<uint8_t>(dst, v);
     return;
@@ -412,7 +423,8 @@ __device__ __forceinline__ void scatter_masked(const MoveArgs& a, const MoveTabl
   if (e >= epr * tb.n_rows) return;
   const int64_t r = e / epr;
   const int64_t off = (e - r * epr) * es;
-  const int64_t row = row_of(a, tb, static_cast<uint32_t>(r));
+  const uint32_t L = static_cast<uint32_t>(tb.seq_len), seq = static_cast<uint32_t>(r) / L;
+  const int64_t row = row_at(a, tb, seq, static_cast<uint32_t>(r) - seq * L);
   const bool keep = gload<uint8_t>(tb.mask_flags + r) == 0;
   const uint8_t* src = key.batch + r * key.rowbytes + off;
   uint8_t* pool = row >= 0 ? key.pool + row * key.rowbytes + off : nullptr;
@@ -442,7 +454,7 @@ __device__ __forceinline__ void scatter_block(const MoveArgs& a, const MoveTable
     return;
   }
   if (unit == 0) {
-    move_wide<false, U, NT>(a, tb, key, local, tb.first_block[k + 1] - tb.first_block[k]);
+    move_wide<false, U, NT>(a, tb, key, k, local);
     return;
   }
   const int64_t upr = key.rowbytes / unit;
@@ -450,7 +462,8 @@ __device__ __forceinline__ void scatter_block(const MoveArgs& a, const MoveTable
   if (u >= upr * tb.n_rows) return;
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
-  const int64_t row = row_of(a, tb, static_cast<uint32_t>(r));
+  const uint32_t L = static_cast<uint32_t>(tb.seq_len), seq = static_cast<uint32_t>(r) / L;
+  const int64_t row = row_at(a, tb, seq, static_cast<uint32_t>(r) - seq * L);
   if (row < 0) return;
   if (k == tb.inline_key) {   // batch bytes of this key ride in the kernel arguments
     const uint32_t w = a.inline_words[tb.inline_key_word0 + r * (key.rowbytes >> 2) + (off >> 2)];
@@ -460,23 +473,13 @@ __device__ __forceinline__ void scatter_block(const MoveArgs& a, const MoveTable
   copy_bytes(key.batch + r * key.rowbytes + off, key.pool + row * key.rowbytes + off, unit);
 }
 
-// A launch has first_block[n_keys] virtual blocks.  Normally the grid is exactly
-// that; with EMB_MOVE_VARIANT's fifth field = w > 0 the grid is capped at
-// w workgroups per CU and every workgroup walks the virtual blocks with a
-// grid stride (no second round of wave launches).  Measured on MI355X: equal at
-// B=16 and 7-8 % SLOWER at B=64/256 with w=8 or 16 (the dispatcher overlaps one
-// workgroup's stores with the next one's loads better than this loop does), so
-// it stays off.
-template <int U, int NT>
-__device__ __forceinline__ void gather_body(const MoveArgs& a, const MoveTables& tb) {
-  const int total = tb.first_block[tb.n_keys];
-  for (int block = blockIdx.x; block < total; block += gridDim.x) gather_block<U, NT>(a, tb, block);
-}
-template <int U, int NT>
-__device__ __forceinline__ void scatter_body(const MoveArgs& a, const MoveTables& tb) {
-  const int total = tb.first_block[tb.n_keys];
-  for (int block = blockIdx.x; block < total; block += gridDim.x) scatter_block<U, NT>(a, tb, block);
-}
+// A flat launch has first_block[n_keys] virtual blocks and exactly that many
+// workgroups.  (A grid capped at a few workgroups per CU that walks the virtual
+// blocks with a stride measured equal at B=16 and 7-8 % slower at B=64/256: the
+// dispatcher overlaps one workgroup's stores with the next one's loads better.)
+constexpr int kFlatUnroll = 2;      // 16-byte units per lane: 2 beats 4/8 by 10-15 % (MI355X sweep)
+constexpr int kFlatNT = 3;          // non-temporal loads and stores: ~3 % faster than plain on cold lines
+constexpr int kFlatThreads = 256;   // 64..512 within noise, 1024 slower
 
 // The kernel-argument segment as raw 16-byte units (MoveArgs is the only
 // parameter of every mover, so it starts the segment).  Indexing the by-value
@@ -504,33 +507,24 @@ static_assert(offsetof(MoveArgs, t) % 16 == 0, "the tables are staged in 16-byte
 // segment (default), the same with the tables staged through LDS (arguments in
 // host memory, small launches), or read through a pointer to a copy in device
 // memory (arguments in host memory, big launches: abi.cpp run_move).
-template <int U, int NT>
-__global__ __launch_bounds__(1024) void gather_kernel(const MoveArgs a) { gather_body<U, NT>(a, a.t); }
-template <int U, int NT>
-__global__ __launch_bounds__(1024) void gather_kernel_staged(const MoveArgs a) {
+template <bool kGather>
+__device__ __forceinline__ void flat_block(const MoveArgs& a, const MoveTables& tb) {
+  if (kGather) gather_block<kFlatUnroll, kFlatNT>(a, tb, blockIdx.x);
+  else scatter_block<kFlatUnroll, kFlatNT>(a, tb, blockIdx.x);
+}
+template <bool kGather>
+__global__ __launch_bounds__(kFlatThreads) void flat_move_kernel(const MoveArgs a) { flat_block<kGather>(a, a.t); }
+template <bool kGather>
+__global__ __launch_bounds__(kFlatThreads) void flat_move_kernel_staged(const MoveArgs a) {
   __shared__ MoveTables tables;
   stage_tables(kernarg_units(), &tables);
-  gather_body<U, NT>(a, tables);
+  flat_block<kGather>(a, tables);
 }
-template <int U, int NT>
-__global__ __launch_bounds__(1024) void gather_kernel_indirect(const MoveArgs* __restrict__ a) {
+template <bool kGather>
+__global__ __launch_bounds__(kFlatThreads) void flat_move_kernel_indirect(const MoveArgs* __restrict__ a) {
   __shared__ MoveTables tables;     // one load latency instead of a chain of scalar loads
   stage_tables(reinterpret_cast<const u32x4*>(a), &tables);
-  gather_body<U, NT>(*a, tables);
-}
-template <int U, int NT>
-__global__ __launch_bounds__(1024) void scatter_kernel(const MoveArgs a) { scatter_body<U, NT>(a, a.t); }
-template <int U, int NT>
-__global__ __launch_bounds__(1024) void scatter_kernel_staged(const MoveArgs a) {
-  __shared__ MoveTables tables;
-  stage_tables(kernarg_units(), &tables);
-  scatter_body<U, NT>(a, tables);
-}
-template <int U, int NT>
-__global__ __launch_bounds__(1024) void scatter_kernel_indirect(const MoveArgs* __restrict__ a) {
-  __shared__ MoveTables tables;
-  stage_tables(reinterpret_cast<const u32x4*>(a), &tables);
-  scatter_body<U, NT>(*a, tables);
+  flat_block<kGather>(*a, tables);
 }
 
 // Span-mode launch: the first `wide_workers` workgroups are the persistent wide
@@ -546,27 +540,38 @@ __device__ __forceinline__ void stage_head(const u32x4* bytes, StagedSpans* dst)
   __syncthreads();
 }
 
-template <bool kGather, int U, int NT>
+// Shape of the persistent mover (MI355X, profiles/r04_gather_shapes.txt and
+// r04_ab_span_shape.txt): 256 threads x 4 units per lane = tiles of 16 KB, four
+// workgroups per CU, every worker slot filled -- B=16 10.1-10.3 us against
+// 10.8-11.2 for 512 threads x 2 per CU; U=2 and 1024-thread shapes were slower.
+constexpr int kSpanUnroll = 4;
+constexpr int kSpanThreads = 256;
+constexpr int kSpanPerCU = 4;
+template <bool kGather, int NT>
 __device__ __forceinline__ void span_move_body(const MoveArgs& a, const u32x4* bytes) {
   __shared__ StagedSpans staged;
   stage_head(bytes, &staged);
   if (static_cast<int>(blockIdx.x) < staged.head.wide_workers) {
-    move_wide_spans<kGather, U, NT>(a, staged);
+    move_wide_spans<kGather, kSpanUnroll, NT>(a, staged);
     return;
   }
   const int block = static_cast<int>(blockIdx.x) - staged.head.wide_workers;
-  if (kGather) gather_block<2, NT>(a, a.t, block);
-  else scatter_block<2, NT>(a, a.t, block);
+  if (kGather) gather_block<kFlatUnroll, NT>(a, a.t, block);
+  else scatter_block<kFlatUnroll, NT>(a, a.t, block);
 }
 
-template <bool kGather, int U, int NT>
-__global__ __launch_bounds__(1024) void span_move_kernel(const MoveArgs a) {
+// NT: non-temporal hints, bit 0 loads, bit 1 stores.  3 (both) is the fastest
+// gather by itself (B=16: 10.7 us against 11.2 / 10.9 / 12.2 for loads-only /
+// stores-only / none); 1 (plain stores) leaves the batch in L2 / Infinity Cache
+// for a reader that follows at once (EMB_GATHER_STORES=plain).
+template <bool kGather, int NT>
+__global__ __launch_bounds__(kSpanThreads) void span_move_kernel(const MoveArgs a) {
   // MoveArgs is the only parameter: it starts the kernel-argument segment.
-  span_move_body<kGather, U, NT>(a, kernarg_units());
+  span_move_body<kGather, NT>(a, kernarg_units());
 }
-template <bool kGather, int U, int NT>
-__global__ __launch_bounds__(1024) void span_move_kernel_indirect(const MoveArgs* __restrict__ a) {
-  span_move_body<kGather, U, NT>(*a, reinterpret_cast<const u32x4*>(a));
+template <bool kGather, int NT>
+__global__ __launch_bounds__(kSpanThreads) void span_move_kernel_indirect(const MoveArgs* __restrict__ a) {
+  span_move_body<kGather, NT>(*a, reinterpret_cast<const u32x4*>(a));
 }
 
 // Host-resident kernel arguments (HIP_FORCE_DEV_KERNARG=0): one workgroup
@@ -582,72 +587,38 @@ __global__ __launch_bounds__(256) void args_writer_kernel(const MoveArgs a, u32x
 static_assert(sizeof(MoveArgs) % 16 == 0 && sizeof(MoveArgs) / 16 <= 256,
               "argument block is copied as one dwordx4 per lane");
 
-// Tuning knobs, read once: EMB_MOVE_VARIANT="U,NT,remap,threads" = 16-byte units
-// per lane, non-temporal hints (bit0 loads, bit1 stores), XCD remap on/off and
-// workgroup size.  Defaults from the MI355X sweep (tools/bench_gather.py):
-// U=2 beats 4/8 by 10-15 %, workgroup size 64..512 is within noise, 1024 is
-// slower; non-temporal loads+stores are ~3 % faster than plain ones inside the
-// benchmark (cold output lines) and equal in a tight loop.
-struct MoveVariant { int unroll; int nt; int remap; int threads; int persist; };
-const MoveVariant& move_variant() {
-  static const MoveVariant variant = [] {
-    MoveVariant v{2, 3, 0, 256, 0};
-    if (const char* s = emb::knob("EMB_MOVE_VARIANT"))
-      std::sscanf(s, "%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.remap, &v.threads, &v.persist);
-    if (v.persist < 0 || v.persist > 64) v.persist = 0;
-    if (v.unroll != 1 && v.unroll != 2 && v.unroll != 4 && v.unroll != 8) v.unroll = 2;
-    if (v.nt < 0 || v.nt > 3) v.nt = 3;
-    if (v.threads != 64 && v.threads != 128 && v.threads != 512 && v.threads != 1024) v.threads = 256;
-    return v;
+// Which mover a launch gets (prepare_move).  The persistent span mover wins
+// clearly while the launch is ramp-dominated and stays level with the flat
+// mover's many short-lived workgroups far beyond that (MI355X, S0 rows, kernel us
+// persistent / flat: B=8 6.8 / 8.7, B=16 10.7 / 13.4, B=32 22.5 / 23.5, B=64
+// 41.7 / 42.1, B=128 81.6 / 79.4; Dreamer keys, 144 MB: 26.8 / 28.7), so gathers
+// use it up to kSpanGatherMB of wide payload per launch.  Write-backs up to
+// kSpanScatterMB: the flat scatter streams 84 MB of Dreamer latents at
+// 6.4-6.8 TB/s (13 us), the persistent one takes 17.6 us for the same bytes.
+// EMB_SPAN_MOVER=0 sends everything to the flat mover (the fallback).
+constexpr int64_t kSpanGatherMB = 160, kSpanScatterMB = 40;
+bool span_mover_enabled() {
+  static const bool value = [] {
+    const char* e = emb::knob("EMB_SPAN_MOVER");
+    return !(e && e[0] == '0');
   }();
-  return variant;
+  return value;
 }
-
-// Span-mode mover (move_wide_spans): EMB_SPAN_VARIANT="U,NT,threads,W" = units
-// per lane per tile (2|4), non-temporal hints, workgroup size (256|512|1024)
-// and persistent workgroups per CU; W=0 turns the path off (flat mover for
-// everything).  Defaults: round 2 from tools/gather_lab.hip (512 threads, 2 per
-// CU, tiles of 32 KB); round 4: 256 threads x 4 per CU, tiles of 16 KB, every
-// worker slot filled -- the same bytes in flight per CU from four independent
-// workgroups: B=16 10.07-10.28 us against 10.8-11.2 in a tight loop (three
-// repetitions each, profiles/r04_gather_shapes.txt), 10.25-10.42 against
-// 11.2-11.3 inside bench.py (three alternating runs, r04_ab_span_shape.txt),
-// B=12 9.2 against 10.4, level (+-1 %) at B <= 8 and B >= 24; the Dreamer keys'
-// 144 MB 25.3 against 26.2 us.
-//
-// The persistent mover wins clearly while the launch is ramp-dominated and stays
-// level with the flat mover's many short-lived workgroups far beyond that
-// (MI355X, S0 rows, kernel us persistent / flat: B=8 6.8 / 8.7, B=16 10.7 / 13.4,
-// B=32 22.5 / 23.5, B=64 41.7 / 42.1, B=128 81.6 / 79.4; Dreamer keys, 144 MB:
-// 26.8 / 28.7), so it is used up to `max_mb` MB of wide payload per launch
-// (fifth field).
-//
-// Non-temporal hints (bit 0 loads, bit 1 stores; second field for gathers,
-// sixth for write-backs).  The sample gather is fastest with both (B=16: 10.7 us
-// against 11.2 / 10.9 / 12.2 for loads-only / stores-only / none).  What they
-// cost is paid by the NEXT reader of the batch: `nt` stores leave nothing of it
-// in L2 / Infinity Cache.  Measured with the write-back of the same tensors as
-// that reader (Dreamer workload, 84 MB, rocprofv3 medians over five GPUs):
-// 13.0-13.4 us behind a gather with plain stores, 16.6-18.3 us behind one with
-// `nt` stores -- whatever the write-back's own hints are (they move it by
-// +-0.3-1 us).  The default keeps the gather kernel itself fastest;
-// EMB_SPAN_VARIANT=4,1 is the setting for a learner that reads the whole batch
-// right after sampling.
-struct SpanVariant { int unroll; int nt; int threads; int per_cu; int max_mb; int nt_scatter; bool nt_given; };
-const SpanVariant& span_variant() {
-  static const SpanVariant variant = [] {
-    SpanVariant v{4, 3, 256, 4, 160, 3, false};
-    if (const char* s = emb::knob("EMB_SPAN_VARIANT"))
-      v.nt_given = std::sscanf(s, "%d,%d,%d,%d,%d,%d", &v.unroll, &v.nt, &v.threads, &v.per_cu, &v.max_mb,
-                               &v.nt_scatter) >= 2;
-    if (v.unroll != 2 && v.unroll != 4) v.unroll = 4;
-    if (v.nt < 0 || v.nt > 3) v.nt = 3;
-    if (v.nt_scatter < 0 || v.nt_scatter > 3) v.nt_scatter = 3;
-    if (v.threads != 256 && v.threads != 512 && v.threads != 1024) v.threads = 512;
-    if (v.per_cu < 0 || v.per_cu > 16) v.per_cu = 2;
-    return v;
+// EMB_GATHER_STORES=plain: sample gathers store with plain instead of
+// non-temporal stores.  What `nt` stores cost is paid by the NEXT reader of the
+// batch, which finds nothing of it in L2 / Infinity Cache: measured with a kernel
+// that reads 84 MB of the batch right behind the gather (rocprofv3 medians over
+// five GPUs): 13.0-13.4 us behind plain stores, 16.6-18.3 us behind `nt` stores.
+// The gather itself is faster with `nt` while the batch is small (60 MB: 12.5
+// against 13.5 us) and slower when it is large (144 MB: 26.7 against 25.3 us;
+// profiles/r05_ab_gather_stores.txt).  `plain` is the setting for a learner that
+// reads the whole batch right after sampling.
+int gather_nt() {      // non-temporal hints of a span gather: bit 0 loads, bit 1 stores
+  static const int value = [] {
+    const char* e = emb::knob("EMB_GATHER_STORES");
+    return e && e[0] == 'p' ? 1 : 3;
   }();
-  return variant;
+  return value;
 }
 // Compute units of the current device (MI355X: 256), asked once: the persistent
 // span mover sizes its grid by it.
@@ -706,48 +677,32 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || (!plan.rows && !use_inline))
     return hipErrorInvalidValue;
   if (plan.n_rows == 0) return hipSuccess;
-  const MoveVariant& variant = move_variant();
-  const SpanVariant& sv = span_variant();
   // Span tables (sample, windowing, write-back) with at least one wide key go
   // to the persistent span mover; everything else to the flat mover.
   bool span_path = false;
-  if (use_inline && plan.spans_host && sv.per_cu > 0 && plan.seq_len >= 1) {
+  if (use_inline && plan.spans_host && span_mover_enabled() && plan.seq_len >= 1) {
     int64_t wide_bytes = 0;
     int wide_keys = 0;
     for (int k = 0; k < plan.n_keys; ++k)
       if (!((plan.mask_bits >> k) & 1u) && k != plan.inline_key && pick_unit(plan.key[k]) == 0) {
-        wide_bytes += plan.key[k].rowbytes * static_cast<int64_t>(plan.n_rows);
+        const int64_t len = plan.key_len[k] > 0 && plan.key_len[k] < plan.seq_len ? plan.key_len[k] : plan.seq_len;
+        wide_bytes += plan.key[k].rowbytes * (static_cast<int64_t>(plan.n_rows) / plan.seq_len) * len;
         ++wide_keys;
       }
-    // Gathers up to max_mb MB of wide payload; scatters (write-back) up to 40 MB:
-    // the flat scatter streams 84 MB of Dreamer latents at 6.4-6.8 TB/s (13 us),
-    // the persistent one takes 17.6 us for the same bytes.
     // With host-resident kernel arguments the big movers read their plan from a
     // ring in fine-grained (uncached) device memory: the span mover touches it
     // once per workgroup (the staged head), the flat mover's waves walk it with
-    // dependent reads (84 MB write-back: 20.3 us flat-indirect, 17.6 us span) —
+    // dependent reads (84 MB write-back: 20.3 us flat-indirect, 17.6 us span) --
     // there the span mover takes every size.
-    static const int64_t scatter_mb = [] {    // EMB_SPAN_SCATTER_MB: size limit of span write-backs
-      const char* e = emb::knob("EMB_SPAN_SCATTER_MB");
-      return e ? std::atoll(e) : 40;
-    }();
-    const int64_t limit_mb = gather ? sv.max_mb : (sv.max_mb < scatter_mb ? sv.max_mb : scatter_mb);
-    static const bool host_all = [] {       // EMB_SPAN_HOST_ALL=0: size limits in host mode too (A/B)
-      const char* e = emb::knob("EMB_SPAN_HOST_ALL");
-      return !(e && e[0] == '0');
-    }();
+    const int64_t limit_mb = gather ? kSpanGatherMB : kSpanScatterMB;
     span_path = wide_bytes > 0 && wide_keys <= kSpanKeys &&
-                ((plan.args_in_host_memory && host_all) || wide_bytes <= limit_mb * 1000000);
+                (plan.args_in_host_memory || wide_bytes <= limit_mb * 1000000);
   }
-  const int unroll = span_path ? sv.unroll : variant.unroll;
-  const int threads = span_path ? sv.threads : variant.threads;
+  const int unroll = span_path ? kSpanUnroll : kFlatUnroll;
+  const int threads = span_path ? kSpanThreads : kFlatThreads;
   out->span = span_path;
   out->stage_tables = plan.args_in_host_memory;
-  // Hints of this launch: the variant's, except that a batch which a write-back
-  // is about to read again is stored with plain stores (unless EMB_SPAN_VARIANT
-  // names the hints itself: the A/B).
-  out->nt = gather ? sv.nt : sv.nt_scatter;
-  if (gather && plan.dst_read_soon && !sv.nt_given) out->nt = sv.nt & 1;
+  out->nt = gather && span_path ? gather_nt() : 3;
   MoveArgs& a = *reinterpret_cast<MoveArgs*>(out->args);
   SpanHead& h = a.head;
   MoveTables& t = a.t;
@@ -762,6 +717,16 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   t.n_keys = plan.n_keys;
   t.n_rows = plan.n_rows;
   t.seq_len = plan.seq_len < 1 ? 1 : plan.seq_len;
+  // Context-only keys (gather): key k moves the first key_len[k] steps of every
+  // sequence into a (n_seq, key_len[k], rowbytes) array.
+  bool heads = false;
+  for (int k = 0; k < plan.n_keys; ++k) {
+    if (plan.key_len[k] < 0 || plan.key_len[k] > t.seq_len) return hipErrorInvalidValue;
+    heads = heads || (plan.key_len[k] > 0 && plan.key_len[k] < t.seq_len);
+  }
+  if (heads && (!gather || plan.n_rows % t.seq_len != 0 || plan.mask_bits || plan.inline_key >= 0))
+    return hipErrorInvalidValue;
+  const int64_t n_seq = plan.n_rows / t.seq_len;
   t.key_is_first = plan.key_is_first;
   t.key_is_last = plan.key_is_last;
   t.is_first_pool = plan.is_first_pool;
@@ -790,13 +755,14 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   } else if (plan.inline_key >= 0) {
     return hipErrorInvalidValue;
   }
-  t.xcd_remap = variant.remap;
   t.mask_bits = plan.mask_bits;
   t.mask_flags = plan.mask_flags;
   if (plan.mask_bits && !plan.mask_flags) return hipErrorInvalidValue;
   int64_t blocks = 0;
   for (int k = 0; k < plan.n_keys; ++k) {
     t.key[k] = plan.key[k];
+    t.key_len[k] = heads && plan.key_len[k] > 0 ? plan.key_len[k] : t.seq_len;
+    t.key_rows[k] = heads ? static_cast<int32_t>(n_seq * t.key_len[k]) : plan.n_rows;
     t.mask_dtype[k] = plan.mask_dtype[k];
     t.mask_out[k] = plan.mask_out[k];
     const bool masked = (plan.mask_bits >> k) & 1u;
@@ -809,21 +775,22 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
     t.first_block[k] = static_cast<int32_t>(blocks);
     if (t.unit[k] == 0 && span_path) {
       // tiles of threads * unroll units per sequence; no virtual blocks
-      const int64_t per_seq = static_cast<int64_t>(t.seq_len) * (plan.key[k].rowbytes >> 4);
+      const int64_t per_seq = static_cast<int64_t>(t.key_len[k]) * (plan.key[k].rowbytes >> 4);
       const int64_t tps = (per_seq + threads * unroll - 1) / (threads * unroll);
       const int64_t first = h.ntiles;
       if (per_seq > UINT32_MAX / 2 || first + tps * plan.n_seq > UINT32_MAX / 2) return hipErrorInvalidValue;
       h.key[h.n_wide] = plan.key[k];
       h.tiles_per_seq[h.n_wide] = static_cast<uint32_t>(tps);
+      h.units_per_seq[h.n_wide] = static_cast<uint32_t>(per_seq);
       h.tile0[h.n_wide] = static_cast<uint32_t>(first);
       h.ntiles = static_cast<uint32_t>(first + tps * plan.n_seq);
       ++h.n_wide;
     } else if (t.unit[k] == 0) {
-      const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes >> 4);
+      const int64_t units = static_cast<int64_t>(t.key_rows[k]) * (plan.key[k].rowbytes >> 4);
       if (units > UINT32_MAX / 2) return hipErrorInvalidValue;
       blocks += (units + threads * unroll - 1) / (threads * unroll);
     } else {
-      const int64_t units = static_cast<int64_t>(plan.n_rows) * (plan.key[k].rowbytes / t.unit[k]);
+      const int64_t units = static_cast<int64_t>(t.key_rows[k]) * (plan.key[k].rowbytes / t.unit[k]);
       blocks += (units + threads - 1) / threads;
     }
     if (blocks > INT32_MAX) return hipErrorInvalidValue;
@@ -831,26 +798,14 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
   t.first_block[plan.n_keys] = static_cast<int32_t>(blocks);
   out->blocks = static_cast<uint32_t>(blocks);
   if (span_path) {
-    // As many workers as the chip takes at once.  EMB_SPAN_BALANCE=1 trims the
-    // count so that every worker walks the same number of tiles (round 2/3's
-    // default with 512-thread workgroups: 896 tiles = 448 workers x 2 rounds
-    // instead of 512 x 1.75); with four 256-thread workgroups per CU the full
-    // count is faster (B=16: 10.1 against 10.8 us).
-    static const bool balance = [] {
-      const char* e = emb::knob("EMB_SPAN_BALANCE");
-      return e && e[0] == '1';
-    }();
-    int64_t workers = std::min<int64_t>(h.ntiles, int64_t(compute_units()) * sv.per_cu);
-    if (balance && workers > 0) {
-      const int64_t rounds = (h.ntiles + workers - 1) / workers;
-      workers = (h.ntiles + rounds - 1) / rounds;
-    }
+    // As many workers as the chip takes at once (trimming the count so that
+    // every worker walks the same number of tiles was slower with this shape:
+    // B=16 10.8 against 10.1 us).
+    const int64_t workers = std::min<int64_t>(h.ntiles, int64_t(compute_units()) * kSpanPerCU);
     h.wide_workers = static_cast<int32_t>(workers);
     h.seq_len = t.seq_len;
     if (blocks + h.wide_workers > INT32_MAX) return hipErrorInvalidValue;
     out->blocks = static_cast<uint32_t>(blocks + h.wide_workers);
-  } else if (variant.persist > 0 && blocks > 256ll * variant.persist) {
-    out->blocks = 256u * variant.persist;
   }
   out->threads = static_cast<uint32_t>(threads);
   return hipSuccess;
@@ -870,16 +825,9 @@ hipError_t launch_marker(hipStream_t stream, hipEvent_t stop) {
 hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t stream,
                               hipEvent_t stop) {
   const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
-  // EMB_ARGS_WRITERS=8 puts one writer on every XCD (workgroup b runs on XCD
-  // b % 8), so the block is in every XCD's L2 when the mover asks for it:
-  // measured -0.15 us on the gather and +3.2 us on this kernel (eight PCIe
-  // readers), so one writer is the default.
-  static const int writers = [] {
-    const char* e = emb::knob("EMB_ARGS_WRITERS");
-    const int n = e ? std::atoi(e) : 1;
-    return n >= 1 && n <= 64 ? n : 1;
-  }();
-  hipExtLaunchKernelGGL(args_writer_kernel, dim3(writers), dim3(256), 0, stream, nullptr, stop, 0, a,
+  // (One writer: one on every XCD -- the block then is in every L2 when the mover
+  // asks for it -- measured -0.15 us on the gather and +3.2 us on this kernel.)
+  hipExtLaunchKernelGGL(args_writer_kernel, dim3(1), dim3(256), 0, stream, nullptr, stop, 0, a,
                         static_cast<u32x4*>(device_dst));
   return hipGetLastError();
 }
@@ -887,54 +835,26 @@ hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStr
 hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device_args,
                        hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
   if (launch.blocks == 0) return hipSuccess;
-  const MoveVariant& variant = move_variant();
   const MoveArgs& a = *reinterpret_cast<const MoveArgs*>(launch.args);
   const MoveArgs* ap = static_cast<const MoveArgs*>(device_args);
   const dim3 grid(launch.blocks), block(launch.threads);
+#define EMB_LAUNCH(BYVALUE_, INDIRECT_)                                                              \
+  do {                                                                                               \
+    if (ap) hipExtLaunchKernelGGL(INDIRECT_, grid, block, 0, stream, start, stop, 0, ap);            \
+    else hipExtLaunchKernelGGL(BYVALUE_, grid, block, 0, stream, start, stop, 0, a);                 \
+  } while (0)
   if (launch.span) {
-    const SpanVariant& sv = span_variant();
-#define EMB_SPAN(G_, U_, NT_)                                                                       \
-  do {                                                                                              \
-    if (ap) hipExtLaunchKernelGGL((span_move_kernel_indirect<G_, U_, NT_>), grid, block, 0, stream, start, stop, 0, ap); \
-    else hipExtLaunchKernelGGL((span_move_kernel<G_, U_, NT_>), grid, block, 0, stream, start, stop, 0, a);             \
-  } while (0)
-#define EMB_SPAN_NT(G_, U_)                                                      \
-  switch (launch.nt) {                                                           \
-    case 0: EMB_SPAN(G_, U_, 0); break;                                          \
-    case 1: EMB_SPAN(G_, U_, 1); break;                                          \
-    case 2: EMB_SPAN(G_, U_, 2); break;                                          \
-    default: EMB_SPAN(G_, U_, 3); break;                                         \
+    if (!gather) EMB_LAUNCH((span_move_kernel<false, 3>), (span_move_kernel_indirect<false, 3>));
+    else if (launch.nt == 1) EMB_LAUNCH((span_move_kernel<true, 1>), (span_move_kernel_indirect<true, 1>));
+    else EMB_LAUNCH((span_move_kernel<true, 3>), (span_move_kernel_indirect<true, 3>));
+  } else if (launch.stage_tables && !ap) {
+    if (gather) hipExtLaunchKernelGGL((flat_move_kernel_staged<true>), grid, block, 0, stream, start, stop, 0, a);
+    else hipExtLaunchKernelGGL((flat_move_kernel_staged<false>), grid, block, 0, stream, start, stop, 0, a);
+  } else {
+    if (gather) EMB_LAUNCH((flat_move_kernel<true>), (flat_move_kernel_indirect<true>));
+    else EMB_LAUNCH((flat_move_kernel<false>), (flat_move_kernel_indirect<false>));
   }
-    if (gather) { if (sv.unroll == 2) { EMB_SPAN_NT(true, 2) } else { EMB_SPAN_NT(true, 4) } }
-    else { if (sv.unroll == 2) { EMB_SPAN_NT(false, 2) } else { EMB_SPAN_NT(false, 4) } }
-#undef EMB_SPAN_NT
-#undef EMB_SPAN
-    return hipGetLastError();
-  }
-#define EMB_MOVE(U_, NT_)                                                                      \
-  do {                                                                                         \
-    if (gather && ap) hipExtLaunchKernelGGL((gather_kernel_indirect<U_, NT_>), grid, block, 0, stream, start, stop, 0, ap); \
-    else if (gather && launch.stage_tables) hipExtLaunchKernelGGL((gather_kernel_staged<U_, NT_>), grid, block, 0, stream, start, stop, 0, a); \
-    else if (gather) hipExtLaunchKernelGGL((gather_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);            \
-    else if (ap) hipExtLaunchKernelGGL((scatter_kernel_indirect<U_, NT_>), grid, block, 0, stream, start, stop, 0, ap);     \
-    else if (launch.stage_tables) hipExtLaunchKernelGGL((scatter_kernel_staged<U_, NT_>), grid, block, 0, stream, start, stop, 0, a); \
-    else hipExtLaunchKernelGGL((scatter_kernel<U_, NT_>), grid, block, 0, stream, start, stop, 0, a);                       \
-  } while (0)
-#define EMB_MOVE_NT(U_)                                                          \
-  switch (variant.nt) {                                                          \
-    case 0: EMB_MOVE(U_, 0); break;                                              \
-    case 2: EMB_MOVE(U_, 2); break;                                              \
-    case 1: EMB_MOVE(U_, 1); break;                                              \
-    default: EMB_MOVE(U_, 3); break;                                             \
-  }
-  switch (variant.unroll) {
-    case 1: EMB_MOVE_NT(1) break;
-    case 2: EMB_MOVE_NT(2) break;
-    case 4: EMB_MOVE_NT(4) break;
-    default: EMB_MOVE_NT(8) break;
-  }
-#undef EMB_MOVE_NT
-#undef EMB_MOVE
+#undef EMB_LAUNCH
   return hipGetLastError();
 }
 
@@ -942,15 +862,12 @@ hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device
 // it (without namespaces and parameter list).
 const char* move_kernel_name(const MoveLaunch& launch, bool gather, bool indirect) {
   static thread_local char name[96];
-  if (launch.span) {
-    const SpanVariant& sv = span_variant();
-    std::snprintf(name, sizeof(name), "span_move_kernel%s<%s, %d, %d>", indirect ? "_indirect" : "",
-                  gather ? "true" : "false", sv.unroll == 2 ? 2 : 4, launch.nt);
-  } else {
-    const MoveVariant& v = move_variant();
-    std::snprintf(name, sizeof(name), "%s_kernel%s<%d, %d>", gather ? "gather" : "scatter",
-                  indirect ? "_indirect" : launch.stage_tables ? "_staged" : "", v.unroll, v.nt);
-  }
+  if (launch.span)
+    std::snprintf(name, sizeof(name), "span_move_kernel%s<%s, %d>", indirect ? "_indirect" : "",
+                  gather ? "true" : "false", gather ? launch.nt : 3);
+  else
+    std::snprintf(name, sizeof(name), "flat_move_kernel%s<%s>",
+                  indirect ? "_indirect" : launch.stage_tables ? "_staged" : "", gather ? "true" : "false");
   return name;
 }
 
@@ -1130,7 +1047,7 @@ struct PreKey {
 struct PreCarry {
   const uint8_t* src;           // (n, rowbytes); null = nothing carried
   uint8_t* pool;
-  const uint8_t* flags;         // the previous step's is_last, one byte per env
+  const uint8_t* flags;         // the replay's is_last POOL (1-byte rows): the carried step's flag is at its own row
   int32_t rowbytes, dtype, elem, pad;
 };
 struct alignas(16) PreTable {
@@ -1169,7 +1086,10 @@ __device__ __forceinline__ void prewrite_carry(const PreTable& t, const uint32_t
   const int64_t prev = static_cast<int32_t>(gload<uint32_t>(tab + 6 * static_cast<int64_t>(n_envs) + n));
   const int64_t off = static_cast<int64_t>(threadIdx.x) * c.elem;
   if (prev < 0 || off >= c.rowbytes) return;
-  const bool keep = gload<uint8_t>(c.flags + n) == 0;
+  // The carried step's is_last as the replay stored it (written by that step's
+  // own early-insert launch, earlier on this stream) -- not the env's output
+  // buffer, which an env with one output set has overwritten by now.
+  const bool keep = gload<uint8_t>(c.flags + prev) == 0;
   const uint8_t* src = c.src + n * c.rowbytes + off;
   uint8_t* pool = c.pool + prev * c.rowbytes + off;
   switch (c.dtype) {
@@ -1309,11 +1229,15 @@ __global__ __launch_bounds__(kThreads) void publish_one_kernel(
   const int64_t r = e / epr;
   const int64_t off = (e - r * epr) * a.elem;
   const int64_t row = a.rows[r];
-  const bool keep = !a.flags || gload<uint8_t>(a.flags + r) == 0;
+  // dtype bit 8: `flags` is a pool of 1-byte rows, the flag of batch row r sits
+  // at its pool row (a carried publish settled late, abi.cpp settle_carry).
+  const bool by_row = (a.dtype & 0x100) != 0;
+  const bool keep = !a.flags || (by_row ? row < 0 || gload<uint8_t>(a.flags + row) == 0
+                                        : gload<uint8_t>(a.flags + r) == 0);
   const uint8_t* src = a.src + r * a.rowbytes + off;
   uint8_t* pool = row >= 0 ? a.pool + row * a.rowbytes + off : nullptr;
   uint8_t* out = a.out ? a.out + r * a.rowbytes + off : nullptr;
-  switch (a.dtype) {
+  switch (a.dtype & 0xFF) {
     case kU8: case kBool: put_masked<uint8_t>(src, pool, out, keep); break;
     case kI8: put_masked<int8_t>(src, pool, out, keep); break;
     case kI16: put_masked<int16_t>(src, pool, out, keep); break;
@@ -1776,21 +1700,13 @@ hipError_t launch_scan(const Op& op, hipStream_t stream) {
     });
     return hipGetLastError();
   }
-  // EMB_SCAN_FORM=1: the one-element-per-lane kernel (A/B against rows4).
-  static const bool one_per_lane = [] {
-    const char* e = emb::knob("EMB_SCAN_FORM");
-    return e && e[0] == '1';
-  }();
   // Short rows in small batches (Dreamer's imagined returns, (1024, 16)) stay
   // with one element per lane: 64 workgroups instead of 16, 3.4 us against 3.7.
-  if (one_per_lane || (n <= 16 && B <= 8192)) {
-    const int W = n <= 16 ? 16 : n <= 32 ? 32 : 64;
-    const int64_t rows_per_block = kThreads / W;
+  if (n <= 16 && B <= 8192) {
+    const int64_t rows_per_block = kThreads / 16;
     const dim3 grid(static_cast<uint32_t>((B + rows_per_block - 1) / rows_per_block));
     op.unpack([&](auto... a) {
-      if (W == 16) hipLaunchKernelGGL((scan_rows_kernel<16, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...);
-      else if (W == 32) hipLaunchKernelGGL((scan_rows_kernel<32, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...);
-      else hipLaunchKernelGGL((scan_rows_kernel<64, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...);
+      hipLaunchKernelGGL((scan_rows_kernel<16, Op, decltype(a)...>), grid, dim3(kThreads), 0, stream, a...);
     });
     return hipGetLastError();
   }
@@ -2128,11 +2044,7 @@ hipError_t launch_synth_env(uint8_t* image, float* reward, uint8_t* is_first, ui
   a.n_turn = static_cast<int32_t>(n << 1 | (turn & 1));
   // A frame over a few workgroups: 64 envs x 4 = one workgroup per CU.
   const int64_t vecs = frame_bytes >> 4;
-  static const int64_t per_env = [] {       // EMB_SYNTH_BLOCKS: workgroups per env (A/B)
-    const char* e = emb::knob("EMB_SYNTH_BLOCKS");
-    const int64_t v = e ? std::atoll(e) : 4;
-    return v >= 1 && v <= 64 ? v : 4;
-  }();
+  constexpr int64_t per_env = 4;
   const uint32_t gx = static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(per_env, vecs / kThreads)));
   const dim3 grid(gx, static_cast<uint32_t>(n));
   const int64_t base = reinterpret_cast<int64_t>(reward);
@@ -2223,7 +2135,7 @@ hipError_t launch_obs_stack_insert(const PrewritePlan& p, hipStream_t stream, hi
 
 hipError_t launch_publish_one(const void* src, void* pool, void* out, const int32_t* rows_dev,
                               const uint8_t* flags, int64_t n, int64_t rowbytes, int dtype,
-                              hipStream_t stream, hipEvent_t stop) {
+                              hipStream_t stream, hipEvent_t stop, bool flags_by_row) {
   if (n <= 0 || rowbytes <= 0) return hipSuccess;
   PublishArgs a;
   a.src = static_cast<const uint8_t*>(src);
@@ -2234,7 +2146,7 @@ hipError_t launch_publish_one(const void* src, void* pool, void* out, const int3
   a.n = static_cast<int32_t>(n);
   a.rowbytes = static_cast<int32_t>(rowbytes);
   if (flags) {
-    a.dtype = dtype;
+    a.dtype = dtype | (flags_by_row ? 0x100 : 0);
     a.elem = dtype_size(dtype);
     if (a.elem == 0 || rowbytes % a.elem) return hipErrorInvalidValue;
   } else {

@@ -92,45 +92,10 @@ def _device(*xs):
       'embodied_amd.scans run as HIP kernels: pass CUDA tensors (no CPU fallback)')
 
 
-_PAIRS = {}
-_STORAGE_USE_COUNT = getattr(torch._C, '_storage_Use_Count', None)
-# Opt-in (EMB_SAMPLE_POOL=1, as for Replay.sample): result pairs that nobody
-# references any more are found through private torch internals and used again.
-# The explicit form is `gae(..., out=(adv, tar))`.
-_POOL = os.environ.get('EMB_SAMPLE_POOL') == '1'
-if _POOL and (_STORAGE_USE_COUNT is None or not hasattr(torch.Tensor, '_use_count')):
-  raise RuntimeError('EMB_SAMPLE_POOL=1 needs torch._C._storage_Use_Count and Tensor._use_count')
-_PROBE = [object()]
-_HELD = sys.getrefcount(_PROBE[0])
-
-
 def _pair(B, n, dev):
-  """Two fresh (B, n) float32 results out of one (2, B, n) allocation.  Sets that
-  nobody references any more (Python reference counts of both views, holders of
-  the storage, C++ owners of the views such as a DLPack consumer) are handed out again instead of allocating: to the caller they
-  are indistinguishable from new tensors, and the host saves the allocation and
-  the two view constructions (~3 us of a ~6 us call)."""
-  if not _POOL:
-    return _lib.empty((2, B, n), torch.float32, dev).unbind(0)
-  key = (B, n, dev, _lib.raw_stream(dev))
-  sets = _PAIRS.get(key)
-  if sets is None:
-    if len(_PAIRS) > 64:
-      _PAIRS.clear()
-    sets = _PAIRS[key] = []
-  for views, cdata, _ in sets:
-    # holders of the storage: the (2, B, n) base, its two views, our handle
-    if (sys.getrefcount(views[0]) == _HELD and sys.getrefcount(views[1]) == _HELD
-        and _STORAGE_USE_COUNT(cdata) == 4
-        and views[0]._use_count() == 1 and views[1]._use_count() == 1):
-      return views[0], views[1]
-  both = _lib.empty((2, B, n), torch.float32, dev)
-  adv, tar = both.unbind(0)
-  if len(sets) < 4:
-    store = both.untyped_storage()
-    if _STORAGE_USE_COUNT(store._cdata) == 4:
-      sets.append(([adv, tar], store._cdata, (both, store)))
-  return adv, tar
+  """Two fresh (B, n) float32 results out of one (2, B, n) allocation (`out=`
+  is the form without an allocation)."""
+  return _lib.empty((2, B, n), torch.float32, dev).unbind(0)
 
 
 def gae(rew, val, last, term, hor=200, lam=0.8, out=None):

@@ -31,7 +31,8 @@ extern "C" {
 /* 3 (round 4): + emb_configure, emb_scan_lambda_multi, emb_replay_carry_publish,
  * emb_replay_settle; emb_replay_profile_report which = 3.  Additions only: a
  * caller written against version 2 runs unchanged.                             */
-#define EMB_ABI_VERSION 3
+/* 4 (round 5): + emb_replay_sample_heads.  Additions only.                      */
+#define EMB_ABI_VERSION 4
 
 #define EMB_OK 0
 #define EMB_ERR_INVALID (-1)   /* bad argument / state                         */
@@ -274,15 +275,32 @@ int32_t emb_replay_publish(emb_replay_t* rep, int64_t n, const int64_t* workers,
  * emb_replay_obs_stack_insert launch on the same stream, or by a launch of its
  * own before any other call reads or writes the pool (sample, update, add,
  * gather / scatter rows, chunk bookkeeping, grow all settle it first).
- * Contract while it is enabled: the key's source buffer and the is_last flags of
- * a publish stay unchanged until the next call on this replay that launches
- * (its early insert, or anything that settles).  emb_replay_settle(rep) settles
- * explicitly (before the caller moves the pool, reads it directly or frees the
- * source).  Results are identical to an immediate publish.                      */
+ * Contract while it is enabled: the key's source buffer of a publish stays
+ * unchanged until the next call on this replay that launches (its early insert,
+ * or anything that settles).  The is_last flags need not: a publish is carried
+ * only when the step's early insert stored that very flag buffer as the
+ * replay's `is_last` key, and the mask then reads the stored rows -- an env that
+ * rewrites its flag outputs in place on the next step is fine.
+ * emb_replay_settle(rep) settles explicitly (before the caller moves the pool,
+ * reads it directly or frees the source).  Results are identical to an
+ * immediate publish.                                                            */
 int32_t emb_replay_carry_publish(emb_replay_t* rep, int32_t enable);
 int32_t emb_replay_settle(emb_replay_t* rep);
 int32_t emb_replay_sample(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
                           uint8_t* online_out, uint8_t* first_stepids_out, void* stream);
+/* The same with per-key head lengths: key k receives only the first
+ * key_len[k] steps of every sampled sequence, dst[k] is (batch, key_len[k],
+ * rowbytes[k]); 0 (or `length`) = the whole sequence, key_len NULL = all whole.
+ * For keys whose consumer reads only the head of the window -- the reference's
+ * DreamerV3 takes x[:, :K] (K = replay_context) of the sampled enc/ dyn/ dec/
+ * latents (dreamerv3/agent.py:322-331) and its _assemble_batch already copies a
+ * [start, stop) sub-range (embodied/core/replay.py:255-275).  Index draws,
+ * PRNG stream and the is_first / is_last annotation (computed over the whole
+ * sequence, then cut) are those of emb_replay_sample: every key equals the
+ * full sample's [:, :key_len[k]].                                              */
+int32_t emb_replay_sample_heads(emb_replay_t* rep, int64_t batch, int32_t mode, void* const* dst,
+                                const int32_t* key_len, uint8_t* online_out,
+                                uint8_t* first_stepids_out, void* stream);
 /* The same with the batch side cut into groups of `group` sequences whose
  * starts are `group_stride` bytes (a multiple of 16) apart: dst[k] is key k's
  * place inside group 0, sequence s of key k lands at dst[k] + (s / group) *

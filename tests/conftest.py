@@ -19,9 +19,8 @@ _build = importlib.util.module_from_spec(_spec)         # its __init__ needs the
 _spec.loader.exec_module(_build)
 import os  # noqa: E402
 os.environ.setdefault('EMB_STRICT_SCRATCH', '1')   # this repo's own builds: no kernel may spill
-# The suite runs on the PRODUCT's default placement of kernel arguments (host
-# memory: embodied_amd/__init__.py and bench.py set the same value; set here too
-# because test modules import torch before the package).  The HIP runtime's own
+# The suite runs on the placement of kernel arguments that bench.py chooses (host
+# memory; the package itself sets nothing).  The HIP runtime's own
 # default (device memory, HIP_FORCE_DEV_KERNARG=1) is covered by child processes
 # in tests/test_gpu_host_kernargs.py.
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '0')

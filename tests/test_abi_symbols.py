@@ -29,7 +29,7 @@ def test_binding_covers_every_declared_symbol():
 
 def test_version_and_device_probe():
   from embodied_amd import _lib
-  assert _lib.lib.emb_abi_version() == 3
+  assert _lib.lib.emb_abi_version() == 4
   assert _lib.device_count() >= 0
 
 
@@ -158,22 +158,24 @@ def test_plain_c_program_against_the_abi(tmp_path):
   assert lines[1] == 'replay: 50 items; sampled workers 0 1 2 2'
 
 
-def test_import_chooses_host_resident_kernel_arguments_unless_told_otherwise():
-  """embodied_amd/__init__.py: HIP_FORCE_DEV_KERNARG defaults to 0 for the
-  process (the HIP runtime reads it at its first API call); a value the process
-  already has is left alone."""
+def test_import_leaves_the_process_alone():
+  """Importing the package changes neither the environment (the placement of
+  kernel arguments, HIP_FORCE_DEV_KERNARG, is the host program's choice) nor the
+  CPU affinity of the process."""
   import os
   import subprocess
   import sys
-  code = ('import os, embodied_amd; '
-          'print(os.environ["HIP_FORCE_DEV_KERNARG"])')
+  code = ('import os\n'
+          'before = (dict(os.environ), os.sched_getaffinity(0))\n'
+          'import embodied_amd\n'
+          'print(before == (dict(os.environ), os.sched_getaffinity(0)))')
   base = {k: v for k, v in os.environ.items() if k != 'HIP_FORCE_DEV_KERNARG'}
-  for given, want in ((None, '0'), ('1', '1'), ('0', '0')):
+  for given in (None, '1', '0'):
     env = dict(base) if given is None else dict(base, HIP_FORCE_DEV_KERNARG=given)
     out = subprocess.run([sys.executable, '-c', code], env=env, cwd=str(ROOT),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.strip().splitlines()[-1] == want, (given, out.stdout)
+    assert out.stdout.strip().splitlines()[-1] == 'True', (given, out.stdout)
 
 
 def test_knobs_are_set_before_their_first_use_or_not_at_all():
@@ -188,8 +190,8 @@ import os
 os.environ["EMB_WHERE_BACKLOG"] = "65536"
 import embodied_amd as emb
 from embodied_amd import _lib
-emb.configure(EMB_WHERE_BACKLOG=7, EMB_SPAN_VARIANT="4,1")
-emb.configure(EMB_SPAN_VARIANT=None)                       # withdrawn again
+emb.configure(EMB_WHERE_BACKLOG=7, EMB_GATHER_STORES="plain")
+emb.configure(EMB_GATHER_STORES=None)                      # withdrawn again
 import numpy as np
 sel = emb.selectors.Prioritized(exponent=0.8, initial=1.0, seed=0)
 sel[0] = np.arange(60, dtype=np.uint8).reshape(3, 20)
@@ -205,9 +207,22 @@ try:
   print("name: accepted")
 except ValueError as e:
   print("name: refused")
+# the knobs the Python layer reads go the same way (one accessor, _lib.knob)
+os.environ["EMB_EARLY_INSERT"] = "1"
+emb.configure(EMB_EARLY_INSERT=0)
+from embodied_amd.core import driver as driverlib
+from embodied_amd.envs import dummy
+d = emb.Driver([lambda: dummy.Dummy("disc")], parallel=False)
+print("python knob:", driverlib._EARLY_INSERT, driverlib._CARRY)
+try:
+  emb.configure(EMB_EARLY_INSERT=1)
+  print("python late: accepted")
+except ValueError as e:
+  print("python late: refused", "already in effect" in str(e))
 '''
   out = subprocess.run([sys.executable, '-c', code], cwd=str(ROOT), capture_output=True, text=True,
                        timeout=300)
   assert out.returncode == 0, out.stderr[-2000:]
   lines = out.stdout.strip().splitlines()
-  assert lines[-2:] == ['late: refused True', 'name: refused'], out.stdout
+  assert lines[-4:] == ['late: refused True', 'name: refused', 'python knob: False True',
+                        'python late: refused True'], out.stdout

@@ -48,7 +48,7 @@ def _fake_host(monkeypatch, bench, busy_cpus, n=32):
 
 def test_ranks_take_distinct_idle_windows(bench, monkeypatch):
   chosen = _fake_host(monkeypatch, bench, busy_cpus={0, 1, 2, 3, 9})
-  monkeypatch.delenv('EMB_BENCH_PIN', raising=False)
+  monkeypatch.setattr(bench.sys, 'argv', ['bench.py'])
   picks = []
   for rank in range(4):
     monkeypatch.setenv('LOCAL_RANK', str(rank))
@@ -60,11 +60,11 @@ def test_ranks_take_distinct_idle_windows(bench, monkeypatch):
 
 def test_pin_knobs(bench, monkeypatch):
   chosen = _fake_host(monkeypatch, bench, busy_cpus=set())
-  monkeypatch.setenv('EMB_BENCH_PIN', '0')
+  monkeypatch.setattr(bench.sys, 'argv', ['bench.py', '--pin', '0'])
   assert bench.pin_cpus() is None and chosen == []
-  monkeypatch.setenv('EMB_BENCH_PIN', '10-13')
+  monkeypatch.setattr(bench.sys, 'argv', ['bench.py', '--pin=10-13'])
   assert bench.pin_cpus() == [10, 11, 12, 13]
-  monkeypatch.setenv('EMB_BENCH_PIN', 'auto')
+  monkeypatch.setattr(bench.sys, 'argv', ['bench.py', '--pin', 'auto'])
   monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(8)), raising=False)
   assert bench.pin_cpus() is None          # a small host (this container): left alone
 

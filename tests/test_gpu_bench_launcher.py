@@ -30,8 +30,7 @@ def run_bench(*flags, env=None):
 
 
 def test_bench_gpus_2_spawns_two_ranks():
-  rec = run_bench('--gpus', '2', '--steps', '20', '--warmup', '5',
-                  env={'EMB_BENCH_BACKEND': 'gloo'})
+  rec = run_bench('--gpus', '2', '--steps', '20', '--warmup', '5', '--backend', 'gloo')
   assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['backend'] == 'gloo'
   assert rec['steps'] == 20 and rec['warmup'] == 5
   assert rec['config']['global_envs'] == 2 * rec['config']['envs_per_gpu']
@@ -55,7 +54,7 @@ def test_bench_gpus_2_native_exchange_between_two_real_ranks():
   lib = str(mod.build())
   rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
                   '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
-                  env={'EMB_BENCH_BACKEND': 'gloo', 'EMB_RCCL_LIB': lib})
+                  '--backend', 'gloo', env={'EMB_RCCL_LIB': lib})
   assert rec['n_gpus'] == 2 and rec['backend'] == 'gloo'
   native = rec['native_comm']
   assert native['status'] == 'ok' and native['ranks'] == 2 and all(native['checks'].values()), native
@@ -73,8 +72,7 @@ def test_bench_gpus_8_control_flow():
   agree on their exchange schedule at every fence and rank 0 prints one line
   (gloo: the eight ranks share the test box's one GPU)."""
   rec = run_bench('--gpus', '8', '--steps', '20', '--warmup', '5', '--capacity', '6000',
-                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '10',
-                  env={'EMB_BENCH_BACKEND': 'gloo'})
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '10', '--backend', 'gloo')
   assert rec['n_gpus'] == 8 and rec['rccl_ranks'] == 8 and rec['backend'] == 'gloo'
   assert rec['config']['global_envs'] == 8 * rec['config']['envs_per_gpu']
   assert rec['scaling'] == 'weak' and rec['value'] > 0 and rec['train_steps_per_s'] > 0
@@ -86,8 +84,7 @@ def test_bench_dreamer_workload_with_ranks():
   """configs[3]'s shape of parallelism: per-rank Replay (sample, lambda-return,
   latent write-back) and one gradient all-reduce per train step."""
   rec = run_bench('--gpus', '2', '--workload', 'dreamer', '--capacity', '20000', '--steps', '40',
-                  '--warmup', '5', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
-                  env={'EMB_BENCH_BACKEND': 'gloo'})
+                  '--warmup', '5', '--sustained-seconds', '1', '--prewarm-train-steps', '20', '--backend', 'gloo')
   assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2
   assert 'per-rank Replay' in rec['config']['parallelism']
   assert 'lambda-return' in rec['config']['workload']
@@ -98,7 +95,7 @@ def test_bench_checks_the_native_collectives_when_it_runs_on_rccl():
   """With RCCL as the transport the line carries `native_comm`: the emb_comm_*
   entry points against torch.distributed on the same GPUs (one rank here)."""
   rec = run_bench('--steps', '200', '--warmup', '50', '--sustained-seconds', '0', '--no-cpu-baseline',
-                  '--no-context', env={'EMB_BENCH_FORCE_DIST': '1'})
+                  '--no-context', '--force-dist')
   assert rec['backend'] == 'nccl' and rec['rccl_ranks'] == 1
   native = rec['native_comm']
   assert native['status'] == 'ok' and all(native['checks'].values()), native
@@ -114,11 +111,10 @@ def test_bench_checks_the_native_collectives_when_it_runs_on_rccl():
 
 def test_bench_comm_c10d_keeps_torch_distributed_in_the_timed_path():
   rec = run_bench('--steps', '200', '--warmup', '50', '--sustained-seconds', '0', '--no-cpu-baseline',
-                  '--no-context', '--comm', 'c10d', env={'EMB_BENCH_FORCE_DIST': '1'})
+                  '--no-context', '--comm', 'c10d', '--force-dist')
   assert 'native_comm' not in rec and 'torch.distributed' in rec['config']['parallelism']
   rec = run_bench('--steps', '200', '--warmup', '50', '--sustained-seconds', '0', '--no-cpu-baseline',
-                  '--no-context', '--workload', 'dreamer', '--capacity', '20000',
-                  env={'EMB_BENCH_FORCE_DIST': '1'})
+                  '--no-context', '--workload', 'dreamer', '--capacity', '20000', '--force-dist')
   assert rec['native_comm']['timed_path'] == 'native' and rec['train_steps_per_s'] > 0
 
 
@@ -147,22 +143,45 @@ def test_default_single_gpu_run_appends_the_dreamer_workload():
   rec = run_bench('--steps', '20', '--warmup', '5', '--sustained-seconds', '0', '--no-cpu-baseline',
                   '--no-context', '--dreamer-leg-steps', '400')
   assert rec['config']['workload'].startswith('ppo_atari_pong_64env')     # metric / value unchanged
-  assert 'span_move_kernel' in rec['roofline']['kernel'] or 'gather_kernel' in rec['roofline']['kernel']
+  assert 'span_move_kernel' in rec['roofline']['kernel'] or 'flat_move_kernel' in rec['roofline']['kernel']
   leg = rec['workloads']['dreamer']
   assert 'error' not in leg, leg
   assert 'dreamerv3_1M_uniform' in leg['workload'] and 'capacity=1000000' in leg['workload']
   assert leg['env_steps_per_s'] > 0 and leg['train_steps_per_s'] > 0
-  assert leg['gather']['bytes_per_launch'] == 2 * 16 * 65 * (28255 + 40960)
+  # the replay-context latents as the shipped agent reads them: K = 1 step of them per sequence
+  assert leg['gather']['bytes_per_launch'] == 2 * 16 * (65 * 28255 + 1 * 40960)
   assert 0 < leg['gather']['frac'] < 1 and leg['gather']['launches'] >= 1
-  assert leg['writeback']['bytes_per_launch'] == 2 * 16 * 65 * 40960
+  assert leg['writeback']['bytes_per_launch'] == 2 * 16 * 65 * 40960       # every step is written back
   assert 0 < leg['writeback']['frac'] < 1 and 'Replay.update' in leg['writeback']['kernel']
+  full = leg['full_gather']                      # ... and all L steps of them, as rounds 1-4 measured
+  assert 'error' not in full, full
+  assert full['gather']['bytes_per_launch'] == 2 * 16 * 65 * (28255 + 40960)
+  assert full['env_steps_per_s'] > 0 and 0 < full['gather']['frac'] < 1
+
+
+def test_short_form_value_is_the_median_of_sixteen_regions():
+  """`--steps 20` (the driver's form): sixteen fenced regions of exactly 20 steps,
+  `value` = the median one; every region's time is in the line."""
+  rec = run_bench('--steps', '20', '--warmup', '5', '--sustained-seconds', '0', '--no-cpu-baseline',
+                  '--no-context', '--no-dreamer-leg')
+  regions = rec['regions']
+  assert regions['n'] == 16 and len(regions['ms']) == 16 and len(regions['train_steps']) == 16
+  assert rec['steps'] == 20
+  ms = sorted(regions['ms'])
+  assert abs(rec['ms_per_step'] * 20 - ms[7]) < 1e-3           # the lower median, a measured region
+  rates = regions['env_steps_per_s']
+  assert rates['min'] <= rates['median'] <= rates['max'] and rates['median'] == rec['value']
+  assert abs(rec['value'] - 20 * 64 / (ms[7] * 1e-3)) / rec['value'] < 1e-3
+  long = run_bench('--steps', '300', '--warmup', '5', '--sustained-seconds', '0', '--no-cpu-baseline',
+                   '--no-context', '--no-dreamer-leg')
+  assert long['regions']['n'] == 1
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():
   import torch
   want = torch.cuda.device_count() + 1
   env = {k: v for k, v in os.environ.items()
-         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'EMB_BENCH_BACKEND')}
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', )}
   res = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(want)], cwd=ROOT,
                        env=env, capture_output=True, text=True, timeout=300)
   assert res.returncode != 0 and 'GPU' in (res.stderr + res.stdout)

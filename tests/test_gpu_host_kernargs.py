@@ -32,11 +32,11 @@ def test_parity_with_kernel_arguments_in_device_memory():
 
 
 def test_parity_with_the_flat_mover_only():
-  """EMB_SPAN_VARIANT=...,0 switches the persistent span mover off (the knob is
+  """EMB_SPAN_MOVER=0 switches the persistent span mover off (the knob is
   read once per process): sample, windowing, write-back and the grouped
   (per-destination-rank) layout must give the same bytes through the flat mover,
   which is what moves > 40 MB launches with device-resident arguments."""
-  env = dict(os.environ, EMB_SPAN_VARIANT='4,3,512,0')
+  env = dict(os.environ, EMB_SPAN_MOVER='0')
   res = subprocess.run(
       [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-m', 'gpu', '-q', '-x',
        '-k', 'golden or full_size or span_mover or fused_sample or grouped or update_table '

@@ -1,10 +1,8 @@
 """Who owns a sampled batch.  `Replay.sample` returns tensors the caller owns,
 like the reference's fresh arrays (embodied/core/replay.py:255-275).  Reuse of
 output tensors is explicit -- `Replay.recycle`, `sample(out=)`,
-`streams.Stateless(recycle=K)`, `scans.gae(out=)`, `Replay(reuse_outputs=K)` --
-or, opt-in, found through private torch internals (EMB_SAMPLE_POOL=1), whose
-meaning is pinned here so that a torch upgrade fails THIS test instead of
-silently handing a live batch out twice."""
+`streams.Stateless(recycle=K)`, `scans.gae(out=)`, `Replay(reuse_outputs=K)`:
+nothing is found out behind the caller's back."""
 import numpy as np
 import pytest
 import torch
@@ -28,7 +26,6 @@ def _filled(emb, **kw):
 
 def test_fresh_tensors_by_default(emb):
   rep = _filled(emb)
-  assert rep._out_pool is None
   seen, kept = set(), []
   for _ in range(6):
     batch = rep.sample(5)
@@ -137,91 +134,3 @@ def test_gae_into_caller_owned_tensors(emb):
   assert len({a.data_ptr() for a, _ in fresh}) == 3
   with pytest.raises(ValueError):
     emb.scans.gae(*args, out=(adv[:, :5], tar))
-
-
-def test_private_torch_internals_mean_what_the_opt_in_pool_assumes():
-  """EMB_SAMPLE_POOL=1 decides from sys.getrefcount, torch._C._storage_Use_Count
-  and Tensor._use_count that a batch is dead.  If a torch release removes them
-  or changes what they count, this test -- not a training run -- says so."""
-  import sys
-  uses = getattr(torch._C, '_storage_Use_Count', None)
-  assert uses is not None, 'torch._C._storage_Use_Count is gone: EMB_SAMPLE_POOL=1 cannot work'
-  assert hasattr(torch.Tensor, '_use_count'), 'Tensor._use_count is gone: EMB_SAMPLE_POOL=1 cannot work'
-  t = torch.empty(64, device='cuda')
-  store = t.untyped_storage()
-  assert uses(store._cdata) == 2                          # the tensor + this handle
-  view = t[:8]
-  assert uses(store._cdata) == 3                          # a view is a holder
-  alias = t.detach()
-  assert uses(store._cdata) == 4                          # so is a detached alias
-  del view, alias
-  assert uses(store._cdata) == 2
-  assert t._use_count() == 1
-  capsule = t.__dlpack__()
-  assert t._use_count() == 2                              # a DLPack consumer owns the tensor in C++
-  del capsule
-  assert t._use_count() == 1
-  box = [object()]
-  held = sys.getrefcount(box[0])
-  tensors = [torch.empty(4, device='cuda')]
-  alone = sys.getrefcount(tensors[0])                     # (outside `assert`: pytest's rewriting
-  extra = tensors[0]                                      # keeps sub-expressions alive in temporaries)
-  shared = sys.getrefcount(tensors[0])
-  del extra
-  assert alone == held and shared == held + 1             # only the list holds it / one more holder
-
-
-def test_opt_in_pool_reuses_only_unreferenced_sets(emb, monkeypatch):
-  """EMB_SAMPLE_POOL=1: `sample` hands an output set out again once nobody
-  references it.  Held batches, views, detached tensors and DLPack capsules keep
-  their set out of rotation; a reused 'stepid' tensor never carries the
-  first-step ids of an older batch into `update`."""
-  monkeypatch.setenv('EMB_SAMPLE_POOL', '1')
-  rep = _filled(emb)
-  monkeypatch.delenv('EMB_SAMPLE_POOL')
-  assert rep._out_pool is not None
-  # batches dropped at once are served from ONE set: nothing is allocated after the first
-  made, plain = [0], rep._new_batch
-  def counting(*a):
-    made[0] += 1
-    return plain(*a)
-  rep._new_batch = counting
-  for _ in range(10):
-    rep.sample(5)
-  assert made[0] == 1, made
-  del rep._new_batch
-  held = rep.sample(5)
-  snapshot = {k: v.clone() for k, v in held.items()}
-  view = rep.sample(5)['x'][:, :2]              # only a view survives
-  view_copy = view.clone()
-  detached = rep.sample(5)['x'].detach()        # only a detached alias survives
-  detached_copy = detached.clone()
-  leaving = rep.sample(5)['x']                  # only an unconsumed DLPack capsule survives
-  exported_copy, exported_ptr = leaving.clone(), leaving.data_ptr()
-  capsule = leaving.__dlpack__()
-  del leaving
-  ptrs = set()
-  for _ in range(12):                           # dropped at once: these may share storage
-    ptrs.add(rep.sample(5)['x'].data_ptr())
-  assert len(ptrs) <= 4
-  assert exported_ptr not in ptrs
-  assert torch.equal(torch.from_dlpack(capsule), exported_copy)
-  for k, v in held.items():
-    assert torch.equal(v, snapshot[k]), k
-  assert torch.equal(view, view_copy) and torch.equal(detached, detached_copy)
-  assert held['x'].data_ptr() not in ptrs and view.data_ptr() not in ptrs
-  # gather() through a reused set, then update(): rows come from THIS batch's ids
-  rows, _ = rep.sample_index(5)
-  batch = rep.gather(rows)
-  assert getattr(batch['stepid'], '_emb_first', None) is None
-  rep.update({'stepid': batch['stepid'], 'x': torch.full_like(batch['x'], -7.0)})
-  again = rep.gather(rows)
-  assert (again['x'] == -7.0).all()
-  # the same draws as a replay without the pool
-  off, on = _filled(emb), rep
-  monkeypatch.setenv('EMB_SAMPLE_POOL', '1')
-  on = _filled(emb)
-  monkeypatch.delenv('EMB_SAMPLE_POOL')
-  for _ in range(6):
-    a, b = off.sample(5), on.sample(5)
-    assert torch.equal(a['x'], b['x']) and torch.equal(a['stepid'], b['stepid'])

@@ -274,3 +274,46 @@ def test_mixer_draws_sources_by_weight_and_restores():
     theirs = Repaired({'a': _Numbered(1), 'b': _Numbered(2)}, dict(weights), seed=7)
     theirs.started = True
     assert [int(next(theirs)['x'][0, 1]) for _ in range(200)] == tags
+
+
+class _LendingReplay:
+  """What the stream checks look at on a Replay, without a GPU."""
+
+  def __init__(self, numpy=False, reuse=0):
+    self.numpy, self._reuse, self.returned = numpy, reuse, []
+
+  def sample(self, batch, mode='train'):
+    return {'is_first': np.zeros((batch, 4), bool)}
+
+  def recycle(self, batch):
+    self.returned.append(batch)
+
+
+def test_streams_refuse_setups_that_would_alias_live_batches():
+  """Batches that are handed out again -- `Stateless(recycle=K)`, a replay that
+  rotates `reuse_outputs=K` sets -- under a Prefetch that holds more of them
+  than K allows; `recycle` over a replay that returns host copies."""
+  with pytest.raises(TypeError):
+    streams.Stateless(_LendingReplay(numpy=True).sample, 3, recycle=2)
+  lending = streams.Stateless(_LendingReplay().sample, 3, recycle=2)
+  with pytest.raises(ValueError):
+    streams.Prefetch(lending, amount=1)                       # needs recycle >= 3
+  streams.Prefetch(streams.Stateless(_LendingReplay().sample, 3, recycle=3), amount=1)
+  rotating = streams.Stateless(_LendingReplay(reuse=2).sample, 3)
+  with pytest.raises(ValueError):
+    streams.Prefetch(streams.Consec(rotating, length=4, consec=1), amount=1)   # seen through Consec
+  streams.Prefetch(streams.Stateless(_LendingReplay(reuse=3).sample, 3), amount=1)
+  streams.Prefetch(streams.Stateless(_LendingReplay(reuse=0).sample, 3), amount=4)
+
+
+def test_consec_refuses_to_window_context_only_keys():
+  """`Replay(heads=)` keys hold the first K steps of the whole sampled sequence:
+  cutting them per window would be wrong, silently."""
+  def source():
+    while True:
+      yield {'is_first': np.zeros((2, 9), bool), 'obs': np.zeros((2, 9, 3)), 'dyn/deter': np.zeros((2, 1, 5))}
+  stream = iter(streams.Consec(streams.Stateless(source()), length=4, consec=2, prefix=1))
+  with pytest.raises(AssertionError, match='context-only'):
+    next(stream)
+  whole = iter(streams.Consec(streams.Stateless(source()), length=8, consec=1, prefix=1))
+  assert next(whole)['dyn/deter'].shape == (2, 1, 5)        # one window = the batch: nothing is cut
