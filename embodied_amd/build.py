@@ -18,7 +18,7 @@ HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
 OUT = HERE / 'libembodied_hip.so'
 OBJ = HERE / 'build'
-SOURCES = ['kernels.hip', 'abi.cpp']
+SOURCES = ['kernels.hip', 'replay_abi.cpp', 'index_abi.cpp', 'kernels_abi.cpp', 'comm_abi.cpp']
 ARCH = 'gfx950'
 # CPython call shim for the hottest entry points (csrc/fastcall.c): plain C,
 # links against nothing; the package falls back to ctypes without it.
@@ -75,7 +75,8 @@ def build(force=False, verbose=True):
   fcntl.flock(lock, fcntl.LOCK_EX)
   if not force and not stale():
     return OUT
-  flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall',
+  flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall', '-fvisibility=hidden',
+           '-fvisibility-inlines-hidden', '-ffunction-sections',
            '-Wno-unused-function', '-Wno-pass-failed', '-x', 'hip']
   # Kernel-argument preload (gfx940+): the first 16 dwords of a kernel's
   # arguments arrive in SGPRs with the wave instead of being fetched by every
@@ -119,7 +120,7 @@ def build(force=False, verbose=True):
   with concurrent.futures.ThreadPoolExecutor(len(SOURCES)) as pool:
     objs = list(pool.map(compile_one, SOURCES))
   tmp = OUT.with_suffix('.so.tmp')
-  cmd = [cc, f'--offload-arch={ARCH}', '-shared', '-fPIC', *map(str, objs), '-o', str(tmp)]
+  cmd = [cc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-Wl,--gc-sections', '-s', *map(str, objs), '-o', str(tmp)]
   res = subprocess.run(cmd, capture_output=True, text=True)
   if res.returncode:
     raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
@@ -193,7 +194,7 @@ def build_compiled(force=False, verbose=True):
   work.mkdir(parents=True, exist_ok=True)
   suffix = sysconfig.get_config_var('EXT_SUFFIX') or '.so'
 
-  def one(name):
+  def to_c(name):
     source = HERE.parent / (name.replace('.', '/') + '.py')
     text = source.read_bytes()
     c_file = work / (name + '.c')
@@ -203,6 +204,10 @@ def build_compiled(force=False, verbose=True):
     result = cython_compile(str(source), options, full_module_name=name)
     if result.num_errors:
       raise RuntimeError(f'cython failed on {source}')
+    return name, c_file, hashlib.sha256(text).hexdigest()
+
+  def to_binary(job):
+    name, c_file, digest = job
     binary = COMPILED_DIR / (name + suffix)
     tmp = binary.with_name(binary.name + '.tmp')
     cmd = [gcc, '-O2', '-shared', '-fPIC', '-fwrapv', '-w', f'-I{include}', str(c_file), '-o', str(tmp)]
@@ -210,14 +215,15 @@ def build_compiled(force=False, verbose=True):
     if res.returncode:
       raise RuntimeError(f'{" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
     os.replace(tmp, binary)
-    return name, {'file': binary.name, 'source': name.replace('.', '/') + '.py',
-                  'sha256': hashlib.sha256(text).hexdigest()}
+    return name, {'file': binary.name, 'source': name.replace('.', '/') + '.py', 'sha256': digest}
 
   manifest_path = COMPILED_DIR / 'manifest.json'
   if manifest_path.exists():
     manifest_path.unlink()          # nothing is trusted while binaries are being replaced
   try:
-    manifest = dict(one(name) for name in COMPILED)     # Cython's compiler is not thread-safe
+    jobs = [to_c(name) for name in COMPILED]            # Cython's compiler is not thread-safe ...
+    with concurrent.futures.ThreadPoolExecutor(min(len(jobs), os.cpu_count() or 2)) as pool:
+      manifest = dict(pool.map(to_binary, jobs))        # ... the C compiler runs are independent
   except Exception as e:
     if verbose:
       print(f'compiling the host modules failed, they stay plain Python: {e}', file=sys.stderr)

@@ -27,6 +27,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with hidden visibility: what this header declares is all
+ * it exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* 3 (round 4): + emb_configure, emb_scan_lambda_multi, emb_replay_carry_publish,
  * emb_replay_settle; emb_replay_profile_report which = 3.  Additions only: a
@@ -498,6 +503,9 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
                            int64_t episode_len, const void* reset, void* counters,
                            int32_t turn, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -28,13 +28,13 @@ def _host(batch):
 
 def _run_pair(emb, n, shape, length, capacity, chunksize, steps, online, stack, out_dtype=torch.bfloat16,
               layout='channels_first', extra_out=False, sample_every=7, episode_len=5, on_replay=None,
-              block=1, unmasked=False, act_dtype=np.int32):
+              block=1, unmasked=False, act_dtype=np.int32, ring=4):
   """Device Driver + Replay next to the oracle Driver + Replay on the same
   envs, policy and seeds; `stack` = the policy builds its batch with
   ops.obs_stack (which takes up the Driver's offer).  Returns the replay, the
   policy batches the agent saw and the number of early inserts."""
   from embodied_amd.envs import synthetic
-  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=episode_len, ring=4,
+  env = synthetic.SyntheticBatchEnv(n, shape=shape, episode_len=episode_len, ring=ring,
                                     takes_unmasked_actions=unmasked)
   rep = emb.Replay(length=length, capacity=capacity, chunksize=chunksize, online=online, seed=0)
   ref = np_oracle.Replay(length, capacity, chunksize, online, seed=0)
@@ -458,6 +458,29 @@ def test_carried_publish_matches_oracle(emb, online, sample_every):
   for k in ('items', 'chunks', 'streams', 'inserts', 'samples'):
     assert got[k] == want[k], k
   assert_same(_host(rep.sample(6)), ref.sample(6), 'final')
+
+
+@pytest.mark.parametrize('ring', [1, 2, 0])
+def test_carried_publish_with_an_env_that_rewrites_its_flags_in_place(emb, ring):
+  """ring=1: the env writes every step's observations -- is_last among them --
+  into the same buffers, so by the time the carried action is written (in the
+  NEXT step's early-insert launch, behind the next env step) the env's flag
+  buffer holds the next step's flags.  The mask reads the step's own is_last
+  from the replay's rows, where that step's early insert stored it: stored
+  actions equal the oracle's whatever the env does with its buffers (ring=0:
+  fresh tensors each step).  Env e's episodes last 3 + 13 * (e % 8) steps: ends
+  fall on different steps for different envs, so flags of the wrong step would
+  mask the wrong actions."""
+  n, steps = 6, 80
+  rep, ref, _ = _run_pair(emb, n, (8, 8, 4), length=3, capacity=300, chunksize=8, steps=steps,
+                          online=False, stack=True, sample_every=9, unmasked=True, episode_len=3, ring=ring)
+  inline, total = rep.profile_report('carried')[:2]
+  assert total >= steps - 2 and inline >= total * 0.7       # the publishes WERE carried
+  for _ in range(5):
+    got, want = _host(rep.sample(16)), ref.sample(16)
+    assert np.array_equal(got['action'], want['action'])
+    assert (want['action'][want['is_last']] == 0).all() and (want['action'] != 0).any()
+    assert_same(got, want, f'ring {ring}')
 
 
 @pytest.mark.parametrize('act_dtype', [np.float32, np.float16, np.int64, np.uint8])
