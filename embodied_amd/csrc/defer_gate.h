@@ -150,7 +150,10 @@ struct DeferGate : std::enable_shared_from_this<DeferGate> {
         }
         std::unique_lock<std::mutex> lock(g.m);
         g.sleeping.store(true);
-        g.cv.wait_for(lock, std::chrono::milliseconds(200), [&] {
+        // (wait_until on the system clock = pthread_cond_timedwait, which every
+        // ThreadSanitizer intercepts; wait_for goes through pthread_cond_clockwait,
+        // which gcc 11's does not -- it then misses the unlock inside the wait)
+        g.cv.wait_until(lock, std::chrono::system_clock::now() + std::chrono::milliseconds(200), [&] {
           return g.state.load() == 1;
         });
         g.sleeping.store(false);

@@ -837,6 +837,8 @@ int32_t emb_replay_gather_rows(emb_replay_t* rep, const int32_t* rows, int64_t n
                                int64_t seq_len, void* const* dst, void* stream) {
   REP_OP({
     need(rows && n_rows >= 0 && dst && seq_len >= 1, "gather_rows: bad arguments");
+    // (whole sequences: the is_last annotation of step t reads row t + 1 of its sequence)
+    need(n_rows % seq_len == 0, "gather_rows: n_rows is not a multiple of seq_len");
     settle_carry(rep);
     if (n_rows == 0) return;
     KeyList list;

@@ -1,0 +1,306 @@
+// TEST INFRASTRUCTURE (tests/fake_hip): host stand-ins for the launchers of
+// embodied_amd/csrc/kernels.h, so that the host side of the library can run --
+// and move real bytes -- without a GPU under ThreadSanitizer / AddressSanitizer
+// (tools/run_sanitizers.sh).  Every "launch" executes at once on the calling
+// thread with plain loops that follow the kernels' contracts as kernels.h states
+// them: a row index the host core got wrong is an out-of-bounds access ASan
+// sees, a pool access outside the replay's locks is a race TSan sees.
+// The product never links this file: libembodied_hip.so is built from
+// csrc/kernels.hip and fails to load without the HIP runtime.
+#include "kernels.h"
+
+#include <cstring>
+#include <vector>
+
+namespace emb {
+namespace {
+
+struct FakeArgs {          // what prepare_move leaves in MoveLaunch::args (plain data)
+  MovePlan plan;
+  int32_t gather;
+};
+static_assert(sizeof(FakeArgs) <= kMoveArgsBytes, "fits the opaque argument block");
+
+int inline_words(const MovePlan& plan) {
+  int64_t words = 0;
+  if (plan.spans_host) words = 3ll * plan.n_seq;
+  else if (plan.rows_host) words = plan.n_rows;
+  else return plan.inline_key >= 0 ? -1 : 0;
+  if (plan.inline_key >= 0) words += int64_t(plan.n_rows) * (plan.key[plan.inline_key].rowbytes >> 2);
+  return words <= kInlineWords ? static_cast<int>(words) : -1;
+}
+
+int dtype_size(int dtype) {
+  switch (dtype) {
+    case kU8: case kI8: case kBool: return 1;
+    case kI16: case kF16: case kBF16: return 2;
+    case kI32: case kF32: return 4;
+    case kI64: case kF64: return 8;
+    default: return 0;
+  }
+}
+
+template <typename T>
+void masked_t(const uint8_t* src, uint8_t* pool, uint8_t* out, int64_t elems, bool keep) {
+  for (int64_t i = 0; i < elems; ++i) {
+    T v;
+    std::memcpy(&v, src + i * sizeof(T), sizeof(T));
+    v = static_cast<T>(v * static_cast<T>(keep ? 1 : 0));
+    if (pool) std::memcpy(pool + i * sizeof(T), &v, sizeof(T));
+    if (out) std::memcpy(out + i * sizeof(T), &v, sizeof(T));
+  }
+}
+
+// value * keep in the key's dtype (16-bit floats: keep the bits or write +-0;
+// the sanitizer runs use integer and f32 actions, exact either way).
+void masked(const uint8_t* src, uint8_t* pool, uint8_t* out, int64_t rowbytes, int dtype, bool keep) {
+  switch (dtype) {
+    case kU8: case kBool: masked_t<uint8_t>(src, pool, out, rowbytes, keep); break;
+    case kI8: masked_t<int8_t>(src, pool, out, rowbytes, keep); break;
+    case kI16: masked_t<int16_t>(src, pool, out, rowbytes / 2, keep); break;
+    case kI32: masked_t<int32_t>(src, pool, out, rowbytes / 4, keep); break;
+    case kI64: masked_t<int64_t>(src, pool, out, rowbytes / 8, keep); break;
+    case kF32: masked_t<float>(src, pool, out, rowbytes / 4, keep); break;
+    case kF64: masked_t<double>(src, pool, out, rowbytes / 8, keep); break;
+    default:
+      for (int64_t i = 0; i < rowbytes / 2; ++i) {
+        uint16_t v;
+        std::memcpy(&v, src + 2 * i, 2);
+        if (!keep) v &= 0x8000u;
+        if (pool) std::memcpy(pool + 2 * i, &v, 2);
+        if (out) std::memcpy(out + 2 * i, &v, 2);
+      }
+  }
+}
+
+int32_t row_at(const MovePlan& p, int64_t seq, int64_t t) {
+  if (p.spans_host) {
+    const int32_t* s = p.spans_host + 3 * seq;
+    return t < s[1] ? s[0] + static_cast<int32_t>(t) : s[2] + static_cast<int32_t>(t - s[1]);
+  }
+  const int32_t* rows = p.rows_host ? p.rows_host : p.rows;
+  return rows[seq * p.seq_len + t];
+}
+
+void run(const FakeArgs& a) {
+  const MovePlan& p = a.plan;
+  const int64_t L = p.seq_len < 1 ? 1 : p.seq_len;
+  bool heads = false;
+  for (int k = 0; k < p.n_keys; ++k) heads = heads || (p.key_len[k] > 0 && p.key_len[k] < L);
+  const int64_t n_seq = p.n_rows / L;
+  for (int k = 0; k < p.n_keys; ++k) {
+    const KeyDesc& key = p.key[k];
+    const int64_t klen = heads && p.key_len[k] > 0 ? p.key_len[k] : L;
+    const int64_t rows = heads ? n_seq * klen : p.n_rows;
+    for (int64_t r = 0; r < rows; ++r) {
+      const int64_t seq = r / klen, t = r - seq * klen;
+      const int64_t row = row_at(p, seq, t);
+      int64_t off = (seq * klen + t) * key.rowbytes;
+      if (p.group > 0) off = (seq / p.group) * p.group_stride + ((seq % p.group) * klen + t) * key.rowbytes;
+      uint8_t* batch = key.batch ? key.batch + off : nullptr;
+      if (a.gather) {
+        if (row < 0) continue;
+        const uint8_t* pool = key.pool + row * key.rowbytes;
+        if (key.rowbytes == 1 && (k == p.key_is_first || k == p.key_is_last)) {
+          uint8_t v = pool[0];
+          const uint8_t* first_pool = p.is_first_pool ? p.is_first_pool
+                                      : p.key_is_first >= 0 ? p.key[p.key_is_first].pool : nullptr;
+          if (k == p.key_is_first) {
+            if (t == 0) v = 1;
+          } else if (first_pool && t + 1 < L) {
+            v |= first_pool[row_at(p, seq, t + 1)];
+          }
+          batch[0] = v;
+        } else {
+          std::memcpy(batch, pool, key.rowbytes);
+        }
+        continue;
+      }
+      const bool is_masked = (p.mask_bits >> k) & 1u;
+      if (is_masked) {
+        const bool keep = p.mask_flags[r] == 0;
+        uint8_t* out = p.mask_out[k] ? p.mask_out[k] + r * key.rowbytes : nullptr;
+        masked(batch, row >= 0 ? key.pool + row * key.rowbytes : nullptr, out, key.rowbytes, p.mask_dtype[k], keep);
+        continue;
+      }
+      if (row < 0) continue;
+      const uint8_t* src = k == p.inline_key ? p.inline_bytes + r * key.rowbytes : batch;
+      std::memcpy(key.pool + row * key.rowbytes, src, key.rowbytes);
+    }
+  }
+}
+
+struct FakePreHead {
+  PrewritePlan plan;
+  int32_t has_carry;
+};
+
+}  // namespace
+
+bool plan_fits_inline(const MovePlan& plan) { return inline_words(plan) > 0; }
+size_t move_args_bytes() { return sizeof(FakeArgs); }
+
+hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
+  out->blocks = 0;
+  const int need = inline_words(plan);
+  const bool use_inline = need > 0 && (plan.spans_host || plan.rows_host);
+  if (plan.n_keys < 1 || plan.n_keys > kMaxKeys || plan.n_rows < 0 || (!plan.rows && !use_inline))
+    return hipErrorInvalidValue;
+  const int64_t L = plan.seq_len < 1 ? 1 : plan.seq_len;
+  for (int k = 0; k < plan.n_keys; ++k) {
+    if (plan.key_len[k] < 0 || plan.key_len[k] > L) return hipErrorInvalidValue;
+    if (plan.key_len[k] > 0 && plan.key_len[k] < L &&
+        (!gather || plan.n_rows % L != 0 || plan.mask_bits || plan.inline_key >= 0))
+      return hipErrorInvalidValue;
+  }
+  FakeArgs a;
+  a.plan = plan;
+  if (!use_inline) a.plan.rows_host = a.plan.spans_host = nullptr;
+  a.gather = gather ? 1 : 0;
+  std::memcpy(out->args, &a, sizeof(a));
+  out->blocks = plan.n_rows > 0 ? 1 : 0;
+  out->threads = 64;
+  out->span = plan.spans_host != nullptr;
+  return hipSuccess;
+}
+
+hipError_t launch_marker(hipStream_t, hipEvent_t) { return hipSuccess; }
+
+hipError_t launch_args_writer(const MoveLaunch& launch, void* device_dst, hipStream_t, hipEvent_t) {
+  std::memcpy(device_dst, launch.args, sizeof(FakeArgs));
+  return hipSuccess;
+}
+
+hipError_t launch_move(const MoveLaunch& launch, bool gather, const void* device_args, hipStream_t,
+                       hipEvent_t, hipEvent_t) {
+  if (launch.blocks == 0) return hipSuccess;
+  FakeArgs a;
+  std::memcpy(&a, device_args ? device_args : launch.args, sizeof(a));     // the copy the "device" reads
+  if ((a.gather != 0) != gather) return hipErrorInvalidValue;
+  run(a);
+  return hipSuccess;
+}
+
+const char* move_kernel_name(const MoveLaunch&, bool gather, bool) { return gather ? "fake gather" : "fake scatter"; }
+
+hipError_t launch_gather(const MovePlan& plan, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  MoveLaunch launch;
+  const hipError_t e = prepare_move(plan, &launch, true);
+  return e != hipSuccess ? e : launch_move(launch, true, nullptr, stream, start, stop);
+}
+
+hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream) {
+  MoveLaunch launch;
+  const hipError_t e = prepare_move(plan, &launch, false);
+  return e != hipSuccess ? e : launch_move(launch, false, nullptr, stream, nullptr, nullptr);
+}
+
+hipError_t launch_window(const uint8_t* src, uint8_t* dst, int64_t batch, int64_t total, int64_t start,
+                         int64_t count, int64_t rowbytes, hipStream_t) {
+  for (int64_t b = 0; b < batch; ++b)
+    std::memcpy(dst + b * count * rowbytes, src + (b * total + start) * rowbytes, count * rowbytes);
+  return hipSuccess;
+}
+
+hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* dst, int64_t n, int64_t pixels,
+                            int64_t channels, int layout, int out_dtype, float, float, hipStream_t) {
+  if (out_dtype != kU8 || layout != kLayoutSame) return hipSuccess;       // (casts are the device's business)
+  for (int64_t e = 0; e < n; ++e)
+    std::memcpy(static_cast<uint8_t*>(dst) + e * pixels * channels,
+                src + (env_ids ? env_ids[e] : e) * pixels * channels, pixels * channels);
+  return hipSuccess;
+}
+
+hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems, int dtype,
+                            const uint8_t* is_last, hipStream_t) {
+  const int64_t rowbytes = row_elems * dtype_size(dtype);
+  for (int64_t r = 0; r < n; ++r)
+    masked(static_cast<const uint8_t*>(act) + r * rowbytes, nullptr, static_cast<uint8_t*>(out) + r * rowbytes,
+           rowbytes, dtype, is_last[r] == 0);
+  return hipSuccess;
+}
+
+hipError_t launch_gae(const float*, const float*, const uint8_t*, const uint8_t*, int64_t, int64_t, float, float,
+                      float*, float*, hipStream_t, int64_t, int64_t) { return hipSuccess; }
+hipError_t launch_lambda_return(const uint8_t*, const uint8_t*, const float*, const float*, int64_t, int64_t,
+                                float, float, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_lambda_return_multi(int, const LambdaProblem*, hipStream_t) { return hipSuccess; }
+hipError_t launch_director_score(const float*, const float*, const float*, int64_t, int64_t, float, float,
+                                 float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_abstract_traj(const float*, const float*, int64_t, int64_t, int, float*, float*, hipStream_t) {
+  return hipSuccess;
+}
+hipError_t launch_synth_env(uint8_t*, float*, uint8_t*, uint8_t*, uint8_t*, int64_t, int64_t, int64_t, int64_t,
+                            const uint8_t*, int32_t*, int, hipStream_t) { return hipSuccess; }
+
+bool carry_supported(int64_t rowbytes, int dtype) {
+  const int elem = dtype_size(dtype);
+  return elem > 0 && rowbytes > 0 && rowbytes % elem == 0 && rowbytes / elem <= 256;
+}
+
+bool prewrite_supported(const PrewritePlan& p) {
+  return p.n > 0 && p.pixels > 0 && p.pixels % 4 == 0 && p.channels >= 1 && p.channels <= 4 &&
+         (p.pixels * p.channels) % 16 == 0 && p.n_narrow >= 0 && p.n_narrow <= kPreNarrow;
+}
+
+size_t prewrite_table_bytes(int64_t n) { return sizeof(FakePreHead) + static_cast<size_t>(n) * (4 + kStepBytes + 4); }
+
+void prewrite_fill_table(void* dst, const PrewritePlan& plan, const int32_t* rows, const uint8_t* stepids) {
+  FakePreHead head;
+  head.plan = plan;
+  head.has_carry = plan.carry_src && plan.carry_rows ? 1 : 0;
+  uint8_t* out = static_cast<uint8_t*>(dst);
+  std::memcpy(out, &head, sizeof(head));
+  out += sizeof(head);
+  std::memcpy(out, rows, size_t(plan.n) * 4);
+  out += size_t(plan.n) * 4;
+  std::memcpy(out, stepids, size_t(plan.n) * kStepBytes);
+  out += size_t(plan.n) * kStepBytes;
+  if (head.has_carry) std::memcpy(out, plan.carry_rows, size_t(plan.n) * 4);
+}
+
+hipError_t launch_obs_stack_insert(const PrewritePlan& p, hipStream_t stream, hipEvent_t) {
+  if (!prewrite_supported(p) || !p.table_dev) return hipErrorInvalidValue;
+  FakePreHead head;
+  const uint8_t* tab = static_cast<const uint8_t*>(p.table_dev);
+  std::memcpy(&head, tab, sizeof(head));
+  const PrewritePlan& t = head.plan;           // what the "device" was told
+  std::vector<int32_t> rows(p.n), prev(p.n, -1);
+  std::memcpy(rows.data(), tab + sizeof(head), size_t(p.n) * 4);
+  const uint8_t* sids = tab + sizeof(head) + size_t(p.n) * 4;
+  if (head.has_carry) std::memcpy(prev.data(), sids + size_t(p.n) * kStepBytes, size_t(p.n) * 4);
+  const int64_t frame = p.pixels * p.channels;
+  launch_obs_stack(p.frames, nullptr, p.dst, p.n, p.pixels, p.channels, p.layout, p.out_dtype, p.scale,
+                   p.offset, stream);
+  for (int64_t e = 0; e < p.n; ++e) {
+    if (head.has_carry && prev[e] >= 0) {
+      // the carried step's is_last, read from the replay's own rows
+      const bool keep = t.carry_flags[prev[e]] == 0;
+      masked(t.carry_src + e * t.carry_rowbytes, t.carry_pool + int64_t(prev[e]) * t.carry_rowbytes, nullptr,
+             t.carry_rowbytes, t.carry_dtype, keep);
+    }
+    const int64_t row = rows[e];
+    if (row < 0) continue;
+    std::memcpy(p.frame_pool + row * frame, p.frames + e * frame, frame);
+    for (int k = 0; k < t.n_narrow; ++k)
+      std::memcpy(t.narrow[k].pool + row * t.narrow[k].rowbytes, t.narrow[k].src + e * t.narrow[k].rowbytes,
+                  t.narrow[k].rowbytes);
+    if (t.stepid_pool) std::memcpy(t.stepid_pool + row * kStepBytes, sids + e * kStepBytes, kStepBytes);
+    if (t.rows_out) t.rows_out[e] = static_cast<int32_t>(row);
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_publish_one(const void* src, void* pool, void* out, const int32_t* rows_dev, const uint8_t* flags,
+                              int64_t n, int64_t rowbytes, int dtype, hipStream_t, hipEvent_t, bool flags_by_row) {
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t row = rows_dev[r];
+    const bool keep = !flags || (flags_by_row ? row < 0 || flags[row] == 0 : flags[r] == 0);
+    masked(static_cast<const uint8_t*>(src) + r * rowbytes,
+           row >= 0 ? static_cast<uint8_t*>(pool) + row * rowbytes : nullptr,
+           out ? static_cast<uint8_t*>(out) + r * rowbytes : nullptr, rowbytes, flags ? dtype : kU8, keep);
+  }
+  return hipSuccess;
+}
+
+}  // namespace emb
