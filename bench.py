@@ -134,12 +134,15 @@ def parse():
                       'all ranks\' envs ((n-1)/n * B*L*S bytes each way per exchanged batch).  '
                       'online = all-gather of those batches ((n-1) * B*L*S received); trajectories '
                       '= all-gather of every batch; returns = all-gather of the GAE outputs only')
-  p.add_argument('--comm', default='auto', choices=['auto', 'native', 'c10d'],
-                 help='N>1: who issues the collectives of the timed path.  c10d = torch.distributed '
+  p.add_argument('--comm', default='auto', choices=['auto', 'native', 'c10d', 'direct'],
+                 help='N>1: who carries the collectives of the timed path.  c10d = torch.distributed '
                       '(ProcessGroupNCCL).  native = the library\'s own RCCL entry points '
-                      '(emb_comm_exchange: one call per train step, ~1/3 of the host time).  auto '
+                      '(emb_comm_exchange: one call per train step, ~1/3 of the host time).  direct = '
+                      'the library\'s direct xGMI schedule (emb_direct_exchange: every rank writes all '
+                      'n-1 peers at once through hipIpc pointers, one link each; no RCCL).  auto '
                       '(default) = native if the self-check against torch.distributed passes on '
-                      'every rank before the timed regions, else c10d')
+                      'every rank before the timed regions, else c10d.  Whatever is chosen, both '
+                      'transports are checked and timed beside each other in `native_comm`')
   p.add_argument('--grad-dtype', default='bf16', choices=['bf16', 'f32'],
                  help='N>1: dtype of the flat gradient buffer that is all-reduced every train '
                       'step (the reference all-reduces f32 leaves, embodied/jax/opt.py:52-54; '
@@ -383,7 +386,8 @@ def main():
   if use_dist:
     from embodied_amd import distributed as D
     issue = D.Done
-  use_native = False
+  use_native = use_direct = False
+  direct_comm = None
   link = None               # who carries a train step's collectives (set after the self-check)
   collectives = {'on': True, 'sliced': 0}
   fresh = {'on': False, 'stream': None}
@@ -522,16 +526,19 @@ def main():
   # suite's loopback transport the native path also runs between gloo ranks that
   # share one GPU, tests/test_gpu_bench_launcher.py)
   if use_dist and args.comm != 'c10d' and (dist.get_backend() == 'nccl' or os.environ.get('EMB_RCCL_LIB')):
-    native, native_stuck, native_comm = native_comm_check(
+    native, native_stuck, native_comm, direct_comm = native_comm_check(
         rank, world, device, args.grad_numel, grad_dtype,
         B * args.prefetch * L * sum(k.rowbytes for k in replay._keys) // world)
     if args.comm == 'native' and native_comm is None:
       raise SystemExit(f'--comm native: the self-check did not pass: {native}')
+    if args.comm == 'direct' and direct_comm is None:
+      raise SystemExit(f'--comm direct: the self-check did not pass: {native.get("direct")}')
     # (all-gather forms of the exchange stay on torch.distributed.)
-    use_native = native_comm is not None and args.exchange in ('dp_slice', 'none')
-    native['timed_path'] = 'native' if use_native else 'c10d'
+    use_direct = args.comm == 'direct' and args.exchange in ('dp_slice', 'none')
+    use_native = not use_direct and native_comm is not None and args.exchange in ('dp_slice', 'none')
+    native['timed_path'] = 'direct' if use_direct else 'native' if use_native else 'c10d'
   if use_dist:
-    link = native_comm if use_native else D.GroupComm()
+    link = direct_comm if use_direct else native_comm if use_native else D.GroupComm()
   # --no-timer: no dispatch stamps (roofline is then null).  Stamps are
   # switched on before the warm-up so that the stamps' events exist by then.
   # One gather in --stamp-every carries stamps, unless the timed region is too
@@ -781,6 +788,11 @@ def main():
     native['per_train_step'] = {
         'collectives_us': round(calls['native_all_reduce']['total_us']
                                 + share * calls['native_all_to_all']['total_us'], 1),
+        # the same train step's collectives on the direct schedule (all n-1 links at once)
+        **({'direct_collectives_us': round(
+            native['direct']['per_call']['direct_all_reduce']['total_us']
+            + share * native['direct']['per_call']['direct_all_to_all']['total_us'], 1)}
+           if (native.get('direct') or {}).get('per_call') else {}),
         'issue_period_us': round(total_elapsed / done * 1e6, 1),
         'sliced_share': round(share, 3),
     }
@@ -989,8 +1001,10 @@ def main():
                             + ('per-rank Replay, ' if args.workload == 'dreamer'
                                else f'trajectory exchange {args.exchange} + ') +
                             f'{args.grad_numel * (2 if args.grad_dtype == "bf16" else 4) >> 20} MiB '
-                            f'{args.grad_dtype} grad all-reduce per train step (RCCL, issued by '
-                            f'{"emb_comm_exchange" if use_native else "torch.distributed"})')
+                            f'{args.grad_dtype} grad all-reduce per train step ('
+                            + ('direct xGMI schedule, emb_direct_exchange' if use_direct else
+                               f'RCCL, issued by {"emb_comm_exchange" if use_native else "torch.distributed"}')
+                            + ')')
                            if use_dist else 'single',
         },
         'publishes': {'deferred': h_deferred, 'predicted': int(h_predicted), 'carried': int(h_carried),
@@ -1016,6 +1030,8 @@ def main():
       comm.close()
     if native_comm is not None:
       native_comm.close()
+    if direct_comm is not None:
+      direct_comm.close()
     dist.destroy_process_group()
 
 
@@ -1144,10 +1160,56 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
       torch.cuda.synchronize(device)
       t2 = time.perf_counter()
       costs[name] = {'host_us': round((t1 - t0) * 1e6 / reps, 2), 'total_us': round((t2 - t0) * 1e6 / reps, 2)}
-    return {'status': 'ok' if all(checks.values()) else 'mismatch', 'ranks': world,
-            'transport': os.environ.get('EMB_RCCL_LIB') or 'rccl',
-            'checks': checks, 'all_reduce_bytes': grads.numel() * grads.element_size(),
-            'all_to_all_bytes': flat.numel(), 'per_call': costs}
+    report = {'status': 'ok' if all(checks.values()) else 'mismatch', 'ranks': world,
+              'transport': os.environ.get('EMB_RCCL_LIB') or 'rccl',
+              'checks': checks, 'all_reduce_bytes': grads.numel() * grads.element_size(),
+              'all_to_all_bytes': flat.numel(), 'per_call': costs}
+    # The direct xGMI schedule (emb_direct_*: every rank writes all n-1 peers at
+    # once through hipIpc pointers) on the same bytes: checked against the same
+    # references, timed beside RCCL.  Its failure never takes the RCCL path down.
+    try:
+      def share_all(data):
+        box = [None] * world
+        dist.all_gather_object(box, data, group=group)
+        return box
+      direct = D.DirectComm(rank, world, device, max_grad_bytes=max(grads.numel() * grads.element_size(), 4 << 20),
+                            max_slice_bytes=max(2 * block, 1 << 20), share_all=share_all)    # (a packed batch pads its keys)
+      kept.append(direct)
+      dchecks = {}
+      mine, ref = direct.all_to_all(flat), torch.empty_like(flat)
+      ref_all_to_all(ref, flat).wait()
+      dchecks['all_to_all'] = bool(torch.equal(mine, ref))
+      for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        whole = torch.randint(-8, 9, (1 << 20,), device=device, generator=gen).to(dtype)
+        a, b = whole.clone(), whole.clone()
+        direct.all_reduce(a, mean=False)
+        ref_all_reduce(b)
+        dchecks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, b))
+      dcosts = {}
+      for name, call in {
+          'direct_all_reduce': lambda: direct.all_reduce(grads, mean=True),
+          'direct_all_to_all': lambda: direct.all_to_all(flat, recv),
+          'direct_exchange_step': lambda: (direct.wait(), direct.exchange(flat, recv, grads)),
+      }.items():
+        reps = 10 if staged else 100
+        for _ in range(reps // 10):
+          call()
+        torch.cuda.synchronize(device)
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+          call()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        dcosts[name] = {'host_us': round((t1 - t0) * 1e6 / reps, 2), 'total_us': round((t2 - t0) * 1e6 / reps, 2)}
+      direct.wait()
+      timed_out = direct.timed_out()
+      report['direct'] = {'status': 'ok' if all(dchecks.values()) and not timed_out else 'mismatch',
+                          'checks': dchecks, 'timed_out': timed_out, 'per_call': dcosts}
+    except Exception as e:
+      report['direct'] = {'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]}
+    return report
 
   def guarded():
     torch.cuda.set_device(device)
@@ -1157,11 +1219,14 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
       local = {'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]}
     # Every rank reaches this reduce whatever happened above, so that all ranks
     # take the same decision about the timed path.
-    agree = torch.tensor([1.0 if local['status'] == 'ok' else 0.0], device=device)
+    direct_ok = (local.get('direct') or {}).get('status') == 'ok'
+    agree = torch.tensor([1.0 if local['status'] == 'ok' else 0.0, 1.0 if direct_ok else 0.0], device=device)
     dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
     torch.cuda.synchronize(device)
-    if agree.item() != 1.0 and local['status'] == 'ok':
+    if agree[0].item() != 1.0 and local['status'] == 'ok':
       local['status'] = 'failed on another rank'
+    if agree[1].item() != 1.0 and direct_ok:
+      local['direct']['status'] = 'failed on another rank'
     result.clear()
     result.update(local)
 
@@ -1172,7 +1237,10 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
   usable = kept[0] if (kept and not stuck and result.get('status') == 'ok') else None
   if kept and usable is None and not stuck:
     kept[0].close()
-  return dict(result), stuck, usable
+  direct = kept[1] if (len(kept) > 1 and not stuck and (result.get('direct') or {}).get('status') == 'ok') else None
+  if len(kept) > 1 and direct is None and not stuck:
+    kept[1].close()
+  return dict(result), stuck, usable, direct
 
 
 def dreamer_leg(args):

@@ -197,6 +197,15 @@ SIGNATURES = {
     'emb_comm_exchange': [p, p, p, p, i64, p, i64, i32, i32],
     'emb_comm_wait': [p, p],
     'emb_comm_destroy': [p],
+    'emb_direct_create': [i32, i32, i64, i64, i32, pp],
+    'emb_direct_handle': [p, p],
+    'emb_direct_connect': [p, p],
+    'emb_direct_allreduce': [p, p, i64, i32, i32, p],
+    'emb_direct_alltoall': [p, p, p, i64, p],
+    'emb_direct_exchange': [p, p, p, p, i64, p, i64, i32, i32],
+    'emb_direct_wait': [p, p],
+    'emb_direct_status': [p, p],
+    'emb_direct_destroy': [p],
 }
 
 lib.emb_last_error.restype = C.c_char_p
@@ -293,6 +302,7 @@ class _FastApi:
       'emb_obs_stack': 'obs_stack', 'emb_scan_gae': 'scan', 'emb_scan_lambda': 'scan',
       'emb_scan_gae_grouped': 'scan', 'emb_scan_lambda_multi': 'ints',
       'emb_comm_exchange': 'ints', 'emb_comm_wait': 'ints',
+      'emb_direct_exchange': 'ints', 'emb_direct_wait': 'ints',
   }
 
   def __init__(self, module):

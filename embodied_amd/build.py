@@ -18,7 +18,7 @@ HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
 OUT = HERE / 'libembodied_hip.so'
 OBJ = HERE / 'build'
-SOURCES = ['kernels.hip', 'replay_abi.cpp', 'index_abi.cpp', 'kernels_abi.cpp', 'comm_abi.cpp']
+SOURCES = ['kernels.hip', 'direct_comm.hip', 'replay_abi.cpp', 'index_abi.cpp', 'kernels_abi.cpp', 'comm_abi.cpp']
 ARCH = 'gfx950'
 # CPython call shim for the hottest entry points (csrc/fastcall.c): plain C,
 # links against nothing; the package falls back to ctypes without it.

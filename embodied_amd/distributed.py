@@ -797,3 +797,107 @@ class NativeComm:
       self.close()
     except Exception:
       pass
+
+
+class DirectComm:
+  """NativeComm's train-step contract on the library's DIRECT xGMI schedule
+  (`emb_direct_*`, csrc/direct_comm.hip) instead of RCCL: every rank writes its
+  peers' shares of the gradient all-reduce (reduce-scatter + all-gather) and of
+  the DP-slice all-to-all straight into their memory through hipIpc handles, all
+  n-1 peers at once -- one xGMI link each, where a ring is bound by one.  One
+  node, at most 8 ranks.
+
+  The 64-byte handle of every rank's buffer reaches the others through
+  `share_all(handle_bytes) -> [handle_bytes of rank 0, 1, ...]` (default: an
+  object all-gather on the torch.distributed group).  `max_grad_bytes` /
+  `max_slice_bytes`: the largest gradient buffer and all-to-all block (bytes per
+  rank) this communicator will see."""
+
+  def __init__(self, rank=0, world=1, device=None, max_grad_bytes=64 << 20, max_slice_bytes=32 << 20,
+               timeout_ms=20000, share_all=None):
+    import ctypes as C
+    from . import _lib
+    from ._lib import api
+    self._lib, self._api, self._C = _lib, api, C
+    self.rank, self.world = int(rank), int(world)
+    self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    torch.cuda.set_device(self.device)
+    self._handle = C.c_void_p()
+    api.emb_direct_create(self.rank, self.world, int(max_grad_bytes), int(max_slice_bytes), int(timeout_ms),
+                          C.byref(self._handle))
+    if self.world > 1:
+      mine = (C.c_uint8 * 64)()
+      api.emb_direct_handle(self._handle, mine)
+      if share_all is None:
+        def share_all(data):
+          box = [None] * self.world
+          dist.all_gather_object(box, data)
+          return box
+      handles = share_all(bytes(mine))
+      assert len(handles) == self.world and all(len(h) == 64 for h in handles)
+      api.emb_direct_connect(self._handle, (C.c_uint8 * (64 * self.world)).from_buffer_copy(b''.join(handles)))
+
+  _CODES = None
+
+  def _code(self, dtype):
+    codes = {torch.float16: self._lib.F16, torch.bfloat16: self._lib.BF16, torch.float32: self._lib.F32}
+    assert dtype in codes, f'DirectComm: {dtype} gradients (f16, bf16, f32 only)'
+    return codes[dtype]
+
+  def all_reduce(self, grads, mean=True):
+    """In-place sum or mean over the ranks of a flat f16 / bf16 / f32 buffer;
+    every rank ends with the same bits."""
+    assert grads.is_contiguous() and grads.is_cuda
+    self._api.emb_direct_allreduce(
+        self._handle, grads.data_ptr(), grads.numel(), self._code(grads.dtype), int(bool(mean)),
+        self._lib.raw_stream(grads.device))
+    return grads
+
+  def all_to_all(self, flat, out=None):
+    """(world * nbytes,) uint8: block r goes to rank r; block r of the result came from rank r."""
+    assert flat.dtype == torch.uint8 and flat.is_contiguous() and flat.is_cuda
+    assert flat.numel() % self.world == 0, (flat.numel(), self.world)
+    if out is None:
+      out = torch.empty_like(flat)
+    self._api.emb_direct_alltoall(
+        self._handle, flat.data_ptr(), out.data_ptr(), flat.numel() // self.world,
+        self._lib.raw_stream(flat.device))
+    return out
+
+  def exchange(self, slices=None, received=None, grads=None, mean=True):
+    """One train step's collectives on the transport's own stream, after what
+    the current stream holds so far (NativeComm.exchange's contract); `wait()`
+    orders the current stream after them."""
+    device = (grads if grads is not None else slices).device
+    code, count = self._lib.F32, 0
+    if grads is not None:
+      code, count = self._code(grads.dtype), grads.numel()
+    per_rank = 0
+    if slices is not None:
+      assert slices.dtype == torch.uint8 and slices.numel() % self.world == 0
+      assert received is not None and received.numel() == slices.numel()
+      per_rank = slices.numel() // self.world
+    self._lib.fast.emb_direct_exchange(
+        self._handle.value, self._lib.raw_stream(device),
+        slices.data_ptr() if per_rank else None, received.data_ptr() if per_rank else None, per_rank,
+        grads.data_ptr() if count else None, count, code, int(bool(mean)))
+
+  def wait(self, device=None):
+    self._lib.fast.emb_direct_wait(self._handle.value, self._lib.raw_stream(device or self.device))
+
+  def timed_out(self):
+    """True if a wait inside one of the kernels gave up on a peer (synchronises)."""
+    word = self._C.c_int32(0)
+    self._api.emb_direct_status(self._handle, self._C.byref(word))
+    return bool(word.value)
+
+  def close(self):
+    handle, self._handle = self._handle, None
+    if handle:
+      self._api.emb_direct_destroy(handle)
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

@@ -36,7 +36,7 @@ extern "C" {
 /* 3 (round 4): + emb_configure, emb_scan_lambda_multi, emb_replay_carry_publish,
  * emb_replay_settle; emb_replay_profile_report which = 3.  Additions only: a
  * caller written against version 2 runs unchanged.                             */
-/* 4 (round 5): + emb_replay_sample_heads.  Additions only.                      */
+/* 4 (round 5): + emb_replay_sample_heads, emb_direct_*.  Additions only.        */
 #define EMB_ABI_VERSION 4
 
 #define EMB_OK 0
@@ -502,6 +502,42 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
                            void* is_terminal, int64_t n, int64_t frame_bytes, int64_t env0,
                            int64_t episode_len, const void* reset, void* counters,
                            int32_t turn, void* stream);
+
+/* ---- direct xGMI schedule (round 5) ----------------------------------------
+ * The two collectives of a train step -- the gradient all-reduce
+ * (embodied/jax/opt.py:52-54) and the DP-slice all-to-all
+ * (embodied/jax/internal.py:145-152) -- without RCCL: every rank writes its
+ * peers' shares straight into their memory (hipIpc handles of one fine-grained
+ * allocation per rank), all n-1 peers at once, one xGMI link each; flags in that
+ * memory order the steps (csrc/direct_comm.hip states the schedule).  One node,
+ * at most 8 ranks, one GPU per rank (or several ranks on one GPU: the tests).
+ *
+ * create: max_reduce_bytes = the largest gradient buffer, max_block_bytes = the
+ *         largest all-to-all block (bytes per rank); every wait inside a kernel
+ *         gives up after timeout_ms and sets the word emb_direct_status reads.
+ * handle / connect: each rank's 64-byte handle reaches every other rank by the
+ *         caller's means (a process-group all-gather, a file); connect takes all
+ *         `world` handles in rank order.
+ * allreduce / alltoall: asynchronous on `stream`; same order of calls on every
+ *         rank.  Results: the sum is taken in rank order in f32 by the rank that
+ *         owns the shard and broadcast, so every rank holds the same bits.
+ * exchange / wait: emb_comm_exchange's contract on the transport's own stream. */
+#define EMB_DIRECT_HANDLE_BYTES 64
+typedef struct emb_direct emb_direct_t;
+int32_t emb_direct_create(int32_t rank, int32_t world, int64_t max_reduce_bytes,
+                          int64_t max_block_bytes, int32_t timeout_ms, emb_direct_t** out);
+int32_t emb_direct_handle(emb_direct_t* d, uint8_t* handle_out);
+int32_t emb_direct_connect(emb_direct_t* d, const uint8_t* handles);
+int32_t emb_direct_allreduce(emb_direct_t* d, void* buf, int64_t count, int32_t dtype,
+                             int32_t mean, void* stream);
+int32_t emb_direct_alltoall(emb_direct_t* d, const void* send, void* recv,
+                            int64_t bytes_per_rank, void* stream);
+int32_t emb_direct_exchange(emb_direct_t* d, void* after_stream, const void* slices_send,
+                            void* slices_recv, int64_t bytes_per_rank, void* grads,
+                            int64_t count, int32_t dtype, int32_t mean);
+int32_t emb_direct_wait(emb_direct_t* d, void* stream);
+int32_t emb_direct_status(emb_direct_t* d, int32_t* timed_out);
+int32_t emb_direct_destroy(emb_direct_t* d);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

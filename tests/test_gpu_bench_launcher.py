@@ -67,6 +67,28 @@ def test_bench_gpus_2_native_exchange_between_two_real_ranks():
   assert 0 < exp['link_bound_x_at_60pct'] <= 2.0 and exp['measured_x']['value'] > 0
 
 
+def test_bench_gpus_2_direct_schedule_between_two_real_ranks():
+  """`--comm direct`: the timed path's collectives go through emb_direct_exchange --
+  every rank writing its peer's shares through hipIpc pointers (two processes on
+  the test box's one GPU) -- after the self-check against torch.distributed
+  passed; the line carries both transports' per-call times."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('_fake_rccl_build', ROOT / 'tests' / 'fake_rccl' / 'build.py')
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  lib = str(mod.build())
+  rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
+                  '--backend', 'gloo', '--comm', 'direct', env={'EMB_RCCL_LIB': lib})
+  native = rec['native_comm']
+  direct = native['direct']
+  assert direct['status'] == 'ok' and all(direct['checks'].values()) and direct['timed_out'] is False, direct
+  assert set(direct['per_call']) == {'direct_all_reduce', 'direct_all_to_all', 'direct_exchange_step'}
+  assert native['timed_path'] == 'direct' and 'emb_direct_exchange' in rec['config']['parallelism']
+  assert rec['train_steps_per_s'] > 0 and rec['value'] > 0
+  assert native['per_train_step']['direct_collectives_us'] > 0
+
+
 def test_bench_gpus_8_control_flow():
   """The driver's largest form, `python bench.py --gpus 8`: eight ranks start,
   agree on their exchange schedule at every fence and rank 0 prints one line

@@ -1,0 +1,171 @@
+"""The direct xGMI schedule (`emb_direct_*`, csrc/direct_comm.hip): the gradient
+all-reduce (embodied/jax/opt.py:52-54) as reduce-scatter + all-gather and the
+DP-slice all-to-all (embodied/jax/internal.py:145-152), every rank writing its
+peers' shares through hipIpc pointers, all peers at once.
+
+Checked with 2 and 3 REAL ranks (processes) that share the test box's one GPU --
+the peers' memory is reached through the same hipIpc handles as on a node with a
+GPU per rank, only the stores stay on one device -- against numpy on the
+concatenation of every rank's seeded inputs, exactly like the loopback test of
+the RCCL entry points (tests/test_gpu_native_comm_ranks.py).  Every in-kernel
+wait is bounded: a rank that never arrives is an error word, not a hung GPU.
+
+With at least two GPUs visible the same worker also runs with one GPU per rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SLICE_BYTES = 700_016                  # 16-byte multiple; + an odd size below
+GRAD_NUMEL = 300_007                   # not a multiple of world * 8: a short last shard and a scalar tail
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def _bytes_of(rank, tag, n):
+  return np.random.default_rng([17, tag, rank]).integers(0, 256, n, dtype=np.uint8)
+
+
+def _floats_of(rank, tag, n):
+  return np.random.default_rng([23, tag, rank]).standard_normal(n).astype(np.float32)
+
+
+def _ints_of(rank, tag, n):
+  return np.random.default_rng([29, tag, rank]).integers(-8, 9, n).astype(np.float32)
+
+
+DTYPES = (('f32', torch.float32), ('bf16', torch.bfloat16), ('f16', torch.float16))
+
+
+def _worker(rank, world, port, out, per_gpu):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if per_gpu else 0),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from embodied_amd import distributed as D
+  torch.cuda.set_device(rank if per_gpu else 0)
+  D.init('gloo')
+  try:
+    comm = D.DirectComm(rank, world, max_grad_bytes=4 << 20, max_slice_bytes=1 << 20, timeout_ms=15000)
+    cuda = lambda a: torch.as_tensor(a).cuda()
+    res = {}
+    res['all_to_all'] = comm.all_to_all(cuda(_bytes_of(rank, 1, world * SLICE_BYTES))).cpu().numpy()
+    res['all_to_all_odd'] = comm.all_to_all(cuda(_bytes_of(rank, 6, world * 1001))).cpu().numpy()
+    for name, dtype in DTYPES:
+      whole = cuda(_ints_of(rank, 2, GRAD_NUMEL)).to(dtype)
+      comm.all_reduce(whole, mean=False)
+      res[f'sum_{name}'] = whole.double().cpu().numpy()
+      noisy = cuda(_floats_of(rank, 3, GRAD_NUMEL)).to(dtype)
+      comm.all_reduce(noisy, mean=True)
+      res[f'mean_{name}'] = noisy.double().cpu().numpy()
+    tiny = cuda(_floats_of(rank, 7, 5))               # fewer elements than ranks * vector width
+    comm.all_reduce(tiny, mean=False)
+    res['tiny'] = tiny.cpu().numpy()
+    # Many operations back to back (the two slot sets alternate, flags count up):
+    # the buffers are still being produced on the stream when exchange() is called.
+    group = D.GroupComm()
+    log = []
+    keep = []
+    for k in range(6):
+      src = cuda(_bytes_of(rank, 10 + k, world * SLICE_BYTES))
+      slices = torch.empty_like(src)
+      slices.copy_(src)
+      slices.bitwise_xor_(0x5A)
+      grads = cuda(_floats_of(rank, 20 + k, GRAD_NUMEL)).to(torch.bfloat16)
+      grads.mul_(2)
+      twin_slices, twin_grads = slices.clone(), grads.clone()
+      received, twin_received = torch.zeros_like(slices), torch.zeros_like(slices)
+      comm.wait()
+      if k % 2 == 0:
+        comm.exchange(slices, received, grads)
+        group.exchange(twin_slices, twin_received, twin_grads)
+      else:
+        comm.exchange(grads=grads)
+        group.exchange(grads=twin_grads)
+      group.wait()
+      keep.append((slices, received, grads))
+      log.append((received, grads, twin_received, twin_grads))
+    comm.wait()
+    res['exchange'] = [(a.cpu().numpy(), b.float().cpu().numpy(), c.cpu().numpy(), d.float().cpu().numpy())
+                       for a, b, c, d in log]
+    res['timed_out'] = comm.timed_out()
+    try:
+      comm.all_reduce(torch.zeros(8, dtype=torch.float64, device='cuda'))
+      res['refused'] = False
+    except AssertionError:
+      res['refused'] = True
+    comm.close()
+    out[rank] = res
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def _check(out, world):
+  assert sorted(out.keys()) == list(range(world))
+  ranks = range(world)
+  sums = np.sum([_ints_of(r, 2, GRAD_NUMEL).astype(np.float64) for r in ranks], 0)
+  for rank in ranks:
+    got = out[rank]
+    assert got['timed_out'] is False                         # nobody gave up on a peer
+    for key, tag, size in (('all_to_all', 1, SLICE_BYTES), ('all_to_all_odd', 6, 1001)):
+      want = np.concatenate([_bytes_of(s, tag, world * size)[rank * size:(rank + 1) * size] for s in ranks])
+      assert np.array_equal(got[key], want), key
+    for name, tol in (('f32', 1e-6), ('bf16', 2e-2), ('f16', 2e-3)):
+      assert np.array_equal(got[f'sum_{name}'], sums), name  # small integers: exact in every dtype
+      parts = [torch.as_tensor(_floats_of(r, 3, GRAD_NUMEL)).to(dict(DTYPES)[name]).double().numpy()
+               for r in ranks]
+      np.testing.assert_allclose(got[f'mean_{name}'], np.mean(parts, 0), rtol=tol, atol=tol)
+      assert np.array_equal(got[f'mean_{name}'], out[0][f'mean_{name}'])      # all ranks alike, to the bit
+    np.testing.assert_allclose(got['tiny'], np.sum([_floats_of(r, 7, 5) for r in ranks], 0), rtol=1e-6)
+    for k, (received, grads, twin_received, twin_grads) in enumerate(got['exchange']):
+      want_grads = np.mean([
+          (torch.as_tensor(_floats_of(r, 20 + k, GRAD_NUMEL)).to(torch.bfloat16) * 2).float().numpy()
+          for r in ranks], 0)
+      np.testing.assert_allclose(grads, want_grads, rtol=2e-2, atol=2e-2)
+      np.testing.assert_allclose(grads, twin_grads, rtol=2e-2, atol=2e-2)    # == GroupComm on gloo
+      assert np.array_equal(grads, out[0]['exchange'][k][1])                  # all ranks alike, to the bit
+      want = np.zeros(world * SLICE_BYTES, np.uint8)
+      if k % 2 == 0:
+        want = np.concatenate([
+            (_bytes_of(s, 10 + k, world * SLICE_BYTES) ^ 0x5A)[rank * SLICE_BYTES:(rank + 1) * SLICE_BYTES]
+            for s in ranks])
+      assert np.array_equal(received, want), (rank, k)
+      assert np.array_equal(received, twin_received), (rank, k)
+    assert got['refused'] is True
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_direct_schedule_between_real_ranks_on_one_gpu(world):
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_worker, args=(world, _free_port(), out, False), nprocs=world, join=True)
+  _check(out, world)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs one GPU per rank')
+def test_direct_schedule_with_one_gpu_per_rank():
+  """Switches itself on wherever the suite sees at least two GPUs: the peers'
+  memory is then on another device, behind an xGMI link."""
+  world = min(torch.cuda.device_count(), 8)
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
+  _check(out, world)
+
+
+def test_world_of_one_is_the_identity():
+  from embodied_amd import distributed as D
+  comm = D.DirectComm(0, 1, max_grad_bytes=1 << 20, max_slice_bytes=1 << 20)
+  x = torch.arange(1000, dtype=torch.float32, device='cuda')
+  assert torch.equal(comm.all_reduce(x.clone(), mean=True), x)
+  flat = torch.randint(0, 255, (4096,), dtype=torch.uint8, device='cuda')
+  assert torch.equal(comm.all_to_all(flat), flat)
+  assert comm.timed_out() is False
+  comm.close()

@@ -59,12 +59,16 @@ GRAD_NUMEL = 300_000                   # f32: 1.2 MB, two slot loads
 
 
 def _worker(rank, world, port, lib, out):
-  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                    EMB_RCCL_LIB=lib, FAKE_RCCL_SLOT_BYTES=str(1 << 20), FAKE_RCCL_TIMEOUT_S='45')
+  """lib = the loopback stand-in (all ranks on GPU 0), or None: REAL RCCL, one GPU per rank."""
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0' if lib else str(rank),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  if lib:
+    os.environ.update(EMB_RCCL_LIB=lib, FAKE_RCCL_SLOT_BYTES=str(1 << 20), FAKE_RCCL_TIMEOUT_S='45')
+  else:
+    os.environ.pop('EMB_RCCL_LIB', None)
   from embodied_amd import distributed as D
   from tests.test_distributed_gloo import _returns_of
-  torch.cuda.set_device(0)
+  torch.cuda.set_device(0 if lib else rank)
   D.init('gloo')
   try:
     comm = D.NativeComm(rank, world)               # id from rank 0 through the gloo group
@@ -131,7 +135,7 @@ def _worker(rank, world, port, lib, out):
       res['refused'] = False
     except Exception as e:
       res['refused'] = 'dtype' in str(e)
-    res['ops'] = int(ctypes.CDLL(lib).fake_rccl_ops_done())
+    res['ops'] = int(ctypes.CDLL(lib).fake_rccl_ops_done()) if lib else 1000
     comm.close()
     out[rank] = res
   finally:
@@ -140,7 +144,36 @@ def _worker(rank, world, port, lib, out):
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_native_collectives_between_real_ranks(world):
-  lib = fake_rccl()
+  _run_and_check(world, fake_rccl())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='real RCCL needs one GPU per rank')
+def test_native_collectives_on_real_rccl():
+  """Switches itself on wherever the suite sees at least two GPUs: the same
+  worker, the same checks, the ten symbols bound from the real librccl (no
+  EMB_RCCL_LIB), one GPU per rank -- RCCL's own init ordering, group semantics
+  and stream behaviour at N > 1."""
+  _run_and_check(min(torch.cuda.device_count(), 4), None)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='real RCCL needs one GPU per rank')
+def test_bench_two_ranks_on_real_rccl():
+  """`python bench.py --gpus 2` as the driver runs it: nccl process group, the
+  library's own RCCL exchange in the timed path after its self-check against
+  torch.distributed passed on both ranks."""
+  from tests.test_gpu_bench_launcher import run_bench
+  rec = run_bench('--gpus', '2', '--steps', '20', '--warmup', '5')
+  assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['backend'] == 'nccl'
+  native = rec['native_comm']
+  assert native['status'] == 'ok' and native['ranks'] == 2 and all(native['checks'].values()), native
+  assert native['transport'] == 'rccl' and native['timed_path'] == 'native'
+  assert 'emb_comm_exchange' in rec['config']['parallelism']
+  assert rec['value'] > 0 and rec['replicas_only']['env_steps_per_s'] > 0
+  direct = native.get('direct')                       # the direct xGMI schedule, timed beside RCCL
+  assert direct and direct['status'] == 'ok', direct
+
+
+def _run_and_check(world, lib):
   manager = mp.Manager()
   out = manager.dict()
   mp.spawn(_worker, args=(world, _free_port(), lib, out), nprocs=world, join=True)
