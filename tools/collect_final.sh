@@ -1,6 +1,6 @@
 # Everything profiles/rNN_* is made from, on one GPU box (run from the repo root):
-#   tools/collect_final.sh r04
-TAG=${1:-r04}
+#   tools/collect_final.sh r05
+TAG=${1:-r05}
 set -x
 mkdir -p gpurun_out/$TAG
 timeout 1500 tools/collect_profiles.sh $TAG > gpurun_out/$TAG/collect.log 2>&1
@@ -16,7 +16,7 @@ timeout 300 python $R/tools/fuzz_add_paths.py --seeds 1000 --steps 600 2>&1 | ta
 HIP_FORCE_DEV_KERNARG=0 python $R/tools/profile_host_step.py > $O/profile_host_step.txt 2>&1
 # timelines (queues, overlap, the sequence of a window) of both workloads
 for w in ppo dreamer; do
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$w -o tr -- python $R/bench.py --workload $w --steps 2000 --warmup 100 --sustained-seconds 0 --no-cpu-baseline --no-context --no-dreamer-leg --capacity 100000 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$w -o tr -- python $R/bench.py --workload $w $([ $w = dreamer ] && echo --context-only) --steps 2000 --warmup 100 --sustained-seconds 0 --no-cpu-baseline --no-context --no-dreamer-leg --capacity 100000 > /dev/null 2>&1
   python $R/tools/trace_overlap.py $(find /tmp/tl_$w -name "*kernel_trace.csv" | head -1) 0.7 > $O/timeline_$w.txt 2>&1
 done
 cd $R

@@ -4,7 +4,7 @@
 # Counters are collected in their own passes (never together with a trace domain
 # other than --kernel-trace); FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -13,9 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$O/bench_default.json" 2>/dev/null
 # the runtime's default argument placement, for DESIGN.md 4's A/B
 HIP_FORCE_DEV_KERNARG=1 python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg > "$O/bench_device_kernargs.json" 2>/dev/null
-python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 3 --no-dreamer-leg 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
+python "$R/bench.py" --workload dreamer --context-only --steps 5000 --sustained-seconds 3 --no-dreamer-leg 2>/dev/null | grep '^{' > "$O/bench_dreamer.json"
+python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 3 --no-dreamer-leg 2>/dev/null | grep '^{' > "$O/bench_dreamer_full_gather.json"
 # the A/B of the early insert on this box (alternating runs; same everything else)
-"$R/tools/ab_bench.sh" "gpurun_out/$TAG/ab_early_insert" "EMB_EARLY_INSERT=0" "EMB_EARLY_INSERT=1" 2 > "$O/ab_early_insert.txt" 2>&1 || true
 # the driver's short form
 python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | grep '^{' > "$O/bench_steps20.json"
 # --stats of the SAME default command
@@ -26,42 +26,37 @@ HIP_FORCE_DEV_KERNARG=1 rocprofv3 --kernel-trace --stats --output-format csv -d 
   python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg > "$O/bench_device_kernargs_under_rocprof.json" 2>/dev/null
 cp /tmp/st1/st_kernel_stats.csv "$O/kernel_stats_bench_device_kernargs.csv"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st2 -o st -- \
-  python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 0 --no-cpu-baseline > /dev/null 2>&1
+  python "$R/bench.py" --workload dreamer --context-only --steps 5000 --sustained-seconds 0 --no-cpu-baseline > /dev/null 2>&1
 cp /tmp/st2/st_kernel_stats.csv "$O/kernel_stats_dreamer.csv"
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter --kernel-trace --output-format csv -d /tmp/p_$counter -o p -- \
     python "$R/bench.py" --steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context --no-dreamer-leg > /dev/null 2>&1
   python "$R/tools/summarize_pmc.py" /tmp/p_$counter/p_counter_collection.csv > "$O/pmc_$counter.csv"
 done
-# the same two counter passes for the configs[2] gather (144 MB per launch)
+# the same two counter passes for the configs[2] gather (context-only: 60 MB per launch)
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter --kernel-trace --output-format csv -d /tmp/pd_$counter -o p -- \
-    python "$R/bench.py" --workload dreamer --steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context > /dev/null 2>&1
+    python "$R/bench.py" --workload dreamer --context-only --steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context > /dev/null 2>&1
   python "$R/tools/summarize_pmc.py" /tmp/pd_$counter/p_counter_collection.csv > "$O/dreamer_pmc_$counter.csv"
 done
 HIP_FORCE_DEV_KERNARG=0 python "$R/tools/bench_gather.py" --batches 1,4,8,16,32,64,128,256 --tight > "$O/gather_sweep.txt" 2>&1
 HIP_FORCE_DEV_KERNARG=1 python "$R/tools/bench_gather.py" --batches 1,4,8,16,32,64,128,256 --tight > "$O/gather_sweep_device_kernargs.txt" 2>&1
-"$R/tools/build/gather_lab" 16 200 4 > "$O/gather_lab_B16.txt" 2>&1 || true
 HIP_FORCE_DEV_KERNARG=0 python "$R/tools/profile_step.py" > "$O/profile_step.txt" 2>&1
 HIP_FORCE_DEV_KERNARG=0 python "$R/tools/profile_train.py" 2>&1 | head -8 > "$O/profile_train.txt"
 rocprofv3 --kernel-trace --output-format csv -d /tmp/km -o km -- \
   python "$R/tools/bench_kernels.py" > /dev/null 2>&1
 python "$R/tools/summarize_trace.py" /tmp/km/km_kernel_trace.csv 3 > "$O/kernels_micro.csv" 2>/dev/null || true
-# return scans at SURVEY 8d's large synthetic size, both kernel forms
-for form in 4 1; do
-  EMB_SCAN_FORM=$form rocprofv3 --kernel-trace --output-format csv -d /tmp/sc$form -o sc -- \
-    python "$R/tools/bench_scans.py" > /dev/null 2>&1
-  python "$R/tools/summarize_trace.py" /tmp/sc$form/sc_kernel_trace.csv 20 | grep -i "kernel\|scan_rows" \
-    > "$O/scans_large_form$form.csv" || true
-done
+# return scans at SURVEY 8d's large synthetic size
+rocprofv3 --kernel-trace --output-format csv -d /tmp/sc -o sc -- python "$R/tools/bench_scans.py" > /dev/null 2>&1
+python "$R/tools/summarize_trace.py" /tmp/sc/sc_kernel_trace.csv 20 | grep -i "kernel\|scan_rows" > "$O/scans_large.csv" || true
 # write-back of image rows through the span mover
 HIP_FORCE_DEV_KERNARG=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/up -o up -- \
   python "$R/tools/bench_update.py" 16 > /dev/null 2>&1
 python "$R/tools/summarize_trace.py" /tmp/up/up_kernel_trace.csv 100 > "$O/update_image_rows.csv" 2>/dev/null || true
 # the multi-rank code path with RCCL as the transport, one rank (what a 1-GPU box can run)
-EMB_BENCH_FORCE_DIST=1 python "$R/bench.py" --no-cpu-baseline --no-context --sustained-seconds 5 2>/dev/null \
+python "$R/bench.py" --force-dist --no-cpu-baseline --no-context --sustained-seconds 5 2>/dev/null \
   | grep '^{' > "$O/bench_world1_rccl.json" || true
-EMB_BENCH_FORCE_DIST=1 python "$R/bench.py" --comm c10d --no-cpu-baseline --no-context --sustained-seconds 5 2>/dev/null \
+python "$R/bench.py" --force-dist --comm c10d --no-cpu-baseline --no-context --sustained-seconds 5 2>/dev/null \
   | grep '^{' > "$O/bench_world1_rccl_c10d.json" || true
 python - "$O" <<'PY'
 import csv, json, sys
@@ -88,7 +83,7 @@ step = {}
 for needle, what in (('obs_stack_insert_kernel', 'obs stack + early insert: 64 frames read once, written as bf16 policy batch and as pool rows'),
                      ('publish_one_kernel', 'masked action to its pool rows and to the next step\'s action buffer'),
                      ('synth_env_kernel', 'synthetic env frames (benchmark input)'),
-                     ('scatter_kernel', 'plain insert (EMB_EARLY_INSERT=0 / first step)'),
+                     ('flat_move_kernel', 'plain insert (EMB_EARLY_INSERT=0 / first step) and narrow keys'),
                      ('obs_stack_kernel', 'plain obs stack')):
   try:
     f, n, name = mean(f'{out}/pmc_FETCH_SIZE.csv', needle)
@@ -106,9 +101,9 @@ try:
   line = json.loads(open(f'{out}/bench_dreamer.json').read().strip().splitlines()[-1])
   algorithmic = line['roofline']['bytes_per_launch']     # 2 * B * L * (bytes per step of all keys)
   json.dump({
-      'kernel': name + ' (Replay.sample, configs[2]: B=16, L=65, image + latents)',
+      'kernel': name + ' (Replay.sample, configs[2]: B=16, L=65 frames + K=1 step of the latents)',
       'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --workload dreamer '
-                 '--steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context (two separate passes)',
+                 '--context-only --steps 300 --sustained-seconds 0 --no-cpu-baseline --no-context (two separate passes)',
       'dispatches': n,
       'fetch_size_kb_per_launch': fetch, 'write_size_kb_per_launch': write,
       'correction': 'FETCH_SIZE doubled: gfx950 counts 128-B requests at 64 B for 16 B/lane streams '
