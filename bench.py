@@ -808,6 +808,17 @@ def main():
         B * args.prefetch * L * S_all,
         sliced_share if args.exchange == 'dp_slice' and args.workload == 'ppo' else 0.0,
         1e6 * world / replicas_only['train_steps_per_s'])
+    # The same bound with the collectives' MEASURED time per train step instead of a
+    # share of link peak, one column per transport: rccl (emb_comm_*) and the direct
+    # schedule (emb_direct_*: all n-1 links at once).  x = n * min(1, period / collectives).
+    step = (native or {}).get('per_train_step') or {}
+    period = expected['train_period_us_collectives_off']
+    expected['link_bound_x_measured'] = {
+        name: round(world * min(1.0, period / max(step[key], 1e-9)), 2)
+        for name, key in (('rccl', 'collectives_us'), ('direct', 'direct_collectives_us')) if key in step}
+    expected['collectives_us_measured'] = {
+        name: step[key] for name, key in (('rccl', 'collectives_us'), ('direct', 'direct_collectives_us'))
+        if key in step}
     # the same two readings, measured: speed-up over ONE rank of the replicas_only loop
     per_rank = replicas_only['env_steps_per_s'] / world
     expected['measured_x'] = {

@@ -31,5 +31,4 @@ from . import utils
 from . import run
 from . import distributed
 from .utils import Counter, LocalClock
-from .core import clock
-from .core.clock import GlobalClock
+from .distributed import GlobalClock

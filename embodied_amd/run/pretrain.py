@@ -15,7 +15,7 @@ import pickle
 import time
 
 from .. import utils
-from ..core import clock
+from .. import distributed
 
 
 def _restorable(value):
@@ -29,7 +29,7 @@ def pretrain(make_model, make_stream, make_logger, args):
   logger = make_logger()
   step = logger.step
   should = {
-      name: clock.GlobalClock(getattr(args, f'{name}_every'))
+      name: distributed.GlobalClock(getattr(args, f'{name}_every'))
       for name in ('log', 'report', 'save')}
   metrics = utils.Agg()
   fps = utils.FPS()

@@ -368,7 +368,6 @@ def _pretrain_job(rank, world, D):
   import time
   import types
   import embodied_amd as emb
-  emb.clock.setup(is_server=(rank == 0), replica=rank, replicas=world, port=0, addr='127.0.0.1')
   logdir = os.path.join(tempfile.gettempdir(), f'emb_pretrain_{os.environ["MASTER_PORT"]}_{rank}')
 
   class Stream:

@@ -87,6 +87,8 @@ def test_bench_gpus_2_direct_schedule_between_two_real_ranks():
   assert native['timed_path'] == 'direct' and 'emb_direct_exchange' in rec['config']['parallelism']
   assert rec['train_steps_per_s'] > 0 and rec['value'] > 0
   assert native['per_train_step']['direct_collectives_us'] > 0
+  assert set(rec['expected']['link_bound_x_measured']) == {'rccl', 'direct'}       # both transports, side by side
+  assert 0 < rec['expected']['link_bound_x_measured']['direct'] <= 2.0
 
 
 def test_bench_gpus_8_control_flow():

@@ -236,19 +236,11 @@ def test_pretrain_starts_from_another_checkpoint(tmp_path):
   assert model.reports == {'report': 0, 'eval': 0}
 
 
-def test_clock_namespace_like_the_reference():
-  """`embodied.clock` / `embodied.GlobalClock` by name (core/__init__.py:3-4,10):
-  one process: GlobalClock is a LocalClock; setup() with one replica does
-  nothing, with more it wants the process group."""
-  import pytest
-  assert emb.clock.LocalClock is emb.LocalClock
-  always, never = emb.GlobalClock(-1), emb.clock.GlobalClock(0)
+def test_global_clock_without_a_process_group_is_a_local_clock():
+  always, never = emb.GlobalClock(-1), emb.GlobalClock(0)
   assert always() and always(skip=False) and not always(skip=True) and not never()
   timed = emb.GlobalClock(1000.0, first=True)
   assert timed() and not timed()
-  emb.clock.setup(is_server=True, replica=0, replicas=1, port=1234, addr='localhost')
-  with pytest.raises(RuntimeError):
-    emb.clock.setup(is_server=True, replica=0, replicas=2, port=1234, addr='localhost')
 
 
 def _reference_logfn(logger, epstats):
