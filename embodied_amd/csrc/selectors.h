@@ -297,9 +297,12 @@ class SampleTree {
 
   SampleTree(int branching, uint64_t seed) : branching_(branching), rng_(seed) {
     if (branching < 2) throw std::invalid_argument("SampleTree: branching < 2");
-    root_ = new Node();
+    root_ = make();
   }
-  ~SampleTree() { destroy(root_); }
+  ~SampleTree() {
+    destroy(root_);
+    for (Node* node : spare_) delete node;
+  }
   SampleTree(const SampleTree&) = delete;
   SampleTree& operator=(const SampleTree&) = delete;
 
@@ -321,17 +324,17 @@ class SampleTree {
         ++climbed;
       }
       if (!spot) {
-        spot = new Node();
+        spot = make();
         attach(spot, root_);
         root_ = spot;
       }
       for (int i = 0; i < climbed; ++i) {
-        Node* fresh = new Node();
+        Node* fresh = make();
         attach(spot, fresh);
         spot = fresh;
       }
     }
-    Node* leaf = new Node();
+    Node* leaf = make();
     leaf->leaf = true;
     leaf->key = key;
     leaf->mass = mass;
@@ -354,10 +357,10 @@ class SampleTree {
     while (node->up && node->kids.empty()) {
       Node* above = node->up;
       detach(above, node);
-      delete node;
+      recycle(node);
       node = above;
     }
-    delete leaf;
+    recycle(leaf);
     if (node->kids.empty()) {
       tail_ = nullptr;
       return;
@@ -431,6 +434,25 @@ class SampleTree {
   }
 
  private:
+  // A replay at capacity inserts and removes one leaf per step and worker: nodes
+  // are taken from and handed back to a free list instead of the allocator.
+  Node* make() {
+    if (spare_.empty()) return new Node();
+    Node* node = spare_.back();
+    spare_.pop_back();
+    return node;
+  }
+  void recycle(Node* node) {
+    node->up = nullptr;
+    node->leaf = false;
+    node->slot = 0;
+    node->key = 0;
+    node->mass = 0.0;
+    node->kids.clear();
+    node->kid_mass.clear();
+    if (spare_.size() < 4096) spare_.push_back(node);
+    else delete node;
+  }
   // Re-sum `node` and its ancestors.  A node whose fresh sum is bit for bit the
   // mass it holds leaves every ancestor as it is (each is the left-to-right sum
   // of its children's masses): the walk stops there.  With +inf masses around
@@ -482,7 +504,7 @@ class SampleTree {
   Node* tail_ = nullptr;
   SlidingMap<Node*> leaves_;
   std::vector<double> prob_, cdf_;
-  std::vector<Node*> dirty_, next_, handles_;
+  std::vector<Node*> dirty_, next_, handles_, spare_;
 };
 
 // Priority-proportional sampling over per-step priorities (selectors.py:128-197).
@@ -563,11 +585,12 @@ class Prioritized : public Selector {
     // (`newest` is a new id: the caller's guarantee -- a Replay issues every step
     // id once.  The general insert() checks it.)
     if (start + st->n - 2 != last) return false;
-    st->push_step(newest, initial_, powered(initial_));
+    const double pw = powered(initial_);
+    st->push_step(newest, initial_, pw);
     where_log(newest, st, last + 1, true);
     st->items.push_back(key);
     owner_.put(key, std::make_pair(st, start));
-    const double mass = stream_mass(*st, start);
+    const double mass = newest_mass(*st, start, pw);
     st->leaves.push_back(tree_.insert(key, mass));
     st->mass.push_back(mass);
     return true;
@@ -688,11 +711,15 @@ class Prioritized : public Selector {
     // Per step, one array each (the aggregation streams through `powered`).
     Sliding<double> prio, powered;
     Sliding<StepId> ids;
+    // No stored step has ever held a NaN or negative powered priority: a window
+    // with a +inf step then sums to +inf with maximum +inf whatever else it holds.
+    bool plain = true;
     int64_t n_steps() const { return static_cast<int64_t>(ids.size()); }
     void push_step(const StepId& id, double p, double pw) {
       ids.push_back(id);
       prio.push_back(p);
       powered.push_back(pw);
+      if (!(pw >= 0.0)) plain = false;
     }
     void pop_step() {
       ids.pop_front();
@@ -711,8 +738,17 @@ class Prioritized : public Selector {
   };
 
   void set_slot(Stream& st, int64_t pos, double prio) const {
+    const double pw = powered(prio);
     st.prio[pos - st.step0] = prio;
-    st.powered[pos - st.step0] = powered(prio);
+    st.powered[pos - st.step0] = pw;
+    if (!(pw >= 0.0)) st.plain = false;
+  }
+  // Mass of the window that ENDS with the step just pushed (`initial` powered =
+  // pw): with `initial: inf` (ppo/configs.yaml:42) it is decided by that step --
+  // what the left-to-right sum over the n steps gives, without walking them.
+  double newest_mass(const Stream& st, int64_t start, double pw) const {
+    if (pw == INFINITY && st.plain) return finish(INFINITY, INFINITY, st.n);
+    return stream_mass(st, start);
   }
   double stream_mass(const Stream& st, int64_t start) const {
     double total = 0.0, top = -INFINITY;
