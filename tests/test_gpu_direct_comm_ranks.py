@@ -169,3 +169,35 @@ def test_world_of_one_is_the_identity():
   assert torch.equal(comm.all_to_all(flat), flat)
   assert comm.timed_out() is False
   comm.close()
+
+
+def _lonely_worker(rank, world, port, out):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  import time
+  from embodied_amd import distributed as D
+  torch.cuda.set_device(0)
+  D.init('gloo')
+  try:
+    comm = D.DirectComm(rank, world, max_grad_bytes=1 << 20, max_slice_bytes=1 << 20, timeout_ms=300)
+    if rank == 0:
+      grads = torch.ones(4096, device='cuda')
+      began = time.perf_counter()
+      comm.all_reduce(grads)                 # rank 1 never joins this one
+      torch.cuda.synchronize()
+      out['seconds'] = time.perf_counter() - began
+      out['timed_out'] = comm.timed_out()
+    torch.distributed.barrier()              # rank 1 stays alive (its memory mapped) until rank 0 is through
+    comm.close()
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def test_a_peer_that_never_arrives_is_an_error_word_not_a_hung_gpu():
+  """Every wait inside the kernels is bounded by `timeout_ms`: the launch ends,
+  the stream goes on and `timed_out()` says what happened."""
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_lonely_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+  assert out['timed_out'] is True
+  assert 0.25 < out['seconds'] < 5.0        # two bounded waits (reduce, collect) of 0.3 s each
