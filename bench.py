@@ -140,9 +140,10 @@ def parse():
                       '(emb_comm_exchange: one call per train step, ~1/3 of the host time).  direct = '
                       'the library\'s direct xGMI schedule (emb_direct_exchange: every rank writes all '
                       'n-1 peers at once through hipIpc pointers, one link each; no RCCL).  auto '
-                      '(default) = native if the self-check against torch.distributed passes on '
-                      'every rank before the timed regions, else c10d.  Whatever is chosen, both '
-                      'transports are checked and timed beside each other in `native_comm`')
+                      '(default): both are checked against torch.distributed on the job\'s own GPUs '
+                      'and timed on its own bytes before the timed regions (`native_comm`); the timed '
+                      'path takes the faster of those that passed on every rank (direct only if it '
+                      'wins by more than 10 %%), c10d if neither did')
   p.add_argument('--grad-dtype', default='bf16', choices=['bf16', 'f32'],
                  help='N>1: dtype of the flat gradient buffer that is all-reduced every train '
                       'step (the reference all-reduces f32 leaves, embodied/jax/opt.py:52-54; '
@@ -535,6 +536,20 @@ def main():
       raise SystemExit(f'--comm direct: the self-check did not pass: {native.get("direct")}')
     # (all-gather forms of the exchange stay on torch.distributed.)
     use_direct = args.comm == 'direct' and args.exchange in ('dp_slice', 'none')
+    if (args.comm == 'auto' and world > 1 and native_comm is not None and direct_comm is not None
+        and args.exchange in ('dp_slice', 'none')):
+      # Both transports passed their checks against torch.distributed on this job's
+      # own GPUs and were timed on the job's own bytes: `auto` takes the one whose
+      # train-step exchange (all-to-all + all-reduce + wait) is faster on the
+      # slowest rank -- the direct schedule only if it wins by more than 10 %.
+      mine = torch.tensor([native['per_call']['native_exchange_step']['total_us'],
+                           native['direct']['per_call']['direct_exchange_step']['total_us']],
+                          dtype=torch.float64, device=device)
+      dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+      rccl_us, direct_us = mine.tolist()
+      use_direct = direct_us < 0.9 * rccl_us
+      native['auto'] = {'rccl_exchange_us': round(rccl_us, 1), 'direct_exchange_us': round(direct_us, 1),
+                        'chose': 'direct' if use_direct else 'native'}
     use_native = not use_direct and native_comm is not None and args.exchange in ('dp_slice', 'none')
     native['timed_path'] = 'direct' if use_direct else 'native' if use_native else 'c10d'
   if use_dist:
@@ -1032,6 +1047,8 @@ def main():
         **({'fresh_batches': fresh_batches} if fresh_batches is not None else {}),
         **({'expected': expected} if expected is not None else {}),
     }), flush=True)
+  if use_direct and rank == 0 and direct_comm.timed_out():
+    print('bench.py: the direct transport ran into a wait time-out during this run', file=sys.stderr)
   if native_stuck:       # a collective of the check never returned: leave without the teardown
     sys.stdout.flush()
     sys.stderr.flush()
@@ -1184,7 +1201,8 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
         dist.all_gather_object(box, data, group=group)
         return box
       direct = D.DirectComm(rank, world, device, max_grad_bytes=max(grads.numel() * grads.element_size(), 4 << 20),
-                            max_slice_bytes=max(2 * block, 1 << 20), share_all=share_all)    # (a packed batch pads its keys)
+                            max_slice_bytes=max(2 * block, 1 << 20), share_all=share_all,    # (a packed batch pads its keys)
+                            timeout_ms=3000)         # a peer that does not answer costs this check seconds, not the job
       kept.append(direct)
       dchecks = {}
       mine, ref = direct.all_to_all(flat), torch.empty_like(flat)
@@ -1197,11 +1215,12 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
         ref_all_reduce(b)
         dchecks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, b))
       dcosts = {}
-      for name, call in {
+      healthy = all(dchecks.values()) and not direct.timed_out()       # (timing a transport that is not: pointless)
+      for name, call in ({} if not healthy else {
           'direct_all_reduce': lambda: direct.all_reduce(grads, mean=True),
           'direct_all_to_all': lambda: direct.all_to_all(flat, recv),
           'direct_exchange_step': lambda: (direct.wait(), direct.exchange(flat, recv, grads)),
-      }.items():
+      }).items():
         reps = 10 if staged else 100
         for _ in range(reps // 10):
           call()
@@ -1217,7 +1236,7 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
       direct.wait()
       timed_out = direct.timed_out()
       report['direct'] = {'status': 'ok' if all(dchecks.values()) and not timed_out else 'mismatch',
-                          'checks': dchecks, 'timed_out': timed_out, 'per_call': dcosts}
+                          'checks': dchecks, 'timed_out': timed_out, **({'per_call': dcosts} if dcosts else {})}
     except Exception as e:
       report['direct'] = {'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]}
     return report

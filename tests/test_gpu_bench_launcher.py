@@ -54,7 +54,7 @@ def test_bench_gpus_2_native_exchange_between_two_real_ranks():
   lib = str(mod.build())
   rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
                   '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
-                  '--backend', 'gloo', env={'EMB_RCCL_LIB': lib})
+                  '--backend', 'gloo', '--comm', 'native', env={'EMB_RCCL_LIB': lib})
   assert rec['n_gpus'] == 2 and rec['backend'] == 'gloo'
   native = rec['native_comm']
   assert native['status'] == 'ok' and native['ranks'] == 2 and all(native['checks'].values()), native
@@ -89,6 +89,25 @@ def test_bench_gpus_2_direct_schedule_between_two_real_ranks():
   assert native['per_train_step']['direct_collectives_us'] > 0
   assert set(rec['expected']['link_bound_x_measured']) == {'rccl', 'direct'}       # both transports, side by side
   assert 0 < rec['expected']['link_bound_x_measured']['direct'] <= 2.0
+
+
+def test_bench_auto_takes_the_faster_transport_that_passed_its_check():
+  """`--comm auto` with two ranks: both transports are checked and timed on the
+  job's own bytes, every rank takes the same choice (MAX over ranks of the
+  measured exchange times).  Here the RCCL stand-in is a host-staged loopback,
+  far slower than stores through hipIpc pointers on one GPU: auto takes direct."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('_fake_rccl_build', ROOT / 'tests' / 'fake_rccl' / 'build.py')
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
+                  '--backend', 'gloo', env={'EMB_RCCL_LIB': str(mod.build())})
+  native = rec['native_comm']
+  assert native['status'] == 'ok' and native['direct']['status'] == 'ok'
+  auto = native['auto']
+  assert auto['chose'] == ('direct' if auto['direct_exchange_us'] < 0.9 * auto['rccl_exchange_us'] else 'native')
+  assert native['timed_path'] == auto['chose'] and rec['value'] > 0
 
 
 def test_bench_gpus_8_control_flow():

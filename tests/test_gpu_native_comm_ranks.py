@@ -166,8 +166,8 @@ def test_bench_two_ranks_on_real_rccl():
   assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['backend'] == 'nccl'
   native = rec['native_comm']
   assert native['status'] == 'ok' and native['ranks'] == 2 and all(native['checks'].values()), native
-  assert native['transport'] == 'rccl' and native['timed_path'] == 'native'
-  assert 'emb_comm_exchange' in rec['config']['parallelism']
+  assert native['transport'] == 'rccl' and native['timed_path'] == native['auto']['chose']
+  assert ('emb_direct_exchange' if native['timed_path'] == 'direct' else 'emb_comm_exchange') in rec['config']['parallelism']
   assert rec['value'] > 0 and rec['replicas_only']['env_steps_per_s'] > 0
   direct = native.get('direct')                       # the direct xGMI schedule, timed beside RCCL
   assert direct and direct['status'] == 'ok', direct
