@@ -20,7 +20,7 @@ python "$R/bench.py" --workload dreamer --steps 5000 --sustained-seconds 3 --no-
 python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | grep '^{' > "$O/bench_steps20.json"
 # --stats of the SAME default command
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -o st -- \
-  python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg > "$O/bench_under_rocprof.json" 2>"$O/stats_bench.log"
+  python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg --no-context > "$O/bench_under_rocprof.json" 2>"$O/stats_bench.log"
 cp /tmp/st/st_kernel_stats.csv "$O/kernel_stats_bench.csv"
 HIP_FORCE_DEV_KERNARG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st1 -o st -- \
   python "$R/bench.py" --no-cpu-baseline --no-dreamer-leg > "$O/bench_device_kernargs_under_rocprof.json" 2>/dev/null
