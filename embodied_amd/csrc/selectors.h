@@ -556,9 +556,7 @@ class Prioritized : public Selector {
     double* pw = &st->powered[start - st->step0];
     for (int i = 0; i < st->n; ++i) prio[i] = 0.0, pw[i] = zero_powered;
     const int64_t last = st->item0 + static_cast<int64_t>(st->items.size()) - 1;
-    ranges_.clear();
-    ranges_.push_back({st, std::max(st->item0, start - st->n + 1), std::min(last, start + st->n - 1)});
-    refresh_ranges();
+    refresh_drawn(st, std::max(st->item0, start - st->n + 1), std::min(last, start + st->n - 1));
     return key;
   }
   int64_t size() const override {
@@ -826,6 +824,51 @@ class Prioritized : public Selector {
     } else {
       ranges_.push_back({st, lo, hi});
     }
+  }
+  // refresh_ranges for the ONE range a zero-on-sample draw touches, as a single
+  // sliding pass: the counts of +inf and of non-zero steps of window j + 1 follow
+  // from window j's by one step out and one step in.  In a stream that has never
+  // held a NaN or negative powered priority (`plain`) a window with a +inf step
+  // sums to +inf with maximum +inf and a window of zeros to +0 with maximum 0 --
+  // the values stream_masses decides by its prefix counts; every other window is
+  // summed left to right as there.  Same masses, same leaf updates.
+  void refresh_drawn(Stream* st, int64_t lo, int64_t hi) {
+    if (!st->plain || lo > hi) {
+      ranges_.clear();
+      if (lo <= hi) ranges_.push_back({st, lo, hi});
+      refresh_ranges();
+      return;
+    }
+    const int n = st->n;
+    const double* base = &st->powered[lo - st->step0];       // steps lo .. hi + n - 1
+    double* held = &st->mass[lo - st->item0];
+    SampleTree::Node* const* leaf = &st->leaves[lo - st->item0];
+    const double all_inf = finish(INFINITY, INFINITY, n), all_zero = finish(0.0, 0.0, n);
+    int hot = 0, some = 0;
+    for (int i = 0; i < n; ++i) {
+      hot += base[i] == INFINITY ? 1 : 0;
+      some += base[i] != 0.0 ? 1 : 0;
+    }
+    leaves_.clear();
+    masses_.clear();
+    const int64_t count = hi - lo + 1;
+    for (int64_t j = 0; j < count; ++j) {
+      const double now = hot > 0 ? all_inf : some == 0 ? all_zero : stream_mass(*st, lo + j);
+      uint64_t a, b;
+      std::memcpy(&a, &now, 8);
+      std::memcpy(&b, &held[j], 8);
+      if (a != b) {
+        held[j] = now;
+        leaves_.push_back(leaf[j]);
+        masses_.push_back(now);
+      }
+      if (j + 1 < count) {
+        const double out = base[j], in = base[j + n];
+        hot += (in == INFINITY ? 1 : 0) - (out == INFINITY ? 1 : 0);
+        some += (in != 0.0 ? 1 : 0) - (out != 0.0 ? 1 : 0);
+      }
+    }
+    if (!leaves_.empty()) tree_.update_leaves(leaves_.data(), masses_.data(), static_cast<int64_t>(leaves_.size()));
   }
   void refresh_ranges() {
     std::sort(ranges_.begin(), ranges_.end(), [](const Range& a, const Range& b) {

@@ -14,7 +14,6 @@ from embodied_amd.envs import synthetic
 p = argparse.ArgumentParser()
 p.add_argument('--capacity', type=int, default=100_000)
 p.add_argument('--iters', type=int, default=50)
-p.add_argument('--variants', default='', help='unused: set EMB_MOVE_VARIANT=U,NT,remap,threads per process')
 p.add_argument('--batches', default='16,64,256')
 p.add_argument('--sleep-us', type=float, default=0, help='host idle time between samples')
 p.add_argument('--tight', action='store_true',
@@ -53,9 +52,7 @@ for B in map(int, args.batches.split(',')):
   print(f'torch copy_  B={B:4d} {us:8.2f} us  {2 * nbytes / us / 1e3:8.1f} GB/s (r+w)', flush=True)
 
 rep.profile(True)
-# The library reads EMB_MOVE_VARIANT once per process: to sweep, run this script
-# once per variant (see --variants help); a single run measures the active one.
-for variant in [os.environ.get('EMB_MOVE_VARIANT', 'default')]:
+for variant in ['ship']:
   for B in map(int, args.batches.split(',')):
     for _ in range(5):
       rep.sample(B)
@@ -80,7 +77,7 @@ if args.tight:
   from embodied_amd import _lib
   from embodied_amd._lib import fast
   for B in map(int, args.batches.split(',')):
-    outs = [rep._new_batch(B, L) for _ in range(4)]
+    outs = [rep._new_batch((B, L)) for _ in range(4)]
     first = (C.c_uint8 * (B * _lib.STEPID_BYTES))()
     stream = rep._stream()
     mode = _lib.MODES['train']

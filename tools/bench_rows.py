@@ -1,5 +1,5 @@
 """Sample gather of one synthetic wide key of `rowbytes` bytes per step (plus
-the flags): run under rocprofv3 --kernel-trace with EMB_SPAN_VARIANT set."""
+the flags): run under rocprofv3 --kernel-trace."""
 import os
 import sys
 

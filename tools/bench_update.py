@@ -1,7 +1,7 @@
 """Write-back (`Replay.update`) of PPO-shaped rows: sample B sequences, write
 the image key back over them.  Run under `rocprofv3 --kernel-trace` and read the
-scatter kernel's duration (tools/summarize_trace.py); EMB_SPAN_VARIANT selects
-the span mover's variant."""
+scatter kernel's duration (tools/summarize_trace.py); EMB_SPAN_MOVER=0 sends it
+through the flat mover."""
 import os
 import sys
 

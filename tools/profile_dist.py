@@ -1,5 +1,5 @@
 """Host cost of the multi-rank train step (run with world 1 on one GPU):
-EMB_BENCH_FORCE_DIST semantics, pieces timed separately."""
+`bench.py --force-dist` semantics, pieces timed separately."""
 import os
 import sys
 import time
