@@ -969,6 +969,14 @@ def main():
 
   env_actions = ('unmasked + reset (Env protocol, base.py:44-52)' if was_unmasked
                  else 'masked (driver.py:72-75)')
+  if use_direct:
+    # A wait inside the direct transport that gave up on a peer on ANY rank makes
+    # the exchanged bytes of this run meaningless: the line says so.
+    gave_up = torch.tensor([1.0 if direct_comm.timed_out() else 0.0], device=device)
+    dist.all_reduce(gave_up, op=dist.ReduceOp.MAX)
+    native['direct_timed_out_during_run'] = bool(gave_up.item())
+    if rank == 0 and gave_up.item():
+      print('bench.py: the direct transport ran into a wait time-out during this run', file=sys.stderr)
   if rank == 0:
     # Libraries that wrote to C stdio (RCCL's version banner) come out first, so
     # that the JSON line is the last line on stdout.
@@ -1047,8 +1055,6 @@ def main():
         **({'fresh_batches': fresh_batches} if fresh_batches is not None else {}),
         **({'expected': expected} if expected is not None else {}),
     }), flush=True)
-  if use_direct and rank == 0 and direct_comm.timed_out():
-    print('bench.py: the direct transport ran into a wait time-out during this run', file=sys.stderr)
   if native_stuck:       # a collective of the check never returned: leave without the teardown
     sys.stdout.flush()
     sys.stderr.flush()
@@ -1059,6 +1065,8 @@ def main():
     if native_comm is not None:
       native_comm.close()
     if direct_comm is not None:
+      torch.cuda.synchronize(device)
+      dist.barrier()           # nobody unmaps a buffer a peer's kernel may still be writing
       direct_comm.close()
     dist.destroy_process_group()
 

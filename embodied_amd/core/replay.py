@@ -1056,6 +1056,9 @@ class Replay:
     route, because the reference annotates the full sequence before slicing."""
     assert mode in _lib.MODES, mode
     assert consec * length + prefix == self.length, (consec, length, prefix, self.length)
+    if self._heads:
+      raise ValueError('sample_windows: this replay cuts keys to their first steps (heads=), which holds for '
+                       'the whole sequence, not for each window: use sample()')
     limiters.wait(
         lambda: len(self._native), f'Replay buffer {self.name} is empty')
     width = length + prefix

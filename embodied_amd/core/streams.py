@@ -246,6 +246,7 @@ class Consec(base.Stream):
         and getattr(fn, '__func__', None) is replaylib.Replay.sample
         and not src.kwargs and 1 <= len(src.args) <= 2
         and 'is_first' in (target._keyid or {'is_first': 0})
+        and not target._heads        # (context-only keys: the sliced route says why they cannot be windowed)
         and target.length == self.consec * self.length + self.prefix):
       mode = src.args[1] if len(src.args) > 1 else 'train'
       self._fused = (target, src.args[0], mode)

@@ -823,19 +823,40 @@ class DirectComm:
     self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     torch.cuda.set_device(self.device)
     self._handle = C.c_void_p()
-    api.emb_direct_create(self.rank, self.world, int(max_grad_bytes), int(max_slice_bytes), int(timeout_ms),
-                          C.byref(self._handle))
-    if self.world > 1:
-      mine = (C.c_uint8 * 64)()
-      api.emb_direct_handle(self._handle, mine)
-      if share_all is None:
-        def share_all(data):
-          box = [None] * self.world
-          dist.all_gather_object(box, data)
-          return box
-      handles = share_all(bytes(mine))
-      assert len(handles) == self.world and all(len(h) == 64 for h in handles)
-      api.emb_direct_connect(self._handle, (C.c_uint8 * (64 * self.world)).from_buffer_copy(b''.join(handles)))
+    if self.world == 1:
+      api.emb_direct_create(0, 1, int(max_grad_bytes), int(max_slice_bytes), int(timeout_ms), C.byref(self._handle))
+      return
+    if share_all is None:
+      def share_all(data):
+        box = [None] * self.world
+        dist.all_gather_object(box, data)
+        return box
+    # A rank whose buffer cannot be made or mapped (no IPC between two of the
+    # GPUs, out of memory) must not leave the others waiting inside share_all:
+    # every rank takes part in both rounds whatever happened to it, and all of
+    # them raise together.
+    failure, mine = None, b''
+    try:
+      api.emb_direct_create(self.rank, self.world, int(max_grad_bytes), int(max_slice_bytes), int(timeout_ms),
+                            C.byref(self._handle))
+      raw = (C.c_uint8 * 64)()
+      api.emb_direct_handle(self._handle, raw)
+      mine = bytes(raw)
+    except Exception as e:
+      failure = e
+    handles = share_all(mine)
+    assert len(handles) == self.world, (len(handles), self.world)
+    if failure is None and all(len(h) == 64 for h in handles):
+      try:
+        api.emb_direct_connect(self._handle, (C.c_uint8 * (64 * self.world)).from_buffer_copy(b''.join(handles)))
+      except Exception as e:
+        failure = e
+    mapped = share_all(b'' if failure is not None else b'ok')
+    if failure is not None or any(m != b'ok' for m in mapped):
+      lost = [r for r, m in enumerate(mapped) if m != b'ok']
+      self.close()
+      raise RuntimeError(f'DirectComm: rank(s) {lost} could not set up the direct transport'
+                         + (f' (here: {type(failure).__name__}: {failure})' if failure is not None else ''))
 
   _CODES = None
 

@@ -201,3 +201,33 @@ def test_a_peer_that_never_arrives_is_an_error_word_not_a_hung_gpu():
   mp.spawn(_lonely_worker, args=(2, _free_port(), out), nprocs=2, join=True)
   assert out['timed_out'] is True
   assert 0.25 < out['seconds'] < 5.0        # two bounded waits (reduce, collect) of 0.3 s each
+
+
+def _failing_worker(rank, world, port, out):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from embodied_amd import distributed as D
+  torch.cuda.set_device(0)
+  D.init('gloo')
+  try:
+    # rank 1 asks for a buffer no GPU has: its setup fails, rank 0's is fine
+    size = (1 << 50) if rank == 1 else (1 << 20)
+    try:
+      D.DirectComm(rank, world, max_grad_bytes=size, max_slice_bytes=1 << 20, timeout_ms=300)
+      out[rank] = 'constructed'
+    except RuntimeError as e:
+      out[rank] = str(e)
+    torch.distributed.barrier()
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def test_a_rank_that_cannot_set_up_fails_every_rank_together():
+  """Setup takes part in both of its rounds whatever happened locally: the
+  healthy rank raises too (naming the rank that failed) instead of waiting for
+  a handle that never comes -- bench.py's `--comm auto` then stays on RCCL."""
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_failing_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+  assert 'rank(s) [1] could not set up' in out[0], out[0]
+  assert 'rank(s) [1] could not set up' in out[1] and 'here:' in out[1], out[1]

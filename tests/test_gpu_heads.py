@@ -259,3 +259,21 @@ def test_heads_are_checked(emb):
   wrong['x'] = torch.empty((3, 4), dtype=torch.float32, device='cuda')
   with pytest.raises(ValueError):
     rep.sample(3, out=wrong)
+
+
+def test_windowed_routes_refuse_context_only_keys(emb):
+  """A head holds for the whole sampled sequence, not for each `Consec` window:
+  both windowed routes (the fused gather and the slicing one) say so instead of
+  handing back keys of two different time axes."""
+  rep = emb.Replay(8, 100, chunksize=8, seed=0, heads={'dyn/': 1})
+  for t in range(30):
+    rep.add({'image': np.uint8(t), 'dyn/deter': np.float32(t), 'is_first': np.bool_(t == 0),
+             'is_last': np.bool_(False)})
+  with pytest.raises(ValueError, match='heads='):
+    rep.sample_windows(2, 4, 2)
+  windows = emb.streams.Consec(emb.streams.Stateless(rep.sample, 2), length=4, consec=2)
+  with pytest.raises(AssertionError, match='context-only'):
+    next(iter(windows))
+  # one window per sequence is the sequence itself: heads pass through
+  whole = next(iter(emb.streams.Consec(emb.streams.Stateless(rep.sample, 2), length=8, consec=1)))
+  assert whole['dyn/deter'].shape == (2, 1) and whole['image'].shape == (2, 8)
