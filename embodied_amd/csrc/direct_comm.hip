@@ -21,7 +21,7 @@
 //   all-to-all  = 1. push block p into peer p's slot r + flag; 2. wait, copy the
 //                 slots into the receive buffer.
 //
-// Peers' memory is reached through hipIpc handles of ONE fine-grained
+// Peers' memory is reached through hipIpc handles of ONE uncached (fine-grained)
 // allocation per rank (header with the flags + double-buffered slots), so the
 // transport needs nothing but the HIP runtime; flags are 32-bit sequence
 // numbers written with system-scope release stores behind a system-scope fence
@@ -393,9 +393,18 @@ int32_t emb_direct_create(int32_t rank, int32_t world, int64_t max_reduce_bytes,
     d->shard_cap = round_up((max_reduce_bytes + world - 1) / world + 16, 256);
     d->region_bytes = sizeof(DirectHeader) + 4ull * world * d->shard_cap + 2ull * world * d->a2a_cap;
     d->timeout_ticks = static_cast<uint64_t>(timeout_ms) * 100000ull;        // wall_clock64: 100 MHz
-    // Fine-grained: stores of a peer GPU become visible to this GPU's loads
-    // without a kernel boundary in between (what RCCL's own buffers are).
-    HIP_OK(hipExtMallocWithFlags(reinterpret_cast<void**>(&d->region), d->region_bytes, hipDeviceMallocFinegrained));
+    // Uncached (fine-grained and never kept in this GPU's L2): stores of a peer GPU
+    // become visible to this GPU's loads without a kernel boundary in between, and
+    // no line of a slot read two operations ago can be served stale.  Slots are
+    // streamed once per operation, so the L2 had nothing to add.  A runtime
+    // without the uncached kind gets fine-grained memory, coherent through the
+    // system-scope acquire of wait_all.
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&d->region), d->region_bytes, hipDeviceMallocUncached) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      HIP_OK(hipExtMallocWithFlags(reinterpret_cast<void**>(&d->region), d->region_bytes,
+                                   hipDeviceMallocFinegrained));
+    }
     HIP_OK(hipMemset(d->region, 0, sizeof(DirectHeader)));
     HIP_OK(hipDeviceSynchronize());
     d->peer[rank] = d->region;

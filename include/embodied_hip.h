@@ -507,8 +507,8 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
  * The two collectives of a train step -- the gradient all-reduce
  * (embodied/jax/opt.py:52-54) and the DP-slice all-to-all
  * (embodied/jax/internal.py:145-152) -- without RCCL: every rank writes its
- * peers' shares straight into their memory (hipIpc handles of one fine-grained
- * allocation per rank), all n-1 peers at once, one xGMI link each; flags in that
+ * peers' shares straight into their memory (hipIpc handles of one uncached,
+ * fine-grained allocation per rank), all n-1 peers at once, one xGMI link each; flags in that
  * memory order the steps (csrc/direct_comm.hip states the schedule).  One node,
  * at most 8 ranks, one GPU per rank (or several ranks on one GPU: the tests).
  *
