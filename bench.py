@@ -434,12 +434,15 @@ def main():
       rows = B * args.prefetch
       sliced = (args.exchange == 'dp_slice' and rows % world == 0
                 and replay.online_pending() > 0)
+      # (packed batches, received slices and scan results rotate through four
+      # buffers each: a buffer is read again one train step later at the latest)
       if sliced:
         # Fresh on-policy windows: cut the batch into one block per rank.
         collectives['sliced'] += 1
-        flat, batch, layout = D.sample_packed(replay, rows, groups=world)
+        flat, batch, layout = D.sample_packed(replay, rows, groups=world, reuse=4)
       else:
-        flat, batch, layout = D.sample_packed(replay, rows)
+        flat, batch, layout = D.sample_packed(replay, rows, reuse=4)
+      scan_out = packed_out[counters['train_steps'] // args.prefetch & 3]
       # Last train step's collectives (they ran behind the env steps since):
       # `link` is the library's own RCCL exchange (emb_comm_exchange, its own
       # stream) or the same contract on the process group (D.GroupComm).
@@ -453,14 +456,16 @@ def main():
         # batch; it is complete one train step later (the wait above) and is
         # what the learner then computes returns on.  Slices and gradients go
         # out in ONE exchange call.
-        received = torch.empty_like(flat)
+        if not received_ring:
+          received_ring.extend(torch.empty_like(flat) for _ in range(4))
+        received = received_ring[collectives['sliced'] & 3]
         link.exchange(flat, received, grads)
         state_keep[:] = [flat, received]
         late, slice_state['recv'] = slice_state.get('recv'), (received, layout)
         source, source_info = late if late is not None else (flat, layout)
-        adv, tar = D.gae_packed(source, source_info, value, hor=200, lam=0.8)
+        adv, tar = D.gae_packed(source, source_info, value, hor=200, lam=0.8, out=scan_out)
       else:
-        adv, tar = D.gae_packed(flat, layout, value, hor=200, lam=0.8)
+        adv, tar = D.gae_packed(flat, layout, value, hor=200, lam=0.8, out=scan_out)
         if args.exchange == 'trajectories' or (args.exchange == 'online' and layout.online.any()):
           send = flat
         elif args.exchange == 'returns':
@@ -477,15 +482,25 @@ def main():
       # When the links are the bottleneck the host could queue train steps far
       # ahead of the GPU (one gathered buffer each): stay within 8 train steps.
       if counters['train_steps'] % 4 == 0:       # one mark per 4 train steps, 8 marks deep
-        marks.append(torch.cuda.Event())
-        marks[-1].record()
-        if len(marks) > 8:
-          marks.pop(0).synchronize()
+        if len(marks) == 8:
+          mark = marks.pop(0)
+          mark.synchronize()                     # the GPU has passed the mark of 32 train steps ago
+        else:
+          mark = torch.cuda.Event()
+        # (eight events, recorded again in turn; the stream is looked up once:
+        # torch.cuda.current_stream() costs more than the record itself)
+        if 'stream' not in slice_state:
+          slice_state['stream'] = torch.cuda.current_stream(device)
+        mark.record(slice_state['stream'])
+        marks.append(mark)
     counters['train_steps'] += args.prefetch
     return adv
 
   state_keep = []
   slice_state = {}
+  received_ring = []
+  packed_out = [tuple(torch.empty(B * args.prefetch, T + args.context - 1, device=device) for _ in range(2))
+                for _ in range(4)] if use_dist else None
 
   # The learner's stream (--streams 2): the Replay orders its pool accesses across
   # the two streams itself (emb_replay_multistream; abi.cpp StreamOrder).

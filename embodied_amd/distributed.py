@@ -141,10 +141,16 @@ class SampleInfo:
     return self.layout.views(flat, lead)
 
 
-def sample_packed(replay, batch, mode='train', groups=1):
+def sample_packed(replay, batch, mode='train', groups=1, reuse=0):
   """`replay.sample` into one packed buffer: returns (flat uint8, per-key views,
   info with `.online` flags and the layout).  The gather kernel writes each key
   at its offset directly.
+
+  `reuse` = K >= 2 rotates K buffers of the replay's own instead of allocating
+  one per call (`Replay(reuse_outputs=K)`'s contract: a packed batch is
+  overwritten by the K-th sample after it, on the sampling stream -- a caller that
+  sends it from another stream waits for that send first, as `exchange` +
+  `wait` one train step later do).
 
   `groups` > 1 cuts the batch into that many equal blocks of `batch / groups`
   sequences, each block a complete packed sub-batch (all keys) of its own:
@@ -169,10 +175,21 @@ def sample_packed(replay, batch, mode='train', groups=1):
       layout.groups = groups
       layout.online_ptrs = [np.zeros(batch, np.uint8) for _ in range(4)]   # handed out in turn
       layout.turn = 0
-    flat = _lib.empty((groups * layout.nbytes,), torch.uint8, replay.device)
-    base, ptrs = flat.data_ptr(), layout.ptrs
-    for i, offset in enumerate(layout.offsets):
-      ptrs[i] = base + offset
+      layout.ring, layout.ring_turn = [], -1        # reuse=K: (buffer, key addresses) sets used in turn
+    if reuse:
+      assert reuse >= 2, reuse
+      ring = layout.ring
+      slot = layout.ring_turn = (layout.ring_turn + 1) % reuse
+      if slot >= len(ring):
+        flat = torch.empty((groups * layout.nbytes,), dtype=torch.uint8, device=replay.device)
+        ptrs = (C.c_void_p * len(replay._keys))(*[flat.data_ptr() + o for o in layout.offsets])
+        ring.append((flat, ptrs))
+      flat, ptrs = ring[slot]
+    else:
+      flat = _lib.empty((groups * layout.nbytes,), torch.uint8, replay.device)
+      base, ptrs = flat.data_ptr(), layout.ptrs
+      for i, offset in enumerate(layout.offsets):
+        ptrs[i] = base + offset
     layout.turn = (layout.turn + 1) & 3
     online = layout.online_ptrs[layout.turn]
     if groups == 1:
@@ -190,11 +207,13 @@ def sample_packed(replay, batch, mode='train', groups=1):
   return flat, views, SampleInfo(layout, online.view(np.bool_).copy())
 
 
-def gae_packed(flat, info, value, hor=200, lam=0.8):
+def gae_packed(flat, info, value, hor=200, lam=0.8, out=None):
   """`scans.gae` on a packed batch (dense or grouped — sampled locally or
   delivered by `exchange_dp_slices`) without materialising views or dense copies:
   the scan kernel reads `reward`, `is_last`, `is_terminal` in place.  `value` is
-  the critic's dense (B, T) float32 output.  Returns adv, tar (B, T-1)."""
+  the critic's dense (B, T) float32 output.  Returns adv, tar (B, T-1); `out` =
+  (adv, tar), two contiguous float32 (B, T-1) tensors of the caller's, is
+  written instead of fresh ones (`scans.gae(out=)`)."""
   from . import _lib, scans
   layout = info.layout
   groups = getattr(layout, 'groups', 1)
@@ -206,8 +225,13 @@ def gae_packed(flat, info, value, hor=200, lam=0.8):
   assert index['reward'][1] == torch.float32, index['reward'][1]
   for name in ('is_last', 'is_terminal'):
     assert index[name][1] in (torch.bool, torch.uint8), (name, index[name][1])
-  both = _lib.empty((2, B, T - 1), torch.float32, flat.device)
-  adv, tar = both.unbind(0)
+  if out is None:
+    both = _lib.empty((2, B, T - 1), torch.float32, flat.device)
+    adv, tar = both.unbind(0)
+  else:
+    adv, tar = out
+    for t in (adv, tar):
+      assert t.shape == (B, T - 1) and t.dtype == torch.float32 and t.is_contiguous() and t.device == flat.device
   _lib.fast.emb_scan_gae_grouped(
       base + index['reward'][3], value.data_ptr(), base + index['is_last'][3],
       base + index['is_terminal'][3], B, T, scans._round32(1 - 1 / hor), scans._round32(lam),

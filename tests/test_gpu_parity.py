@@ -807,6 +807,29 @@ def test_sample_packed_equals_sample(emb):
   fill(c)
   _, _, first = D.sample_packed(c, 6)
   assert first.online.all()                # 3 workers x 8 windows are queued
+  # reuse=K: the replay's own K buffers in turn (same bytes, the K-th later
+  # sample overwrites), for both layouts; gae_packed(out=) writes the caller's
+  d = emb.Replay(length=5, capacity=60, chunksize=8, online=True, seed=2)
+  fill(d)
+  d.sample(6)                              # (c has handed out one batch above)
+  seen, value = [], torch.randn(6, 5, device='cuda')
+  mine = (torch.empty(6, 4, device='cuda'), torch.empty(6, 4, device='cuda'))
+  for n in range(7):
+    flat, views, info = D.sample_packed(c, 6, reuse=3, groups=2 if n % 2 else 1)
+    want = d.sample(6)
+    for key in want:
+      assert torch.equal(views[key].reshape(want[key].shape), want[key]), (n, key)
+    seen.append((n % 2, flat.data_ptr()))
+    adv, tar = D.gae_packed(flat, info, value, out=mine)
+    assert adv is mine[0] and tar is mine[1]
+    ref = emb.scans.gae(want['reward'], value, want['is_last'], want['is_terminal'])
+    assert torch.equal(adv, ref[0]) and torch.equal(tar, ref[1])
+  dense = [p for kind, p in seen if kind == 0]          # four samples through three buffers
+  grouped = [p for kind, p in seen if kind == 1]        # three samples, a layout (and a ring) of their own
+  assert len(set(dense)) == 3 and dense[3] == dense[0]
+  assert len(set(grouped)) == 3 and not set(grouped) & set(dense)
+  with pytest.raises(AssertionError):
+    D.gae_packed(flat, info, value, out=(mine[0][:, :3], mine[1]))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.int32, torch.int64])

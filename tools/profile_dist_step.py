@@ -44,31 +44,38 @@ def main():
     laps.setdefault(name, []).append(t1 - t0)
     return time.perf_counter_ns()
 
-  keep = []
+  keep, ring, marks = [], [], []
+  outs = [tuple(torch.empty(B, T + args.context - 1, device=device) for _ in range(2)) for _ in range(4)]
   for it in range(mine.iters):
     for _ in range(5):
       driver(policy, steps=args.envs)
     t = time.perf_counter_ns()
     pending = replay.online_pending() > 0
     t = lap('online_pending', t)
-    flat, batch, layout = D.sample_packed(replay, B, groups=1)
+    flat, batch, layout = D.sample_packed(replay, B, groups=1, reuse=4)
     t = lap('sample_packed', t)
     link.wait()
     t = lap('link.wait', t)
     if it % 3 == 0:
-      received = torch.empty_like(flat)
-      t = lap('empty_like', t)
+      if not ring:
+        ring.extend(torch.empty_like(flat) for _ in range(4))
+      received = ring[it // 3 & 3]
       link.exchange(flat, received, grads)
       t = lap('exchange(slices+grads)', t)
       keep[:] = [flat, received]
     else:
       link.exchange(grads=grads)
       t = lap('exchange(grads)', t)
-    adv, tar = D.gae_packed(flat, layout, value, hor=200, lam=0.8)
+    adv, tar = D.gae_packed(flat, layout, value, hor=200, lam=0.8, out=outs[it & 3])
     t = lap('gae_packed', t)
     if it % 4 == 0:
-      mark = torch.cuda.Event()
+      if len(marks) == 8:
+        mark = marks.pop(0)
+        mark.synchronize()
+      else:
+        mark = torch.cuda.Event()
       mark.record()
+      marks.append(mark)
       t = lap('mark', t)
     if it % 64 == 0:
       torch.cuda.synchronize()
