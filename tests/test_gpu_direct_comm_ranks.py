@@ -231,3 +231,66 @@ def test_a_rank_that_cannot_set_up_fails_every_rank_together():
   mp.spawn(_failing_worker, args=(2, _free_port(), out), nprocs=2, join=True)
   assert 'rank(s) [1] could not set up' in out[0], out[0]
   assert 'rank(s) [1] could not set up' in out[1] and 'here:' in out[1], out[1]
+
+
+STRESS_SIZES = (1, 7, 4096, 300_007, 1 << 20)            # elements; also bytes per all-to-all block
+
+
+def _stress_worker(rank, world, port, out, per_gpu, rounds):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if per_gpu else 0),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from embodied_amd import distributed as D
+  torch.cuda.set_device(rank if per_gpu else 0)
+  D.init('gloo')
+  try:
+    comm = D.DirectComm(rank, world, max_grad_bytes=4 << 20, max_slice_bytes=1 << 20, timeout_ms=20000)
+    bad = torch.zeros(3, dtype=torch.int64, device='cuda')       # all-reduce, all-to-all, exchange
+    peers = torch.arange(world, device='cuda')
+    for i in range(rounds):
+      n = STRESS_SIZES[i % len(STRESS_SIZES)]
+      # every operation's payload is a function of (rank, i): a slot read one
+      # operation late, or overwritten one early, shows as a wrong value
+      grads = torch.full((n,), float(rank + 1 + i % 7), device='cuda')
+      want = world * (world + 1) / 2 + world * (i % 7)
+      blocks = ((peers * 16 + rank * 3 + i) % 251).to(torch.uint8)              # block p of mine
+      flat = blocks.repeat_interleave(n)
+      arrive = ((rank * 16 + peers * 3 + i) % 251).to(torch.uint8).repeat_interleave(n)   # block s from rank s
+      if i % 3 == 2:
+        received = torch.empty_like(flat)
+        comm.wait()
+        comm.exchange(flat, received, grads, mean=False)
+        comm.wait()
+        bad[2] += (grads != want).any() | (received != arrive).any()
+      else:
+        comm.all_reduce(grads, mean=False)
+        bad[0] += (grads != want).any()
+        bad[1] += (comm.all_to_all(flat) != arrive).any()
+    torch.cuda.synchronize()
+    out[rank] = {'bad': bad.cpu().tolist(), 'timed_out': comm.timed_out()}
+    torch.distributed.barrier()
+    comm.close()
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_a_thousand_operations_back_to_back(world):
+  """The two slot sets alternate and the sequence flags count up through 1 000
+  operations of five sizes, queued without a host synchronisation in between:
+  every result is checked on the device against the value its (rank, round)
+  alone determines."""
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_stress_worker, args=(world, _free_port(), out, False, 1000), nprocs=world, join=True)
+  for rank in range(world):
+    assert out[rank] == {'bad': [0, 0, 0], 'timed_out': False}, (rank, out[rank])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs one GPU per rank')
+def test_a_thousand_operations_back_to_back_with_one_gpu_per_rank():
+  world = min(torch.cuda.device_count(), 8)
+  manager = mp.Manager()
+  out = manager.dict()
+  mp.spawn(_stress_worker, args=(world, _free_port(), out, True, 1000), nprocs=world, join=True)
+  for rank in range(world):
+    assert out[rank] == {'bad': [0, 0, 0], 'timed_out': False}, (rank, out[rank])
