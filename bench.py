@@ -190,8 +190,8 @@ def parse():
                       'write-back -- is issued on a HIP stream of its own (the actor / learner split '
                       'of run/actor_learner.py; the reference dispatches its train step '
                       'asynchronously as well); 1: everything on one stream; 0 (default): 2 for the '
-                      'dreamer workload (+6-7 %: the env steps\' small kernels run in the ramps of the '
-                      '144 MB gathers), 1 for ppo (measured 12 % SLOWER with 2: the persistent gather '
+                      'dreamer workload (+6-7 %%: the env steps\' small kernels run in the ramps of the '
+                      '144 MB gathers), 1 for ppo (measured 12 %% SLOWER with 2: the persistent gather '
                       'holds every CU\'s registers for its 11 us, the three dependent small kernels '
                       'of the env step wait behind it instead of beside it)')
   p.add_argument('--mask-actions-for-env', action='store_true',

@@ -80,3 +80,13 @@ def test_the_rank_launcher_does_not_pin_itself(bench, monkeypatch):
   monkeypatch.setenv('WORLD_SIZE', '8')
   monkeypatch.setattr(bench.sys, 'argv', ['bench.py', '--gpus', '8'])
   assert not bench._is_launcher()          # a rank under torch.distributed.run pins itself
+
+
+def test_help_text_renders(bench, monkeypatch, capsys):
+  """argparse formats every help string with %: a bare per-cent sign in one of
+  them breaks `python bench.py --help` (and nothing else)."""
+  monkeypatch.setattr('sys.argv', ['bench.py', '--help'])
+  with pytest.raises(SystemExit) as stop:
+    bench.parse()
+  assert stop.value.code == 0
+  assert '--comm' in capsys.readouterr().out
