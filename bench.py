@@ -581,11 +581,19 @@ def main():
     stamp_every = args.stamp_every
   elif expected >= 256:
     stamp_every = 32 if expected >= 8192 else 16 if expected >= 4096 else 4
+  elif args.sustained_seconds > 0 and expected >= 2:
+    # A handful of gathers per region (the driver's --steps 20 has four, sixty
+    # over its sixteen regions).  A stamped launch costs the stepping thread 7.4 us
+    # instead of 1.6 (two event records), and a 260 us region has nowhere to hide
+    # that: with every second gather stamped `value` read 6.5 % lower than with
+    # no stamps at all, with one in eight 1-2 % (profiles/r05_ab_stamps.txt).  The
+    # roofline figure of such a run stands on the sustained window's thousands of
+    # stamped launches anyway (`roofline.source`); the regions keep one in eight.
+    stamp_every = 8
   else:
-    # A handful of gathers in the region (the driver's --steps 20 has four):
-    # every second one is stamped, beginning with the second (the stamp counter
-    # restarts right before the timed region; the region's first gather runs on
-    # a GPU that the fence has just drained).
+    # No sustained window behind the regions: every second gather is stamped,
+    # beginning with the second (the stamp counter restarts right before the timed
+    # region; the region's first gather runs on a GPU the fence has just drained).
     stamp_every = 2 if expected >= 2 else 1
   replay.profile(not args.no_timer, every=stamp_every)
   # Like `timeit`: no pass of the interpreter's cyclic collector over its whole
