@@ -376,7 +376,8 @@ def _pretrain_job(rank, world, D):
   import time
   import types
   import embodied_amd as emb
-  logdir = os.path.join(tempfile.gettempdir(), f'emb_pretrain_{os.environ["MASTER_PORT"]}_{rank}')
+  import shutil
+  logdir = tempfile.mkdtemp(prefix=f'emb_pretrain_{rank}_')      # (a fresh one: a checkpoint left behind would be resumed)
 
   class Stream:
     def __init__(self):
@@ -414,6 +415,7 @@ def _pretrain_job(rank, world, D):
       save_every=0.04, consec_report=1, report_batches=1, replica=rank, from_checkpoint='')
   emb.run.pretrain(lambda: model, lambda replay, mode: Stream(), lambda: emb.utils.Logger(), args)
   wrote = os.path.exists(os.path.join(logdir, 'checkpoint.pkl'))
+  shutil.rmtree(logdir, ignore_errors=True)
   return model.trains, sorted(set(model.report_steps)), model.saves, wrote
 
 
