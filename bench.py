@@ -883,9 +883,10 @@ def main():
     avg_s = gather_ms / (samples if per_sample else launches) / 1e3
     region = {'avg_launch_us': round(avg_s * 1e6, 2), 'launches': launches,
               'frac': round(algo_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
-    source = f'stamped launches of the timed region ({args.steps} steps)'
-    # A short region (the driver's --steps 20 holds three or four gathers, two of
-    # them stamped) gives a two-launch sample that moves by 10 % from run to run:
+    source, one_in = f'stamped launches of the timed region ({args.steps} steps)', stamp_every
+    # A short region (the driver's --steps 20 holds three or four gathers, sixty
+    # over its sixteen regions, a handful of them stamped) gives a sample that
+    # moves by 10 % from run to run:
     # the figure the line stands on is then the mean over the sustained window's
     # stamped launches (same loop, same kernel, >= 1000 of them), which is what
     # `rocprofv3 --kernel-trace --stats` of the same command averages over; the
@@ -894,6 +895,8 @@ def main():
         and (sustained.get('gather_launches') or 0) >= 1000):
       avg_s = sustained['gather_avg_us'] * 1e-6
       launches = sustained['gather_launches']
+      one_in = sustained['stamped_one_in']
+      region['stamped_one_in'] = stamp_every
       source = f'stamped launches of the sustained window ({sustained["seconds"]} s)'
     achieved = algo_bytes / avg_s / 1e9
     roofline = {
@@ -909,7 +912,7 @@ def main():
         # context: the same bytes against the chip's measured copy rate (a gather cannot beat a copy)
         'frac_of_copy_rate': round(achieved / HBM_COPY_GBS, 4),
         'bytes_per_launch': algo_bytes, 'avg_launch_us': round(avg_s * 1e6, 2),
-        'launches': launches, 'stamped_one_in': stamp_every, 'source': source,
+        'launches': launches, 'stamped_one_in': one_in, 'source': source,
         'headline_region': region,
     }
 
