@@ -609,14 +609,19 @@ def _env_server(envid, pipe, ctor, wakes=None, worker=None):
   blocks, slabs = [], {}
 
   def open_block(name):
-    # (Attaching registers the block with this process's resource tracker, which
-    # would try to unlink the parent's memory at exit and warn about "leaks".)
-    block = shared_memory.SharedMemory(name=name)
+    # Attaching must leave the resource tracker alone: the block is the parent's
+    # to unlink.  A tracker of this process's own (spawn) would unlink it at exit
+    # and warn about "leaks"; the parent's tracker (fork: shared) holds the name
+    # once -- registering here and unregistering again would take the PARENT's
+    # entry away, and its unlink would then raise KeyError inside the tracker.
+    # (Python 3.13 has SharedMemory(track=False) for this.)
+    from multiprocessing import resource_tracker
+    register = resource_tracker.register
+    resource_tracker.register = lambda *a, **k: None
     try:
-      from multiprocessing import resource_tracker
-      resource_tracker.unregister(block._name, 'shared_memory')
-    except Exception:
-      pass
+      block = shared_memory.SharedMemory(name=name)
+    finally:
+      resource_tracker.register = register
     blocks.append(block)
     return block
 

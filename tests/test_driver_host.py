@@ -12,6 +12,97 @@ import embodied_amd as emb
 from embodied_amd.envs import dummy
 
 
+class Taped(dummy.Dummy):
+  """The dummy env with a tape of what it was handed."""
+
+  def __init__(self, length, tape):
+    super().__init__('disc', length=length)
+    self.tape = tape
+
+  def step(self, action):
+    self.tape.append({k: np.array(v) for k, v in action.items()})
+    return super().step(action)
+
+
+class Session:
+  """One Driver run over `n` dummy envs of `length` steps with a policy that
+  numbers its calls: keeps what every party saw -- the envs' inputs, the
+  policy's inputs and carries, the transitions handed to the callbacks."""
+
+  def __init__(self, n=1, length=10, parallel=False, **run):
+    self.n, self.length = n, length
+    self.handed = [[] for _ in range(n)]          # per env: the action dicts it received
+    self.asked, self.carries, self.trans = [], [], [[] for _ in range(n)]
+    makers = [bind(Taped, length, self.handed[i]) for i in range(n)] if not parallel else [
+        bind(dummy.Dummy, 'disc', length=length) for _ in range(n)]
+    driver = emb.Driver(makers, parallel=parallel)
+    driver.reset(lambda count: 0)
+    driver.on_step(lambda tran, worker: self.trans[worker].append({k: np.array(v) for k, v in tran.items()}))
+    driver(self.policy, **run)
+    driver.close()
+
+  def policy(self, carry, obs, **kw):
+    self.asked.append({k: np.array(v) for k, v in obs.items()})
+    self.carries.append(carry)
+    acts = {'act_disc': np.full(self.n, 1 + carry % 3, np.int32),
+            'act_cont': np.full((self.n, 6), 0.25 * (1 + carry % 3), np.float32)}
+    return carry + 1, acts, {}
+
+  def column(self, worker, key):
+    return np.array([t[key] for t in self.trans[worker]])
+
+
+@pytest.mark.parametrize('parallel', [False, True])
+@pytest.mark.parametrize('length,episodes', [(10, 1), (10, 2), (3, 4)])
+def test_episodes_are_framed_by_their_flags(parallel, length, episodes):
+  """An episode of a `length`-step env is length + 1 transitions (the reset
+  observation comes first): is_first on the first only, is_last on the last
+  only -- test_driver.py:9-44 as one statement over several shapes."""
+  run = Session(1, length, parallel, episodes=episodes)
+  first, last = run.column(0, 'is_first'), run.column(0, 'is_last')
+  span = length + 1
+  assert len(first) == episodes * span
+  where = np.arange(len(first)) % span
+  assert np.array_equal(first, where == 0)
+  assert np.array_equal(last, where == span - 1)
+
+
+@pytest.mark.parametrize('n,length', [(1, 5), (3, 4)])
+def test_the_step_that_ends_an_episode_stores_no_action_and_asks_for_a_reset(n, length):
+  """driver.py:72-76: where is_last is set the stored action is zero and the
+  env's next input carries reset (the reference's test reads tran['reset'],
+  which the current Driver no longer stores: checked on what the env receives)."""
+  run = Session(n, length, steps=3 * (length + 1) * n)
+  for w in range(n):
+    last = run.column(w, 'is_last')
+    disc, cont = run.column(w, 'act_disc'), run.column(w, 'act_cont')
+    assert last.sum() == 3
+    assert (disc[last] == 0).all() and (cont[last] == 0).all()
+    assert (disc[~last] != 0).all() and (cont[~last] != 0).all()      # the policy never says zero
+    assert 'reset' not in run.trans[w][0]
+    resets = np.array([bool(a['reset']) for a in run.handed[w]])
+    # the very first input resets; after that: exactly the inputs that follow an is_last
+    assert resets[0] and np.array_equal(resets[1:len(last)], last[:len(resets) - 1][:len(last) - 1])
+    # what the env is handed on step t + 1 is what was stored on step t
+    for t in range(len(last) - 1):
+      assert np.array_equal(run.handed[w][t + 1]['act_disc'], disc[t])
+
+
+def test_the_policy_sees_the_stored_observations_and_its_own_carry():
+  """test_driver.py:46-68: the policy's inputs are the transitions'
+  observations, stacked over the envs, and its carry comes back to it."""
+  run = Session(2, 10, episodes=4)              # (episodes are counted over both envs)
+  assert run.carries == list(range(len(run.asked)))           # reset's carry, then the policy's own
+  steps = len(run.asked)
+  assert steps == len(run.trans[0]) == len(run.trans[1])
+  for t, obs in enumerate(run.asked):
+    for w in range(2):
+      for key in ('is_first', 'is_last', 'is_terminal', 'reward'):
+        assert np.array_equal(obs[key][w], run.trans[w][t][key]), (t, w, key)
+  assert run.asked[0]['is_first'].all() and not run.asked[1]['is_first'].any()
+  assert run.asked[10]['is_last'].all() and run.asked[11]['is_first'].all()
+
+
 def make_env(length=10):
   return dummy.Dummy('disc', length=length)
 
@@ -21,87 +112,6 @@ def make_agent():
   agent = emb.RandomAgent(env.obs_space, env.act_space)
   env.close()
   return agent
-
-
-@pytest.mark.parametrize('parallel', [False, True])
-def test_episode_length(parallel):
-  agent = make_agent()
-  driver = emb.Driver([make_env], parallel=parallel)
-  driver.reset(agent.init_policy)
-  seq = []
-  driver.on_step(lambda tran, _: seq.append(tran))
-  driver(agent.policy, episodes=1)
-  driver.close()
-  assert len(seq) == 11
-
-
-def test_first_and_last_step_flags():
-  agent = make_agent()
-  driver = emb.Driver([make_env], parallel=False)
-  driver.reset(agent.init_policy)
-  seq = []
-  driver.on_step(lambda tran, _: seq.append(tran))
-  driver(agent.policy, episodes=2)
-  assert len(seq) == 22
-  for index in [0, 11]:
-    assert seq[index]['is_first'].item() is True
-    assert seq[index]['is_last'].item() is False
-  for index in [1, 10, 12]:
-    assert seq[index]['is_first'].item() is False
-  for index in [10, 21]:
-    assert seq[index]['is_last'].item() is True
-    assert seq[index]['is_first'].item() is False
-  for index in [0, 1, 9, 11, 20]:
-    assert seq[index]['is_last'].item() is False
-
-
-def test_env_reset_zeroes_action_and_requests_reset():
-  received = []
-
-  class Spy(dummy.Dummy):
-    def step(self, action):
-      received.append({k: np.array(v) for k, v in action.items()})
-      return super().step(action)
-
-  driver = emb.Driver([lambda: Spy('disc', length=5)], parallel=False)
-  driver.reset(lambda n: ())
-  seq = []
-  driver.on_step(lambda tran, _: seq.append(tran))
-  action = {'act_disc': np.ones(1, np.int32), 'act_cont': np.zeros((1, 6), np.float32)}
-  driver(lambda carry, obs: (carry, action, {}), episodes=2)
-  assert len(seq) == 12
-  cols = {k: np.array([s[k] for s in seq]) for k in seq[0]}
-  assert (cols['is_first'] == [1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0]).all()
-  assert (cols['is_last'] == [0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1]).all()
-  assert (cols['act_disc'] == [1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0]).all()
-  assert 'reset' not in cols
-  resets = [bool(a['reset']) for a in received]
-  assert resets == [True, False, False, False, False, False, True] + [False] * 5
-
-
-def test_agent_inputs_and_carry_threading():
-  agent = make_agent()
-  driver = emb.Driver([make_env], parallel=False)
-  driver.reset(agent.init_policy)
-  inputs, states = [], []
-
-  def policy(carry, obs, mode='train'):
-    inputs.append(obs)
-    states.append(carry)
-    _, act, _ = agent.policy(carry, obs, mode)
-    return 'carry', act, {}
-
-  seq = []
-  driver.on_step(lambda tran, _: seq.append(tran))
-  driver(policy, episodes=2)
-  assert len(seq) == 22
-  assert states == ([()] + ['carry'] * 21)
-  for index in [0, 11]:
-    assert inputs[index]['is_first'].item() is True
-  for index in [1, 10, 12, 21]:
-    assert inputs[index]['is_first'].item() is False
-  for index in [10, 21]:
-    assert inputs[index]['is_last'].item() is True
 
 
 def test_unexpected_reset_mid_episode():
