@@ -125,7 +125,11 @@ def parse():
   p.add_argument('--context', type=int, default=1)
   p.add_argument('--capacity', type=int, default=100_000)   # ppo/configs.yaml:39
   p.add_argument('--train-ratio', type=float, default=3.0)  # ppo/configs.yaml:51
-  p.add_argument('--grad-numel', type=int, default=10_000_000)   # PPO-sized f32 gradient
+  # The shipped PPO model at the benchmark's shapes (84x84x4 image, 6 actions), counted module by
+  # module from ppo/configs.yaml:86-96 + ppo/agent.py:128-151 + ppo/nets.py:11-80 by tools/count_params.py
+  # (profiles/r06_param_counts.txt): impala encoder 4 354 464 + action embedding 8 192 + GRU 7 872 512
+  # + policy 6 150 + value 1 025.  (DreamerV3's default size, configs[2]/[3]: 181.7 M / 166.0 M.)
+  p.add_argument('--grad-numel', type=int, default=12_242_343)
   p.add_argument('--exchange', default='dp_slice',
                  choices=['dp_slice', 'online', 'trajectories', 'returns', 'none'],
                  help='N>1: how trajectories cross xGMI.  dp_slice (default) = SURVEY 8e\'s cheaper '
@@ -144,10 +148,12 @@ def parse():
                       'and timed on its own bytes before the timed regions (`native_comm`); the timed '
                       'path takes the faster of those that passed on every rank (direct only if it '
                       'wins by more than 10 %%), c10d if neither did')
-  p.add_argument('--grad-dtype', default='bf16', choices=['bf16', 'f32'],
+  p.add_argument('--grad-dtype', default='f32', choices=['bf16', 'f32'],
                  help='N>1: dtype of the flat gradient buffer that is all-reduced every train '
-                      'step (the reference all-reduces f32 leaves, embodied/jax/opt.py:52-54; '
-                      'bf16 halves the bytes on the links)')
+                      'step.  f32 (default) is the reference\'s precision: it averages f32 gradient '
+                      'leaves, embodied/jax/opt.py:52-54.  bf16 halves the bytes on the links and is a '
+                      'LOWER precision than the reference: a line taken with it says so in '
+                      '`config.parallelism` and is context, not the headline')
   p.add_argument('--cpu-seconds', type=float, default=15.0)
   p.add_argument('--sustained-seconds', type=float, default=10.0,
                  help='after the headline region: the same loop for this long (SURVEY 8d asks for '
@@ -331,6 +337,8 @@ def main():
       args.capacity = 1_000_000
     if args.train_ratio == 3.0:
       args.train_ratio = 32.0
+    if args.grad_numel == 12_242_343:     # DreamerV3's default size on configs[2]'s inputs (tools/count_params.py)
+      args.grad_numel = 181_738_790
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -381,16 +389,16 @@ def main():
   grads = (torch.zeros(args.grad_numel, dtype=grad_dtype, device=device)
            if use_dist and args.grad_numel else None)
   counters = {'env_steps': 0, 'train_steps': 0}
-  pending, marks = [], []
+  marks = []
   comm = None
   native, native_stuck, native_comm = None, False, None
   if use_dist:
     from embodied_amd import distributed as D
-    issue = D.Done
   use_native = use_direct = False
   direct_comm = None
   link = None               # who carries a train step's collectives (set after the self-check)
-  collectives = {'on': True, 'sliced': 0}
+  collectives = {'on': True, 'sliced': 0, 'gathered': 0}
+  schedule = {'fences': 0}          # fences at which the ranks compared their exchange schedules (and agreed)
   fresh = {'on': False, 'stream': None}
 
   def train_step():
@@ -446,9 +454,6 @@ def main():
       # Last train step's collectives (they ran behind the env steps since):
       # `link` is the library's own RCCL exchange (emb_comm_exchange, its own
       # stream) or the same contract on the process group (D.GroupComm).
-      for future in pending:
-        future.result().wait()
-      pending.clear()
       link.wait()
       send = None
       if sliced:
@@ -469,15 +474,26 @@ def main():
         if args.exchange == 'trajectories' or (args.exchange == 'online' and layout.online.any()):
           send = flat
         elif args.exchange == 'returns':
-          send = torch.cat([adv, tar], 1).contiguous().view(torch.uint8).reshape(-1)
-        # The all-gather forms stay on torch.distributed, issued inline in the
-        # same order on every rank (EMB_BENCH_COMM=thread: from a helper thread;
-        # measured slower, the GIL changes hands at every library call).
+          returns = returns_ring[counters['train_steps'] // args.prefetch & 3]
+          returns[0].copy_(adv)
+          returns[1].copy_(tar)
+          send = returns.view(torch.uint8).reshape(-1)
+        # The all-gather forms (north_star's "all-gather of trajectories"; the reference
+        # assembles every process's slice into the global batch, jax/internal.py:145-152)
+        # go through the SAME transport as the gradients, in ONE exchange call: RCCL's
+        # all-gather on the library's stream (emb_comm_exchange_gather), the direct
+        # schedule's push to all n-1 peers (emb_direct_exchange_gather), or the process
+        # group (GroupComm) -- whichever carries the timed path.
         if send is not None:
-          gathered = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
-          pending.append(issue(lambda g=gathered, s=send: D.async_all_gather(g, s)))
+          ring = gathered_ring.setdefault(send.numel(), [])
+          slot = collectives['gathered'] & 3
+          if slot >= len(ring):
+            ring.append(torch.empty(world * send.numel(), dtype=torch.uint8, device=device))
+          gathered = ring[slot]
+          link.exchange(send, gathered, grads, gather=True)
+          collectives['gathered'] += 1
           state_keep[:] = [gathered, send]
-        if grads is not None:
+        elif grads is not None:
           link.exchange(grads=grads)
       # When the links are the bottleneck the host could queue train steps far
       # ahead of the GPU (one gathered buffer each): stay within 8 train steps.
@@ -499,6 +515,9 @@ def main():
   state_keep = []
   slice_state = {}
   received_ring = []
+  gathered_ring = {}
+  returns_ring = [torch.empty(2, B * args.prefetch, T + args.context - 1, device=device)
+                  for _ in range(4)] if use_dist else None
   packed_out = [tuple(torch.empty(B * args.prefetch, T + args.context - 1, device=device) for _ in range(2))
                 for _ in range(4)] if use_dist else None
 
@@ -542,31 +561,59 @@ def main():
   # suite's loopback transport the native path also runs between gloo ranks that
   # share one GPU, tests/test_gpu_bench_launcher.py)
   if use_dist and args.comm != 'c10d' and (dist.get_backend() == 'nccl' or os.environ.get('EMB_RCCL_LIB')):
+    packed = D.PackedLayout([(k.name, k.dtype, k.shape) for k in replay._keys], B * args.prefetch, L).nbytes
     native, native_stuck, native_comm, direct_comm = native_comm_check(
         rank, world, device, args.grad_numel, grad_dtype,
-        B * args.prefetch * L * sum(k.rowbytes for k in replay._keys) // world)
+        B * args.prefetch * L * sum(k.rowbytes for k in replay._keys) // world,
+        # the unit of the all-gather forms: one rank's packed batch, or its GAE results
+        2 * B * args.prefetch * (T + args.context - 1) * 4 if args.exchange == 'returns' else packed)
+    # Which transport carries the timed path.  An explicitly named one that did not
+    # pass its check ends the job; `auto` NEVER does: it degrades -- direct, else
+    # RCCL through the library, else torch.distributed -- and says why in
+    # `native_comm.auto`.  Every input of the choice is the same on every rank (the
+    # check's verdicts are MIN-reduced, its times MAX-reduced below).
     if args.comm == 'native' and native_comm is None:
       raise SystemExit(f'--comm native: the self-check did not pass: {native}')
     if args.comm == 'direct' and direct_comm is None:
       raise SystemExit(f'--comm direct: the self-check did not pass: {native.get("direct")}')
-    # (all-gather forms of the exchange stay on torch.distributed.)
-    use_direct = args.comm == 'direct' and args.exchange in ('dp_slice', 'none')
-    if (args.comm == 'auto' and world > 1 and native_comm is not None and direct_comm is not None
-        and args.exchange in ('dp_slice', 'none')):
-      # Both transports passed their checks against torch.distributed on this job's
-      # own GPUs and were timed on the job's own bytes: `auto` takes the one whose
-      # train-step exchange (all-to-all + all-reduce + wait) is faster on the
-      # slowest rank -- the direct schedule only if it wins by more than 10 %.
-      mine = torch.tensor([native['per_call']['native_exchange_step']['total_us'],
-                           native['direct']['per_call']['direct_exchange_step']['total_us']],
-                          dtype=torch.float64, device=device)
-      dist.all_reduce(mine, op=dist.ReduceOp.MAX)
-      rccl_us, direct_us = mine.tolist()
-      use_direct = direct_us < 0.9 * rccl_us
-      native['auto'] = {'rccl_exchange_us': round(rccl_us, 1), 'direct_exchange_us': round(direct_us, 1),
-                        'chose': 'direct' if use_direct else 'native'}
-    use_native = not use_direct and native_comm is not None and args.exchange in ('dp_slice', 'none')
+    gathering = args.exchange in ('online', 'trajectories', 'returns')
+    step_key = 'exchange_gather_step' if gathering else 'exchange_step'
+    use_direct = args.comm == 'direct'
+    if args.comm == 'auto':
+      why = []
+      if native_stuck:
+        why.append('the self-check never returned (watchdog): torch.distributed')
+      if native_comm is None and not native_stuck:
+        why.append(f'emb_comm_* did not pass its check ({native.get("status")}'
+                   + (f': {native["error"]}' if native.get('error') else '') + ')')
+      if direct_comm is None and not native_stuck:
+        d = native.get('direct') or {}
+        why.append(f'emb_direct_* did not pass its check ({d.get("status", "not run")}'
+                   + (f': {d["error"]}' if d.get('error') else '') + ')')
+      auto = {}
+      if native_comm is not None and direct_comm is not None and world > 1:
+        # Both passed against torch.distributed on this job's own GPUs and were timed on
+        # the job's own bytes: the one whose train-step exchange (trajectories + gradient
+        # all-reduce + wait) is faster on the slowest rank -- direct only if it wins by > 10 %.
+        mine = torch.tensor([native['per_call'][f'native_{step_key}']['total_us'],
+                             native['direct']['per_call'][f'direct_{step_key}']['total_us']],
+                            dtype=torch.float64, device=device)
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        rccl_us, direct_us = mine.tolist()
+        use_direct = direct_us < 0.9 * rccl_us
+        auto.update({'rccl_exchange_us': round(rccl_us, 1), 'direct_exchange_us': round(direct_us, 1)})
+        why.append('both passed; ' + ('direct wins by more than 10 %' if use_direct else 'direct does not win by 10 %'))
+      elif direct_comm is not None and native_comm is None:
+        use_direct = True
+      elif native_comm is not None and direct_comm is not None:
+        why.append('one rank: nothing to choose')
+      auto['chose'] = 'direct' if use_direct else 'native' if native_comm is not None else 'c10d'
+      auto['why'] = '; '.join(why)
+      native['auto'] = auto
+    use_native = not use_direct and native_comm is not None
     native['timed_path'] = 'direct' if use_direct else 'native' if use_native else 'c10d'
+    if native_stuck:
+      native['stuck'] = True
   if use_dist:
     link = direct_comm if use_direct else native_comm if use_native else D.GroupComm()
   # --no-timer: no dispatch stamps (roofline is then null).  Stamps are
@@ -621,9 +668,6 @@ def main():
   base = dict(counters)
 
   def fence():
-    for future in pending:
-      future.result().wait()
-    pending.clear()
     if link is not None:
       link.wait()
     torch.cuda.synchronize(device)
@@ -633,13 +677,16 @@ def main():
       # it alike -- checked here, where the ranks meet anyway: a rank that ever
       # chose differently would have paired its collectives wrongly.
       digest = torch.tensor([float(collectives['sliced']), -float(collectives['sliced']),
-                             float(counters['train_steps']), -float(counters['train_steps'])],
+                             float(counters['train_steps']), -float(counters['train_steps']),
+                             float(collectives['gathered']), -float(collectives['gathered'])],
                             dtype=torch.float64, device=device)
       dist.all_reduce(digest, op=dist.ReduceOp.MAX)      # doubles as the barrier
-      hi_s, neg_lo_s, hi_t, neg_lo_t = digest.tolist()
-      if hi_s != -neg_lo_s or hi_t != -neg_lo_t:
+      hi_s, neg_lo_s, hi_t, neg_lo_t, hi_g, neg_lo_g = digest.tolist()
+      if hi_s != -neg_lo_s or hi_t != -neg_lo_t or hi_g != -neg_lo_g:
         raise SystemExit(f'rank {rank}: ranks disagree on the exchange schedule '
-                         f'(sliced {-neg_lo_s:.0f}..{hi_s:.0f}, train steps {-neg_lo_t:.0f}..{hi_t:.0f})')
+                         f'(sliced {-neg_lo_s:.0f}..{hi_s:.0f}, gathered {-neg_lo_g:.0f}..{hi_g:.0f}, '
+                         f'train steps {-neg_lo_t:.0f}..{hi_t:.0f})')
+      schedule['fences'] += 1
       torch.cuda.synchronize(device)      # (the barrier's own kernels)
 
   # The timed region: EXACTLY --steps steps between two fences (barrier +
@@ -817,27 +864,32 @@ def main():
         'train_steps_per_s': round((counters['train_steps'] - r_before) * world / r_elapsed, 2),
         'what': 'same loop, collectives off: N independent replicas',
     }
+  gather_share = min(1.0, collectives['gathered'] / max(1, counters['train_steps']))
   if native is not None and 'per_call' in native and train_steps_local(counters, base, headline) > 0:
-    # RCCL's own time for one train step's collectives at this world size
-    # against the period at which the timed region issued train steps.
-    calls = native['per_call']
+    # Every transport's own time for one train step's collectives at this world size
+    # (measured by the self-check on the job's own bytes) against the period at which
+    # the timed region issued train steps.
     done = train_steps_local(counters, base, headline)
-    share = sliced_share
+    traj, share = (('all_gather', gather_share) if args.exchange in ('online', 'trajectories', 'returns')
+                   else ('all_to_all', sliced_share))
+    per_step = {}
+    for name, prefix, calls in (('c10d', 'c10d', native['per_call']), ('rccl', 'native', native['per_call']),
+                                ('direct', 'direct', (native.get('direct') or {}).get('per_call') or {})):
+      if f'{prefix}_all_reduce' in calls and f'{prefix}_{traj}' in calls:
+        per_step[name] = round(calls[f'{prefix}_all_reduce']['total_us'] + share * calls[f'{prefix}_{traj}']['total_us'], 1)
     native['per_train_step'] = {
-        'collectives_us': round(calls['native_all_reduce']['total_us']
-                                + share * calls['native_all_to_all']['total_us'], 1),
-        # the same train step's collectives on the direct schedule (all n-1 links at once)
-        **({'direct_collectives_us': round(
-            native['direct']['per_call']['direct_all_reduce']['total_us']
-            + share * native['direct']['per_call']['direct_all_to_all']['total_us'], 1)}
-           if (native.get('direct') or {}).get('per_call') else {}),
+        **({'collectives_us': per_step['rccl']} if 'rccl' in per_step else {}),
+        # the same train step's collectives on the direct schedule (all n-1 links at once) / the process group
+        **({'direct_collectives_us': per_step['direct']} if 'direct' in per_step else {}),
+        **({'c10d_collectives_us': per_step['c10d']} if 'c10d' in per_step else {}),
         'issue_period_us': round(total_elapsed / done * 1e6, 1),
-        'sliced_share': round(share, 3),
+        'trajectory_collective': traj, 'trajectory_share': round(share, 3), 'sliced_share': round(sliced_share, 3),
     }
-    # links bound the job when RCCL needs longer for one train step's collectives
-    # than the path takes to issue the next train step
-    native['per_train_step']['link_bound'] = bool(
-        native['per_train_step']['collectives_us'] > native['per_train_step']['issue_period_us'])
+    # links bound the job when the transport of the timed path needs longer for one train
+    # step's collectives than the path takes to issue the next train step
+    on_path = per_step.get({'native': 'rccl'}.get(native.get('timed_path'), native.get('timed_path')))
+    if on_path is not None:
+      native['per_train_step']['link_bound'] = bool(on_path > native['per_train_step']['issue_period_us'])
   expected = None
   if use_dist and replicas_only is not None and replicas_only['train_steps_per_s'] > 0:
     S_all = sum(k.rowbytes for k in replay._keys)
@@ -845,18 +897,18 @@ def main():
         world, (grads.numel() * grads.element_size()) if grads is not None else 0,
         B * args.prefetch * L * S_all,
         sliced_share if args.exchange == 'dp_slice' and args.workload == 'ppo' else 0.0,
-        1e6 * world / replicas_only['train_steps_per_s'])
+        1e6 * world / replicas_only['train_steps_per_s'],
+        gather_share if args.workload == 'ppo' else 0.0,
+        (2 * B * args.prefetch * (T + args.context - 1) * 4) if args.exchange == 'returns' else None)
     # The same bound with the collectives' MEASURED time per train step instead of a
     # share of link peak, one column per transport: rccl (emb_comm_*) and the direct
     # schedule (emb_direct_*: all n-1 links at once).  x = n * min(1, period / collectives).
     step = (native or {}).get('per_train_step') or {}
     period = expected['train_period_us_collectives_off']
+    columns = (('rccl', 'collectives_us'), ('direct', 'direct_collectives_us'), ('c10d', 'c10d_collectives_us'))
     expected['link_bound_x_measured'] = {
-        name: round(world * min(1.0, period / max(step[key], 1e-9)), 2)
-        for name, key in (('rccl', 'collectives_us'), ('direct', 'direct_collectives_us')) if key in step}
-    expected['collectives_us_measured'] = {
-        name: step[key] for name, key in (('rccl', 'collectives_us'), ('direct', 'direct_collectives_us'))
-        if key in step}
+        name: round(world * min(1.0, period / max(step[key], 1e-9)), 2) for name, key in columns if key in step}
+    expected['collectives_us_measured'] = {name: step[key] for name, key in columns if key in step}
     # the same two readings, measured: speed-up over ONE rank of the replicas_only loop
     per_rank = replicas_only['env_steps_per_s'] / world
     expected['measured_x'] = {
@@ -864,6 +916,7 @@ def main():
         **({'sustained': round(sustained['env_steps_per_s'] / per_rank, 2)} if sustained else {}),
         'replicas_only': float(world),
         'unit': 'x one rank of this run with the collectives off'}
+  step_name = 'exchange_gather_step' if args.exchange in ('online', 'trajectories', 'returns') else 'exchange_step'
   counters.update(headline)
   env_steps = args.steps * args.envs * world                     # of ONE region (the median one is `value`)
   train_steps = (counters['train_steps'] - base['train_steps']) * world     # of all regions together
@@ -1060,8 +1113,10 @@ def main():
             'parallelism': (f'env-sharded x{world}, '
                             + ('per-rank Replay, ' if args.workload == 'dreamer'
                                else f'trajectory exchange {args.exchange} + ') +
-                            f'{args.grad_numel * (2 if args.grad_dtype == "bf16" else 4) >> 20} MiB '
-                            f'{args.grad_dtype} grad all-reduce per train step ('
+                            f'{args.grad_numel * (2 if args.grad_dtype == "bf16" else 4) / 2**20:.1f} MiB '
+                            f'{args.grad_dtype} grad all-reduce per train step'
+                            + (' [bf16: LOWER precision than the reference\'s f32 pmean, opt.py:52-54]'
+                               if args.grad_dtype == 'bf16' else '') + ' ('
                             + ('direct xGMI schedule, emb_direct_exchange' if use_direct else
                                f'RCCL, issued by {"emb_comm_exchange" if use_native else "torch.distributed"}')
                             + ')')
@@ -1074,8 +1129,23 @@ def main():
         **({'writeback': writeback} if writeback is not None else {}),
         **({'workloads': workloads} if workloads is not None else {}),
         **({'native_comm': native} if native is not None else {}),
+        # N > 1, one place to read the scaling story from: who carried the timed path, every
+        # transport's measured train-step exchange (host + end to end) on this job's own bytes,
+        # and how often the ranks compared their exchange schedules at a fence (they agreed
+        # every time, or the job would have ended)
+        **({'transports': {
+            'timed_path': (native or {}).get('timed_path', 'c10d'),
+            'exchange': args.exchange, 'grad_dtype': args.grad_dtype,
+            'grad_bytes': (grads.numel() * grads.element_size()) if grads is not None else 0,
+            'exchange_step_us': {
+                name: calls[key] for name, key, calls in (
+                    ('c10d', f'c10d_{step_name}', (native or {}).get('per_call') or {}),
+                    ('rccl', f'native_{step_name}', (native or {}).get('per_call') or {}),
+                    ('direct', f'direct_{step_name}', ((native or {}).get('direct') or {}).get('per_call') or {}))
+                if key in calls},
+            'schedule_agreed_at_fences': schedule['fences']}} if use_dist else {}),
         **({'link_bound': native['per_train_step']['link_bound']}
-           if native is not None and 'per_train_step' in native else {}),
+           if native is not None and 'link_bound' in native.get('per_train_step', {}) else {}),
         **({'replicas_only': replicas_only} if replicas_only is not None else {}),
         **({'masked_env_actions': masked_env_actions} if masked_env_actions is not None else {}),
         **({'fresh_batches': fresh_batches} if fresh_batches is not None else {}),
@@ -1100,16 +1170,20 @@ def main():
 XGMI_LINK_GBS = 76.8         # one xGMI link, one direction (MI355X_MICROARCH.md: 153.6 GB/s bidirectional)
 
 
-def scaling_expectation(world, grad_bytes, batch_bytes, sliced_share, train_period_us):
+def scaling_expectation(world, grad_bytes, batch_bytes, sliced_share, train_period_us, gather_share=0.0,
+                        gather_bytes=None):
   """DESIGN.md 5's link budget as a formula, so that a measured curve can be held
   against it: per train step and rank, one way, a direct all-reduce moves
-  2*(n-1)/n * G bytes and -- on the share of train steps that exchange DP slices
-  -- the all-to-all (n-1)/n * B*L*S more, over the (n-1) point-to-point links a
-  rank has to its peers.  `train_period_us` is the period at which one rank
-  issues train steps with the collectives off (the `replicas_only` loop of the
-  same run).  x = speed-up over one such rank."""
+  2*(n-1)/n * G bytes; on the share of train steps that exchange DP slices the
+  all-to-all moves (n-1)/n * B*L*S more, on the share that all-gathers (n-1) *
+  `gather_bytes` (default: the whole batch B*L*S) -- all over the (n-1)
+  point-to-point links a rank has to its peers.  `train_period_us` is the
+  period at which one rank issues train steps with the collectives off (the
+  `replicas_only` loop of the same run).  x = speed-up over one such rank."""
   n = world
-  one_way = 2 * (n - 1) / n * grad_bytes + sliced_share * (n - 1) / n * batch_bytes
+  gather_bytes = batch_bytes if gather_bytes is None else gather_bytes
+  one_way = (2 * (n - 1) / n * grad_bytes + sliced_share * (n - 1) / n * batch_bytes
+             + gather_share * (n - 1) * gather_bytes)
   out = {'bytes_one_way_per_train_step': round(one_way), 'links': n - 1,
          'train_period_us_collectives_off': round(train_period_us, 1), 'replicas_only_x': float(n)}
   for pct in (100, 60, 40):
@@ -1119,31 +1193,61 @@ def scaling_expectation(world, grad_bytes, batch_bytes, sliced_share, train_peri
   return out
 
 
-def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, seconds=90.0):
+def _fault(kind, rank):
+  """Test hook (tests/test_gpu_bench_launcher.py): `EMB_BENCH_FAULT=kind:rank` makes
+  ONE rank misbehave inside the self-check of the transports, the way a node
+  might on first contact -- `direct_open:R` (rank R cannot make / map its hipIpc
+  buffer), `direct_stuck:R` (rank R never arrives at one direct collective),
+  `direct_wrong:R` (rank R's direct all-to-all delivers wrong bytes), `native_open:R`
+  (rank R's RCCL communicator set-up fails before it starts).  The job must end
+  with rc 0 and a valid line on the transport that is left."""
+  spec = os.environ.get('EMB_BENCH_FAULT', '')
+  return spec == f'{kind}:{rank}'
+
+
+def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, gather_bytes, seconds=120.0):
   """Ranks only, before the timed regions (no part of `value`): the library's own
-  RCCL entry points (`emb_comm_*`, include/embodied_hip.h) on the GPUs of this
-  job, checked against torch.distributed on the same bytes -- all-gather, the
-  DP-slice all-to-all, f32 and bf16 gradient all-reduce -- with the host cost
-  per call of both routes.  Returns (report, stuck, communicator or None): the
-  communicator only if every rank passed.  Runs under a watchdog: if a
-  collective never returns the job goes on with torch.distributed."""
+  transports on the GPUs of this job -- the RCCL entry points (`emb_comm_*`) and
+  the direct xGMI schedule (`emb_direct_*`, include/embodied_hip.h) -- checked
+  against torch.distributed on the same bytes (all-gather, DP-slice all-to-all,
+  f32 and bf16 gradient all-reduce) and timed, per call and per train-step
+  exchange, beside the process group's own route.
+
+  Built so that a transport that FAILS on some rank costs this check seconds and
+  the job nothing: (1) every torch.distributed collective of the check runs on a
+  group of its own, unconditionally and in one fixed order on every rank -- the
+  references are computed first, a transport's own operations (which may raise,
+  time out or deliver garbage on one rank only) contain no process-group call;
+  (2) after each phase the ranks agree (MIN all-reduce) whether the transport is
+  still healthy EVERYWHERE, and all take the same branch; (3) the whole check
+  runs under a watchdog: if a collective never returns the job goes on with
+  torch.distributed.  Returns (report, stuck, NativeComm or None, DirectComm or
+  None): a communicator only if every rank passed."""
   import threading
   import torch.distributed as dist
   from embodied_amd import distributed as D
   result = {'status': 'timeout'}
-  kept = []
-  # The torch.distributed side of the check has a process group of its own: if
-  # the check derails on some rank (its collectives no longer pair up), the
-  # job's default group has seen none of it.
+  kept = {}
   backend = dist.get_backend()
   group = dist.new_group(backend=backend)
   pg = group
   staged = backend != 'nccl'      # gloo moves host memory: the reference side goes through the CPU
+  reps = 10 if staged else 100    # (a loopback test transport: the figures mean nothing there)
 
   def share(data):
     box = [data]
     dist.broadcast_object_list(box, src=0, group=group, **({} if staged else {'device': device}))
     return box[0]
+
+  def share_all(data):
+    box = [None] * world
+    dist.all_gather_object(box, data, group=group)
+    return box
+
+  def agree(ok):
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() == 1.0)
 
   def ref_all_gather(out, part):
     if not staged:
@@ -1167,130 +1271,193 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
     dist.all_reduce(host, group=group)
     buf.copy_((host / world if mean else host).to(buf.dtype))
 
-  def body():
-    comm = D.NativeComm(rank, world, device, share=share)
-    kept.append(comm)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(977 + rank)
-    block = max(16, slice_bytes // 16 * 16)
-    flat = torch.randint(0, 256, (world * block,), dtype=torch.uint8, device=device, generator=gen)
-    checks = {}
-    mine, ref = comm.all_gather(flat[:block].contiguous()), torch.empty_like(flat)
-    ref_all_gather(ref, flat[:block].contiguous())
-    checks['all_gather'] = bool(torch.equal(mine, ref))
-    mine, ref = comm.all_to_all(flat), torch.empty_like(flat)
-    ref_all_to_all(ref, flat).wait()
-    checks['all_to_all'] = bool(torch.equal(mine, ref))
-    # Small integers: sums over ranks are exact in f32 and bf16, so the two
-    # routes must agree to the bit whatever order the links add in.
-    for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16)):
-      whole = torch.randint(-8, 9, (1 << 20,), device=device, generator=gen).to(dtype)
-      a, b = whole.clone(), whole.clone()
-      comm.all_reduce(a, mean=False)
-      ref_all_reduce(b)
-      checks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, b))
-      a, b = torch.randn(1 << 20, device=device, generator=gen).to(dtype), None
-      b = a.clone()
-      comm.all_reduce(a, mean=True)
-      ref_all_reduce(b, mean=True)
-      tol = 1e-5 if dtype == torch.float32 else 2e-2
-      checks[f'all_reduce_mean_{name}'] = bool(torch.allclose(a.float(), b.float(), rtol=tol, atol=tol))
-    # Host and end-to-end cost per call at the job's own sizes.
-    grads = torch.zeros(max(grad_numel, 1), dtype=grad_dtype, device=device)
-    recv = torch.empty_like(flat)
-    routes = {
-        'native_all_reduce': lambda: comm.all_reduce(grads, mean=True),
-        'c10d_all_reduce': lambda: pg.allreduce([grads]),
-        'native_all_to_all': lambda: comm.all_to_all(flat, recv),
-        'c10d_all_to_all': lambda: ref_all_to_all(recv, flat),
-        # one train step's worth, own stream, with the wait of the previous one
-        'native_exchange_step': lambda: (comm.wait(), comm.exchange(flat, recv, grads)),
-        'c10d_exchange_step': lambda: (ref_all_to_all(recv, flat).wait(),
-                                       pg.allreduce([grads]).wait()),
-    }
+  def timed(routes, failed):
+    """host_us / total_us per call of every route.  The barrier in front of each
+    route is taken by every rank whatever happened to its own calls."""
     costs = {}
     for name, call in routes.items():
-      reps = 10 if staged else 100       # a loopback test transport: the figures mean nothing there
-      for _ in range(reps // 10):
-        call()
-      torch.cuda.synchronize(device)
-      dist.barrier(group=group)
-      t0 = time.perf_counter()
-      for _ in range(reps):
-        call()
-      t1 = time.perf_counter()
-      torch.cuda.synchronize(device)
-      t2 = time.perf_counter()
-      costs[name] = {'host_us': round((t1 - t0) * 1e6 / reps, 2), 'total_us': round((t2 - t0) * 1e6 / reps, 2)}
-    report = {'status': 'ok' if all(checks.values()) else 'mismatch', 'ranks': world,
-              'transport': os.environ.get('EMB_RCCL_LIB') or 'rccl',
-              'checks': checks, 'all_reduce_bytes': grads.numel() * grads.element_size(),
-              'all_to_all_bytes': flat.numel(), 'per_call': costs}
-    # The direct xGMI schedule (emb_direct_*: every rank writes all n-1 peers at
-    # once through hipIpc pointers) on the same bytes: checked against the same
-    # references, timed beside RCCL.  Its failure never takes the RCCL path down.
-    try:
-      def share_all(data):
-        box = [None] * world
-        dist.all_gather_object(box, data, group=group)
-        return box
-      direct = D.DirectComm(rank, world, device, max_grad_bytes=max(grads.numel() * grads.element_size(), 4 << 20),
-                            max_slice_bytes=max(2 * block, 1 << 20), share_all=share_all,    # (a packed batch pads its keys)
-                            timeout_ms=3000)         # a peer that does not answer costs this check seconds, not the job
-      kept.append(direct)
-      dchecks = {}
-      mine, ref = direct.all_to_all(flat), torch.empty_like(flat)
-      ref_all_to_all(ref, flat).wait()
-      dchecks['all_to_all'] = bool(torch.equal(mine, ref))
-      for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16)):
-        whole = torch.randint(-8, 9, (1 << 20,), device=device, generator=gen).to(dtype)
-        a, b = whole.clone(), whole.clone()
-        direct.all_reduce(a, mean=False)
-        ref_all_reduce(b)
-        dchecks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, b))
-      dcosts = {}
-      healthy = all(dchecks.values()) and not direct.timed_out()       # (timing a transport that is not: pointless)
-      for name, call in ({} if not healthy else {
-          'direct_all_reduce': lambda: direct.all_reduce(grads, mean=True),
-          'direct_all_to_all': lambda: direct.all_to_all(flat, recv),
-          'direct_exchange_step': lambda: (direct.wait(), direct.exchange(flat, recv, grads)),
-      }).items():
-        reps = 10 if staged else 100
-        for _ in range(reps // 10):
+      ok = not failed[0]
+      try:
+        for _ in range(reps // 10 if ok else 0):
           call()
         torch.cuda.synchronize(device)
-        dist.barrier(group=group)
+      except Exception as e:
+        failed[0] = f'{name}: {type(e).__name__}: {e}'[:300]
+        ok = False
+      dist.barrier(group=group)
+      if not ok:
+        continue
+      try:
         t0 = time.perf_counter()
         for _ in range(reps):
           call()
         t1 = time.perf_counter()
         torch.cuda.synchronize(device)
         t2 = time.perf_counter()
-        dcosts[name] = {'host_us': round((t1 - t0) * 1e6 / reps, 2), 'total_us': round((t2 - t0) * 1e6 / reps, 2)}
-      direct.wait()
-      timed_out = direct.timed_out()
-      report['direct'] = {'status': 'ok' if all(dchecks.values()) and not timed_out else 'mismatch',
-                          'checks': dchecks, 'timed_out': timed_out, **({'per_call': dcosts} if dcosts else {})}
+        costs[name] = {'host_us': round((t1 - t0) * 1e6 / reps, 2), 'total_us': round((t2 - t0) * 1e6 / reps, 2)}
+      except Exception as e:
+        failed[0] = f'{name}: {type(e).__name__}: {e}'[:300]
+    return costs
+
+  def body():
+    gen = torch.Generator(device=device)
+    gen.manual_seed(977 + rank)
+    block = max(16, slice_bytes // 16 * 16)
+    whole_block = max(16, gather_bytes // 16 * 16)          # one rank's packed batch (the all-gather's unit)
+    flat = torch.randint(0, 256, (world * block,), dtype=torch.uint8, device=device, generator=gen)
+    mine = torch.randint(0, 256, (whole_block,), dtype=torch.uint8, device=device, generator=gen)
+    ints = {name: torch.randint(-8, 9, (1 << 20,), device=device, generator=gen).to(dtype)
+            for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16))}
+    noise = {name: torch.randn(1 << 20, device=device, generator=gen).to(dtype)
+             for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16))}
+    # ---- the references, on the process group: every rank, one order, nothing else in between
+    ref = {'all_gather': torch.empty(world * whole_block, dtype=torch.uint8, device=device),
+           'all_to_all': torch.empty_like(flat)}
+    ref_all_gather(ref['all_gather'], mine)
+    ref_all_to_all(ref['all_to_all'], flat).wait()
+    for name in ints:
+      ref[f'sum_{name}'] = ints[name].clone()
+      ref_all_reduce(ref[f'sum_{name}'])
+      ref[f'mean_{name}'] = noise[name].clone()
+      ref_all_reduce(ref[f'mean_{name}'], mean=True)
+    torch.cuda.synchronize(device)
+    grads = torch.zeros(max(grad_numel, 1), dtype=grad_dtype, device=device)
+    recv = torch.empty_like(flat)
+    everyone = torch.empty(world * whole_block, dtype=torch.uint8, device=device)
+    report = {'ranks': world, 'all_reduce_bytes': grads.numel() * grads.element_size(),
+              'all_to_all_bytes': flat.numel(), 'all_gather_bytes_per_rank': whole_block}
+
+    def close(a, b, dtype):
+      tol = 1e-5 if dtype == 'f32' else 2e-2
+      return bool(torch.allclose(a.float(), b.float(), rtol=tol, atol=tol))
+
+    # ---- the process group's own route, timed (the figure the other two stand beside)
+    failed = [None]
+    report['c10d'] = {'per_call': timed({
+        'c10d_all_reduce': lambda: pg.allreduce([grads]),
+        'c10d_all_to_all': lambda: ref_all_to_all(recv, flat),
+        'c10d_all_gather': lambda: ref_all_gather(everyone, mine),
+        'c10d_exchange_step': lambda: (ref_all_to_all(recv, flat).wait(), pg.allreduce([grads]).wait()),
+        'c10d_exchange_gather_step': lambda: (ref_all_gather(everyone, mine), pg.allreduce([grads]).wait()),
+    }, failed)}
+
+    # ---- RCCL through the library's own entry points (emb_comm_*)
+    comm, error, checks = None, None, {}
+    try:
+      if _fault('native_open', rank):
+        raise RuntimeError('injected: this rank cannot set up its RCCL communicator')
+      ident_ok = True
     except Exception as e:
-      report['direct'] = {'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]}
+      ident_ok, error = False, f'{type(e).__name__}: {e}'[:300]
+    if agree(ident_ok):           # (ncclCommInitRank blocks until every rank has joined: all or nobody)
+      try:
+        comm = D.NativeComm(rank, world, device, share=share)
+        kept['native'] = comm
+        checks['all_gather'] = bool(torch.equal(comm.all_gather(mine), ref['all_gather']))
+        checks['all_to_all'] = bool(torch.equal(comm.all_to_all(flat), ref['all_to_all']))
+        for name in ints:
+          a = ints[name].clone()
+          comm.all_reduce(a, mean=False)
+          checks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, ref[f'sum_{name}']))
+          a = noise[name].clone()
+          comm.all_reduce(a, mean=True)
+          checks[f'all_reduce_mean_{name}'] = close(a, ref[f'mean_{name}'], name)
+        a, b = torch.zeros_like(everyone), noise['f32'].clone()
+        comm.exchange(mine, a, b, gather=True)
+        comm.wait()
+        checks['exchange_gather'] = bool(torch.equal(a, ref['all_gather'])) and close(b, ref['mean_f32'], 'f32')
+      except Exception as e:
+        error = f'{type(e).__name__}: {e}'[:300]
+    passed = agree(error is None and bool(checks) and all(checks.values()))
+    failed = [None if passed else 'the check did not pass on every rank']
+    costs = timed({
+        'native_all_reduce': lambda: comm.all_reduce(grads, mean=True),
+        'native_all_to_all': lambda: comm.all_to_all(flat, recv),
+        'native_all_gather': lambda: comm.all_gather(mine, everyone),
+        # one train step's worth, own stream, with the wait of the previous one
+        'native_exchange_step': lambda: (comm.wait(), comm.exchange(flat, recv, grads)),
+        'native_exchange_gather_step': lambda: (comm.wait(), comm.exchange(mine, everyone, grads, gather=True)),
+    }, failed)
+    passed = agree(passed and failed[0] is None)
+    report.update({
+        'status': ('ok' if passed else 'error' if error else 'mismatch' if checks and not all(checks.values())
+                   else 'failed on another rank'),
+        'transport': os.environ.get('EMB_RCCL_LIB') or 'rccl', 'checks': checks,
+        **({'error': error or failed[0]} if (error or failed[0]) else {}),
+        'per_call': {**report['c10d']['per_call'], **costs}})
+
+    # ---- the direct xGMI schedule (emb_direct_*): every rank writes all n-1 peers at once through
+    # hipIpc pointers.  Its failure never takes the RCCL path down.
+    direct, derror, dchecks = None, None, {}
+    try:
+      direct = D.DirectComm(
+          rank, world, device,
+          max_grad_bytes=(1 << 50) if _fault('direct_open', rank) else max(grads.numel() * grads.element_size(), 4 << 20),
+          max_slice_bytes=max(2 * block, whole_block + 4096, 1 << 20),      # (a packed batch pads its keys)
+          share_all=share_all, timeout_ms=3000)     # a peer that does not answer costs this check seconds, not the job
+      kept['direct'] = direct
+    except Exception as e:
+      derror = f'{type(e).__name__}: {e}'[:300]
+    if agree(direct is not None):
+      try:
+        if not _fault('direct_stuck', rank):
+          got = direct.all_to_all(flat)
+          if _fault('direct_wrong', rank):
+            got = got ^ 1
+          dchecks['all_to_all'] = bool(torch.equal(got, ref['all_to_all']))
+        dchecks['all_gather'] = bool(torch.equal(direct.all_gather(mine), ref['all_gather']))
+        for name in ints:
+          a = ints[name].clone()
+          direct.all_reduce(a, mean=False)
+          dchecks[f'all_reduce_sum_{name}'] = bool(torch.equal(a, ref[f'sum_{name}']))
+          a = noise[name].clone()
+          direct.all_reduce(a, mean=True)
+          dchecks[f'all_reduce_mean_{name}'] = close(a, ref[f'mean_{name}'], name)
+        a, b = torch.zeros_like(everyone), noise['f32'].clone()
+        direct.exchange(mine, a, b, gather=True)
+        direct.wait()
+        dchecks['exchange_gather'] = bool(torch.equal(a, ref['all_gather'])) and close(b, ref['mean_f32'], 'f32')
+        direct.check()            # synchronises; raises if a wait inside a kernel gave up on a peer
+      except Exception as e:
+        derror = f'{type(e).__name__}: {e}'[:300]
+      dpassed = agree(derror is None and len(dchecks) == 7 and all(dchecks.values()))
+      failed = [None if dpassed else 'the check did not pass on every rank']
+      dcosts = timed({
+          'direct_all_reduce': lambda: direct.all_reduce(grads, mean=True),
+          'direct_all_to_all': lambda: direct.all_to_all(flat, recv),
+          'direct_all_gather': lambda: direct.all_gather(mine, everyone),
+          'direct_exchange_step': lambda: (direct.wait(), direct.exchange(flat, recv, grads)),
+          'direct_exchange_gather_step': lambda: (direct.wait(), direct.exchange(mine, everyone, grads, gather=True)),
+      }, failed)
+      timed_out = False
+      try:
+        if dpassed:
+          direct.wait()
+        timed_out = direct.timed_out()
+      except Exception as e:
+        failed[0] = failed[0] or f'{type(e).__name__}: {e}'[:300]
+        timed_out = True
+      dpassed = agree(dpassed and failed[0] is None and not timed_out)
+      report['direct'] = {
+          'status': ('ok' if dpassed else 'error' if derror else 'mismatch' if dchecks and not all(dchecks.values())
+                     else 'failed on another rank'),
+          'checks': dchecks, 'timed_out': timed_out,
+          **({'error': derror or failed[0]} if (derror or failed[0]) else {}),
+          **({'per_call': dcosts} if dcosts else {})}
+    else:
+      report['direct'] = {'status': 'error' if derror else 'failed on another rank',
+                          **({'error': derror} if derror else {})}
+    # nobody closes (unmaps) a buffer that a peer's kernel may still be writing
+    torch.cuda.synchronize(device)
+    dist.barrier(group=group)
     return report
 
   def guarded():
     torch.cuda.set_device(device)
     try:
       local = body()
-    except Exception as e:
+    except Exception as e:       # (a bug of the check itself; the transports' own failures are handled above)
       local = {'status': 'error', 'error': f'{type(e).__name__}: {e}'[:300]}
-    # Every rank reaches this reduce whatever happened above, so that all ranks
-    # take the same decision about the timed path.
-    direct_ok = (local.get('direct') or {}).get('status') == 'ok'
-    agree = torch.tensor([1.0 if local['status'] == 'ok' else 0.0, 1.0 if direct_ok else 0.0], device=device)
-    dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
-    torch.cuda.synchronize(device)
-    if agree[0].item() != 1.0 and local['status'] == 'ok':
-      local['status'] = 'failed on another rank'
-    if agree[1].item() != 1.0 and direct_ok:
-      local['direct']['status'] = 'failed on another rank'
     result.clear()
     result.update(local)
 
@@ -1298,13 +1465,20 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
   worker.start()
   worker.join(seconds)
   stuck = worker.is_alive()
-  usable = kept[0] if (kept and not stuck and result.get('status') == 'ok') else None
-  if kept and usable is None and not stuck:
-    kept[0].close()
-  direct = kept[1] if (len(kept) > 1 and not stuck and (result.get('direct') or {}).get('status') == 'ok') else None
-  if len(kept) > 1 and direct is None and not stuck:
-    kept[1].close()
-  return dict(result), stuck, usable, direct
+  report = dict(result)
+  usable = kept.get('native') if (not stuck and report.get('status') == 'ok') else None
+  if kept.get('native') is not None and usable is None and not stuck:
+    kept['native'].close()
+  direct = kept.get('direct') if (not stuck and (report.get('direct') or {}).get('status') == 'ok') else None
+  if kept.get('direct') is not None and direct is None and not stuck:
+    try:
+      torch.cuda.synchronize(device)
+      kept['direct'].close()
+    except Exception:
+      pass
+  if direct is not None:
+    direct.set_timeout(600_000)       # the job itself: a collective watchdog, not the check's three seconds
+  return report, stuck, usable, direct
 
 
 def dreamer_leg(args):

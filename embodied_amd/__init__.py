@@ -32,3 +32,8 @@ from . import run
 from . import distributed
 from .utils import Counter, LocalClock
 from .distributed import GlobalClock
+# `embodied.clock.*` by name (embodied/core/__init__.py:4-5,11): the two clocks and
+# `setup`; the replicas meet on a torch.distributed group instead of an RPC server.
+import types as _types
+clock = _types.SimpleNamespace(
+    LocalClock=LocalClock, GlobalClock=GlobalClock, setup=distributed.clock_setup)

@@ -195,6 +195,7 @@ SIGNATURES = {
     'emb_comm_allgather_returns': [p, p, p, i64, p],
     'emb_comm_pmean_scalars': [p, p, i64, p],
     'emb_comm_exchange': [p, p, p, p, i64, p, i64, i32, i32],
+    'emb_comm_exchange_gather': [p, p, p, p, i64, p, i64, i32, i32],
     'emb_comm_wait': [p, p],
     'emb_comm_destroy': [p],
     'emb_direct_create': [i32, i32, i64, i64, i32, pp],
@@ -203,6 +204,9 @@ SIGNATURES = {
     'emb_direct_allreduce': [p, p, i64, i32, i32, p],
     'emb_direct_alltoall': [p, p, p, i64, p],
     'emb_direct_exchange': [p, p, p, p, i64, p, i64, i32, i32],
+    'emb_direct_allgather': [p, p, p, i64, p],
+    'emb_direct_set_timeout': [p, i32],
+    'emb_direct_exchange_gather': [p, p, p, p, i64, p, i64, i32, i32],
     'emb_direct_wait': [p, p],
     'emb_direct_status': [p, p],
     'emb_direct_destroy': [p],
@@ -303,6 +307,7 @@ class _FastApi:
       'emb_scan_gae_grouped': 'scan', 'emb_scan_lambda_multi': 'ints',
       'emb_comm_exchange': 'ints', 'emb_comm_wait': 'ints',
       'emb_direct_exchange': 'ints', 'emb_direct_wait': 'ints',
+      'emb_comm_exchange_gather': 'ints', 'emb_direct_exchange_gather': 'ints',
   }
 
   def __init__(self, module):
@@ -382,7 +387,8 @@ def configure(**knobs):
   """`configure(EMB_DEFER_INDEX=0, EMB_GATHER_STORES='plain')`: the tuning knobs
   (INTEGRATION.md lists them) from the host program instead of the environment.
   Each knob is read once by the first call that needs it; setting it later
-  raises, as does a name that is not a knob of this package."""
+  raises, as does a name that is not a knob of this package (the library holds
+  the list: csrc/knobs.h)."""
   for name, value in knobs.items():
     if name in PY_KNOBS:
       if name in _py_read:

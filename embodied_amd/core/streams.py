@@ -104,6 +104,13 @@ def window_batch(batch, start, count):
   names = list(batch)
   first = batch[names[0]]
   total = first.shape[1]
+  # One (batch, total) addresses every key inside the kernel: a key of another
+  # length (a context-only key of `Replay(heads=)`, (B, K, ...)) would be read
+  # out of bounds or from the wrong sequences.
+  odd = [k for k in names if batch[k].shape[:2] != first.shape[:2]]
+  if odd:
+    raise ValueError(f'window_batch: keys {odd} are not shaped ({first.shape[0]}, {total}, ...) like '
+                     f'{names[0]!r} (context-only keys cannot be windowed)')
   if start == 0 and count == total:
     return {k: (v if v.is_contiguous() else v.contiguous()) for k, v in batch.items()}
   srcs = [batch[k] if batch[k].is_contiguous() else batch[k].contiguous() for k in names]
@@ -182,7 +189,9 @@ class Consec(base.Stream):
         raise AssertionError(
             f'Consec(length={self.length}, consec={self.consec}, prefix={self.prefix}) needs '
             f'{"exactly" if self.strict else "at least"} {need} steps per sequence, got {have}')
-      if self.consec > 1:
+      if self.consec > 1 or have != need:
+        # whenever a window is not the whole batch -- consec > 1, or consec == 1 cutting
+        # `need` of `have` steps (strict=False) -- every key must span the batch
         short = [k for k, v in self.current.items() if v.shape[1] != have]
         if short:       # `Replay(heads=)` keys hold the head of the WHOLE sequence, not of each window
           raise AssertionError(f'Consec(consec={self.consec}): keys {short} do not span the {have} steps '

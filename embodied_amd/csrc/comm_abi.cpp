@@ -199,18 +199,22 @@ int32_t emb_comm_allreduce_grads_as(emb_comm_t* comm, void* buf, int64_t count, 
   return allreduce_typed(comm, buf, count, dtype, mean, stream);
 }
 
-int32_t emb_comm_exchange(emb_comm_t* comm, void* after_stream, const void* slices_send,
-                          void* slices_recv, int64_t bytes_per_rank, void* grads, int64_t count,
-                          int32_t dtype, int32_t mean) {
+static int32_t comm_exchange(emb_comm_t* comm, void* after_stream, const void* send, void* recv,
+                             int64_t bytes_per_rank, void* grads, int64_t count, int32_t dtype, int32_t mean,
+                             bool gather) {
   return guarded([&] {
     need(comm && bytes_per_rank >= 0 && count >= 0, "comm_exchange: bad arguments");
-    need(bytes_per_rank == 0 || (slices_send && slices_recv), "comm_exchange: null slice buffers");
+    need(bytes_per_rank == 0 || (send && recv), "comm_exchange: null slice / trajectory buffers");
     need(count == 0 || grads, "comm_exchange: null gradient buffer");
     const ncclDataType_t type = grad_type(count ? dtype : EMB_F32);
     if (bytes_per_rank == 0 && count == 0) return;
     HIP_OK(hipEventRecord(comm->forked, static_cast<hipStream_t>(after_stream)));
     HIP_OK(hipStreamWaitEvent(comm->side, comm->forked, 0));
-    if (bytes_per_rank) alltoall_on(comm, slices_send, slices_recv, bytes_per_rank, comm->side);
+    if (bytes_per_rank && gather)
+      rccl_ok(rccl().all_gather(send, recv, static_cast<size_t>(bytes_per_rank), ncclUint8, comm->comm, comm->side),
+              "ncclAllGather");
+    else if (bytes_per_rank)
+      alltoall_on(comm, send, recv, bytes_per_rank, comm->side);
     if (count)
       rccl_ok(rccl().all_reduce(grads, grads, static_cast<size_t>(count), type,
                                 mean ? ncclAvg : ncclSum, comm->comm, comm->side),
@@ -218,6 +222,18 @@ int32_t emb_comm_exchange(emb_comm_t* comm, void* after_stream, const void* slic
     HIP_OK(hipEventRecord(comm->done, comm->side));
     comm->in_flight = true;
   });
+}
+
+int32_t emb_comm_exchange(emb_comm_t* comm, void* after_stream, const void* slices_send,
+                          void* slices_recv, int64_t bytes_per_rank, void* grads, int64_t count,
+                          int32_t dtype, int32_t mean) {
+  return comm_exchange(comm, after_stream, slices_send, slices_recv, bytes_per_rank, grads, count, dtype, mean, false);
+}
+
+int32_t emb_comm_exchange_gather(emb_comm_t* comm, void* after_stream, const void* traj_send,
+                                 void* traj_recv, int64_t bytes_per_rank, void* grads, int64_t count,
+                                 int32_t dtype, int32_t mean) {
+  return comm_exchange(comm, after_stream, traj_send, traj_recv, bytes_per_rank, grads, count, dtype, mean, true);
 }
 
 int32_t emb_comm_wait(emb_comm_t* comm, void* stream) {

@@ -29,8 +29,16 @@
 // that starts operation s has seen every peer's flags of operation s-1, i.e.
 // every peer has finished reading the slots of operation s-2.
 //
+//   all-gather  = the all-to-all with the SAME block pushed to every peer (the
+//                 trajectory all-gather of embodied/jax/internal.py:145-152).
+//
 // Every wait is bounded (timeout_ms of emb_direct_create): a peer that never
-// arrives turns into an error word (emb_direct_status), never into a hung GPU.
+// arrives turns into an error word, never into a hung GPU -- and the error is
+// FATAL for the communicator: the kernel that gave up writes no result and
+// raises no peer's flag (so every rank runs into the same time-out instead of
+// reducing half-arrived slots), every later kernel of the communicator returns
+// at once, and every later host call fails (the word also lives in host-mapped
+// memory that the entry points read without synchronising).
 #include "abi_common.h"
 
 #include <hip/hip_runtime.h>
@@ -47,7 +55,7 @@ struct alignas(256) DirectHeader {
   uint32_t rs_flag[kMaxRanks];      // written by the peers
   uint32_t ag_flag[kMaxRanks];
   uint32_t a2a_flag[kMaxRanks];
-  uint32_t error;                   // local: a wait ran into its timeout
+  uint32_t error;                   // local, sticky: a wait ran into its timeout (the communicator is dead)
   uint32_t counter[3][kMaxRanks];   // local: blocks that finished pushing to peer p (rs, ag, a2a)
 };
 
@@ -57,7 +65,8 @@ __device__ __forceinline__ void signal(uint32_t* flag, uint32_t seq) {
 
 // Blocks of one launch that push to the same peer: the last one to finish (its
 // stores fenced at system scope) raises the peer's flag.
-__device__ __forceinline__ void arrive(uint32_t* counter, uint32_t expected, uint32_t* peer_flag, uint32_t seq) {
+__device__ __forceinline__ void arrive(uint32_t* counter, uint32_t expected, uint32_t* peer_flag, uint32_t seq,
+                                       const uint32_t* error) {
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -65,30 +74,46 @@ __device__ __forceinline__ void arrive(uint32_t* counter, uint32_t expected, uin
     if (seen + 1 == expected) {
       __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
-      signal(peer_flag, seq);
+      // (a dead communicator raises no flags: its peers give up as well)
+      if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) signal(peer_flag, seq);
     }
   }
 }
 
 // Wait until flags[p] has reached `seq` for every peer p != me (wrap-safe), at
 // most `timeout` ticks of the 100 MHz wall clock; then make the peers' stores
-// visible to every lane of the workgroup.
-__device__ __forceinline__ void wait_all(const uint32_t* flags, int me, int world, uint32_t seq,
-                                         uint64_t timeout, uint32_t* error) {
+// visible to every lane of the workgroup.  False (for the whole workgroup) if a
+// peer did not arrive in time, now or in an earlier operation: the caller
+// writes nothing and signals nobody.
+struct ErrorWords {
+  uint32_t* device;                   // DirectHeader::error
+  uint32_t* host;                     // the same word in host-mapped memory (read by the entry points)
+};
+
+__device__ __forceinline__ bool wait_all(const uint32_t* flags, int me, int world, uint32_t seq,
+                                         uint64_t timeout, ErrorWords error) {
+  int failed = 0;
   if (threadIdx.x < static_cast<unsigned>(world) && static_cast<int>(threadIdx.x) != me) {
-    const uint64_t began = wall_clock64();
-    for (;;) {
-      const uint32_t seen = __hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (static_cast<int32_t>(seen - seq) >= 0) break;
-      if (wall_clock64() - began > timeout) {
-        __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
+    if (__hip_atomic_load(error.device, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      failed = 1;
+    } else {
+      const uint64_t began = wall_clock64();
+      for (;;) {
+        const uint32_t seen = __hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (static_cast<int32_t>(seen - seq) >= 0) break;
+        if (wall_clock64() - began > timeout) {
+          __hip_atomic_store(error.device, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(error.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          failed = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
       }
-      __builtin_amdgcn_s_sleep(8);
     }
   }
-  __syncthreads();
+  failed = __syncthreads_or(failed);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: drops what this CU had cached of the slots
+  return failed == 0;
 }
 
 struct PushArgs {
@@ -99,6 +124,7 @@ struct PushArgs {
   int32_t n, per_peer;                // peers listed, workgroups per peer
   uint32_t seq;
   uint32_t* counter;                  // local header: counter[which][0..]
+  const uint32_t* error;              // local header
 };
 
 // Bytes of any alignment: 16-byte body, byte tail.
@@ -116,7 +142,7 @@ __device__ __forceinline__ void copy_span(const uint8_t* src, uint8_t* dst, int6
 __global__ __launch_bounds__(kThreads) void direct_push_kernel(const PushArgs a) {
   const int p = blockIdx.x / a.per_peer, part = blockIdx.x - p * a.per_peer;
   copy_span(a.src[p], a.dst[p], a.bytes[p], part, a.per_peer);
-  arrive(a.counter + p, static_cast<uint32_t>(a.per_peer), a.flag[p], a.seq);
+  arrive(a.counter + p, static_cast<uint32_t>(a.per_peer), a.flag[p], a.seq, a.error);
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
@@ -141,7 +167,7 @@ struct ReduceArgs {
   uint8_t* gather[kMaxRanks];         // peer p's ag slot for ME (gather[me] = nullptr)
   uint32_t* flag[kMaxRanks];          // peer p's ag flag for me
   const uint32_t* rs_flags;           // my header
-  uint32_t* error;
+  ErrorWords error;
   uint32_t* counter;                  // local header: ag counters
   int64_t shard_off, shard_elems;     // my shard, in elements
   int32_t me, world;
@@ -152,7 +178,7 @@ struct ReduceArgs {
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void direct_reduce_kernel(const ReduceArgs a) {
-  wait_all(a.rs_flags, a.me, a.world, a.seq, a.timeout, a.error);
+  if (!wait_all(a.rs_flags, a.me, a.world, a.seq, a.timeout, a.error)) return;
   constexpr int V = 16 / static_cast<int>(sizeof(T));      // elements per 16-byte access
   union Pack { u32x4 raw; T e[V]; };
   uint8_t* mine = a.local + a.shard_off * static_cast<int64_t>(sizeof(T));
@@ -210,7 +236,7 @@ struct CollectArgs {
   uint8_t* own_dst;
   int64_t own_bytes;
   const uint32_t* flags;
-  uint32_t* error;
+  ErrorWords error;
   int32_t me, world;
   uint32_t seq;
   uint64_t timeout;
@@ -218,7 +244,7 @@ struct CollectArgs {
 
 __global__ __launch_bounds__(kThreads) void direct_collect_kernel(const CollectArgs a) {
   if (a.own_bytes) copy_span(a.own_src, a.own_dst, a.own_bytes, blockIdx.x, gridDim.x);    // needs no peer
-  wait_all(a.flags, a.me, a.world, a.seq, a.timeout, a.error);
+  if (!wait_all(a.flags, a.me, a.world, a.seq, a.timeout, a.error)) return;
   for (int p = 0; p < a.world; ++p)
     if (p != a.me) copy_span(a.slot[p], a.dst[p], a.bytes[p], blockIdx.x, gridDim.x);
 }
@@ -237,11 +263,21 @@ struct emb_direct {
   bool connected = false;
   uint32_t red_seq = 0, a2a_seq = 0;
   uint64_t timeout_ticks = 0;
+  uint32_t* host_error = nullptr;           // host-mapped twin of DirectHeader::error
+  uint32_t* host_error_dev = nullptr;       // its device address
   hipStream_t side = nullptr;
   hipEvent_t forked = nullptr, done = nullptr;
   bool in_flight = false;
 
   DirectHeader* header(int r) const { return reinterpret_cast<DirectHeader*>(peer[r]); }
+  ErrorWords errors() const { return ErrorWords{&header(rank)->error, host_error_dev}; }
+  // A wait inside one of the kernels gave up on a peer (read without synchronising):
+  // nothing this communicator has produced since can be trusted.
+  void alive(const char* what) const {
+    if (host_error && *static_cast<volatile uint32_t*>(host_error) != 0u)
+      throw std::runtime_error(std::string(what) + ": the direct transport timed out waiting for a peer; "
+                               "this communicator is dead (no result was written by the operation that gave up)");
+  }
   // slots of rank r's region: rs[parity][src], ag[parity][src], a2a[parity][src]
   uint8_t* rs_slot(int r, int parity, int src) const {
     return peer[r] + sizeof(DirectHeader) + (static_cast<int64_t>(parity) * world + src) * shard_cap;
@@ -263,6 +299,9 @@ static void direct_allreduce(emb_direct* d, void* buf, int64_t count, int32_t dt
   const int n = d->world, me = d->rank;
   if (count == 0 || n == 1) return;
   need(d->connected, "direct_allreduce: call emb_direct_connect first");
+  // (the reduce and collect kernels move 16 bytes per lane from / to shard offsets of this buffer)
+  need(reinterpret_cast<uintptr_t>(buf) % 16 == 0, "direct_allreduce: the buffer must be 16-byte aligned");
+  d->alive("direct_allreduce");
   const uint32_t seq = ++d->red_seq;
   const int parity = seq & 1;
   // shards of a multiple of 16 bytes (the last one may be shorter, or empty)
@@ -290,6 +329,7 @@ static void direct_allreduce(emb_direct* d, void* buf, int64_t count, int32_t dt
   push.per_peer = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(64, most / (kThreads * 16 * 4))));
   push.seq = seq;
   push.counter = mine->counter[0];
+  push.error = &mine->error;
   hipLaunchKernelGGL(direct_push_kernel, dim3(push.n * push.per_peer), dim3(kThreads), 0, s, push);
   // 2. reduce my shard, store it here and into every peer's ag slot [me]
   ReduceArgs red{};
@@ -301,7 +341,7 @@ static void direct_allreduce(emb_direct* d, void* buf, int64_t count, int32_t dt
     red.flag[p] = p == me ? nullptr : &d->header(p)->ag_flag[me];
   }
   red.rs_flags = mine->rs_flag;
-  red.error = &mine->error;
+  red.error = d->errors();
   red.counter = &mine->counter[1][0];
   red.me = me;
   red.world = n;
@@ -322,7 +362,7 @@ static void direct_allreduce(emb_direct* d, void* buf, int64_t count, int32_t dt
     col.bytes[p] = elems * es;
   }
   col.flags = mine->ag_flag;
-  col.error = &mine->error;
+  col.error = d->errors();
   col.me = me;
   col.world = n;
   col.seq = seq;
@@ -331,17 +371,23 @@ static void direct_allreduce(emb_direct* d, void* buf, int64_t count, int32_t dt
   HIP_OK(hipGetLastError());
 }
 
-static void direct_alltoall(emb_direct* d, const void* send, void* recv, int64_t bytes, hipStream_t s) {
-  need(bytes <= d->a2a_cap, "direct_alltoall: block larger than the capacity given to emb_direct_create");
+// all-to-all: block p of `send` goes to peer p (gather = false); all-gather: the one
+// block `send` holds goes to every peer (gather = true).  Either way block p of
+// `recv` came from rank p.
+static void direct_alltoall(emb_direct* d, const void* send, void* recv, int64_t bytes, hipStream_t s,
+                            bool gather = false) {
+  need(bytes <= d->a2a_cap, "direct_alltoall / allgather: block larger than the capacity given to emb_direct_create");
   const int n = d->world, me = d->rank;
   if (bytes == 0) return;
   const uint8_t* from = static_cast<const uint8_t*>(send);
   uint8_t* to = static_cast<uint8_t*>(recv);
   if (n == 1) {
-    HIP_OK(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s));
+    if (to != from) HIP_OK(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s));
     return;
   }
   need(d->connected, "direct_alltoall: call emb_direct_connect first");
+  d->alive("direct_alltoall");
+  const int64_t stride = gather ? 0 : bytes;
   const uint32_t seq = ++d->a2a_seq;
   const int parity = seq & 1;
   DirectHeader* mine = d->header(me);
@@ -349,7 +395,7 @@ static void direct_alltoall(emb_direct* d, const void* send, void* recv, int64_t
   for (int p = 0; p < n; ++p) {
     if (p == me) continue;
     const int k = push.n++;
-    push.src[k] = from + p * bytes;
+    push.src[k] = from + p * stride;
     push.dst[k] = d->a2a_slot(p, parity, me);
     push.flag[k] = &d->header(p)->a2a_flag[me];
     push.bytes[k] = bytes;
@@ -357,6 +403,7 @@ static void direct_alltoall(emb_direct* d, const void* send, void* recv, int64_t
   push.per_peer = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(64, bytes / (kThreads * 16 * 4))));
   push.seq = seq;
   push.counter = mine->counter[2];
+  push.error = &mine->error;
   hipLaunchKernelGGL(direct_push_kernel, dim3(push.n * push.per_peer), dim3(kThreads), 0, s, push);
   CollectArgs col{};
   for (int p = 0; p < n; ++p) {
@@ -364,11 +411,11 @@ static void direct_alltoall(emb_direct* d, const void* send, void* recv, int64_t
     col.dst[p] = to + p * bytes;
     col.bytes[p] = bytes;
   }
-  col.own_src = from + me * bytes;
+  col.own_src = from + me * stride;
   col.own_dst = to + me * bytes;
   col.own_bytes = bytes;
   col.flags = mine->a2a_flag;
-  col.error = &mine->error;
+  col.error = d->errors();
   col.me = me;
   col.world = n;
   col.seq = seq;
@@ -406,6 +453,9 @@ int32_t emb_direct_create(int32_t rank, int32_t world, int64_t max_reduce_bytes,
                                    hipDeviceMallocFinegrained));
     }
     HIP_OK(hipMemset(d->region, 0, sizeof(DirectHeader)));
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&d->host_error), 64, hipHostMallocMapped));
+    *d->host_error = 0u;
+    HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d->host_error_dev), d->host_error, 0));
     HIP_OK(hipDeviceSynchronize());
     d->peer[rank] = d->region;
     d->connected = world == 1;
@@ -456,28 +506,56 @@ int32_t emb_direct_alltoall(emb_direct_t* d, const void* send, void* recv, int64
   });
 }
 
-int32_t emb_direct_exchange(emb_direct_t* d, void* after_stream, const void* slices_send, void* slices_recv,
-                            int64_t bytes_per_rank, void* grads, int64_t count, int32_t dtype, int32_t mean) {
+int32_t emb_direct_allgather(emb_direct_t* d, const void* send, void* recv, int64_t bytes_per_rank, void* stream) {
+  return guarded([&] {
+    need(d && bytes_per_rank >= 0 && (bytes_per_rank == 0 || (send && recv)), "direct_allgather: bad arguments");
+    direct_alltoall(d, send, recv, bytes_per_rank, static_cast<hipStream_t>(stream), true);
+  });
+}
+
+static int32_t direct_exchange(emb_direct_t* d, void* after_stream, const void* send, void* recv,
+                               int64_t bytes_per_rank, void* grads, int64_t count, int32_t dtype, int32_t mean,
+                               bool gather) {
   return guarded([&] {
     need(d && bytes_per_rank >= 0 && count >= 0, "direct_exchange: bad arguments");
-    need(bytes_per_rank == 0 || (slices_send && slices_recv), "direct_exchange: null slice buffers");
+    need(bytes_per_rank == 0 || (send && recv), "direct_exchange: null slice / trajectory buffers");
     need(count == 0 || grads, "direct_exchange: null gradient buffer");
     if (bytes_per_rank == 0 && count == 0) return;
+    d->alive("direct_exchange");
     HIP_OK(hipEventRecord(d->forked, static_cast<hipStream_t>(after_stream)));
     HIP_OK(hipStreamWaitEvent(d->side, d->forked, 0));
-    if (bytes_per_rank) direct_alltoall(d, slices_send, slices_recv, bytes_per_rank, d->side);
+    if (bytes_per_rank) direct_alltoall(d, send, recv, bytes_per_rank, d->side, gather);
     if (count) direct_allreduce(d, grads, count, dtype, mean != 0, d->side);
     HIP_OK(hipEventRecord(d->done, d->side));
     d->in_flight = true;
   });
 }
 
+int32_t emb_direct_exchange(emb_direct_t* d, void* after_stream, const void* slices_send, void* slices_recv,
+                            int64_t bytes_per_rank, void* grads, int64_t count, int32_t dtype, int32_t mean) {
+  return direct_exchange(d, after_stream, slices_send, slices_recv, bytes_per_rank, grads, count, dtype, mean, false);
+}
+
+int32_t emb_direct_exchange_gather(emb_direct_t* d, void* after_stream, const void* traj_send, void* traj_recv,
+                                   int64_t bytes_per_rank, void* grads, int64_t count, int32_t dtype,
+                                   int32_t mean) {
+  return direct_exchange(d, after_stream, traj_send, traj_recv, bytes_per_rank, grads, count, dtype, mean, true);
+}
+
 int32_t emb_direct_wait(emb_direct_t* d, void* stream) {
   return guarded([&] {
     need(d, "direct_wait: null handle");
+    d->alive("direct_wait");
     if (!d->in_flight) return;
     HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), d->done, 0));
     d->in_flight = false;
+  });
+}
+
+int32_t emb_direct_set_timeout(emb_direct_t* d, int32_t timeout_ms) {
+  return guarded([&] {
+    need(d && timeout_ms > 0, "direct_set_timeout: bad arguments");
+    d->timeout_ticks = static_cast<uint64_t>(timeout_ms) * 100000ull;     // launches from now on
   });
 }
 
@@ -486,7 +564,7 @@ int32_t emb_direct_status(emb_direct_t* d, int32_t* timed_out) {
     need(d && timed_out, "direct_status: bad arguments");
     uint32_t word = 0;
     HIP_OK(hipMemcpy(&word, &d->header(d->rank)->error, sizeof(word), hipMemcpyDeviceToHost));    // (synchronises)
-    *timed_out = static_cast<int32_t>(word);
+    *timed_out = static_cast<int32_t>(word | *static_cast<volatile uint32_t*>(d->host_error));
   });
 }
 
@@ -502,6 +580,7 @@ int32_t emb_direct_destroy(emb_direct_t* d) {
       (void)hipStreamDestroy(d->side);
     }
     if (d->region) (void)hipFree(d->region);
+    if (d->host_error) (void)hipHostFree(d->host_error);
     delete d;
   });
 }

@@ -10,6 +10,11 @@ int32_t emb_abi_version(void) { return EMB_ABI_VERSION; }
 int32_t emb_configure(const char* name, const char* value) {
   return guarded([&] {
     need(name && std::strncmp(name, "EMB_", 4) == 0, "configure: knob names start with EMB_");
+    if (!emb::knob_known(name)) {
+      std::string known;
+      for (const char* k : emb::kKnobNames) known += std::string(known.empty() ? "" : ", ") + k;
+      throw std::invalid_argument(std::string("configure: ") + name + " is not a knob of this library (" + known + ")");
+    }
     if (emb::knob_set(name, value) != 0)
       throw std::invalid_argument(std::string("configure: ") + name +
                                   " is already in effect (knobs are read once: set them before the "

@@ -16,6 +16,19 @@
 
 namespace emb {
 
+// Every knob the library reads (tests/test_abi_symbols.py checks this list
+// against the knob("EMB_...") calls in csrc/): emb_configure refuses any other
+// name, so a misspelt or retired knob is an error instead of a silent no-op.
+constexpr const char* kKnobNames[] = {
+    "EMB_ARGS_BAR",     "EMB_DEFER_INDEX", "EMB_DEFER_MAX_GAP_US", "EMB_GATHER_STORES", "EMB_HOST_PROFILE",
+    "EMB_PREDICT_ROWS", "EMB_RCCL_LIB",    "EMB_SPAN_MOVER",       "EMB_WHERE_BACKLOG",
+};
+inline bool knob_known(const char* name) {
+  for (const char* known : kKnobNames)
+    if (std::string(known) == name) return true;
+  return false;
+}
+
 struct KnobTable {
   std::mutex mu;
   std::map<std::string, std::string> given;      // emb_configure values

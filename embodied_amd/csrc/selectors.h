@@ -583,8 +583,9 @@ class Prioritized : public Selector {
     // (`newest` is a new id: the caller's guarantee -- a Replay issues every step
     // id once.  The general insert() checks it.)
     if (start + st->n - 2 != last) return false;
-    const double pw = powered(initial_);
-    st->push_step(newest, initial_, pw);
+    const double born = birth_priority(newest);
+    const double pw = powered(born);
+    st->push_step(newest, born, pw);
     where_log(newest, st, last + 1, true);
     st->items.push_back(key);
     owner_.put(key, std::make_pair(st, start));
@@ -635,7 +636,10 @@ class Prioritized : public Selector {
       begin_touch();
       for (int64_t i = 0; i < n; ++i) {
         auto it = steps_.find(steps[i]);
-        if (it == steps_.end()) continue;  // step no longer in any item
+        if (it == steps_.end()) {          // in no item (yet, or any more): kept for an item that arrives later
+          early_[steps[i]] = prios[i];
+          continue;
+        }
         set_priority(it->second, prios[i]);
         touch_users(it->second);
       }
@@ -654,7 +658,8 @@ class Prioritized : public Selector {
         auto it = where().find(steps[i]);
         if (it == where_.end()) {
           st = nullptr;
-          continue;                  // step no longer in any item
+          early_[steps[i]] = prios[i];       // in no item (yet, or any more): kept for an item that arrives later
+          continue;
         }
         st = it->second.first;
         pos = it->second.second;
@@ -930,7 +935,8 @@ class Prioritized : public Selector {
       if (start != st->item0 + static_cast<int64_t>(st->items.size())) return false;
       for (int i = 0; i < n - 2; ++i)
         if (!(st->ids[start + i - st->step0] == ids[i])) return false;
-      st->push_step(ids[n - 1], initial_, powered(initial_));
+      const double born = birth_priority(ids[n - 1]);
+      st->push_step(ids[n - 1], born, powered(born));
       where_.emplace(ids[n - 1], std::make_pair(st, pos + 1));
       st->items.push_back(key);
       owner_.put(key, std::make_pair(st, start));
@@ -950,7 +956,8 @@ class Prioritized : public Selector {
     streams_.insert(st);
     st->n = n;
     for (int i = 0; i < n; ++i) {
-      st->push_step(ids[i], initial_, powered(initial_));
+      const double born = birth_priority(ids[i]);
+      st->push_step(ids[i], born, powered(born));
       where_.emplace(ids[i], std::make_pair(st, static_cast<int64_t>(i)));
     }
     st->items.push_back(key);
@@ -1031,7 +1038,7 @@ class Prioritized : public Selector {
       if (found == steps_.end()) {
         found = steps_.emplace(steps[i], Step()).first;
         found->second.id = &found->first;
-        set_priority(found->second, initial_);
+        set_priority(found->second, birth_priority(steps[i]));
       }
       mine.steps.push_back(&found->second);       // node addresses are stable
     }
@@ -1081,6 +1088,22 @@ class Prioritized : public Selector {
   }
 
   double exponent_, initial_;
+  // Priorities given to step ids that belong to NO item at that moment.  The
+  // reference's table takes a priority for any step id (selectors.py:143-150,
+  // `prios` is a defaultdict) and an item that arrives later aggregates it
+  // (:187-197) -- unreachable through Replay.update (sampled steps are in
+  // items), reachable through the selector protocol.  A new step record takes
+  // its entry from here; like the reference's, entries of ids that never arrive
+  // stay.
+  std::unordered_map<StepId, double, StepIdHash> early_;
+  double birth_priority(const StepId& id) {
+    if (early_.empty()) return initial_;
+    auto it = early_.find(id);
+    if (it == early_.end()) return initial_;
+    const double prio = it->second;
+    early_.erase(it);
+    return prio;
+  }
   bool zero_;
   double maxfrac_;
   SampleTree tree_;

@@ -245,11 +245,17 @@ def _default_pg():
   return distributed_c10d._get_default_group()
 
 
-def async_all_gather(out, tensor):
+def async_all_gather(out, tensor, group=None):
   """Async all-gather into one flat tensor; returns a Work handle.  Calls the
   process group's own method: no Python-side argument checking, the GIL is
   released for the whole call (what matters when issued from CommThread)."""
-  pg = _default_pg()
+  pg = group or _default_pg()
+  if dist.get_backend(group) == 'gloo' and tensor.is_cuda:
+    # (gloo moves host memory only: the test transport, see async_all_to_all)
+    parts = [torch.empty(tensor.shape, dtype=tensor.dtype) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, tensor.cpu(), group=group)
+    out.copy_(torch.cat(parts).view(out.dtype).reshape(out.shape))
+    return _Finished()
   try:
     return pg._allgather_base(out, tensor)
   except AttributeError:
@@ -564,6 +570,19 @@ class GlobalClock:
     return bool(due) and not bool(skipped)
 
 
+def clock_setup(is_server, replica, replicas, port, addr):
+  """`embodied.clock.setup` by name (clock.py:11-23: connect this replica to the
+  clock server).  Here the replicas' clocks meet on a torch.distributed group
+  (GlobalClock above), so "connecting" = making sure that group exists: a gloo
+  group at tcp://addr:port if the host program has not initialised one.  One
+  replica: nothing to do, as in the reference (`replicas <= 1`)."""
+  if replicas <= 1 or (dist.is_available() and dist.is_initialized()):
+    return
+  host = (addr or '127.0.0.1').split(':')[0]
+  dist.init_process_group('gloo', init_method=f'tcp://{host}:{int(port)}', rank=int(replica),
+                          world_size=int(replicas))
+
+
 def pmean(x, comm=None, group=None):
   """Mean over the data-parallel ranks of a (small) float32 tensor, e.g. a local
   mean (embodied/jax/utils.py:76-81: `x.mean()` then `jax.lax.pmean`).  `comm`:
@@ -675,9 +694,16 @@ class GroupComm:
     self._pending = []
     self._scale = None
 
-  def exchange(self, slices=None, received=None, grads=None, mean=True):
+  def exchange(self, slices=None, received=None, grads=None, mean=True, gather=False):
     assert not self._pending, 'GroupComm.exchange: wait() for the previous exchange first'
-    if slices is not None:
+    if slices is not None and gather:
+      # the trajectory all-gather: this rank's block -> world blocks in rank order
+      assert received is not None and received.numel() == self.world * slices.numel()
+      if self.world == 1:
+        received.copy_(slices)
+      else:
+        self._pending.append(async_all_gather(received, slices, self.group))
+    elif slices is not None:
       assert received is not None and received.numel() == slices.numel()
       assert slices.numel() % self.world == 0
       if self.world == 1:
@@ -786,12 +812,13 @@ class NativeComm:
         self._handle, values.data_ptr(), values.numel(), self._lib.raw_stream(values.device))
     return values
 
-  def exchange(self, slices=None, received=None, grads=None, mean=True):
+  def exchange(self, slices=None, received=None, grads=None, mean=True, gather=False):
     """One train step's collectives on the communicator's own stream, after
     what the current stream holds so far: the DP-slice all-to-all of `slices`
-    into `received` (both (world * nbytes,) uint8) and / or the in-place
-    all-reduce of `grads`.  `wait()` orders the current stream after them; the
-    caller keeps the buffers until then."""
+    into `received` (both (world * nbytes,) uint8) -- or, with `gather`, the
+    trajectory all-gather of `slices` (nbytes,) into `received` (world * nbytes,)
+    -- and / or the in-place all-reduce of `grads`.  `wait()` orders the current
+    stream after them; the caller keeps the buffers until then."""
     device = (grads if grads is not None else slices).device
     code, count = self._lib.F32, 0
     if grads is not None:
@@ -799,11 +826,15 @@ class NativeComm:
               torch.float32: self._lib.F32, torch.float64: self._lib.F64}[grads.dtype]
       count = grads.numel()
     per_rank = 0
-    if slices is not None:
+    if slices is not None and gather:
+      assert slices.dtype == torch.uint8 and received is not None
+      assert received.numel() == self.world * slices.numel()
+      per_rank = slices.numel()
+    elif slices is not None:
       assert slices.dtype == torch.uint8 and slices.numel() % self.world == 0
       assert received is not None and received.numel() == slices.numel()
       per_rank = slices.numel() // self.world
-    self._lib.fast.emb_comm_exchange(
+    (self._lib.fast.emb_comm_exchange_gather if gather else self._lib.fast.emb_comm_exchange)(
         self._handle.value, self._lib.raw_stream(device),
         slices.data_ptr() if per_rank else None, received.data_ptr() if per_rank else None, per_rank,
         grads.data_ptr() if count else None, count, code, int(bool(mean)))
@@ -834,11 +865,17 @@ class DirectComm:
   The 64-byte handle of every rank's buffer reaches the others through
   `share_all(handle_bytes) -> [handle_bytes of rank 0, 1, ...]` (default: an
   object all-gather on the torch.distributed group).  `max_grad_bytes` /
-  `max_slice_bytes`: the largest gradient buffer and all-to-all block (bytes per
-  rank) this communicator will see."""
+  `max_slice_bytes`: the largest gradient buffer and all-to-all / all-gather
+  block (bytes per rank) this communicator will see.
+
+  `timeout_ms` is a watchdog, not a latency bound: a kernel that waits longer
+  than that for a peer gives up, writes NO result and kills the communicator --
+  the next `exchange` / `wait` / collective on any rank raises (RCCL would keep
+  waiting; a wrong gradient must never pass for a reduced one).  Default: ten
+  minutes, as torch.distributed's own collective watchdog."""
 
   def __init__(self, rank=0, world=1, device=None, max_grad_bytes=64 << 20, max_slice_bytes=32 << 20,
-               timeout_ms=20000, share_all=None):
+               timeout_ms=600_000, share_all=None):
     import ctypes as C
     from . import _lib
     from ._lib import api
@@ -891,8 +928,10 @@ class DirectComm:
 
   def all_reduce(self, grads, mean=True):
     """In-place sum or mean over the ranks of a flat f16 / bf16 / f32 buffer;
-    every rank ends with the same bits."""
+    every rank ends with the same bits.  The buffer starts on a 16-byte boundary
+    (a view such as `flat[1:]` does not: reduce the whole allocation)."""
     assert grads.is_contiguous() and grads.is_cuda
+    assert grads.data_ptr() % 16 == 0, 'DirectComm.all_reduce: the buffer must be 16-byte aligned'
     self._api.emb_direct_allreduce(
         self._handle, grads.data_ptr(), grads.numel(), self._code(grads.dtype), int(bool(mean)),
         self._lib.raw_stream(grads.device))
@@ -909,20 +948,38 @@ class DirectComm:
         self._lib.raw_stream(flat.device))
     return out
 
-  def exchange(self, slices=None, received=None, grads=None, mean=True):
+  def all_gather(self, flat, out=None):
+    """(nbytes,) uint8 per rank -> (world * nbytes,) uint8 on every rank, rank order
+    (the trajectory all-gather, embodied/jax/internal.py:145-152): this rank's
+    block goes to all n-1 peers at once, one link each."""
+    assert flat.dtype == torch.uint8 and flat.is_contiguous() and flat.is_cuda
+    if out is None:
+      out = torch.empty(self.world * flat.numel(), dtype=torch.uint8, device=flat.device)
+    assert out.numel() == self.world * flat.numel()
+    self._api.emb_direct_allgather(
+        self._handle, flat.data_ptr(), out.data_ptr(), flat.numel(), self._lib.raw_stream(flat.device))
+    return out
+
+  def exchange(self, slices=None, received=None, grads=None, mean=True, gather=False):
     """One train step's collectives on the transport's own stream, after what
-    the current stream holds so far (NativeComm.exchange's contract); `wait()`
-    orders the current stream after them."""
+    the current stream holds so far (NativeComm.exchange's contract, `gather`
+    included); `wait()` orders the current stream after them.  Raises if a wait
+    inside an earlier operation timed out (the communicator is dead then)."""
     device = (grads if grads is not None else slices).device
     code, count = self._lib.F32, 0
     if grads is not None:
       code, count = self._code(grads.dtype), grads.numel()
+      assert grads.data_ptr() % 16 == 0, 'DirectComm.exchange: the gradient buffer must be 16-byte aligned'
     per_rank = 0
-    if slices is not None:
+    if slices is not None and gather:
+      assert slices.dtype == torch.uint8 and received is not None
+      assert received.numel() == self.world * slices.numel()
+      per_rank = slices.numel()
+    elif slices is not None:
       assert slices.dtype == torch.uint8 and slices.numel() % self.world == 0
       assert received is not None and received.numel() == slices.numel()
       per_rank = slices.numel() // self.world
-    self._lib.fast.emb_direct_exchange(
+    (self._lib.fast.emb_direct_exchange_gather if gather else self._lib.fast.emb_direct_exchange)(
         self._handle.value, self._lib.raw_stream(device),
         slices.data_ptr() if per_rank else None, received.data_ptr() if per_rank else None, per_rank,
         grads.data_ptr() if count else None, count, code, int(bool(mean)))
@@ -930,11 +987,21 @@ class DirectComm:
   def wait(self, device=None):
     self._lib.fast.emb_direct_wait(self._handle.value, self._lib.raw_stream(device or self.device))
 
+  def set_timeout(self, timeout_ms):
+    """The watchdog of the operations issued from now on."""
+    self._api.emb_direct_set_timeout(self._handle, int(timeout_ms))
+
   def timed_out(self):
     """True if a wait inside one of the kernels gave up on a peer (synchronises)."""
     word = self._C.c_int32(0)
     self._api.emb_direct_status(self._handle, self._C.byref(word))
     return bool(word.value)
+
+  def check(self):
+    """Synchronise and raise if the transport is dead (for the end of a run, or
+    before results of the last exchange are trusted without another call)."""
+    if self.timed_out():
+      raise RuntimeError('DirectComm: a wait for a peer timed out; the results since are invalid')
 
   def close(self):
     handle, self._handle = self._handle, None

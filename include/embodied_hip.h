@@ -37,7 +37,10 @@ extern "C" {
  * emb_replay_settle; emb_replay_profile_report which = 3.  Additions only: a
  * caller written against version 2 runs unchanged.                             */
 /* 4 (round 5): + emb_replay_sample_heads, emb_direct_*.  Additions only.        */
-#define EMB_ABI_VERSION 4
+/* 5 (round 6): + emb_comm_exchange_gather, emb_direct_allgather,
+ * emb_direct_exchange_gather (additions); emb_configure refuses names that are
+ * no knob; a time-out inside emb_direct_* is fatal for the communicator.        */
+#define EMB_ABI_VERSION 5
 
 #define EMB_OK 0
 #define EMB_ERR_INVALID (-1)   /* bad argument / state                         */
@@ -76,12 +79,14 @@ typedef struct emb_replay emb_replay_t;
 const char* emb_last_error(void);
 int32_t emb_abi_version(void);
 
-/* Tuning knobs (INTEGRATION.md lists them: EMB_SPAN_VARIANT, EMB_DEFER_INDEX,
- * EMB_DEFER_MAX_GAP_US, EMB_ARGS_BAR, ...).  Each is read once, by the first
- * call that needs it, from emb_configure's value or else from the environment
- * variable of the same name.  emb_configure after that first use is refused
- * (EMB_ERR_INVALID): a setting is never half in effect.  value NULL withdraws
- * an earlier emb_configure.  The reference has no counterpart (its knobs are
+/* Tuning knobs (INTEGRATION.md lists them: EMB_SPAN_MOVER, EMB_DEFER_INDEX,
+ * EMB_DEFER_MAX_GAP_US, EMB_ARGS_BAR, ...; csrc/knobs.h holds the list).  Each
+ * is read once, by the first call that needs it, from emb_configure's value or
+ * else from the environment variable of the same name.  emb_configure after
+ * that first use is refused (EMB_ERR_INVALID): a setting is never half in
+ * effect; a name that is no knob of the library is refused as well (ABI 5: a
+ * retired or misspelt knob is an error, not a silent no-op).  value NULL
+ * withdraws an earlier emb_configure.  The reference has no counterpart (its knobs are
  * Python config fields); this replaces "export EMB_...=" for host programs. */
 int32_t emb_configure(const char* name, const char* value);
 int32_t emb_device_count(int32_t* count);
@@ -490,6 +495,14 @@ int32_t emb_comm_pmean_scalars(emb_comm_t* comm, void* values, int64_t count, vo
 int32_t emb_comm_exchange(emb_comm_t* comm, void* after_stream, const void* slices_send,
                           void* slices_recv, int64_t bytes_per_rank, void* grads, int64_t count,
                           int32_t dtype, int32_t mean);
+/* The same with the trajectory ALL-GATHER in front of the gradients instead of the
+ * DP-slice all-to-all (north_star's "RCCL all-gather of trajectories"; the
+ * reference assembles every process's batch slice into the global batch,
+ * embodied/jax/internal.py:145-152): `traj_send` = this rank's bytes_per_rank
+ * bytes, `traj_recv` = world * bytes_per_rank bytes in rank order.  (ABI 5)    */
+int32_t emb_comm_exchange_gather(emb_comm_t* comm, void* after_stream, const void* traj_send,
+                                 void* traj_recv, int64_t bytes_per_rank, void* grads,
+                                 int64_t count, int32_t dtype, int32_t mean);
 int32_t emb_comm_wait(emb_comm_t* comm, void* stream);
 int32_t emb_comm_destroy(emb_comm_t* comm);
 
@@ -513,15 +526,27 @@ int32_t emb_synth_env_step(void* image, void* reward, void* is_first, void* is_l
  * at most 8 ranks, one GPU per rank (or several ranks on one GPU: the tests).
  *
  * create: max_reduce_bytes = the largest gradient buffer, max_block_bytes = the
- *         largest all-to-all block (bytes per rank); every wait inside a kernel
- *         gives up after timeout_ms and sets the word emb_direct_status reads.
+ *         largest all-to-all / all-gather block (bytes per rank); every wait
+ *         inside a kernel gives up after timeout_ms.  A time-out is FATAL for
+ *         the communicator (RCCL would keep waiting; a bounded wait must not
+ *         turn into a silently wrong gradient): the kernel that gave up writes
+ *         no result and raises no peer's flag, every later kernel returns at
+ *         once and every later call of allreduce / alltoall / allgather /
+ *         exchange / wait returns an error (the word is read from host-mapped
+ *         memory, no synchronisation); emb_direct_status synchronises and
+ *         reports it.  Choose timeout_ms like a collective watchdog (minutes),
+ *         not like a latency bound.
  * handle / connect: each rank's 64-byte handle reaches every other rank by the
  *         caller's means (a process-group all-gather, a file); connect takes all
  *         `world` handles in rank order.
- * allreduce / alltoall: asynchronous on `stream`; same order of calls on every
- *         rank.  Results: the sum is taken in rank order in f32 by the rank that
- *         owns the shard and broadcast, so every rank holds the same bits.
- * exchange / wait: emb_comm_exchange's contract on the transport's own stream. */
+ * allreduce / alltoall / allgather: asynchronous on `stream`; same order of
+ *         calls on every rank.  Results: the sum is taken in rank order in f32 by
+ *         the rank that owns the shard and broadcast, so every rank holds the
+ *         same bits.  The all-reduce buffer must be 16-byte aligned.  allgather
+ *         (ABI 5): this rank's bytes_per_rank bytes reach every peer, all n-1
+ *         links at once; recv = world * bytes_per_rank bytes in rank order.
+ * exchange / exchange_gather / wait: emb_comm_exchange[_gather]'s contract on
+ *         the transport's own stream.                                         */
 #define EMB_DIRECT_HANDLE_BYTES 64
 typedef struct emb_direct emb_direct_t;
 int32_t emb_direct_create(int32_t rank, int32_t world, int64_t max_reduce_bytes,
@@ -535,7 +560,15 @@ int32_t emb_direct_alltoall(emb_direct_t* d, const void* send, void* recv,
 int32_t emb_direct_exchange(emb_direct_t* d, void* after_stream, const void* slices_send,
                             void* slices_recv, int64_t bytes_per_rank, void* grads,
                             int64_t count, int32_t dtype, int32_t mean);
+int32_t emb_direct_allgather(emb_direct_t* d, const void* send, void* recv,
+                             int64_t bytes_per_rank, void* stream);
+int32_t emb_direct_exchange_gather(emb_direct_t* d, void* after_stream, const void* traj_send,
+                                   void* traj_recv, int64_t bytes_per_rank, void* grads,
+                                   int64_t count, int32_t dtype, int32_t mean);
 int32_t emb_direct_wait(emb_direct_t* d, void* stream);
+/* The watchdog of the launches from now on (a short one while a set-up is being
+ * checked, minutes for the job itself).  (ABI 5)                               */
+int32_t emb_direct_set_timeout(emb_direct_t* d, int32_t timeout_ms);
 int32_t emb_direct_status(emb_direct_t* d, int32_t* timed_out);
 int32_t emb_direct_destroy(emb_direct_t* d);
 

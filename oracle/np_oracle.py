@@ -279,14 +279,14 @@ class Prioritized:
         del self.prio[sid]
 
   def prioritize(self, stepids, priorities):
-    # selectors.py:143-158.  Steps no item refers to any more are ignored: in
-    # the reference they only leave an unreachable defaultdict entry behind.
+    # selectors.py:143-158.  The table takes a priority for ANY step id (`prios`
+    # is a defaultdict, :139,147): one that belongs to no item yet keeps it, and
+    # an item that arrives later aggregates it (__setitem__ -> _mass).
     stepids = self._asbytes(stepids)
     touched = []
     for sid, value in zip(stepids, priorities):
-      if sid in self.users:
-        self.prio[sid] = float(value)
-        touched += self.users[sid]
+      self.prio[sid] = float(value)
+      touched += self.users.get(sid, [])
     for key in set(touched):
       self.tree.update(key, self._mass(key))
 

@@ -196,6 +196,19 @@ def sel_prioritized(ns):
       sel[k] = np.stack([_sid(s) for s in range(k, k + length)])
     sel.prioritize(np.stack([_sid(s) for s in (25, 26, 9)]), np.array([7.0, 0.0, 2.0]))
     draws += [sel() for _ in range(24)]
+    # Priorities for step ids that belong to NO item at that moment (selectors.py:143-150
+    # takes them: `prios` is a defaultdict): 33..36 arrive with later items and keep what
+    # they were given; 0 lost its last item above; 31, 32 are in items 28, 29 already.
+    early = (31, 32, 33, 34, 35, 36, 0)
+    sel.prioritize(np.stack([_sid(s) for s in early]), np.array([0.5, 3.0, 6.0, 0.0, 2.5, 9.0, 4.0]))
+    draws += [sel() for _ in range(8)]
+    for k in range(30, 34):         # items 30..33 cover steps 30..36
+      sel[k] = np.stack([_sid(s) for s in range(k, k + length)])
+    draws += [sel() for _ in range(24)]
+    sel.prioritize(np.stack([_sid(s) for s in (35, 37)]), np.array([0.25, 5.0]))   # 37: early again
+    del sel[8]
+    sel[34] = np.stack([_sid(s) for s in range(34, 34 + length)])
+    draws += [sel() for _ in range(16)]
     out[name] = np.array(draws)
   return out
 

@@ -29,7 +29,7 @@ def test_binding_covers_every_declared_symbol():
 
 def test_version_and_device_probe():
   from embodied_amd import _lib
-  assert _lib.lib.emb_abi_version() == 4
+  assert _lib.lib.emb_abi_version() == 5
   assert _lib.device_count() >= 0
 
 
@@ -176,6 +176,25 @@ def test_import_leaves_the_process_alone():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == 'True', (given, out.stdout)
+
+
+def test_knob_list_matches_the_knobs_the_sources_read():
+  """csrc/knobs.h names every knob; emb_configure refuses anything else (a retired
+  knob such as EMB_SPAN_VARIANT is an error, not a silent no-op)."""
+  import pytest
+  from embodied_amd import _lib
+  src = ROOT / 'embodied_amd' / 'csrc'
+  read = set()
+  for path in src.iterdir():
+    if path.suffix in ('.h', '.cpp', '.hip', '.c'):
+      read |= set(re.findall(r'knob\("(EMB_[A-Z0-9_]+)"\)', path.read_text()))
+  listed = set(re.findall(r'"(EMB_[A-Z0-9_]+)"', (src / 'knobs.h').read_text().split('kKnobNames[]')[1].split('};')[0]))
+  assert read == listed, (read - listed, listed - read)
+  documented = (ROOT / 'INTEGRATION.md').read_text()
+  assert all(name in documented for name in listed), [n for n in listed if n not in documented]
+  for name in ('EMB_SPAN_VARIANT', 'EMB_SAMPLE_POOL', 'EMB_NOT_A_KNOB'):
+    with pytest.raises(ValueError, match='not a knob'):
+      _lib.configure(**{name: 1})
 
 
 def test_knobs_are_set_before_their_first_use_or_not_at_all():

@@ -126,7 +126,7 @@ def test_bench_gpus_8_control_flow():
 def test_bench_dreamer_workload_with_ranks():
   """configs[3]'s shape of parallelism: per-rank Replay (sample, lambda-return,
   latent write-back) and one gradient all-reduce per train step."""
-  rec = run_bench('--gpus', '2', '--workload', 'dreamer', '--capacity', '20000', '--steps', '40',
+  rec = run_bench('--gpus', '2', '--workload', 'dreamer', '--capacity', '20000', '--steps', '40', '--grad-numel', '100000',
                   '--warmup', '5', '--sustained-seconds', '1', '--prewarm-train-steps', '20', '--backend', 'gloo')
   assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2
   assert 'per-rank Replay' in rec['config']['parallelism']

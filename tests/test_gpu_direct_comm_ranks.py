@@ -58,6 +58,9 @@ def _worker(rank, world, port, out, per_gpu):
     res = {}
     res['all_to_all'] = comm.all_to_all(cuda(_bytes_of(rank, 1, world * SLICE_BYTES))).cpu().numpy()
     res['all_to_all_odd'] = comm.all_to_all(cuda(_bytes_of(rank, 6, world * 1001))).cpu().numpy()
+    # the trajectory all-gather (north_star; embodied/jax/internal.py:145-152): ONE block per rank to every peer
+    res['all_gather'] = comm.all_gather(cuda(_bytes_of(rank, 8, SLICE_BYTES))).cpu().numpy()
+    res['all_gather_odd'] = comm.all_gather(cuda(_bytes_of(rank, 9, 1001))).cpu().numpy()
     for name, dtype in DTYPES:
       whole = cuda(_ints_of(rank, 2, GRAD_NUMEL)).to(dtype)
       comm.all_reduce(whole, mean=False)
@@ -95,12 +98,32 @@ def _worker(rank, world, port, out, per_gpu):
     comm.wait()
     res['exchange'] = [(a.cpu().numpy(), b.float().cpu().numpy(), c.cpu().numpy(), d.float().cpu().numpy())
                        for a, b, c, d in log]
+    # exchange(gather=True): the trajectory all-gather + the f32 gradient all-reduce in one call
+    gathers = []
+    for k in range(4):
+      mine = cuda(_bytes_of(rank, 40 + k, SLICE_BYTES if k % 2 == 0 else 1001))
+      grads = cuda(_floats_of(rank, 50 + k, GRAD_NUMEL))
+      everyone = torch.zeros(world * mine.numel(), dtype=torch.uint8, device='cuda')
+      twin_everyone, twin_grads = torch.zeros_like(everyone), grads.clone()
+      comm.wait()
+      comm.exchange(mine, everyone, grads, gather=True)
+      group.exchange(mine.clone(), twin_everyone, twin_grads, gather=True)
+      group.wait()
+      keep.append((mine, everyone, grads))
+      gathers.append((everyone, grads, twin_everyone, twin_grads))
+    comm.wait()
+    res['gathers'] = [(a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy(), d.cpu().numpy()) for a, b, c, d in gathers]
     res['timed_out'] = comm.timed_out()
     try:
       comm.all_reduce(torch.zeros(8, dtype=torch.float64, device='cuda'))
       res['refused'] = False
     except AssertionError:
       res['refused'] = True
+    try:      # a view that does not start on a 16-byte boundary: refused, not reduced with misaligned 16-byte accesses
+      comm.all_reduce(torch.zeros(4099, device='cuda')[1:])
+      res['refused_unaligned'] = False
+    except AssertionError:
+      res['refused_unaligned'] = True
     comm.close()
     out[rank] = res
   finally:
@@ -117,6 +140,8 @@ def _check(out, world):
     for key, tag, size in (('all_to_all', 1, SLICE_BYTES), ('all_to_all_odd', 6, 1001)):
       want = np.concatenate([_bytes_of(s, tag, world * size)[rank * size:(rank + 1) * size] for s in ranks])
       assert np.array_equal(got[key], want), key
+    for key, tag, size in (('all_gather', 8, SLICE_BYTES), ('all_gather_odd', 9, 1001)):
+      assert np.array_equal(got[key], np.concatenate([_bytes_of(s, tag, size) for s in ranks])), key
     for name, tol in (('f32', 1e-6), ('bf16', 2e-2), ('f16', 2e-3)):
       assert np.array_equal(got[f'sum_{name}'], sums), name  # small integers: exact in every dtype
       parts = [torch.as_tensor(_floats_of(r, 3, GRAD_NUMEL)).to(dict(DTYPES)[name]).double().numpy()
@@ -138,7 +163,15 @@ def _check(out, world):
             for s in ranks])
       assert np.array_equal(received, want), (rank, k)
       assert np.array_equal(received, twin_received), (rank, k)
-    assert got['refused'] is True
+    for k, (everyone, grads, twin_everyone, twin_grads) in enumerate(got['gathers']):
+      size = SLICE_BYTES if k % 2 == 0 else 1001
+      assert np.array_equal(everyone, np.concatenate([_bytes_of(s, 40 + k, size) for s in ranks])), (rank, k)
+      assert np.array_equal(everyone, twin_everyone), (rank, k)
+      np.testing.assert_allclose(grads, np.mean([_floats_of(r, 50 + k, GRAD_NUMEL) for r in ranks], 0),
+                                 rtol=1e-5, atol=1e-6)
+      np.testing.assert_allclose(grads, twin_grads, rtol=1e-5, atol=1e-6)
+      assert np.array_equal(grads, out[0]['gathers'][k][1])                   # all ranks alike, to the bit
+    assert got['refused'] is True and got['refused_unaligned'] is True
 
 
 @pytest.mark.parametrize('world', [2, 3])
@@ -180,27 +213,55 @@ def _lonely_worker(rank, world, port, out):
   D.init('gloo')
   try:
     comm = D.DirectComm(rank, world, max_grad_bytes=1 << 20, max_slice_bytes=1 << 20, timeout_ms=300)
+    res = {}
     if rank == 0:
-      grads = torch.ones(4096, device='cuda')
+      grads = torch.arange(4096, dtype=torch.float32, device='cuda')
       began = time.perf_counter()
       comm.all_reduce(grads)                 # rank 1 never joins this one
       torch.cuda.synchronize()
-      out['seconds'] = time.perf_counter() - began
-      out['timed_out'] = comm.timed_out()
+      res['seconds'] = time.perf_counter() - began
+      res['timed_out'] = comm.timed_out()
+      # fatal, not silent: nothing was reduced into the buffer ...
+      res['untouched'] = bool(torch.equal(grads, torch.arange(4096, dtype=torch.float32, device='cuda')))
+      # ... and every later call on the dead communicator raises
+      raised = []
+      for call in (lambda: comm.wait(), lambda: comm.exchange(grads=grads), lambda: comm.all_reduce(grads),
+                   lambda: comm.all_to_all(torch.zeros(64, dtype=torch.uint8, device='cuda')), comm.check):
+        try:
+          call()
+          raised.append(None)
+        except (RuntimeError, ValueError) as e:
+          raised.append(str(e))
+      res['raised'] = raised
     torch.distributed.barrier()              # rank 1 stays alive (its memory mapped) until rank 0 is through
+    if rank == 1:
+      # The dead rank raised no flag for the operation it gave up on: its peer runs
+      # into the same time-out instead of reducing half-arrived slots.
+      grads = torch.ones(4096, device='cuda')
+      comm.all_reduce(grads)
+      torch.cuda.synchronize()
+      res['timed_out'] = comm.timed_out()
+      res['untouched'] = bool(torch.equal(grads, torch.ones(4096, device='cuda')))
+    out[rank] = res
+    torch.distributed.barrier()
     comm.close()
   finally:
     torch.distributed.destroy_process_group()
 
 
-def test_a_peer_that_never_arrives_is_an_error_word_not_a_hung_gpu():
-  """Every wait inside the kernels is bounded by `timeout_ms`: the launch ends,
-  the stream goes on and `timed_out()` says what happened."""
+def test_a_peer_that_never_arrives_kills_the_communicator_not_the_gpu():
+  """Every wait inside the kernels is bounded by `timeout_ms` -- and giving up is
+  fatal for the communicator, never a silently wrong gradient: the kernel that
+  gave up writes no result and raises no flag, `timed_out()` says what happened,
+  every later call raises, and the late peer fails the same way."""
   manager = mp.Manager()
   out = manager.dict()
   mp.spawn(_lonely_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-  assert out['timed_out'] is True
-  assert 0.25 < out['seconds'] < 5.0        # two bounded waits (reduce, collect) of 0.3 s each
+  first, late = out[0], out[1]
+  assert first['timed_out'] is True and first['untouched'] is True
+  assert 0.25 < first['seconds'] < 5.0        # two bounded waits (reduce, collect) of at most 0.3 s each
+  assert all(msg and 'timed out' in msg for msg in first['raised']), first['raised']
+  assert late['timed_out'] is True and late['untouched'] is True
 
 
 def _failing_worker(rank, world, port, out):

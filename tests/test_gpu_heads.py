@@ -277,3 +277,15 @@ def test_windowed_routes_refuse_context_only_keys(emb):
   # one window per sequence is the sequence itself: heads pass through
   whole = next(iter(emb.streams.Consec(emb.streams.Stateless(rep.sample, 2), length=8, consec=1)))
   assert whole['dyn/deter'].shape == (2, 1) and whole['image'].shape == (2, 8)
+  # ... and a single window that is NOT the whole sequence (strict=False, more steps
+  # than needed) is refused like the others, whichever key comes first in the dict
+  cut = emb.streams.Consec(emb.streams.Stateless(rep.sample, 2), length=6, consec=1, strict=False)
+  with pytest.raises(AssertionError, match='context-only'):
+    next(iter(cut))
+  batch = rep.sample(2)
+  for order in (list(batch), list(batch)[::-1]):
+    with pytest.raises(ValueError, match='cannot be windowed'):
+      emb.streams.window_batch({k: batch[k] for k in order}, 1, 4)
+  full = {k: v for k, v in batch.items() if v.shape[1] == 8}
+  got = emb.streams.window_batch(full, 1, 4)
+  assert all(torch.equal(got[k], full[k][:, 1:5]) for k in full)

@@ -249,6 +249,20 @@ def test_random_prioritized_histories_against_oracle(seed):
         ref.update({'stepid': stepid, 'priority': prio})
 
 
+@pytest.mark.filterwarnings('ignore:invalid value encountered:RuntimeWarning')
+def test_prioritized_protocol_with_priorities_for_steps_in_no_item():
+  """The selector protocol alone (selectors.py:128-197), with priorities for ANY
+  step id -- also ids that belong to no item yet, which the reference's table
+  keeps (`prios` is a defaultdict, :139,147) for an item that arrives later:
+  the library against the oracle and, in the build container, against the real
+  reference class, draw for draw (tools/fuzz_prioritized.py --protocol runs the
+  same histories by the thousand)."""
+  from tools import fuzz_prioritized
+  others = fuzz_prioritized.reference_classes()
+  drawn = sum(fuzz_prioritized.protocol(seed, 300, others) for seed in range(60))
+  assert drawn > 3000
+
+
 @pytest.mark.parametrize('seed', range(6))
 @pytest.mark.parametrize('break_at', [None, 40, 140])
 def test_prioritized_window_streams_then_arbitrary_use(seed, break_at):

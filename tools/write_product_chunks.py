@@ -49,6 +49,10 @@ def write(out, emb=None):
 
 
 if __name__ == '__main__':
-  target = sys.argv[1] if len(sys.argv) > 1 else ROOT / 'gpurun_out' / 'product_chunks'
-  for name in write(target):
+  # (argparse, not sys.argv[1]: `--help` once became a directory of that name in the repo root)
+  import argparse
+  parser = argparse.ArgumentParser(description=__doc__)
+  parser.add_argument('target', nargs='?', default=str(ROOT / 'gpurun_out' / 'product_chunks'),
+                      help='directory to (re)write the chunk files into')
+  for name in write(parser.parse_args().target):
     print(name)
