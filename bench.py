@@ -200,13 +200,23 @@ def parse():
                       '144 MB gathers), 1 for ppo (measured 12 %% SLOWER with 2: the persistent gather '
                       'holds every CU\'s registers for its 11 us, the three dependent small kernels '
                       'of the env step wait behind it instead of beside it)')
+  p.add_argument('--learner-cus', type=int, default=-1,
+                 help='--streams 2: compute units the learner\'s stream may use (emb_stream_create_on_cus: a '
+                      'CU-masked HIP stream; the sample gather sizes its persistent grid by it) so that it '
+                      'runs BESIDE the env step\'s small kernels instead of in front of them.  0 = no mask '
+                      '(a plain second stream); -1 (default) = the measured optimum of the workload')
+  p.add_argument('--learner-first-cu', type=int, default=0, help='with --learner-cus: the first unit of the range')
+  p.add_argument('--unmasked-env-actions', action='store_true',
+                 help='the synthetic env declares that it takes the policy\'s actions unmasked together with '
+                      '`reset` (it ignores the action of an env it resets, Env protocol base.py:44-52): the '
+                      'Driver then skips the masked copy and the Replay carries its masked pool write into '
+                      'the next launch -- two dependent launches per step instead of three.  NOT the '
+                      'reference\'s Driver form (driver.py:72-75 masks before the env sees the action), so '
+                      'not the default: `value` is measured on the masked form, this rate rides beside it '
+                      'as context (`config.env_actions`)')
   p.add_argument('--mask-actions-for-env', action='store_true',
-                 help='the synthetic env asks for masked actions like an env that reads the action of '
-                      'an env it resets would: the Driver then makes the masked copy and the Replay '
-                      'its publish launch after the policy (three dependent launches per step instead '
-                      'of two; same as EMB_CARRY_PUBLISH=0).  Default: the env takes the policy\'s '
-                      'actions unmasked together with `reset` (Env protocol, base.py:44-52), the '
-                      'stored transition holds value * ~is_last either way')
+                 help='(the default since round 6; kept so that older command lines still parse) the env '
+                      'receives masked actions, the reference\'s form (driver.py:72-75)')
   p.add_argument('--context-only', action='store_true',
                  help='dreamer workload: Replay(heads={"dyn/": context}) -- the replay-context latents come '
                       'back (B, K, ...) instead of (B, L, ...), which is all the shipped agent reads of them '
@@ -227,9 +237,10 @@ def parse():
                       '(PCIe-inclusive rate; never the headline value)')
   p.add_argument('--parallel-envs', action='store_true',
                  help='with --host-envs: one process per env writing into the shared slab')
-  p.add_argument('--envs-per-worker', type=int, default=1,
+  p.add_argument('--envs-per-worker', default='auto',
                  help='with --parallel-envs: this many envs per worker process (Driver(envs_per_worker=K)); '
-                      'for hosts whose CPU budget is smaller than the env count')
+                      'auto (default) = as many worker processes as the CPU budget (affinity mask, cgroup '
+                      'quota) runs at once, one per env if it allows (the reference\'s form, driver.py:17-25)')
   return p.parse_args()
 
 
@@ -268,14 +279,15 @@ def build_path(args, rank, device):
   if args.host_envs:
     fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]
     driver = emb.Driver(fns, parallel=args.parallel_envs, device=device,
-                        **({'envs_per_worker': args.envs_per_worker} if args.parallel_envs else {}))
+                        **({'envs_per_worker': (args.envs_per_worker if args.envs_per_worker == 'auto'
+                                                else int(args.envs_per_worker))} if args.parallel_envs else {}))
     env = None
   else:
     # The env owns a 4-deep ring of output buffers (transitions are copied into
     # the replay pool within the step, `reset` aliases the previous is_last).
     env = synthetic.SyntheticBatchEnv(
         n, shape=(84, 84, 4), episode_len=1000, env0=rank * n, device=device, ring=4,
-        takes_unmasked_actions=not args.mask_actions_for_env)
+        takes_unmasked_actions=args.unmasked_env_actions)
     driver = emb.Driver(batch_env=env, device=device)
   driver.on_step(replay.add)
   # 4096 pre-drawn action rows (the stub policy hands them out in turn).
@@ -351,6 +363,14 @@ def main():
   local %= max(torch.cuda.device_count(), 1)
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
+  if args.learner_cus < 0:
+    args.learner_cus = 0
+  if args.streams == 2 and args.learner_cus > 0:
+    # hipExtStreamCreateWithCUMask makes a BLOCKING stream (no flags argument): it and the
+    # NULL stream wait for each other at every launch (measured: 52 us per step instead of
+    # 13.6 with the Driver on torch's default = NULL stream).  The Driver's side of such a
+    # run therefore gets a non-blocking stream of its own, current from here on.
+    torch.cuda.set_stream(torch.cuda.Stream(device))
   use_dist = world > 1 or args.force_dist
   if use_dist:
     import torch.distributed as dist
@@ -365,6 +385,7 @@ def main():
   rccl_ranks = dist.get_world_size() if use_dist else 1
 
   emb, env, replay, driver, policy = build_path(args, rank, device)
+  driver_ref = [driver if args.parallel_envs else None]     # (read for the line's config only)
   B, T, L = args.batch, args.length, args.consec * args.length + args.context
   # The learner lends nothing out: a batch is consumed inside its train step, so
   # the stream takes every batch back one draw later (two output sets circulate
@@ -524,7 +545,15 @@ def main():
   # The learner's stream (--streams 2): the Replay orders its pool accesses across
   # the two streams itself (emb_replay_multistream; abi.cpp StreamOrder).
   # (a low-priority learner stream measured level for PPO)
-  learner = torch.cuda.Stream(device) if args.streams == 2 else None
+  learner_cus = max(0, args.learner_cus) if args.streams == 2 else 0
+  cu_stream = None
+  if learner_cus > 0:
+    # The learner confined to a share of the chip (a CU-masked HIP stream): its 10 us sample
+    # gather then runs beside the env step's latency-bound kernels instead of in front of them.
+    cu_stream = emb.ops.CuStream(learner_cus, first_cu=args.learner_first_cu, device=device)
+    learner = cu_stream.stream
+  else:
+    learner = torch.cuda.Stream(device) if args.streams == 2 else None
   if learner is not None:
     main_stream = torch.cuda.current_stream(device)
     set_stream = torch._C._cuda_setStream
@@ -777,18 +806,23 @@ def main():
         # a few steps' worth = the host sets the pace, milliseconds = the GPU does
         'closing_fence_us': round((s_start + s_elapsed - s_issued) * 1e6, 1),
     }
-  # Context (single GPU, device envs, no part of `value`): the same loop for two
-  # more seconds with the env asking for MASKED actions, i.e. the reference's form
-  # of the env's input (driver.py:72-75) -- the Driver makes the masked copy, the
-  # Replay its publish launch after the policy: three dependent launches per step
-  # instead of two.  The stored transitions are the same either way.
-  masked_env_actions = None
+  # Context (single GPU, device envs, no part of `value`): the same loop for two more
+  # seconds with the OTHER form of the env's input.  `value` is measured on the
+  # reference's form -- the env receives masked actions (driver.py:72-75): a masked
+  # copy + the Replay's publish launch after the policy, three dependent launches per
+  # step.  The other form: an env that declares `takes_unmasked_actions` (it ignores the
+  # action of an env it resets, base.py:44-52) gets the policy's actions as they are
+  # and the masked pool write rides in the next early-insert launch -- two launches.
+  # The stored transitions are the same either way.
+  other_env_actions = None
   if (not use_dist and env is not None and args.sustained_seconds > 0 and not args.no_context
-      and getattr(env, 'takes_unmasked_actions', False) and driver._unmasked):
+      and hasattr(env, 'takes_unmasked_actions') and driver._unmasked is not None):
     fence()
-    env.takes_unmasked_actions = False
+    flipped = not was_unmasked
+    env.takes_unmasked_actions = flipped
     driver._unmasked = None
-    replay.carry_publish(False)
+    if not flipped:
+      replay.carry_publish(False)
     for _ in range(64):
       one_step()
     fence()
@@ -799,13 +833,23 @@ def main():
       m_steps += 256
     fence()
     m_elapsed = time.perf_counter() - m_start
-    masked_env_actions = {
+    assert bool(driver._unmasked) == flipped
+    other_env_actions = {
+        'form': 'unmasked + reset' if flipped else 'masked',
         'env_steps_per_s': round(m_steps * args.envs / m_elapsed, 1), 'steps': m_steps,
         'ms_per_step': round(m_elapsed / m_steps * 1e3, 5),
-        'what': 'same loop, the env handed masked actions (--mask-actions-for-env): a masked copy and a '
-                'publish launch after the policy, three dependent launches per step'}
-    env.takes_unmasked_actions = True
+        'what': ('same loop, the env takes the policy\'s actions unmasked together with `reset` (Env protocol '
+                 'base.py:44-52): no masked copy, the masked pool write carried into the next launch, two '
+                 'dependent launches per step' if flipped else
+                 'same loop, the env handed masked actions (the reference\'s form): a masked copy and a publish '
+                 'launch after the policy, three dependent launches per step')}
+    env.takes_unmasked_actions = was_unmasked
     driver._unmasked = None
+    if not was_unmasked:
+      replay.carry_publish(False)
+    for _ in range(16):
+      one_step()
+    fence()
     replay.profile_read(reset=True)
   # Context (single GPU, ppo, no part of `value`): the same loop for two more
   # seconds with the learner written as the shipped mains write it -- the stream
@@ -843,6 +887,7 @@ def main():
   # itself does on N GPUs, next to what the links allow with them.
   replicas_only = None
   sliced_share = min(1.0, collectives['sliced'] / max(1, counters['train_steps']))
+  gather_share = min(1.0, collectives['gathered'] / max(1, counters['train_steps']))
   if use_dist and args.sustained_seconds > 0:
     fence()
     collectives['on'] = False
@@ -864,7 +909,6 @@ def main():
         'train_steps_per_s': round((counters['train_steps'] - r_before) * world / r_elapsed, 2),
         'what': 'same loop, collectives off: N independent replicas',
     }
-  gather_share = min(1.0, collectives['gathered'] / max(1, counters['train_steps']))
   if native is not None and 'per_call' in native and train_steps_local(counters, base, headline) > 0:
     # Every transport's own time for one train step's collectives at this world size
     # (measured by the self-check on the job's own bytes) against the period at which
@@ -1092,19 +1136,26 @@ def main():
                 f'B={B}, T={T}, train_ratio={args.train_ratio}, '
                 f'{"lambda-return" if args.workload == "dreamer" else "GAE"}'),
             'envs_per_gpu': args.envs, 'global_envs': args.envs * world,
+            **({'envs_per_worker': getattr(driver_ref[0], '_per_worker', None),
+                'cpu_budget': round(emb.core.driver.cpu_budget(), 1)} if args.parallel_envs else {}),
             'batch': B, 'seq_len': L, 'batches_per_launch': args.prefetch, 'consec': args.consec,
             # 2: the train step's gather / scans / write-back on the learner's own HIP stream
             'streams': args.streams,
-            # how the policy's actions reach the env: 'unmasked + reset' = the env declared that it
-            # ignores the action of an env it resets, the Driver skips the masked copy and the
-            # Replay carries the masked pool write into its next launch (carried
-            # publish); 'masked' = the reference's form, one more dependent launch per step
+            **({'learner_cus': learner_cus, 'learner_first_cu': args.learner_first_cu} if args.streams == 2 else {}),
+            # how the policy's actions reach the env: 'masked' = the reference's form (the default);
+            # 'unmasked + reset' = the env declared that it ignores the action of an env it resets,
+            # the Driver skips the masked copy and the Replay carries the masked pool write into its
+            # next launch (carried publish): one dependent launch less per step
             'env_actions': {
                 'value_measured_with': env_actions,
                 **({'env_steps_per_s': {
-                    'unmasked + reset (Env protocol, base.py:44-52)': sustained['env_steps_per_s'],
-                    'masked (driver.py:72-75)': masked_env_actions['env_steps_per_s']}}
-                   if (masked_env_actions is not None and sustained is not None) else {})},
+                    env_actions: sustained['env_steps_per_s'],
+                    ('masked (driver.py:72-75)' if was_unmasked else 'unmasked + reset (Env protocol, base.py:44-52)'):
+                        other_env_actions['env_steps_per_s']},
+                    'masked_over_unmasked': round(
+                        (other_env_actions['env_steps_per_s'] / sustained['env_steps_per_s']) if was_unmasked
+                        else (sustained['env_steps_per_s'] / other_env_actions['env_steps_per_s']), 3)}
+                   if (other_env_actions is not None and sustained is not None) else {})},
             'kernargs': 'host' if os.environ.get('HIP_FORCE_DEV_KERNARG') == '0' else 'device',
             'cpus': PINNED,         # CPUs this process was pinned to (pin_cpus), None = scheduler's choice
             # the per-step Python of Driver / Replay / streams: Cython-compiled copies of the
@@ -1147,7 +1198,7 @@ def main():
         **({'link_bound': native['per_train_step']['link_bound']}
            if native is not None and 'link_bound' in native.get('per_train_step', {}) else {}),
         **({'replicas_only': replicas_only} if replicas_only is not None else {}),
-        **({'masked_env_actions': masked_env_actions} if masked_env_actions is not None else {}),
+        **({'other_env_actions': other_env_actions} if other_env_actions is not None else {}),
         **({'fresh_batches': fresh_batches} if fresh_batches is not None else {}),
         **({'expected': expected} if expected is not None else {}),
     }), flush=True)
@@ -1342,16 +1393,17 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
     }, failed)}
 
     # ---- RCCL through the library's own entry points (emb_comm_*)
-    comm, error, checks = None, None, {}
+    comm, error, checks, ident = None, None, {}, None
     try:
       if _fault('native_open', rank):
         raise RuntimeError('injected: this rank cannot set up its RCCL communicator')
-      ident_ok = True
+      ident = D.NativeComm.unique_id()        # every rank: binds the RCCL symbols (rank 0's id is the one used)
     except Exception as e:
-      ident_ok, error = False, f'{type(e).__name__}: {e}'[:300]
-    if agree(ident_ok):           # (ncclCommInitRank blocks until every rank has joined: all or nobody)
+      error = f'{type(e).__name__}: {e}'[:300]
+    if agree(error is None):      # (ncclCommInitRank blocks until every rank has joined: all or nobody)
+      ident = share(ident)
       try:
-        comm = D.NativeComm(rank, world, device, share=share)
+        comm = D.NativeComm(rank, world, device, ident=ident)
         kept['native'] = comm
         checks['all_gather'] = bool(torch.equal(comm.all_gather(mine), ref['all_gather']))
         checks['all_to_all'] = bool(torch.equal(comm.all_to_all(flat), ref['all_to_all']))
@@ -1400,11 +1452,12 @@ def native_comm_check(rank, world, device, grad_numel, grad_dtype, slice_bytes, 
       derror = f'{type(e).__name__}: {e}'[:300]
     if agree(direct is not None):
       try:
-        if not _fault('direct_stuck', rank):
-          got = direct.all_to_all(flat)
-          if _fault('direct_wrong', rank):
-            got = got ^ 1
-          dchecks['all_to_all'] = bool(torch.equal(got, ref['all_to_all']))
+        if _fault('direct_stuck', rank):
+          raise RuntimeError('injected: this rank never arrives at the direct collectives')
+        got = direct.all_to_all(flat)
+        if _fault('direct_wrong', rank):
+          got = got ^ 1
+        dchecks['all_to_all'] = bool(torch.equal(got, ref['all_to_all']))
         dchecks['all_gather'] = bool(torch.equal(direct.all_gather(mine), ref['all_gather']))
         for name in ints:
           a = ints[name].clone()

@@ -204,6 +204,8 @@ SIGNATURES = {
     'emb_direct_allreduce': [p, p, i64, i32, i32, p],
     'emb_direct_alltoall': [p, p, p, i64, p],
     'emb_direct_exchange': [p, p, p, p, i64, p, i64, i32, i32],
+    'emb_stream_create_on_cus': [i32, i32, p],
+    'emb_stream_destroy': [p],
     'emb_direct_allgather': [p, p, p, i64, p],
     'emb_direct_set_timeout': [p, i32],
     'emb_direct_exchange_gather': [p, p, p, p, i64, p, i64, i32, i32],

@@ -64,6 +64,41 @@ _DTYPE_CODE = {
 }
 
 
+def cpu_budget():
+  """CPUs this process may keep busy: the smaller of its affinity mask and its
+  cgroup's CPU quota (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`); a container
+  on a 256-CPU host often has 16."""
+  try:
+    budget = float(len(os.sched_getaffinity(0)))
+  except (AttributeError, OSError):
+    budget = float(os.cpu_count() or 1)
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:
+      quota, period = f.read().split()[:2]
+    if quota != 'max':
+      budget = min(budget, int(quota) / int(period))
+  except (OSError, ValueError):
+    try:
+      with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+        quota = int(f.read())
+      with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+        period = int(f.read())
+      if quota > 0:
+        budget = min(budget, quota / period)
+    except (OSError, ValueError):
+      pass
+  return max(1.0, budget)
+
+
+def auto_envs_per_worker(n_envs):
+  """Driver(envs_per_worker='auto'): as many worker processes as the CPU budget
+  can run AT ONCE beside the stepping thread (one process per env -- the
+  reference's form, driver.py:17-25 -- when the budget allows): more runnable
+  processes than CPUs turn a lock-step round trip into time slices."""
+  workers = max(1, int(cpu_budget()) - 2)
+  return max(1, -(-n_envs // workers))
+
+
 def mask_actions(value, is_last):
   """value * ~is_last in value's dtype (driver.py:72-74, 84-87)."""
   if torch.is_tensor(value) and value.is_cuda:
@@ -113,6 +148,8 @@ class Driver:
         # container quota): N processes that all become runnable at once then
         # cost more in wake-ups and time slices than their env steps take.
         # Needs the shared-memory step protocol (`shared_obs`).
+        if envs_per_worker == 'auto':
+          envs_per_worker = auto_envs_per_worker(self.length)
         self._per_worker = K = max(1, int(envs_per_worker))
         if K > 1 and not shared_obs:
           raise ValueError('envs_per_worker > 1 needs shared_obs=True')
@@ -360,17 +397,51 @@ class Driver:
   def _fetch_acts(self):
     """Device mode with host envs: start bringing the next step's actions to
     pinned host memory now (asynchronously, behind the policy's kernels), so
-    that the copy and its latency run under the replay insert's host work
-    instead of in front of the next env step."""
+    that the transfer and its latency run under the replay insert's host work
+    instead of in front of the next env step.
+
+    Each action key travels as ONE small kernel that stores `value * ~is_last`
+    straight into the pinned (device-mapped) buffer -- `emb_mask_actions` with a
+    host destination -- instead of a device-to-host copy per key through the DMA
+    engines (14 us for 256 bytes on an idle GPU, most of it the copy's set-up);
+    `reset` is the step's `is_last`, which the host has already.  The first step
+    checks the stores against a plain copy and keeps the copies if they differ
+    (a pinned allocation the GPU cannot address)."""
     if not all(torch.is_tensor(v) and v.is_cuda for v in self.acts.values()):
       self._acts_on_host = None
       return
     host = {}
+    flags = getattr(self, '_host_flags', {}).get('is_last')
+    reset = self.acts.get('reset')
+    by_store = getattr(self, '_acts_by_store', None)
     for k, v in self.acts.items():
+      if k == 'reset' and flags is not None:
+        host[k] = flags.astype(bool, copy=True)
+        continue
       pinned = self._acts_pinned.get(k)
       if pinned is None or pinned.shape != v.shape or pinned.dtype != v.dtype:
         pinned = self._acts_pinned[k] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
-      pinned.copy_(v, non_blocking=True)
+      stored = False
+      if (by_store is not False and k != 'reset' and reset is not None and v.dtype in _DTYPE_CODE
+          and v.is_contiguous() and v.numel() and reset.dtype in (torch.bool, torch.uint8)):
+        n = v.shape[0]
+        if by_store is None:
+          # once: the same values by store and by copy must agree
+          try:
+            probe = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+            fast.emb_mask_actions(v.data_ptr(), probe.data_ptr(), n, v.numel() // n, _DTYPE_CODE[v.dtype],
+                                  reset.data_ptr(), _lib.raw_stream(v.device))
+            want = mask_actions(v, reset).cpu()
+            torch.cuda.current_stream(v.device).synchronize()
+            by_store = self._acts_by_store = bool(torch.equal(probe.view(torch.uint8), want.view(torch.uint8)))
+          except Exception:
+            by_store = self._acts_by_store = False
+        if by_store:
+          fast.emb_mask_actions(v.data_ptr(), pinned.data_ptr(), n, v.numel() // n, _DTYPE_CODE[v.dtype],
+                                reset.data_ptr(), _lib.raw_stream(v.device))
+          stored = True
+      if not stored:
+        pinned.copy_(v, non_blocking=True)
       host[k] = pinned.numpy()
     if self._acts_landed is None:
       self._acts_landed = torch.cuda.Event()
@@ -480,8 +551,15 @@ class Driver:
     for wake in self._wake[:_FANOUT]:
       wake.release()
     done, deadline, spins = self._done, None, 0
+    pieces = self._begin_upload()
     while True:
       state = done == seq
+      # The observation slab goes up in pieces, each as soon as the envs that write
+      # it are through (they finish over the ~50 us of the wake tree): the copies run
+      # under the slower workers' steps instead of after the last one.
+      while pieces and state[pieces[0][0]: pieces[0][1]].all():
+        _, _, dst, src = pieces.pop(0)
+        dst.copy_(src, non_blocking=True)
       if state.all():
         break
       if (done < 0).any():
@@ -501,6 +579,44 @@ class Driver:
       else:
         results.append({})
     return results
+
+  def _begin_upload(self):
+    """Device mode with the shared slab: pick this step's device buffer and return
+    the pieces of the slab as (first env, end env, device view, pinned view), in
+    env order -- the widest key cut into _UPLOAD_GROUPS row ranges, the rest of
+    the block (the narrow keys of every env) last.  [] when there is no slab."""
+    self._upload_dev = None
+    if self.device is None or self._upload_src is None:
+      return []
+    plan = getattr(self, '_upload_plan', None)
+    if plan is None:
+      total, n = self._upload_src.numel(), self.length
+      _, _, _, at, nbytes = max(self._upload_layout.values(), key=lambda entry: entry[4])
+      groups = _UPLOAD_GROUPS if nbytes >= (256 << 10) and n >= 2 * _UPLOAD_GROUPS else 1
+      if groups == 1:
+        plan = [(0, n, 0, total)]
+      else:
+        per, row = -(-n // groups), nbytes // n
+        plan = [(g * per, min(n, (g + 1) * per), at + g * per * row, at + min(n, (g + 1) * per) * row)
+                for g in range(groups) if g * per < n]
+        plan += [(0, n, a, b) for a, b in ((0, at), (at + nbytes, total)) if b > a]
+      self._upload_plan = plan
+      self._upload_pieces = {}
+    if self._rotate():
+      self._upload_turn = turn = (self._upload_turn + 1) & 3
+      dev, self._upload_views = self._upload_ring[turn]
+      pieces = self._upload_pieces.get(turn)
+      if pieces is None:       # the views of this ring slot, made once
+        pieces = self._upload_pieces[turn] = [
+            (lo, hi, dev[a:b], self._upload_src[a:b]) for lo, hi, a, b in plan]
+    else:
+      dev = torch.empty(self._upload_src.numel(), dtype=torch.uint8, device=self.device)
+      self._upload_views = {
+          key: dev[at: at + nbytes].view(replaylib._TORCH_OF[np.dtype(dtype)]).view(self.length, *shape)
+          for key, (_, shape, dtype, at, nbytes) in self._upload_layout.items()}
+      pieces = [(lo, hi, dev[a:b], self._upload_src[a:b]) for lo, hi, a, b in plan]
+    self._upload_dev = dev
+    return list(pieces)
 
   def _to_device(self, value):
     if torch.is_tensor(value):
@@ -525,18 +641,14 @@ class Driver:
       for k in ('is_first', 'is_last', 'is_terminal'):
         if k in shared:
           self._host_flags[k] = shared[k][1].copy()
-      # the whole observation slab in one copy: into the next device buffer of
-      # the ring, or into a fresh one when user callbacks see the tensors
-      if self._rotate():
-        self._upload_turn = (self._upload_turn + 1) & 3
-        dev, views = self._upload_ring[self._upload_turn]
-      else:
-        dev = torch.empty(self._upload_src.numel(), dtype=torch.uint8, device=self.device)
-        views = {}
-        for key, (_, shape, dtype, at, nbytes) in self._upload_layout.items():
-          views[key] = dev[at: at + nbytes].view(replaylib._TORCH_OF[np.dtype(dtype)]).view(self.length, *shape)
-      dev.copy_(self._upload_src, non_blocking=True)
-      out.update(views)
+      # The observation slab: uploaded piece by piece while the workers were still
+      # stepping (_step_workers / _begin_upload) when the step protocol runs through
+      # shared memory; else in one copy here.
+      if getattr(self, '_upload_dev', None) is None:
+        for _, _, dst, src in self._begin_upload():
+          dst.copy_(src, non_blocking=True)
+      out.update(self._upload_views)
+      self._upload_dev = None
     for k in keys:
       first = np.asarray(results[0][k])
       slab = self._slab.get(k)
@@ -585,6 +697,7 @@ class Driver:
 
 
 _FANOUT = 8
+_UPLOAD_GROUPS = 4      # pieces the widest observation key is uploaded in (64 envs x 28 KB: 450 KB each)
 
 
 def _wake_children(envid, wakes):

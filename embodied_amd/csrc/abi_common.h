@@ -71,6 +71,24 @@ struct HostLap {
   }
 };
 
+// Streams made by emb_stream_create_on_cus: how many compute units each may use.
+// The persistent movers size their grids by it (a grid for 256 CUs queued onto
+// 64 would run in rounds).  A handful of entries, read on every mover launch only
+// while there are any.
+struct CuStreams {
+  std::atomic<int> count{0};
+  std::mutex mu;
+  std::vector<std::pair<hipStream_t, int>> streams;
+  int cus_of(hipStream_t s) {
+    if (count.load(std::memory_order_acquire) == 0) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& entry : streams)
+      if (entry.first == s) return entry.second;
+    return 0;
+  }
+};
+inline CuStreams g_cu_streams;
+
 inline thread_local std::string g_error;
 
 inline int32_t fail(int32_t code, const std::string& msg) {

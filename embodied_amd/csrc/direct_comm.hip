@@ -253,6 +253,14 @@ int elem_size(int32_t dtype) { return dtype == EMB_F32 ? 4 : 2; }
 
 }  // namespace
 
+// (a std::exception that is none of guarded()'s named kinds: EMB_ERR_INTERNAL, a
+// RuntimeError in Python -- not the ValueError of a bad argument)
+struct DeadTransport : std::exception {
+  std::string msg;
+  explicit DeadTransport(std::string m) : msg(std::move(m)) {}
+  const char* what() const noexcept override { return msg.c_str(); }
+};
+
 struct emb_direct {
   int32_t rank = 0, world = 1;
   int64_t reduce_cap = 0, a2a_cap = 0;      // bytes: whole gradient buffer / one all-to-all block
@@ -275,8 +283,8 @@ struct emb_direct {
   // nothing this communicator has produced since can be trusted.
   void alive(const char* what) const {
     if (host_error && *static_cast<volatile uint32_t*>(host_error) != 0u)
-      throw std::runtime_error(std::string(what) + ": the direct transport timed out waiting for a peer; "
-                               "this communicator is dead (no result was written by the operation that gave up)");
+      throw DeadTransport(std::string(what) + ": the direct transport timed out waiting for a peer; "
+                          "this communicator is dead (no result was written by the operation that gave up)");
   }
   // slots of rank r's region: rs[parity][src], ag[parity][src], a2a[parity][src]
   uint8_t* rs_slot(int r, int parity, int src) const {

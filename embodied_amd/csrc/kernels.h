@@ -64,6 +64,9 @@ struct MovePlan {
   // rows of existing items (a write-back): what cross-stream ordering it needs
   // (abi.cpp StreamOrder).
   bool fresh_rows = false;
+  // The launch's stream may use this many compute units only (a stream made by
+  // emb_stream_create_on_cus; 0 = all): the persistent mover sizes its grid by it.
+  int32_t cu_limit = 0;
 };
 
 // True if this plan's tables fit the kernel-argument block (else the caller

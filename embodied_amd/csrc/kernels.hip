@@ -132,8 +132,18 @@ __device__ __forceinline__ int find_key(const MoveTables& tb, int block) {
 // Pool row of step t of sequence seq.  (A launch's row table is n_seq
 // sequences of tb.seq_len steps; a key's batch side holds the first klen of
 // them, so batch row r of that key is (seq, t) = (r / klen, r % klen).)
-__device__ __forceinline__ int32_t row_at(const MoveArgs& a, const MoveTables& tb, uint32_t seq, uint32_t t) {
+// kLds: the launch's first kFlatStagedSeqs spans were staged into LDS (`lds`)
+// together with the tables -- the indirect flat movers, whose argument block
+// lives in uncached device memory (see flat_move_kernel_indirect).
+constexpr int kFlatStagedSeqs = 64;      // 192 words = 48 lanes, one 16-byte load each
+template <bool kLds = false>
+__device__ __forceinline__ int32_t row_at(const MoveArgs& a, const MoveTables& tb, uint32_t seq, uint32_t t,
+                                          const uint32_t* lds = nullptr) {
   if (tb.rows_mode == 2) {
+    if (kLds && seq < static_cast<uint32_t>(kFlatStagedSeqs)) {
+      const uint32_t row0 = lds[3 * seq], n0 = lds[3 * seq + 1];
+      return static_cast<int32_t>(t < n0 ? row0 + t : lds[3 * seq + 2] + (t - n0));
+    }
     const uint32_t row0 = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
     return static_cast<int32_t>(t < n0 ? row0 + t : a.inline_words[3 * seq + 2] + (t - n0));
   }
@@ -184,9 +194,9 @@ __device__ __forceinline__ void copy_bytes(const uint8_t* s, uint8_t* d, int uni
 // 16 bytes on both sides, every lane has U independent row lookups and then U
 // independent loads in flight before its first store, and no lane waits on a
 // per-workgroup scalar dependency chain.
-template <bool kGather, int U, int NT>
+template <bool kGather, int U, int NT, bool kLds = false>
 __device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& tb, const KeyDesc& key, int k,
-                                          int local) {
+                                          int local, const uint32_t* lds = nullptr) {
   const uint32_t upr = static_cast<uint32_t>(key.rowbytes >> 4);
   const uint32_t klen = static_cast<uint32_t>(tb.key_len[k]);
   const uint32_t nrows = static_cast<uint32_t>(tb.key_rows[k]);
@@ -217,8 +227,13 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& t
       // by-value argument block makes the compiler copy the whole block -- 3.8 KB
       // per lane -- to scratch)
       if (r0 + i < nrows) {
-        const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
-        row_tab[i] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
+        if (kLds && seq < static_cast<uint32_t>(kFlatStagedSeqs)) {
+          const uint32_t start = lds[3 * seq], n0 = lds[3 * seq + 1];
+          row_tab[i] = static_cast<int32_t>(t < n0 ? start + t : lds[3 * seq + 2] + (t - n0));
+        } else {
+          const uint32_t start = a.inline_words[3 * seq], n0 = a.inline_words[3 * seq + 1];
+          row_tab[i] = static_cast<int32_t>(t < n0 ? start + t : a.inline_words[3 * seq + 2] + (t - n0));
+        }
       } else {
         row_tab[i] = -1;
       }
@@ -241,7 +256,7 @@ __device__ __forceinline__ void move_wide(const MoveArgs& a, const MoveTables& t
     } else if (few_rows) {
       row[j] = dr == 0 ? row_tab[0] : dr == 1 ? row_tab[1] : row_tab[2];
     } else {
-      row[j] = row_at(a, tb, seq, t);
+      row[j] = row_at<kLds>(a, tb, seq, t, lds);
     }
   }
   u32x4 buf[U];
@@ -361,14 +376,15 @@ __device__ __forceinline__ void move_wide_spans(const MoveArgs& a, const StagedS
 
 // pool[rows[r]] -> batch[r] for every key of the replay in ONE launch, with
 // the is_first / is_last annotation of replay.py:277-292 applied in flight.
-template <int U, int NT>
-__device__ __forceinline__ void gather_block(const MoveArgs& a, const MoveTables& tb, int block) {
+template <int U, int NT, bool kLds = false>
+__device__ __forceinline__ void gather_block(const MoveArgs& a, const MoveTables& tb, int block,
+                                             const uint32_t* lds = nullptr) {
   const int k = find_key(tb, block);
   const KeyDesc key = tb.key[k];
   const int local = block - tb.first_block[k];
   const int unit = tb.unit[k];
   if (unit == 0) {
-    move_wide<true, U, NT>(a, tb, key, k, local);
+    move_wide<true, U, NT, kLds>(a, tb, key, k, local, lds);
     return;
   }
   const uint32_t klen = static_cast<uint32_t>(tb.key_len[k]);
@@ -378,7 +394,7 @@ __device__ __forceinline__ void gather_block(const MoveArgs& a, const MoveTables
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
   const uint32_t seq = static_cast<uint32_t>(r) / klen, t = static_cast<uint32_t>(r) - seq * klen;
-  const int64_t row = row_at(a, tb, seq, t);
+  const int64_t row = row_at<kLds>(a, tb, seq, t, lds);
   if (row < 0) return;   // not this rank's sequence (sharded pools): leave as is
   const uint8_t* src = key.pool + row * key.rowbytes + off;
   uint8_t* dst = key.batch + batch_offset(tb, key, klen, seq, t) + off;
@@ -389,7 +405,7 @@ __device__ __forceinline__ void gather_block(const MoveArgs& a, const MoveTables
     if (k == tb.key_is_first) {
       if (t == 0) v = 1;
     } else if (tb.is_first_pool && t + 1 < static_cast<uint32_t>(tb.seq_len)) {
-      v |= gload<uint8_t>(tb.is_first_pool + row_at(a, tb, seq, t + 1));
+      v |= gload<uint8_t>(tb.is_first_pool + row_at<kLds>(a, tb, seq, t + 1, lds));
     }
     gstore<uint8_t>(dst, v);
     return;
@@ -416,7 +432,9 @@ __device__ __forceinline__ void put_masked_bf16(const uint8_t* src, uint8_t* poo
   if (out) gstore<uint16_t>(out, v);
 }
 
-__device__ __forceinline__ void scatter_masked(const MoveArgs& a, const MoveTables& tb, int k, const KeyDesc& key, int local) {
+template <bool kLds = false>
+__device__ __forceinline__ void scatter_masked(const MoveArgs& a, const MoveTables& tb, int k, const KeyDesc& key, int local,
+                                               const uint32_t* lds = nullptr) {
   const int es = tb.unit[k];                       // element size of the key's dtype
   const int64_t epr = key.rowbytes / es;
   const int64_t e = static_cast<int64_t>(local) * blockDim.x + threadIdx.x;
@@ -424,7 +442,7 @@ __device__ __forceinline__ void scatter_masked(const MoveArgs& a, const MoveTabl
   const int64_t r = e / epr;
   const int64_t off = (e - r * epr) * es;
   const uint32_t L = static_cast<uint32_t>(tb.seq_len), seq = static_cast<uint32_t>(r) / L;
-  const int64_t row = row_at(a, tb, seq, static_cast<uint32_t>(r) - seq * L);
+  const int64_t row = row_at<kLds>(a, tb, seq, static_cast<uint32_t>(r) - seq * L, lds);
   const bool keep = gload<uint8_t>(tb.mask_flags + r) == 0;
   const uint8_t* src = key.batch + r * key.rowbytes + off;
   uint8_t* pool = row >= 0 ? key.pool + row * key.rowbytes + off : nullptr;
@@ -443,18 +461,19 @@ __device__ __forceinline__ void scatter_masked(const MoveArgs& a, const MoveTabl
 }
 
 // batch[r] -> pool[rows[r]]; rows[r] < 0 are skipped (evicted update targets).
-template <int U, int NT>
-__device__ __forceinline__ void scatter_block(const MoveArgs& a, const MoveTables& tb, int block) {
+template <int U, int NT, bool kLds = false>
+__device__ __forceinline__ void scatter_block(const MoveArgs& a, const MoveTables& tb, int block,
+                                              const uint32_t* lds = nullptr) {
   const int k = find_key(tb, block);
   const KeyDesc key = tb.key[k];
   const int local = block - tb.first_block[k];
   const int unit = tb.unit[k];
   if ((tb.mask_bits >> k) & 1u) {
-    scatter_masked(a, tb, k, key, local);
+    scatter_masked<kLds>(a, tb, k, key, local, lds);
     return;
   }
   if (unit == 0) {
-    move_wide<false, U, NT>(a, tb, key, k, local);
+    move_wide<false, U, NT, kLds>(a, tb, key, k, local, lds);
     return;
   }
   const int64_t upr = key.rowbytes / unit;
@@ -463,7 +482,7 @@ __device__ __forceinline__ void scatter_block(const MoveArgs& a, const MoveTable
   const int64_t r = u / upr;
   const int64_t off = (u - r * upr) * unit;
   const uint32_t L = static_cast<uint32_t>(tb.seq_len), seq = static_cast<uint32_t>(r) / L;
-  const int64_t row = row_at(a, tb, seq, static_cast<uint32_t>(r) - seq * L);
+  const int64_t row = row_at<kLds>(a, tb, seq, static_cast<uint32_t>(r) - seq * L, lds);
   if (row < 0) return;
   if (k == tb.inline_key) {   // batch bytes of this key ride in the kernel arguments
     const uint32_t w = a.inline_words[tb.inline_key_word0 + r * (key.rowbytes >> 2) + (off >> 2)];
@@ -507,10 +526,10 @@ static_assert(offsetof(MoveArgs, t) % 16 == 0, "the tables are staged in 16-byte
 // segment (default), the same with the tables staged through LDS (arguments in
 // host memory, small launches), or read through a pointer to a copy in device
 // memory (arguments in host memory, big launches: abi.cpp run_move).
-template <bool kGather>
-__device__ __forceinline__ void flat_block(const MoveArgs& a, const MoveTables& tb) {
-  if (kGather) gather_block<kFlatUnroll, kFlatNT>(a, tb, blockIdx.x);
-  else scatter_block<kFlatUnroll, kFlatNT>(a, tb, blockIdx.x);
+template <bool kGather, bool kLds = false>
+__device__ __forceinline__ void flat_block(const MoveArgs& a, const MoveTables& tb, const uint32_t* lds = nullptr) {
+  if (kGather) gather_block<kFlatUnroll, kFlatNT, kLds>(a, tb, blockIdx.x, lds);
+  else scatter_block<kFlatUnroll, kFlatNT, kLds>(a, tb, blockIdx.x, lds);
 }
 template <bool kGather>
 __global__ __launch_bounds__(kFlatThreads) void flat_move_kernel(const MoveArgs a) { flat_block<kGather>(a, a.t); }
@@ -520,11 +539,28 @@ __global__ __launch_bounds__(kFlatThreads) void flat_move_kernel_staged(const Mo
   stage_tables(kernarg_units(), &tables);
   flat_block<kGather>(a, tables);
 }
+// The device copy of the argument block sits in a ring of fine-grained (uncached)
+// memory the CPU wrote through the BAR: every read of it goes to memory.  The
+// tables AND the first kFlatStagedSeqs spans therefore come into LDS with one
+// 16-byte load per lane -- wave 0 the tables, wave 1 the spans, both in flight
+// together: one latency per workgroup, where a wave's scalar reads of its spans
+// were a second, dependent one in front of every payload load (an 85 MB
+// write-back through this mover: 20.3 us before, the by-value mover's 13 us with
+// device-resident arguments).
+static_assert(kFlatThreads >= 64 + 3 * kFlatStagedSeqs / 4, "wave 1 stages the spans");
+static_assert(3 * kFlatStagedSeqs <= kInlineWords && sizeof(SpanHead) % 16 == 0, "the staged spans lie inside the block");
 template <bool kGather>
 __global__ __launch_bounds__(kFlatThreads) void flat_move_kernel_indirect(const MoveArgs* __restrict__ a) {
   __shared__ MoveTables tables;     // one load latency instead of a chain of scalar loads
-  stage_tables(reinterpret_cast<const u32x4*>(a), &tables);
-  flat_block<kGather>(*a, tables);
+  __shared__ __attribute__((aligned(16))) uint32_t spans[3 * kFlatStagedSeqs];
+  const u32x4* bytes = reinterpret_cast<const u32x4*>(a);
+  constexpr uint32_t first_table = offsetof(MoveArgs, t) / 16, first_span = sizeof(SpanHead) / 16;
+  if (threadIdx.x < sizeof(MoveTables) / 16)
+    reinterpret_cast<u32x4*>(&tables)[threadIdx.x] = bytes[first_table + threadIdx.x];
+  else if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * kFlatStagedSeqs / 4)
+    reinterpret_cast<u32x4*>(spans)[threadIdx.x - 64] = bytes[first_span + threadIdx.x - 64];
+  __syncthreads();
+  flat_block<kGather, true>(*a, tables, spans);
 }
 
 // Span-mode launch: the first `wide_workers` workgroups are the persistent wide
@@ -691,12 +727,17 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
       }
     // With host-resident kernel arguments the big movers read their plan from a
     // ring in fine-grained (uncached) device memory: the span mover touches it
-    // once per workgroup (the staged head), the flat mover's waves walk it with
-    // dependent reads (84 MB write-back: 20.3 us flat-indirect, 17.6 us span) --
-    // there the span mover takes every size.
+    // once per workgroup (the staged head); the flat mover stages its tables and
+    // its first kFlatStagedSeqs spans the same way (round 6; before, its waves
+    // walked the spans with dependent uncached reads: 84 MB write-back 20.3 us
+    // flat-indirect, 17.6 us span, and the span mover took every size).  Gathers
+    // and launches with more sequences than the flat mover stages stay with the
+    // span mover there.
     const int64_t limit_mb = gather ? kSpanGatherMB : kSpanScatterMB;
+    static const int lab_flat = [] { const char* e = std::getenv("EMB_LAB_SCATTER_FLAT"); return e ? std::atoi(e) : 0; }();
     span_path = wide_bytes > 0 && wide_keys <= kSpanKeys &&
-                (plan.args_in_host_memory || wide_bytes <= limit_mb * 1000000);
+                ((plan.args_in_host_memory && (gather || !lab_flat || plan.n_seq > kFlatStagedSeqs)) ||
+                 wide_bytes <= limit_mb * 1000000);
   }
   const int unroll = span_path ? kSpanUnroll : kFlatUnroll;
   const int threads = span_path ? kSpanThreads : kFlatThreads;
@@ -801,7 +842,10 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
     // As many workers as the chip takes at once (trimming the count so that
     // every worker walks the same number of tiles was slower with this shape:
     // B=16 10.8 against 10.1 us).
-    const int64_t workers = std::min<int64_t>(h.ntiles, int64_t(compute_units()) * kSpanPerCU);
+    const int cus = plan.cu_limit > 0 ? std::min(plan.cu_limit, compute_units()) : compute_units();
+    static const int lab_per_cu = [] { const char* e = std::getenv("EMB_LAB_SCATTER_PER_CU"); return e ? std::atoi(e) : 0; }();
+    const int per_cu = (!gather && lab_per_cu > 0) ? lab_per_cu : kSpanPerCU;
+    const int64_t workers = std::min<int64_t>(h.ntiles, int64_t(cus) * per_cu);
     h.wide_workers = static_cast<int32_t>(workers);
     h.seq_len = t.seq_len;
     if (blocks + h.wide_workers > INT32_MAX) return hipErrorInvalidValue;

@@ -13,6 +13,46 @@ int32_t emb_device_count(int32_t* count) {
   });
 }
 
+// A HIP stream whose kernels run on `n_cus` compute units only, beginning with
+// unit `first_cu` of the driver's own numbering (which deals consecutive units
+// round-robin over the XCDs and their shader engines, so a range is spread
+// evenly over the chip).
+int32_t emb_stream_create_on_cus(int32_t first_cu, int32_t n_cus, void** stream_out) {
+  return guarded([&] {
+    need(stream_out && first_cu >= 0 && n_cus >= 1, "stream_create_on_cus: bad arguments");
+    int device = 0;
+    HIP_OK(hipGetDevice(&device));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    const int total = prop.multiProcessorCount;
+    need(first_cu + n_cus <= total, "stream_create_on_cus: the range exceeds the device's compute units");
+    std::vector<uint32_t> mask(static_cast<size_t>((total + 31) / 32), 0u);
+    for (int cu = first_cu; cu < first_cu + n_cus; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+    hipStream_t s = nullptr;
+    HIP_OK(hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>(mask.size()), mask.data()));
+    {
+      std::lock_guard<std::mutex> lock(g_cu_streams.mu);
+      g_cu_streams.streams.emplace_back(s, n_cus);
+      g_cu_streams.count.store(static_cast<int>(g_cu_streams.streams.size()), std::memory_order_release);
+    }
+    *stream_out = s;
+  });
+}
+
+int32_t emb_stream_destroy(void* stream) {
+  return guarded([&] {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    need(s != nullptr, "stream_destroy: null stream");
+    {
+      std::lock_guard<std::mutex> lock(g_cu_streams.mu);
+      auto& v = g_cu_streams.streams;
+      v.erase(std::remove_if(v.begin(), v.end(), [&](const auto& e) { return e.first == s; }), v.end());
+      g_cu_streams.count.store(static_cast<int>(v.size()), std::memory_order_release);
+    }
+    HIP_OK(hipStreamDestroy(s));
+  });
+}
+
 // ------------------------------------------------------------------ kernels --
 
 int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_t pixels,

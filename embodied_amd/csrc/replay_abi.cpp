@@ -169,6 +169,7 @@ static void run_move(emb_replay* rep, emb::MovePlan& plan, const int32_t* rows, 
   plan.n_rows = static_cast<int32_t>(n_rows);
   plan.rows_host = rows;
   plan.args_in_host_memory = host_kernargs();
+  plan.cu_limit = g_cu_streams.cus_of(stream);
   if (spans && !spans->empty()) {
     plan.spans_host = spans->data();
     plan.n_seq = static_cast<int32_t>(spans->size() / 3);

@@ -556,7 +556,7 @@ class Prioritized : public Selector {
     double* pw = &st->powered[start - st->step0];
     for (int i = 0; i < st->n; ++i) prio[i] = 0.0, pw[i] = zero_powered;
     const int64_t last = st->item0 + static_cast<int64_t>(st->items.size()) - 1;
-    refresh_drawn(st, std::max(st->item0, start - st->n + 1), std::min(last, start + st->n - 1));
+    refresh_drawn(st, std::max(st->item0, start - st->n + 1), std::min(last, start + st->n - 1), start);
     return key;
   }
   int64_t size() const override {
@@ -837,7 +837,17 @@ class Prioritized : public Selector {
   // sums to +inf with maximum +inf and a window of zeros to +0 with maximum 0 --
   // the values stream_masses decides by its prefix counts; every other window is
   // summed left to right as there.  Same masses, same leaf updates.
-  void refresh_drawn(Stream* st, int64_t lo, int64_t hi) {
+  //
+  // Which of the <= 2n - 1 windows can have changed at all (round 6): only the n
+  // steps of the drawn item at `start` were written, all to zero.  A window that
+  // holds a +inf step OUTSIDE them held it before and holds it now: its mass was
+  // and is `all_inf`, bit for bit, and needs neither a look nor a leaf update.
+  // With p_left the nearest +inf step left of the drawn item and p_right the
+  // nearest one right of it, those are the windows that begin at or before p_left
+  // or at or after p_right - n + 1; the pass runs over what lies between -- with
+  // `initial: inf` (ppo/configs.yaml:42) and unsampled neighbours that is the
+  // drawn window alone, found by reading two steps instead of sliding over 2n.
+  void refresh_drawn(Stream* st, int64_t lo, int64_t hi, int64_t start) {
     if (!st->plain || lo > hi) {
       ranges_.clear();
       if (lo <= hi) ranges_.push_back({st, lo, hi});
@@ -845,6 +855,21 @@ class Prioritized : public Selector {
       return;
     }
     const int n = st->n;
+    {
+      const double* pw = &st->powered[0];        // index: position - step0
+      const int64_t s0 = st->step0;
+      for (int64_t p = start - 1; p >= lo; --p)
+        if (pw[p - s0] == INFINITY) {
+          lo = p + 1;
+          break;
+        }
+      for (int64_t p = start + n; p <= hi + n - 1; ++p)
+        if (pw[p - s0] == INFINITY) {
+          hi = p - n;
+          break;
+        }
+      if (lo > hi) return;
+    }
     const double* base = &st->powered[lo - st->step0];       // steps lo .. hi + n - 1
     double* held = &st->mass[lo - st->item0];
     SampleTree::Node* const* leaf = &st->leaves[lo - st->item0];

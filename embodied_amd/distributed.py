@@ -737,10 +737,10 @@ class NativeComm:
   (`emb_comm_*`, include/embodied_hip.h) instead of torch.distributed: for hosts
   that have no process group.  The 128-byte id made by rank 0 reaches the other
   ranks through `share(id_bytes) -> id_bytes` (default: a torch.distributed
-  object broadcast if a group exists; world 1 needs none).  Collectives are
+  object broadcast if a group exists; world 1 needs none), or is given as `ident`.  Collectives are
   asynchronous on the caller's current stream."""
 
-  def __init__(self, rank=0, world=1, device=None, share=None):
+  def __init__(self, rank=0, world=1, device=None, share=None, ident=None):
     import ctypes as C
     from . import _lib
     from ._lib import api
@@ -748,18 +748,29 @@ class NativeComm:
     self.rank, self.world = int(rank), int(world)
     self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     torch.cuda.set_device(self.device)
-    ident = (C.c_uint8 * 128)()
-    if self.rank == 0:
-      api.emb_comm_unique_id(ident)
-    if self.world > 1:
-      if share is None:
-        def share(data):
-          box = [data]
-          dist.broadcast_object_list(box, src=0)
-          return box[0]
-      ident = (C.c_uint8 * 128).from_buffer_copy(share(bytes(ident)))
+    if ident is None:
+      ident = self.unique_id() if self.rank == 0 else bytes(128)
+      if self.world > 1:
+        if share is None:
+          def share(data):
+            box = [data]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        ident = share(ident)
+    # (`ident`: rank 0's id, already handed round by the caller -- a caller that must
+    # not have a process-group call inside this constructor, bench.py's self-check)
     self._handle = C.c_void_p()
-    api.emb_comm_init(ident, self.rank, self.world, C.byref(self._handle))
+    api.emb_comm_init((C.c_uint8 * 128).from_buffer_copy(ident), self.rank, self.world, C.byref(self._handle))
+
+  @staticmethod
+  def unique_id():
+    """A fresh 128-byte communicator id (rank 0 makes it, every rank passes the same
+    one to the constructor).  Also loads RCCL: raises if it cannot be bound."""
+    import ctypes as C
+    from ._lib import api
+    ident = (C.c_uint8 * 128)()
+    api.emb_comm_unique_id(ident)
+    return bytes(ident)
 
   def all_gather(self, flat, out=None):
     """(nbytes,) uint8 per rank -> (world * nbytes,) uint8 on every rank."""

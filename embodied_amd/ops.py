@@ -101,3 +101,35 @@ def rows_scatter(table, ids, rows):
   api.emb_rows_scatter(table.data_ptr(), rowbytes, _lib.ptr(ids), len(ids),
                        rows.data_ptr(), _stream(table))
   return table
+
+
+class CuStream:
+  """A HIP stream whose kernels may use `n_cus` compute units only (from unit
+  `first_cu` on; the driver deals consecutive units round-robin over the XCDs),
+  as a torch stream: `with torch.cuda.stream(cs.stream): ...`.  For a learner
+  whose sample gather / scans / write-back run BESIDE the Driver's latency-bound
+  step kernels instead of in front of them (`emb_stream_create_on_cus`,
+  include/embodied_hip.h); the replay's movers size their grids by the share."""
+
+  def __init__(self, n_cus, first_cu=0, device=None):
+    import ctypes as C
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index is None:
+      device = torch.device('cuda', torch.cuda.current_device())
+    self.device, self.n_cus, self.first_cu = device, int(n_cus), int(first_cu)
+    self._raw = C.c_void_p()
+    with torch.cuda.device(device):
+      api.emb_stream_create_on_cus(self.first_cu, self.n_cus, C.byref(self._raw))
+    self.stream = torch.cuda.ExternalStream(self._raw.value, device=device)
+
+  def close(self):
+    raw, self._raw = self._raw, None
+    if raw:
+      self.stream.synchronize()
+      api.emb_stream_destroy(raw)
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

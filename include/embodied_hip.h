@@ -91,6 +91,18 @@ int32_t emb_abi_version(void);
 int32_t emb_configure(const char* name, const char* value);
 int32_t emb_device_count(int32_t* count);
 
+/* A HIP stream whose kernels may use `n_cus` compute units only, beginning with
+ * unit `first_cu` (ABI 5).  For a learner that samples / scans / writes back
+ * beside the Driver's latency-bound step kernels (the reference dispatches its
+ * train step asynchronously too, embodied/jax/agent.py:286-294): a sample gather
+ * that fills every CU makes the step's small kernels queue behind it; confined
+ * to a share of the chip it runs beside them.  The replay's movers size their
+ * persistent grids by the stream's share.  The driver numbers compute units
+ * round-robin over XCDs and shader engines, so a range is spread evenly.
+ * emb_stream_destroy for streams made here only.                               */
+int32_t emb_stream_create_on_cus(int32_t first_cu, int32_t n_cus, void** stream_out);
+int32_t emb_stream_destroy(void* stream);
+
 /* ---- numpy-compatible PRNG ------------------------------------------------
  * Replaces numpy.random.default_rng as used by selectors.py:34,42,240,305,212
  * and the per-batch seeds of embodied/jax/agent.py:405-408.  `words` is the

@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
+def fake_rccl():
+  """The suite's loopback stand-in for RCCL (RCCL itself refuses two ranks on one
+  GPU), bound behind the library's dlsym table with EMB_RCCL_LIB."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('_fake_rccl_build', ROOT / 'tests' / 'fake_rccl' / 'build.py')
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return str(mod.build())
+
+
 def run_bench(*flags, env=None):
   full = dict(os.environ, **(env or {}))
   # (HIP_FORCE_DEV_KERNARG: conftest pins the suite to the runtime's placement; the
@@ -47,11 +57,7 @@ def test_bench_gpus_2_native_exchange_between_two_real_ranks():
   two REAL ranks and the timed path then issues one emb_comm_exchange per train
   step.  Transport: the suite's loopback stand-in for RCCL (RCCL itself refuses
   two ranks on one GPU), selected with EMB_RCCL_LIB; process group: gloo."""
-  import importlib.util
-  spec = importlib.util.spec_from_file_location('_fake_rccl_build', ROOT / 'tests' / 'fake_rccl' / 'build.py')
-  mod = importlib.util.module_from_spec(spec)
-  spec.loader.exec_module(mod)
-  lib = str(mod.build())
+  lib = fake_rccl()
   rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
                   '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
                   '--backend', 'gloo', '--comm', 'native', env={'EMB_RCCL_LIB': lib})
@@ -72,22 +78,24 @@ def test_bench_gpus_2_direct_schedule_between_two_real_ranks():
   every rank writing its peer's shares through hipIpc pointers (two processes on
   the test box's one GPU) -- after the self-check against torch.distributed
   passed; the line carries both transports' per-call times."""
-  import importlib.util
-  spec = importlib.util.spec_from_file_location('_fake_rccl_build', ROOT / 'tests' / 'fake_rccl' / 'build.py')
-  mod = importlib.util.module_from_spec(spec)
-  spec.loader.exec_module(mod)
-  lib = str(mod.build())
+  lib = fake_rccl()
   rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
                   '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
                   '--backend', 'gloo', '--comm', 'direct', env={'EMB_RCCL_LIB': lib})
   native = rec['native_comm']
   direct = native['direct']
   assert direct['status'] == 'ok' and all(direct['checks'].values()) and direct['timed_out'] is False, direct
-  assert set(direct['per_call']) == {'direct_all_reduce', 'direct_all_to_all', 'direct_exchange_step'}
+  assert set(direct['per_call']) == {'direct_all_reduce', 'direct_all_to_all', 'direct_all_gather',
+                                     'direct_exchange_step', 'direct_exchange_gather_step'}
+  assert set(direct['checks']) == {'all_to_all', 'all_gather', 'all_reduce_sum_f32', 'all_reduce_mean_f32',
+                                   'all_reduce_sum_bf16', 'all_reduce_mean_bf16', 'exchange_gather'}
   assert native['timed_path'] == 'direct' and 'emb_direct_exchange' in rec['config']['parallelism']
   assert rec['train_steps_per_s'] > 0 and rec['value'] > 0
   assert native['per_train_step']['direct_collectives_us'] > 0
-  assert set(rec['expected']['link_bound_x_measured']) == {'rccl', 'direct'}       # both transports, side by side
+  assert set(rec['expected']['link_bound_x_measured']) == {'rccl', 'direct', 'c10d'}     # every transport, side by side
+  assert rec['transports']['timed_path'] == 'direct' and rec['transports']['grad_dtype'] == 'f32'
+  assert set(rec['transports']['exchange_step_us']) == {'c10d', 'rccl', 'direct'}
+  assert rec['transports']['schedule_agreed_at_fences'] >= 2
   assert 0 < rec['expected']['link_bound_x_measured']['direct'] <= 2.0
 
 
@@ -96,18 +104,73 @@ def test_bench_auto_takes_the_faster_transport_that_passed_its_check():
   job's own bytes, every rank takes the same choice (MAX over ranks of the
   measured exchange times).  Here the RCCL stand-in is a host-staged loopback,
   far slower than stores through hipIpc pointers on one GPU: auto takes direct."""
-  import importlib.util
-  spec = importlib.util.spec_from_file_location('_fake_rccl_build', ROOT / 'tests' / 'fake_rccl' / 'build.py')
-  mod = importlib.util.module_from_spec(spec)
-  spec.loader.exec_module(mod)
   rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
                   '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
-                  '--backend', 'gloo', env={'EMB_RCCL_LIB': str(mod.build())})
+                  '--backend', 'gloo', env={'EMB_RCCL_LIB': fake_rccl()})
   native = rec['native_comm']
   assert native['status'] == 'ok' and native['direct']['status'] == 'ok'
   auto = native['auto']
   assert auto['chose'] == ('direct' if auto['direct_exchange_us'] < 0.9 * auto['rccl_exchange_us'] else 'native')
   assert native['timed_path'] == auto['chose'] and rec['value'] > 0
+
+
+@pytest.mark.parametrize('fault,left', [
+    ('direct_open:1', 'native'),      # rank 1 cannot make / map its hipIpc buffer
+    ('direct_stuck:1', 'native'),     # rank 1 never arrives at one direct collective: rank 0's wait gives up
+    ('direct_wrong:0', 'native'),     # rank 0's direct all-to-all delivers wrong bytes
+    ('native_open:1', 'direct'),      # rank 1's RCCL communicator cannot be set up: the direct schedule is left
+])
+def test_bench_auto_degrades_when_a_transport_fails_on_one_rank(fault, left):
+  """First contact with a node: a transport that fails its self-check on ONE rank
+  -- set-up error, a peer that never arrives (the bounded wait gives up, the
+  communicator dies on every rank), wrong bytes -- must cost the job seconds and
+  nothing else: every rank takes the same decision, `--comm auto` goes on with
+  what is left, the line is valid and the exit code 0."""
+  rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
+                  '--backend', 'gloo', env={'EMB_RCCL_LIB': fake_rccl(), 'EMB_BENCH_FAULT': fault})
+  native = rec['native_comm']
+  broken = native['direct'] if fault.startswith('direct') else native
+  assert broken['status'] != 'ok', broken
+  assert native['auto']['chose'] == left and native['timed_path'] == left, native['auto']
+  assert ('emb_direct' if fault.startswith('direct') else 'emb_comm') in native['auto']['why']
+  assert rec['transports']['timed_path'] == left
+  assert rec['n_gpus'] == 2 and rec['value'] > 0 and rec['train_steps_per_s'] > 0
+  assert rec['replicas_only']['env_steps_per_s'] > 0 and rec['expected']['links'] == 1
+  assert rec['transports']['schedule_agreed_at_fences'] >= 2
+
+
+def test_bench_auto_falls_back_to_c10d_when_both_transports_fail():
+  """Neither transport passes (here: RCCL set-up fails on rank 1 AND a direct
+  peer never arrives): the timed path stays on torch.distributed, rc 0."""
+  # (one fault per run: the second failure is a transport library that does not load at all)
+  rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
+                  '--backend', 'gloo', env={'EMB_RCCL_LIB': '/nonexistent/librccl.so', 'EMB_BENCH_FAULT': 'direct_stuck:0'})
+  native = rec['native_comm']
+  assert native['status'] != 'ok' and native['direct']['status'] != 'ok'
+  assert native['auto']['chose'] == 'c10d' and native['timed_path'] == 'c10d'
+  assert 'torch.distributed' in rec['config']['parallelism']
+  assert rec['value'] > 0 and rec['train_steps_per_s'] > 0
+
+
+@pytest.mark.parametrize('exchange', ['trajectories', 'online', 'returns'])
+@pytest.mark.parametrize('comm', ['direct', 'native'])
+def test_bench_all_gather_forms_run_on_the_librarys_transports(exchange, comm):
+  """north_star's "all-gather of trajectories": `--exchange trajectories | online |
+  returns` go through the same transport as the gradients, ONE exchange call per
+  train step (emb_direct_exchange_gather / emb_comm_exchange_gather)."""
+  rec = run_bench('--gpus', '2', '--steps', '40', '--warmup', '5', '--capacity', '20000',
+                  '--grad-numel', '100000', '--sustained-seconds', '1', '--prewarm-train-steps', '20',
+                  '--backend', 'gloo', '--comm', comm, '--exchange', exchange, env={'EMB_RCCL_LIB': fake_rccl()})
+  native = rec['native_comm']
+  assert native['timed_path'] == comm and rec['transports']['exchange'] == exchange
+  step = native['per_train_step']
+  assert step['trajectory_collective'] == 'all_gather'
+  assert step['trajectory_share'] > 0 and (exchange == 'online' or step['trajectory_share'] == 1.0)
+  assert set(rec['transports']['exchange_step_us']) == {'c10d', 'rccl', 'direct'}
+  assert rec['expected']['bytes_one_way_per_train_step'] > 2 * 0.5 * 400000      # gradients + the gathered blocks
+  assert rec['value'] > 0 and rec['train_steps_per_s'] > 0
 
 
 def test_bench_gpus_8_control_flow():
@@ -121,6 +184,39 @@ def test_bench_gpus_8_control_flow():
   assert rec['scaling'] == 'weak' and rec['value'] > 0 and rec['train_steps_per_s'] > 0
   assert rec['replicas_only']['env_steps_per_s'] > 0
   assert rec['expected']['replicas_only_x'] == 8.0 and rec['expected']['links'] == 7
+
+
+def test_bench_gpus_8_full_length_rehearsal():
+  """`python bench.py --gpus 8` as the driver will run it on an 8-GPU node -- default
+  steps / warm-up / sustained window, the default f32 gradient of the counted PPO
+  model (49 MB per train step), `--comm auto` with both transports checked -- on
+  the test box's ONE GPU (gloo process group, eight ranks sharing the device; the
+  direct schedule's hipIpc stores stay on it).  Everything but the links is the
+  real thing: launcher, self-checks, transport choice, exchange schedule agreed
+  at every fence, the line's fields.  And the N = 1 line of the same build agrees
+  with what eight ranks get out of the same single GPU with the collectives off."""
+  rec = run_bench('--gpus', '8', '--backend', 'gloo', '--no-cpu-baseline', env={'EMB_RCCL_LIB': fake_rccl()})
+  assert rec['n_gpus'] == 8 and rec['rccl_ranks'] == 8 and rec['backend'] == 'gloo'
+  assert rec['steps'] == 50000 and rec['warmup'] == 2000 and rec['sustained']['seconds'] >= 10
+  assert rec['config']['global_envs'] == 8 * 64 and rec['scaling'] == 'weak'
+  assert '46.7 MiB f32 grad all-reduce' in rec['config']['parallelism']
+  t = rec['transports']
+  assert t['grad_dtype'] == 'f32' and t['grad_bytes'] == 4 * 12_242_343
+  assert set(t['exchange_step_us']) == {'c10d', 'rccl', 'direct'}
+  assert t['schedule_agreed_at_fences'] >= 4
+  native = rec['native_comm']
+  assert native['status'] == 'ok' and native['direct']['status'] == 'ok', native
+  assert native['auto']['chose'] == t['timed_path'] and native.get('direct_timed_out_during_run') in (None, False)
+  exp = rec['expected']
+  assert exp['links'] == 7 and exp['replicas_only_x'] == 8.0
+  assert set(exp['link_bound_x_measured']) == {'rccl', 'direct', 'c10d'}
+  assert rec['value'] > 0 and rec['train_steps_per_s'] > 0 and rec['replicas_only']['env_steps_per_s'] > 0
+  # the same build, one rank: eight ranks time-sharing the one GPU (collectives off) deliver
+  # about what one rank does alone -- not 8x (they share it), not a fraction (they overlap
+  # each other's launch gaps).  Wide bounds: boxes and contention vary.
+  single = run_bench('--no-cpu-baseline', '--no-context', '--no-dreamer-leg', '--sustained-seconds', '4')
+  ratio = rec['replicas_only']['env_steps_per_s'] / single['sustained']['env_steps_per_s']
+  assert 0.35 < ratio < 2.5, (ratio, rec['replicas_only'], single['sustained'])
 
 
 def test_bench_dreamer_workload_with_ranks():
@@ -144,7 +240,7 @@ def test_bench_checks_the_native_collectives_when_it_runs_on_rccl():
   assert native['status'] == 'ok' and all(native['checks'].values()), native
   assert set(native['checks']) == {
       'all_gather', 'all_to_all', 'all_reduce_sum_f32', 'all_reduce_mean_f32',
-      'all_reduce_sum_bf16', 'all_reduce_mean_bf16'}
+      'all_reduce_sum_bf16', 'all_reduce_mean_bf16', 'exchange_gather'}
   assert native['per_call']['native_all_reduce']['host_us'] > 0
   # ... and, having passed, they carry the timed path (one emb_comm_exchange per train step).
   assert native['timed_path'] == 'native' and 'emb_comm_exchange' in rec['config']['parallelism']

@@ -230,18 +230,23 @@ def _lonely_worker(rank, world, port, out):
         try:
           call()
           raised.append(None)
-        except (RuntimeError, ValueError) as e:
+        except RuntimeError as e:          # (EmbError: a transport failure, not a bad argument)
           raised.append(str(e))
       res['raised'] = raised
     torch.distributed.barrier()              # rank 1 stays alive (its memory mapped) until rank 0 is through
     if rank == 1:
-      # The dead rank raised no flag for the operation it gave up on: its peer runs
-      # into the same time-out instead of reducing half-arrived slots.
+      # The dead rank's reduce raised no flag for the operation it gave up on: its peer's
+      # collect runs into the same time-out (what its buffer holds then is undefined -- its
+      # own shard is reduced, the dead rank's never arrives -- and it is told so).
       grads = torch.ones(4096, device='cuda')
       comm.all_reduce(grads)
       torch.cuda.synchronize()
       res['timed_out'] = comm.timed_out()
-      res['untouched'] = bool(torch.equal(grads, torch.ones(4096, device='cuda')))
+      try:
+        comm.wait()
+        res['raised'] = None
+      except RuntimeError as e:
+        res['raised'] = str(e)
     out[rank] = res
     torch.distributed.barrier()
     comm.close()
@@ -253,7 +258,7 @@ def test_a_peer_that_never_arrives_kills_the_communicator_not_the_gpu():
   """Every wait inside the kernels is bounded by `timeout_ms` -- and giving up is
   fatal for the communicator, never a silently wrong gradient: the kernel that
   gave up writes no result and raises no flag, `timed_out()` says what happened,
-  every later call raises, and the late peer fails the same way."""
+  every later call raises, and the late peer runs into the same time-out."""
   manager = mp.Manager()
   out = manager.dict()
   mp.spawn(_lonely_worker, args=(2, _free_port(), out), nprocs=2, join=True)
@@ -261,7 +266,7 @@ def test_a_peer_that_never_arrives_kills_the_communicator_not_the_gpu():
   assert first['timed_out'] is True and first['untouched'] is True
   assert 0.25 < first['seconds'] < 5.0        # two bounded waits (reduce, collect) of at most 0.3 s each
   assert all(msg and 'timed out' in msg for msg in first['raised']), first['raised']
-  assert late['timed_out'] is True and late['untouched'] is True
+  assert late['timed_out'] is True and 'timed out' in late['raised']
 
 
 def _failing_worker(rank, world, port, out):

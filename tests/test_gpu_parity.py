@@ -436,6 +436,62 @@ def test_parallel_env_workers_upload_from_shared_slab(emb):
     assert_same(b, a, 'parallel-device')
 
 
+@pytest.mark.parametrize('per_worker', [1, 3, 'auto'])
+def test_wide_observations_go_up_in_pieces_and_actions_come_down_by_store(emb, per_worker):
+  """The real-simulator path at a size where its two shortcuts are on (round 6):
+  the observation slab (16 envs x 32 KB = 512 KB) is uploaded in four pieces, each
+  as soon as the envs that write it are through, and the next step's actions reach
+  pinned host memory through one kernel's stores (value * ~is_last) instead of a
+  device-to-host copy per key.  Rewards depend on the actions, episodes end at
+  different steps: every transition equals the serial host loop's, and the
+  Replay behind the Driver holds what the oracle pair holds."""
+  from functools import partial
+  from embodied_amd.core import driver as driverlib
+  n = 16
+  fns = [partial(scenarios.ScriptEnv, i, 3 + i % 5, image=(64, 64, 8)) for i in range(n)]
+
+  def policy(carry, obs):
+    count = len(obs['is_first'])
+    act = {'act_disc': (np.arange(count) * 3 + carry).astype(np.int32),
+           'act_cont': np.full((count, 3), -0.5 * carry, np.float32)}
+    return carry + 1, act, {}
+
+  def run(**kw):
+    driver = emb.Driver(fns, **kw)
+    log = []
+    driver.on_batch(lambda trans, workers, **k: log.append(
+        {key: (v.cpu().numpy() if torch.is_tensor(v) else np.array(v)) for key, v in trans.items()}))
+    driver.reset(lambda count: 0)
+    driver(policy, steps=n * 14)
+    state = (getattr(driver, '_upload_plan', None), getattr(driver, '_acts_by_store', None))
+    driver.close()
+    return log, state
+
+  want, _ = run(parallel=False)
+  got, (plan, by_store) = run(parallel=True, device='cuda', envs_per_worker=per_worker)
+  assert len(plan) == driverlib._UPLOAD_GROUPS + 1         # four pieces of the image key + the narrow keys
+  assert [p[:2] for p in plan[:4]] == [(0, 4), (4, 8), (8, 12), (12, 16)]
+  assert by_store is True                                  # the stores agreed with a plain copy on the first step
+  assert len(want) == len(got) == 14
+  for a, b in zip(want, got):
+    assert_same(b, a, f'wide-parallel-{per_worker}')
+  # ... and with the Replay as the step's only consumer (rotating device buffers, early insert)
+  driver = emb.Driver(fns, parallel=True, device='cuda', envs_per_worker=per_worker)
+  rep = emb.Replay(length=4, capacity=300, chunksize=32, seed=5)
+  driver.on_step(rep.add)
+  oracle = np_oracle.Driver([fn() for fn in fns])
+  ref = np_oracle.Replay(4, 300, 32, seed=5)
+  oracle.on_step(ref.add)
+  driver.reset(lambda count: 0)
+  oracle.reset(lambda count: 0)
+  for _ in range(6):
+    driver(policy, steps=n * 5)
+    oracle(policy, steps=n * 5)
+    assert len(rep) == len(ref)
+    assert_same({k: v.cpu().numpy() for k, v in rep.sample(8).items()}, ref.sample(8), 'wide-parallel-sink')
+  driver.close()
+
+
 @pytest.mark.parametrize('parallel', [False, True])
 def test_host_mode_driver_with_a_replay_sink_matches_the_oracle_pair(emb, parallel):
   """The unchanged reference program: `Driver(fns, parallel)` in host mode with
