@@ -279,6 +279,12 @@ def build_path(args, rank, device):
   if args.host_envs:
     fns = [(lambda e=e: synthetic.HostSyntheticEnv(rank * n + e)) for e in range(n)]
     driver = emb.Driver(fns, parallel=args.parallel_envs, device=device,
+                        **({'upload_groups': int(os.environ['EMB_BENCH_UPLOAD_GROUPS'])}
+                           if 'EMB_BENCH_UPLOAD_GROUPS' in os.environ else {}),
+                        **({'acts_by_store': os.environ['EMB_BENCH_ACTS_BY_STORE'] != '0'}
+                           if 'EMB_BENCH_ACTS_BY_STORE' in os.environ else {}),
+                        **({'worker_spin_us': int(os.environ['EMB_BENCH_WORKER_SPIN_US'])}
+                           if 'EMB_BENCH_WORKER_SPIN_US' in os.environ and args.parallel_envs else {}),
                         **({'envs_per_worker': (args.envs_per_worker if args.envs_per_worker == 'auto'
                                                 else int(args.envs_per_worker))} if args.parallel_envs else {}))
     env = None

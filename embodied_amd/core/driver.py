@@ -123,8 +123,16 @@ def mask_actions(value, is_last):
 class Driver:
 
   def __init__(self, make_env_fns=None, parallel=True, device=None,
-               batch_env=None, shared_obs=True, fresh_obs=None, envs_per_worker=1, **kwargs):
+               batch_env=None, shared_obs=True, fresh_obs=None, envs_per_worker=1,
+               upload_groups=None, acts_by_store=None, worker_spin_us=None, **kwargs):
     self.kwargs = kwargs
+    # (device mode with env processes; both default to the measured optimum: the
+    # observation slab goes up in `upload_groups` pieces under the workers' steps,
+    # actions come down by kernel stores into pinned memory -- False / 1: one copy each)
+    self._upload_groups = _UPLOAD_GROUPS if upload_groups is None else max(1, int(upload_groups))
+    self._spin_us = _SPIN_US if worker_spin_us is None else max(0, int(worker_spin_us))
+    if acts_by_store is not None and not acts_by_store:
+      self._acts_by_store = False
     _read_knobs()
     self._fresh_obs = fresh_obs
     self.device = torch.device(device) if device is not None else None
@@ -261,11 +269,17 @@ class Driver:
       block = shared_memory.SharedMemory(create=True, size=nbytes)
       self._act_slab[key] = (block, np.ndarray((self.length, *shape), dtype, buffer=block.buf))
       act_layout[key] = (block.name, shape, dtype)
-    self._ctrl_block = shared_memory.SharedMemory(create=True, size=8 * (2 + 2 * self.length))
-    self._ctrl = np.ndarray(2 + 2 * self.length, np.int64, buffer=self._ctrl_block.buf)
+    n_workers = len(self.pipes)
+    self._ctrl_block = shared_memory.SharedMemory(create=True, size=8 * (2 + 2 * self.length + n_workers))
+    self._ctrl = np.ndarray(2 + 2 * self.length + n_workers, np.int64, buffer=self._ctrl_block.buf)
     self._ctrl[:] = 0
     self._done = self._ctrl[2: 2 + self.length]
-    self._extra = self._ctrl[2 + self.length:]
+    self._extra = self._ctrl[2 + self.length: 2 + 2 * self.length]
+    # per worker: 1 while it sleeps on its semaphore (it spins on the sequence word for
+    # a while after a step first, see _env_server); ctrl[1] = how long, in microseconds
+    self._asleep = self._ctrl[2 + 2 * self.length:]
+    self._asleep[:] = 1
+    self._ctrl[1] = int(self._spin_us)
     self._seq = 0
     [pipe.send(('attach', layout, self.length, act_layout, self._ctrl_block.name))
      for pipe in self.pipes]
@@ -382,7 +396,10 @@ class Driver:
       ended = self._host_flags['is_last']
       if ended.any():
         acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
-      self.acts = {**acts, 'reset': is_last.clone()}
+      # (`reset` may alias the step's is_last, as with a device vector env: device flags
+      # are never mutated in place, and with the rotating upload buffers the tensor lives
+      # four steps -- user callbacks, which may keep it, get fresh tensors every step)
+      self.acts = {**acts, 'reset': is_last if self._rotate() else is_last.clone()}
     else:
       ended = is_last
       if ended.any():
@@ -390,6 +407,14 @@ class Driver:
       self.acts = {**acts, 'reset': is_last.copy()}
     if self.device is not None:
       self._fetch_acts()
+      if self._upload_pending == 'unrecorded':
+        if self._acts_on_host is not None:
+          # the event behind the actions' transfer also covers the uploads queued before
+          # it on the same stream; it is waited for before the slab is written again
+          self._upload_pending = False
+        else:
+          self._uploaded.record()
+          self._upload_pending = True
     trans = {**obs, **acts, **outs, **logs}
     self._dispatch(trans)
     return step + self.length, episode + int(ended.sum())
@@ -414,35 +439,38 @@ class Driver:
     flags = getattr(self, '_host_flags', {}).get('is_last')
     reset = self.acts.get('reset')
     by_store = getattr(self, '_acts_by_store', None)
+    stream = None
     for k, v in self.acts.items():
       if k == 'reset' and flags is not None:
-        host[k] = flags.astype(bool, copy=True)
+        host[k] = flags.copy()
         continue
-      pinned = self._acts_pinned.get(k)
-      if pinned is None or pinned.shape != v.shape or pinned.dtype != v.dtype:
-        pinned = self._acts_pinned[k] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+      entry = self._acts_pinned.get(k)
+      if entry is None or entry[0].shape != v.shape or entry[0].dtype != v.dtype:
+        pinned = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+        entry = self._acts_pinned[k] = (pinned, pinned.numpy(), pinned.data_ptr(), _DTYPE_CODE.get(v.dtype))
+      pinned, view, ptr, code = entry
       stored = False
-      if (by_store is not False and k != 'reset' and reset is not None and v.dtype in _DTYPE_CODE
+      if (by_store is not False and k != 'reset' and reset is not None and code is not None
           and v.is_contiguous() and v.numel() and reset.dtype in (torch.bool, torch.uint8)):
         n = v.shape[0]
+        if stream is None:
+          stream = _lib.raw_stream(v.device)
         if by_store is None:
           # once: the same values by store and by copy must agree
           try:
             probe = torch.empty(v.shape, dtype=v.dtype).pin_memory()
-            fast.emb_mask_actions(v.data_ptr(), probe.data_ptr(), n, v.numel() // n, _DTYPE_CODE[v.dtype],
-                                  reset.data_ptr(), _lib.raw_stream(v.device))
+            fast.emb_mask_actions(v.data_ptr(), probe.data_ptr(), n, v.numel() // n, code, reset.data_ptr(), stream)
             want = mask_actions(v, reset).cpu()
             torch.cuda.current_stream(v.device).synchronize()
             by_store = self._acts_by_store = bool(torch.equal(probe.view(torch.uint8), want.view(torch.uint8)))
           except Exception:
             by_store = self._acts_by_store = False
         if by_store:
-          fast.emb_mask_actions(v.data_ptr(), pinned.data_ptr(), n, v.numel() // n, _DTYPE_CODE[v.dtype],
-                                reset.data_ptr(), _lib.raw_stream(v.device))
+          fast.emb_mask_actions(v.data_ptr(), ptr, n, v.numel() // n, code, reset.data_ptr(), stream)
           stored = True
       if not stored:
         pinned.copy_(v, non_blocking=True)
-      host[k] = pinned.numpy()
+      host[k] = view
     if self._acts_landed is None:
       self._acts_landed = torch.cuda.Event()
     self._acts_landed.record()
@@ -545,11 +573,20 @@ class Driver:
     self._seq += 1
     seq = self._seq
     self._ctrl[0] = seq
-    # Wake-up as a tree (a semaphore release is ~1.4 us: 64 of them in a row
-    # were 90 us of a 250 us step): the Driver wakes the first _FANOUT workers,
-    # every worker wakes its own children before it steps its env.
-    for wake in self._wake[:_FANOUT]:
-      wake.release()
+    # Workers that stepped a moment ago are still spinning on the sequence word and
+    # are off already (no wake-up latency: a futex wake + the scheduler were ~10 us
+    # per level of the tree).  Only when every worker sleeps -- the first step, the
+    # step after a pause -- the wake-up goes out as a tree (a semaphore release is
+    # ~1.4 us: 64 of them in a row were 90 us of a 250 us step): the Driver wakes
+    # the first _FANOUT workers, every worker wakes its own children before it steps
+    # its env.  Mixed: each sleeper is woken directly.
+    asleep = self._asleep
+    if self._spin_us == 0 or asleep.all():
+      for wake in self._wake[:_FANOUT]:
+        wake.release()
+    elif asleep.any():
+      for w in np.flatnonzero(asleep):
+        self._wake[w].release()
     done, deadline, spins = self._done, None, 0
     pieces = self._begin_upload()
     while True:
@@ -558,8 +595,7 @@ class Driver:
       # it are through (they finish over the ~50 us of the wake tree): the copies run
       # under the slower workers' steps instead of after the last one.
       while pieces and state[pieces[0][0]: pieces[0][1]].all():
-        _, _, dst, src = pieces.pop(0)
-        dst.copy_(src, non_blocking=True)
+        self._upload_piece(pieces.pop(0))
       if state.all():
         break
       if (done < 0).any():
@@ -580,6 +616,18 @@ class Driver:
         results.append({})
     return results
 
+  def _upload_piece(self, piece):
+    """One piece of the pinned slab to its place in the device buffer.  With more
+    than one piece per step: a KERNEL that reads the pinned memory across PCIe
+    (emb_copy_bytes) -- a copy through the DMA engines costs ~10 us of set-up per
+    call here, five of them per step were slower than one (profiles/
+    r06_ab_hostenvs.txt); the single whole-slab copy stays with the DMA engines."""
+    _, _, dst, src = piece
+    if self._upload_by_kernel:
+      fast.emb_copy_bytes(src.data_ptr(), dst.data_ptr(), src.numel(), _lib.raw_stream(self.device))
+    else:
+      dst.copy_(src, non_blocking=True)
+
   def _begin_upload(self):
     """Device mode with the shared slab: pick this step's device buffer and return
     the pieces of the slab as (first env, end env, device view, pinned view), in
@@ -592,7 +640,7 @@ class Driver:
     if plan is None:
       total, n = self._upload_src.numel(), self.length
       _, _, _, at, nbytes = max(self._upload_layout.values(), key=lambda entry: entry[4])
-      groups = _UPLOAD_GROUPS if nbytes >= (256 << 10) and n >= 2 * _UPLOAD_GROUPS else 1
+      groups = self._upload_groups if nbytes >= (256 << 10) and n >= 2 * self._upload_groups else 1
       if groups == 1:
         plan = [(0, n, 0, total)]
       else:
@@ -602,6 +650,7 @@ class Driver:
         plan += [(0, n, a, b) for a, b in ((0, at), (at + nbytes, total)) if b > a]
       self._upload_plan = plan
       self._upload_pieces = {}
+      self._upload_by_kernel = len(plan) > 1 and bool(getattr(self, '_registered', None))
     if self._rotate():
       self._upload_turn = turn = (self._upload_turn + 1) & 3
       dev, self._upload_views = self._upload_ring[turn]
@@ -645,8 +694,8 @@ class Driver:
       # stepping (_step_workers / _begin_upload) when the step protocol runs through
       # shared memory; else in one copy here.
       if getattr(self, '_upload_dev', None) is None:
-        for _, _, dst, src in self._begin_upload():
-          dst.copy_(src, non_blocking=True)
+        for piece in self._begin_upload():
+          self._upload_piece(piece)
       out.update(self._upload_views)
       self._upload_dev = None
     for k in keys:
@@ -664,14 +713,18 @@ class Driver:
       out[k] = pinned.to(self.device, non_blocking=True)
     # The slab is overwritten by the next step's env results: uploads must be
     # done by then.  One event per step, waited for right before the slab is
-    # written again (`_wait_uploads`), so the policy call overlaps the copies.
+    # written again (`_wait_uploads`), so the policy call overlaps the copies; when
+    # the step's actions go down to the host behind an event of their own, that one
+    # serves (`_step`): an event record is 3.7 us of host time.
     if self._uploaded is None:
       self._uploaded = torch.cuda.Event()
-    self._uploaded.record()
-    self._upload_pending = True
+    self._upload_pending = 'unrecorded'
     return out
 
   def _wait_uploads(self):
+    if self._upload_pending == 'unrecorded':      # (nobody recorded behind the uploads: do it now)
+      self._uploaded.record()
+      self._upload_pending = True
     if self._upload_pending:
       self._uploaded.synchronize()
       self._upload_pending = False
@@ -697,14 +750,18 @@ class Driver:
 
 
 _FANOUT = 8
-_UPLOAD_GROUPS = 4      # pieces the widest observation key is uploaded in (64 envs x 28 KB: 450 KB each)
+_SPIN_US = 400          # how long a worker spins on the sequence word after a step before it sleeps
+_UPLOAD_GROUPS = 2      # pieces the widest observation key is uploaded in (64 envs x 28 KB: 900 KB each;
+                        # 2 measured ahead of 4, 8 and 1: profiles/r06_ab_hostenvs.txt)
 
 
-def _wake_children(envid, wakes):
-  """Workers (envid + 1) * _FANOUT ... + _FANOUT - 1 (heap order under the Driver)."""
+def _wake_children(envid, wakes, asleep=None):
+  """Workers (envid + 1) * _FANOUT ... + _FANOUT - 1 (heap order under the Driver);
+  with `asleep`: those of them that sleep."""
   first = (envid + 1) * _FANOUT
   for child in range(first, min(first + _FANOUT, len(wakes))):
-    wakes[child].release()
+    if asleep is None or asleep[child]:
+      wakes[child].release()
 
 
 def _env_server(envid, pipe, ctor, wakes=None, worker=None):
@@ -769,14 +826,35 @@ def _env_server(envid, pipe, ctor, wakes=None, worker=None):
       return
     acts = attach(act_layout, n)
     ctrl_block = open_block(ctrl_name)
-    ctrl = np.ndarray(2 + 2 * n, np.int64, buffer=ctrl_block.buf)
-    done, extra = ctrl[2: 2 + n], ctrl[2 + n:]
+    ctrl = np.ndarray(ctrl_block.size // 8, np.int64, buffer=ctrl_block.buf)
+    done, extra = ctrl[2: 2 + n], ctrl[2 + n: 2 + 2 * n]
+    asleep = ctrl[2 + 2 * n:]
+    spin_s = float(ctrl[1]) * 1e-6
+    seen = int(ctrl[0])             # (before the reply: the Driver may start its first step right behind it)
+    asleep[worker] = 0
     pipe.send(('result', True))
     wake = wakes[worker]
+    clock = time.perf_counter
     while True:
-      wake.acquire()
-      _wake_children(worker, wakes)       # first: they are woken even if an env then fails
-      seq = int(ctrl[0])
+      # After a step: spin on the sequence word for a while -- in a stepping loop the
+      # next step arrives within it and starts without a wake-up -- then sleep on the
+      # semaphore.  `asleep` tells the Driver whom to wake.  (A wake-up that crosses
+      # the announcement is caught by the re-check and, at worst, by the timed wait.)
+      slept = False
+      until = clock() + spin_s
+      while int(ctrl[0]) == seen:
+        if clock() < until:
+          continue
+        slept = True
+        asleep[worker] = 1
+        if int(ctrl[0]) != seen:
+          break
+        wake.acquire(timeout=0.05)
+        until = 0.0                       # (asleep once: straight back to sleep until a step comes)
+      if slept:
+        asleep[worker] = 0
+        _wake_children(worker, wakes, asleep)       # first: they are woken even if an env then fails
+      seq = seen = int(ctrl[0])
       for j, one in enumerate(envs):
         row = envid + j
         try:

@@ -112,6 +112,8 @@ hipError_t launch_scatter(const MovePlan& plan, hipStream_t stream);
 
 // (B, total, rowbytes) -> (B, count, rowbytes) window starting at `start`
 // (streams.py:133-138).
+// dst[0 .. bytes) = src[0 .. bytes) by a kernel (src may be pinned host memory).
+hipError_t launch_copy_bytes(const void* src, void* dst, int64_t bytes, hipStream_t stream);
 hipError_t launch_window(const uint8_t* src, uint8_t* dst, int64_t batch,
                          int64_t total, int64_t start, int64_t count,
                          int64_t rowbytes, hipStream_t stream);

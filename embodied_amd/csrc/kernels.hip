@@ -545,8 +545,8 @@ __global__ __launch_bounds__(kFlatThreads) void flat_move_kernel_staged(const Mo
 // 16-byte load per lane -- wave 0 the tables, wave 1 the spans, both in flight
 // together: one latency per workgroup, where a wave's scalar reads of its spans
 // were a second, dependent one in front of every payload load (an 85 MB
-// write-back through this mover: 20.3 us before, the by-value mover's 13 us with
-// device-resident arguments).
+// write-back through this mover: 20.3 us before, 17.1 us now; the by-value mover
+// with device-resident arguments takes 13 us).
 static_assert(kFlatThreads >= 64 + 3 * kFlatStagedSeqs / 4, "wave 1 stages the spans");
 static_assert(3 * kFlatStagedSeqs <= kInlineWords && sizeof(SpanHead) % 16 == 0, "the staged spans lie inside the block");
 template <bool kGather>
@@ -727,17 +727,14 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
       }
     // With host-resident kernel arguments the big movers read their plan from a
     // ring in fine-grained (uncached) device memory: the span mover touches it
-    // once per workgroup (the staged head); the flat mover stages its tables and
-    // its first kFlatStagedSeqs spans the same way (round 6; before, its waves
-    // walked the spans with dependent uncached reads: 84 MB write-back 20.3 us
-    // flat-indirect, 17.6 us span, and the span mover took every size).  Gathers
-    // and launches with more sequences than the flat mover stages stay with the
-    // span mover there.
+    // once per workgroup (the staged head), ~1000 workgroups; the flat mover's
+    // ~10 000 short-lived workgroups each fetch their tables and spans from it
+    // (staged through LDS since round 6: an 85 MB write-back 20.3 -> 17.1 us,
+    // still behind the span mover's 15.2 us; profiles/r06_scatter_lab.txt) --
+    // there the span mover takes every size.
     const int64_t limit_mb = gather ? kSpanGatherMB : kSpanScatterMB;
-    static const int lab_flat = [] { const char* e = std::getenv("EMB_LAB_SCATTER_FLAT"); return e ? std::atoi(e) : 0; }();
     span_path = wide_bytes > 0 && wide_keys <= kSpanKeys &&
-                ((plan.args_in_host_memory && (gather || !lab_flat || plan.n_seq > kFlatStagedSeqs)) ||
-                 wide_bytes <= limit_mb * 1000000);
+                (plan.args_in_host_memory || wide_bytes <= limit_mb * 1000000);
   }
   const int unroll = span_path ? kSpanUnroll : kFlatUnroll;
   const int threads = span_path ? kSpanThreads : kFlatThreads;
@@ -843,9 +840,7 @@ hipError_t prepare_move(const MovePlan& plan, MoveLaunch* out, bool gather) {
     // every worker walks the same number of tiles was slower with this shape:
     // B=16 10.8 against 10.1 us).
     const int cus = plan.cu_limit > 0 ? std::min(plan.cu_limit, compute_units()) : compute_units();
-    static const int lab_per_cu = [] { const char* e = std::getenv("EMB_LAB_SCATTER_PER_CU"); return e ? std::atoi(e) : 0; }();
-    const int per_cu = (!gather && lab_per_cu > 0) ? lab_per_cu : kSpanPerCU;
-    const int64_t workers = std::min<int64_t>(h.ntiles, int64_t(cus) * per_cu);
+    const int64_t workers = std::min<int64_t>(h.ntiles, int64_t(cus) * kSpanPerCU);
     h.wide_workers = static_cast<int32_t>(workers);
     h.seq_len = t.seq_len;
     if (blocks + h.wide_workers > INT32_MAX) return hipErrorInvalidValue;
@@ -1952,6 +1947,39 @@ hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* ds
     case kF32: return obs_stack_typed<float>(src, env_ids, dst, n, pixels, channels, layout, scale, offset, stream);
     default: return hipErrorInvalidValue;
   }
+}
+
+namespace {
+// Bytes of any alignment from `src` to `dst`: 16-byte units when both allow it, a
+// byte tail.  `src` may be pinned host memory the GPU reads across PCIe (a piece
+// of the Driver's shared observation slab): four units per lane in flight.
+__global__ __launch_bounds__(kThreads) void copy_bytes_kernel(const uint8_t* __restrict__ src,
+                                                             uint8_t* __restrict__ dst, int64_t bytes) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  const int64_t vecs = aligned ? bytes >> 4 : 0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  for (; i + 3 * stride < vecs; i += 4 * stride) {
+    const u32x4 a = reinterpret_cast<const u32x4*>(src)[i], b = reinterpret_cast<const u32x4*>(src)[i + stride];
+    const u32x4 c = reinterpret_cast<const u32x4*>(src)[i + 2 * stride], d = reinterpret_cast<const u32x4*>(src)[i + 3 * stride];
+    reinterpret_cast<u32x4*>(dst)[i] = a;
+    reinterpret_cast<u32x4*>(dst)[i + stride] = b;
+    reinterpret_cast<u32x4*>(dst)[i + 2 * stride] = c;
+    reinterpret_cast<u32x4*>(dst)[i + 3 * stride] = d;
+  }
+  for (; i < vecs; i += stride) reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+  for (int64_t j = (vecs << 4) + static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; j < bytes; j += stride)
+    dst[j] = src[j];
+}
+}  // namespace
+
+hipError_t launch_copy_bytes(const void* src, void* dst, int64_t bytes, hipStream_t stream) {
+  if (bytes <= 0) return hipSuccess;
+  // one unit per lane up to 256 workgroups, then several per lane
+  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(256, ((bytes >> 4) + kThreads - 1) / kThreads));
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(kThreads), 0, stream,
+                     static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), bytes);
+  return hipGetLastError();
 }
 
 hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems, int dtype,

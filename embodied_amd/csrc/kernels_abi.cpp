@@ -78,6 +78,13 @@ int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_
   });
 }
 
+int32_t emb_copy_bytes(const void* src, void* dst, int64_t bytes, void* stream) {
+  return guarded([&] {
+    need(bytes >= 0 && (bytes == 0 || (src && dst)), "copy_bytes: bad arguments");
+    HIP_OK(emb::launch_copy_bytes(src, dst, bytes, static_cast<hipStream_t>(stream)));
+  });
+}
+
 int32_t emb_mask_actions(const void* act, void* out, int64_t n, int64_t row_elems, int32_t dtype,
                          const void* is_last, void* stream) {
   return guarded([&] {

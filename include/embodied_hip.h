@@ -393,6 +393,14 @@ int32_t emb_replay_load_items(emb_replay_t* rep, uint64_t uid, int64_t amount);
 int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_t pixels,
                       int64_t channels, int32_t layout, int32_t out_dtype, float scale,
                       float offset, void* dst, void* stream);
+/* dst[0 .. bytes) = src[0 .. bytes) by a KERNEL on `stream` (ABI 5).  `src` may be
+ * pinned, device-mapped host memory: the Driver brings a piece of its shared
+ * observation slab (embodied/core/driver.py:17-25,61-65: what env processes wrote)
+ * to the device this way while other env processes are still stepping -- a copy
+ * through the DMA engines costs ~10 us of set-up per call on this system, a kernel
+ * that reads across PCIe does not.  Any alignment.                              */
+int32_t emb_copy_bytes(const void* src, void* dst, int64_t bytes, void* stream);
+
 /* acts zeroed where is_last (driver.py:72-74,84-87): out = act * ~is_last as a
  * real multiply in `dtype`; act, out (n, row_elems), out may alias act.      */
 int32_t emb_mask_actions(const void* act, void* out, int64_t n, int64_t row_elems,

@@ -211,6 +211,11 @@ hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* ds
   return hipSuccess;
 }
 
+hipError_t launch_copy_bytes(const void* src, void* dst, int64_t bytes, hipStream_t) {
+  if (bytes > 0) std::memcpy(dst, src, static_cast<size_t>(bytes));
+  return hipSuccess;
+}
+
 hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems, int dtype,
                             const uint8_t* is_last, hipStream_t) {
   const int64_t rowbytes = row_elems * dtype_size(dtype);

@@ -439,8 +439,10 @@ def test_parallel_env_workers_upload_from_shared_slab(emb):
 @pytest.mark.parametrize('per_worker', [1, 3, 'auto'])
 def test_wide_observations_go_up_in_pieces_and_actions_come_down_by_store(emb, per_worker):
   """The real-simulator path at a size where its two shortcuts are on (round 6):
-  the observation slab (16 envs x 32 KB = 512 KB) is uploaded in four pieces, each
-  as soon as the envs that write it are through, and the next step's actions reach
+  the observation slab (16 envs x 32 KB = 512 KB) is uploaded in pieces (four here,
+  two by default), each as soon as the envs that write it are through, by a kernel
+  that reads the pinned slab across PCIe; workers spin on the sequence word between
+  steps instead of sleeping; and the next step's actions reach
   pinned host memory through one kernel's stores (value * ~is_last) instead of a
   device-to-host copy per key.  Rewards depend on the actions, episodes end at
   different steps: every transition equals the serial host loop's, and the
@@ -468,9 +470,10 @@ def test_wide_observations_go_up_in_pieces_and_actions_come_down_by_store(emb, p
     return log, state
 
   want, _ = run(parallel=False)
-  got, (plan, by_store) = run(parallel=True, device='cuda', envs_per_worker=per_worker)
-  assert len(plan) == driverlib._UPLOAD_GROUPS + 1         # four pieces of the image key + the narrow keys
+  got, (plan, by_store) = run(parallel=True, device='cuda', envs_per_worker=per_worker, upload_groups=4)
+  assert len(plan) == 4 + 1                                # four pieces of the image key + the narrow keys
   assert [p[:2] for p in plan[:4]] == [(0, 4), (4, 8), (8, 12), (12, 16)]
+  assert driverlib._UPLOAD_GROUPS == 2                     # (the default: two pieces, used by the Replay-sink half below)
   assert by_store is True                                  # the stores agreed with a plain copy on the first step
   assert len(want) == len(got) == 14
   for a, b in zip(want, got):

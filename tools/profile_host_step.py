@@ -28,24 +28,29 @@ def lap(name, t0):
 
 iters = 2000
 d = driver
+from embodied_amd.core.driver import mask_actions
 for _ in range(iters):
   t = time.perf_counter()
-  acts = d.acts
-  host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in acts.items()}
-  t = lap('actions to the host (D2H + sync: waits for everything queued)', t)
+  host = d._acts_on_host
+  if host is not None:
+    d._acts_landed.synchronize()
+    d._acts_on_host = None
+  else:
+    host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.acts.items()}
+  t = lap('actions on the host (wait for the store kernel / the copies of the last step)', t)
   d._wait_uploads(); t = lap('wait for the last upload', t)
-  results = d._step_workers(host); t = lap('workers: actions down, wake tree, env steps, flags up', t)
-  obs = d._stack(results); t = lap('stack: host flags + ONE H2D copy of the obs slab', t)
+  results = d._step_workers(host); t = lap('workers: actions down, wake tree, env steps, flags up (+ slab pieces issued)', t)
+  obs = d._stack(results); t = lap('stack: host flags (+ whatever of the slab is not up yet)', t)
   d._sinks[0].offer(obs, d._workers); t = lap('offer', t)
   d.carry, acts, outs = policy(d.carry, obs); t = lap('policy (obs stack + early insert)', t)
   is_last = obs['is_last']
   acts = {k: d._to_device(v) for k, v in acts.items()}
   ended = d._host_flags['is_last']
   if ended.any():
-    from embodied_amd.core.driver import mask_actions
     acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
   d.acts = {**acts, 'reset': is_last.clone()}
   t = lap('mask / reset clone', t)
+  d._fetch_acts(); t = lap('actions towards the host (issue)', t)
   d._dispatch({**obs, **acts, **outs}); t = lap('replay.add_batch (publish)', t)
 torch.cuda.synchronize()
 total = sum(T.values())
