@@ -24,7 +24,8 @@ def test_parity_with_kernel_arguments_in_device_memory():
       [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', 'tests/test_gpu_early_insert.py',
        '-m', 'gpu', '-q', '-x',
        '-k', '(golden or full_size or large_tables or update_roundtrip or sharded or very_large_rows '
-             'or span_mover or fused_sample or early or many_envs or host_envs or checkpoint_between) '
+             'or span_mover or fused_sample or early or many_envs or host_envs or checkpoint_between '
+             'or wide_observations or parallel_env_workers) '          # (round 6: slab pieces by kernel, actions by store)
              'and not soak and not readers_on_other'],
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
@@ -38,9 +39,11 @@ def test_parity_with_the_flat_mover_only():
   which is what moves > 40 MB launches with device-resident arguments."""
   env = dict(os.environ, EMB_SPAN_MOVER='0')
   res = subprocess.run(
-      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-m', 'gpu', '-q', '-x',
+      [sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', 'tests/test_gpu_heads.py', '-m', 'gpu', '-q', '-x',
+       # (with host-resident arguments these all run the indirect flat movers, whose tables AND
+       # spans are staged through LDS since round 6; heads: per-key lengths through that path)
        '-k', 'golden or full_size or span_mover or fused_sample or grouped or update_table '
-             'or window or random_schemas'],
+             'or window or random_schemas or heads'],
       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
   assert ' passed' in res.stdout

@@ -115,6 +115,14 @@ def _worker(rank, world, port, lib, out):
       log.append((received, grads, twin_received, twin_grads))
     comm.wait()
     comm.wait()                                     # nothing in flight: a no-op
+    # exchange(gather=True): the trajectory all-gather north_star names + the f32 gradient
+    # all-reduce in ONE call on the communicator's stream (emb_comm_exchange_gather, ABI 5)
+    mine = cuda(_bytes_of(rank, 40, SLICE_BYTES + 3))
+    everyone = torch.zeros(world * mine.numel(), dtype=torch.uint8, device='cuda')
+    g32 = cuda(_floats_of(rank, 41, GRAD_NUMEL))
+    comm.exchange(mine, everyone, g32, gather=True)
+    comm.wait()
+    res['gather_exchange'] = (everyone.cpu().numpy(), g32.cpu().numpy())
     res['exchange'] = [(a.cpu().numpy(), b.float().cpu().numpy(), c.cpu().numpy(), d.float().cpu().numpy())
                        for a, b, c, d in log]
 
@@ -201,6 +209,9 @@ def _run_and_check(world, lib):
     assert np.array_equal(got['returns'], np.concatenate([_floats_of(r, 4, 16 * 63) for r in ranks]))
     np.testing.assert_allclose(got['pmean'], np.mean([_floats_of(r, 5, 7) for r in ranks], 0),
                                rtol=1e-6, atol=1e-7)
+    everyone, g32 = got['gather_exchange']
+    assert np.array_equal(everyone, np.concatenate([_bytes_of(s, 40, SLICE_BYTES + 3) for s in ranks]))
+    np.testing.assert_allclose(g32, np.mean([_floats_of(r, 41, GRAD_NUMEL) for r in ranks], 0), rtol=1e-5, atol=1e-6)
     for k, (received, grads, twin_received, twin_grads) in enumerate(got['exchange']):
       want_grads = np.mean([
           (torch.as_tensor(_floats_of(r, 20 + k, GRAD_NUMEL)).to(torch.bfloat16) * 2).float().numpy()

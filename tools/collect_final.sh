@@ -1,6 +1,6 @@
 # Everything profiles/rNN_* is made from, on one GPU box (run from the repo root):
-#   tools/collect_final.sh r05
-TAG=${1:-r05}
+#   tools/collect_final.sh r06
+TAG=${1:-r06}
 set -x
 mkdir -p gpurun_out/$TAG
 timeout 1500 tools/collect_profiles.sh $TAG > gpurun_out/$TAG/collect.log 2>&1
@@ -8,6 +8,9 @@ R=$(pwd); O=$R/gpurun_out/$TAG
 cd /tmp
 for i in 1 2 3; do python $R/bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' > $O/bench_steps20_$i.json; done
 python $R/bench.py --selector prioritized --no-cpu-baseline --no-dreamer-leg 2>/dev/null | grep '^{' > $O/bench_selectorprioritized.json
+# alternating A/Bs on this box: the env's action form (value = masked, the reference's) and the shipped selector
+python $R/tools/ab_runs.py $O/ab_masked.txt 3 "masked (default, driver.py:72-75)::" "unmasked + reset::--unmasked-env-actions"
+python $R/tools/ab_runs.py $O/ab_prioritized.txt 3 "uniform (default)::" "prioritized (ppo/configs.yaml:42)::--selector prioritized"
 python $R/bench.py --host-envs --parallel-envs --no-cpu-baseline --no-dreamer-leg 2>/dev/null | grep '^{' > $O/bench_hostenvsparallelenvs.json
 python $R/tools/bench_index.py > $O/bench_index.txt 2>&1
 # the reference's own perf loops (per-step add, sample(1), Driver over Dummy envs) and the insert-route fuzz

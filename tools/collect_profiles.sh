@@ -4,7 +4,7 @@
 # Counters are collected in their own passes (never together with a trace domain
 # other than --kernel-trace); FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set +e
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
