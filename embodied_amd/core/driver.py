@@ -825,6 +825,7 @@ def _env_server(envid, pipe, ctor, wakes=None, worker=None):
       pipe.send(('result', True))
       return
     acts = attach(act_layout, n)
+    act_rows = [(k, v, v.ndim > 1) for k, v in acts.items()]
     ctrl_block = open_block(ctrl_name)
     ctrl = np.ndarray(ctrl_block.size // 8, np.int64, buffer=ctrl_block.buf)
     done, extra = ctrl[2: 2 + n], ctrl[2 + n: 2 + 2 * n]
@@ -858,10 +859,23 @@ def _env_server(envid, pipe, ctor, wakes=None, worker=None):
       for j, one in enumerate(envs):
         row = envid + j
         try:
-          rest = put(one.step({k: v[row].copy() for k, v in acts.items()}), row)
+          # (a row of a one-dimensional action array is a numpy scalar, a copy already;
+          # rows of wider ones are views of the shared slab and are copied)
+          obs = one.step({k: (v[row].copy() if wide else v[row]) for k, v, wide in act_rows})
+          rest = None
+          for key, value in obs.items():
+            slab = slabs.get(key)
+            if slab is not None:
+              slab[row] = value
+            elif rest is None:
+              rest = {key: value}
+            else:
+              rest[key] = value
           if rest:
             pipe.send(('result', rest))
-          extra[row] = 1 if rest else 0
+            extra[row] = 1
+          elif extra[row]:
+            extra[row] = 0
           done[row] = seq
         except Exception as e:
           pipe.send(('error', e))

@@ -50,7 +50,10 @@ for _ in range(iters):
     acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
   d.acts = {**acts, 'reset': is_last.clone()}
   t = lap('mask / reset clone', t)
-  d._fetch_acts(); t = lap('actions towards the host (issue)', t)
+  d._fetch_acts()
+  if d._upload_pending == 'unrecorded':        # as Driver._step: the actions' event also covers the uploads
+    d._upload_pending = False if d._acts_on_host is not None else d._upload_pending
+  t = lap('actions towards the host (issue)', t)
   d._dispatch({**obs, **acts, **outs}); t = lap('replay.add_batch (publish)', t)
 torch.cuda.synchronize()
 total = sum(T.values())

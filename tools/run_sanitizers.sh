@@ -9,7 +9,7 @@
 #
 #   tools/run_sanitizers.sh [seconds per run, default 20] [output dir, default profiles]
 #
-# Writes <dir>/r05_tsan.txt and <dir>/r05_asan.txt; exit status 0 = no report.
+# Writes <dir>/r06_tsan.txt and <dir>/r06_asan.txt; exit status 0 = no report.
 set -u
 R="$(cd "$(dirname "$0")/.." && pwd)"
 SECONDS_EACH="${1:-20}"
@@ -33,7 +33,7 @@ run() {     # report file, binary, args...
 }
 build tsan "-fsanitize=thread"
 build asan "-fsanitize=address,undefined -fno-sanitize-recover=undefined"
-T="$OUT/r05_tsan.txt"; A="$OUT/r05_asan.txt"
+T="$OUT/r06_tsan.txt"; A="$OUT/r06_asan.txt"
 { echo "# tools/run_sanitizers.sh: ThreadSanitizer, $(g++ --version | head -1), $(nproc) CPUs, $SECONDS_EACH s per run"; } > "$T"
 { echo "# tools/run_sanitizers.sh: AddressSanitizer + UBSan, $(g++ --version | head -1), $(nproc) CPUs, $SECONDS_EACH s per run"; } > "$A"
 export TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 history_size=4"
