@@ -130,6 +130,7 @@ class Driver:
     # observation slab goes up in `upload_groups` pieces under the workers' steps,
     # actions come down by kernel stores into pinned memory -- False / 1: one copy each)
     self._upload_groups = _UPLOAD_GROUPS if upload_groups is None else max(1, int(upload_groups))
+    self._upload_groups_given = upload_groups
     self._spin_us = _SPIN_US if worker_spin_us is None else max(0, int(worker_spin_us))
     if acts_by_store is not None and not acts_by_store:
       self._acts_by_store = False
@@ -151,8 +152,11 @@ class Driver:
       self.length = len(make_env_fns)
       if self.parallel:
         # envs_per_worker = K > 1 (an addition; the reference starts one process
-        # per env, driver.py:17-25): worker w steps envs [w*K, (w+1)*K) one after
-        # the other.  For hosts whose CPU budget is smaller than the env count (a
+        # per env, driver.py:17-25): with W = ceil(N / K) worker processes, worker w
+        # steps envs w, w + W, w + 2W, ... one after the other -- so rows [0, W) of
+        # the observation slab are complete when every worker has stepped its first
+        # env, rows [W, 2W) after the second, ...: each such group goes up to the
+        # device while the workers step the next one (`_begin_upload`).  For hosts whose CPU budget is smaller than the env count (a
         # container quota): N processes that all become runnable at once then
         # cost more in wake-ups and time slices than their env steps take.
         # Needs the shared-memory step protocol (`shared_obs`).
@@ -167,7 +171,9 @@ class Driver:
         fns = [cloudpickle.dumps(fn) for fn in make_env_fns]
         self._wake = [context.Semaphore(0) for _ in range(n_workers)]
         self.procs = [
-            context.Process(target=_env_server, args=(w * K, pipe, fns[w * K: (w + 1) * K], self._wake, w),
+            context.Process(target=_env_server,
+                            args=(list(range(w, self.length, n_workers)) if K > 1 else w, pipe,
+                                  fns[w::n_workers] if K > 1 else fns[w: w + 1], self._wake, w),
                             daemon=True)
             for w, pipe in enumerate(pipes)]
         [proc.start() for proc in self.procs]
@@ -611,7 +617,7 @@ class Driver:
     results = []
     for i in range(self.length):
       if done[i] < 0 or self._extra[i]:
-        results.append(self._receive(self.pipes[i // self._per_worker]))    # raises on ('error', e)
+        results.append(self._receive(self.pipes[i % len(self.pipes)]))    # raises on ('error', e)
       else:
         results.append({})
     return results
@@ -641,10 +647,16 @@ class Driver:
       total, n = self._upload_src.numel(), self.length
       _, _, _, at, nbytes = max(self._upload_layout.values(), key=lambda entry: entry[4])
       groups = self._upload_groups if nbytes >= (256 << 10) and n >= 2 * self._upload_groups else 1
+      per = -(-n // groups)
+      if (self.parallel and getattr(self, '_per_worker', 1) > 1 and nbytes >= (256 << 10)
+          and getattr(self, '_upload_groups_given', None) is None):
+        # several envs per worker process: rows [j * W, (j + 1) * W) are the workers' j-th
+        # envs and complete together -- one piece each, uploaded under the (j + 1)-th
+        per, groups = len(self.pipes), -(-n // len(self.pipes))
       if groups == 1:
         plan = [(0, n, 0, total)]
       else:
-        per, row = -(-n // groups), nbytes // n
+        row = nbytes // n
         plan = [(g * per, min(n, (g + 1) * per), at + g * per * row, at + min(n, (g + 1) * per) * row)
                 for g in range(groups) if g * per < n]
         plan += [(0, n, a, b) for a, b in ((0, at), (at + nbytes, total)) if b > a]
@@ -770,11 +782,15 @@ def _env_server(envid, pipe, ctor, wakes=None, worker=None):
   ('attach', obs layout, n, act layout, ctrl name) it switches to the shared
   memory protocol: wait on `wake`, read its action row, step, write the
   observation row, publish `done[envid] = seq`.  `ctor` may be a LIST of pickled
-  constructors (Driver(envs_per_worker=K)): envs envid .. envid + K - 1, stepped
-  one after the other per wake-up; the pipe protocol then speaks for the first."""
+  constructors (Driver(envs_per_worker=K)) with `envid` the list of their slab rows
+  (w, w + W, w + 2W, ...): stepped one after the other per wake-up; the pipe protocol
+  then speaks for the first."""
   env = None
   envs = []
   ctors = ctor if isinstance(ctor, (list, tuple)) else [ctor]
+  rows = list(envid) if isinstance(envid, (list, tuple)) else None      # Driver(envs_per_worker=K): this worker's slab rows
+  if rows is not None:
+    envid = rows[0]
   worker = envid if worker is None else worker
   blocks, slabs = [], {}
 
@@ -857,7 +873,7 @@ def _env_server(envid, pipe, ctor, wakes=None, worker=None):
         _wake_children(worker, wakes, asleep)       # first: they are woken even if an env then fails
       seq = seen = int(ctrl[0])
       for j, one in enumerate(envs):
-        row = envid + j
+        row = rows[j] if rows is not None else envid + j
         try:
           # (a row of a one-dimensional action array is a numpy scalar, a copy already;
           # rows of wider ones are views of the shared slab and are copied)

@@ -204,7 +204,7 @@ def test_parallel_workers_match_serial(shared_obs):
 
 @pytest.mark.parametrize('per_worker', [2, 3, 5])
 def test_several_envs_per_worker_process_match_serial(per_worker):
-  """Driver(envs_per_worker=K): worker w steps envs [w*K, (w+1)*K) one after the
+  """Driver(envs_per_worker=K): worker w of W steps envs w, w + W, w + 2W, ... one after the
   other (for hosts whose CPU budget is smaller than the env count); the
   transitions are the in-process loop's, also when N is no multiple of K."""
   from tests import scenarios
