@@ -131,7 +131,7 @@ class Driver:
     # actions come down by kernel stores into pinned memory -- False / 1: one copy each)
     self._upload_groups = _UPLOAD_GROUPS if upload_groups is None else max(1, int(upload_groups))
     self._upload_groups_given = upload_groups
-    self._spin_us = _SPIN_US if worker_spin_us is None else max(0, int(worker_spin_us))
+    self._spin_us = worker_spin_us if worker_spin_us is None else max(0, int(worker_spin_us))
     if acts_by_store is not None and not acts_by_store:
       self._acts_by_store = False
     _read_knobs()
@@ -276,6 +276,10 @@ class Driver:
       self._act_slab[key] = (block, np.ndarray((self.length, *shape), dtype, buffer=block.buf))
       act_layout[key] = (block.name, shape, dtype)
     n_workers = len(self.pipes)
+    if self._spin_us is None:
+      # spinning workers must each have a CPU of their own beside the stepping thread:
+      # more of them than the budget would spin in the way of workers that still step
+      self._spin_us = _SPIN_US if n_workers <= int(cpu_budget()) - 1 else 0
     self._ctrl_block = shared_memory.SharedMemory(create=True, size=8 * (2 + 2 * self.length + n_workers))
     self._ctrl = np.ndarray(2 + 2 * self.length + n_workers, np.int64, buffer=self._ctrl_block.buf)
     self._ctrl[:] = 0
