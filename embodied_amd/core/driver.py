@@ -6,10 +6,13 @@ Three ways to run the same loop:
 * `Driver(fns, device=None)` — host plumbing exactly like the reference: numpy
   stack, numpy mask, per-env callbacks (BASELINE config "numpy Driver on CPU").
 * `Driver(fns, device='cuda')` — per-env observations are written into a pinned
-  (N, S) slab, uploaded with one copy per key and handed to the policy as
-  device tensors; the action mask (`emb_mask_actions`) runs on the GPU; the
-  build's own `Replay.add` callback is served by ONE batched scatter per step
-  instead of N Python calls.
+  (N, S) slab (by the env processes themselves with `parallel=True`: one shared,
+  HIP-registered block), uploaded -- in pieces, under the slower workers' steps,
+  by a kernel that reads the pinned memory -- and handed to the policy as device
+  tensors; the action mask (`emb_mask_actions`) runs on the GPU and its stores
+  bring the next step's actions down to pinned host memory; the build's own
+  `Replay.add` callback is served by ONE batched scatter per step instead of N
+  Python calls.
 * `Driver(batch_env=env, device='cuda')` — a device-resident vector env
   (`step(acts) -> dict of (N, ...) tensors`): nothing leaves HBM.
 
