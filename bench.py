@@ -283,6 +283,8 @@ def build_path(args, rank, device):
                            if 'EMB_BENCH_UPLOAD_GROUPS' in os.environ else {}),
                         **({'acts_by_store': os.environ['EMB_BENCH_ACTS_BY_STORE'] != '0'}
                            if 'EMB_BENCH_ACTS_BY_STORE' in os.environ else {}),
+                        **({'acts_notify': os.environ['EMB_BENCH_ACTS_NOTIFY'] != '0'}
+                           if 'EMB_BENCH_ACTS_NOTIFY' in os.environ and args.parallel_envs else {}),
                         **({'worker_spin_us': int(os.environ['EMB_BENCH_WORKER_SPIN_US'])}
                            if 'EMB_BENCH_WORKER_SPIN_US' in os.environ and args.parallel_envs else {}),
                         **({'envs_per_worker': (args.envs_per_worker if args.envs_per_worker == 'auto'

@@ -205,6 +205,7 @@ SIGNATURES = {
     'emb_direct_alltoall': [p, p, p, i64, p],
     'emb_direct_exchange': [p, p, p, p, i64, p, i64, i32, i32],
     'emb_copy_bytes': [p, p, i64, p],
+    'emb_mask_actions_notify': [p, p, i64, i64, i32, p, p, p, C.c_uint32, p],
     'emb_stream_create_on_cus': [i32, i32, p],
     'emb_stream_destroy': [p],
     'emb_direct_allgather': [p, p, p, i64, p],
@@ -311,7 +312,7 @@ class _FastApi:
       'emb_comm_exchange': 'ints', 'emb_comm_wait': 'ints',
       'emb_direct_exchange': 'ints', 'emb_direct_wait': 'ints',
       'emb_comm_exchange_gather': 'ints', 'emb_direct_exchange_gather': 'ints',
-      'emb_copy_bytes': 'ints',
+      'emb_copy_bytes': 'ints', 'emb_mask_actions_notify': 'ints',
   }
 
   def __init__(self, module):

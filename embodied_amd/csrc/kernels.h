@@ -133,8 +133,11 @@ hipError_t launch_obs_stack(const uint8_t* src, const int32_t* env_ids, void* ds
                             hipStream_t stream);
 
 // out[n, :] = act[n, :] * !is_last[n] in the action's own dtype (out may be act) (driver.py:72-74,84-87).
+// flag (optional, pinned host memory) receives `seq` when the whole launch has stored;
+// counter: a zeroed device word of the caller's.
 hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems,
-                            int dtype, const uint8_t* is_last, hipStream_t stream);
+                            int dtype, const uint8_t* is_last, hipStream_t stream,
+                            uint32_t* counter = nullptr, uint32_t* flag = nullptr, uint32_t seq = 0);
 
 // Return scans (float32).  Batch-major (B, T) unless stated.
 // group > 0: rew / last / term are keys of a grouped packed batch (row b starts

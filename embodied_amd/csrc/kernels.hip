@@ -1320,9 +1320,29 @@ hipError_t obs_stack_insert_typed(const PrewriteArgs& a, int64_t channels, int l
 
 // ------------------------------------------------------------- action mask --
 
+// `flag` (optional): a word in pinned host memory that receives `seq` when every
+// workgroup of the launch has stored its part -- with `out` in pinned memory too
+// (the Driver bringing the next step's actions down to its env processes) the host
+// sees the rows complete by reading one word, without an event.  `counter`: a
+// zeroed device word of the caller's, left zeroed again.
+__device__ __forceinline__ void notify_host(uint32_t* counter, uint32_t* flag, uint32_t seq) {
+  if (!flag) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t seen = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen + 1 == gridDim.x) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mask_rows_kernel(
-    const T* act, T* out, int64_t n, int64_t row_elems, const uint8_t* is_last) {
+    const T* act, T* out, int64_t n, int64_t row_elems, const uint8_t* is_last, uint32_t* counter,
+    uint32_t* flag, uint32_t seq) {
   const int64_t total = n * row_elems;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
        i += static_cast<int64_t>(gridDim.x) * kThreads) {
@@ -1331,6 +1351,7 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel(
     // NaN stays NaN exactly as numpy does (driver.py:84-87).
     out[i] = act[i] * static_cast<T>(is_last[r] ? 0 : 1);
   }
+  notify_host(counter, flag, seq);
 }
 
 // bf16 has no native multiply: widen to f32 (exact), multiply, narrow (the
@@ -1338,7 +1359,7 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel(
 template <>
 __global__ __launch_bounds__(kThreads) void mask_rows_kernel<__hip_bfloat16>(
     const __hip_bfloat16* act, __hip_bfloat16* out, int64_t n, int64_t row_elems,
-    const uint8_t* is_last) {
+    const uint8_t* is_last, uint32_t* counter, uint32_t* flag, uint32_t seq) {
   const int64_t total = n * row_elems;
   const uint16_t* bits = reinterpret_cast<const uint16_t*>(act);
   uint16_t* obits = reinterpret_cast<uint16_t*>(out);
@@ -1348,6 +1369,7 @@ __global__ __launch_bounds__(kThreads) void mask_rows_kernel<__hip_bfloat16>(
     const float y = x * (is_last[i / row_elems] ? 0.f : 1.f);
     obits[i] = static_cast<uint16_t>(__float_as_uint(y) >> 16);
   }
+  notify_host(counter, flag, seq);
 }
 
 // ------------------------------------------------------------ return scans --
@@ -1983,11 +2005,12 @@ hipError_t launch_copy_bytes(const void* src, void* dst, int64_t bytes, hipStrea
 }
 
 hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems, int dtype,
-                            const uint8_t* is_last, hipStream_t stream) {
+                            const uint8_t* is_last, hipStream_t stream, uint32_t* counter, uint32_t* flag,
+                            uint32_t seq) {
   const int64_t total = n * row_elems;
-  if (total <= 0) return hipSuccess;
+  if (total <= 0) return flag ? hipErrorInvalidValue : hipSuccess;
   const dim3 grid(static_cast<uint32_t>(std::min<int64_t>((total + kThreads - 1) / kThreads, 2048)));
-#define EMB_MASK(T) hipLaunchKernelGGL(mask_rows_kernel<T>, grid, dim3(kThreads), 0, stream, static_cast<const T*>(act), static_cast<T*>(out), n, row_elems, is_last)
+#define EMB_MASK(T) hipLaunchKernelGGL(mask_rows_kernel<T>, grid, dim3(kThreads), 0, stream, static_cast<const T*>(act), static_cast<T*>(out), n, row_elems, is_last, counter, flag, seq)
   switch (dtype) {
     case kU8: case kBool: EMB_MASK(uint8_t); break;
     case kI8: EMB_MASK(int8_t); break;

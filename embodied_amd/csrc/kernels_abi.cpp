@@ -94,6 +94,16 @@ int32_t emb_mask_actions(const void* act, void* out, int64_t n, int64_t row_elem
   });
 }
 
+int32_t emb_mask_actions_notify(const void* act, void* out, int64_t n, int64_t row_elems, int32_t dtype,
+                                const void* is_last, void* counter, void* flag, uint32_t seq, void* stream) {
+  return guarded([&] {
+    need(act && out && is_last && counter && flag && n > 0 && row_elems > 0, "mask_actions_notify: bad arguments");
+    HIP_OK(emb::launch_mask_rows(act, out, n, row_elems, dtype, static_cast<const uint8_t*>(is_last),
+                                 static_cast<hipStream_t>(stream), static_cast<uint32_t*>(counter),
+                                 static_cast<uint32_t*>(flag), seq));
+  });
+}
+
 static void rows_move(void* table, int64_t rowbytes, const int32_t* ids, int64_t n, void* batch,
                       bool gather, hipStream_t s) {
   need(table && batch && ids && rowbytes > 0 && n >= 0, "rows_gather/scatter: bad arguments");

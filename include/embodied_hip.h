@@ -393,6 +393,17 @@ int32_t emb_replay_load_items(emb_replay_t* rep, uint64_t uid, int64_t amount);
 int32_t emb_obs_stack(const void* src, const int32_t* env_ids, int64_t n, int64_t pixels,
                       int64_t channels, int32_t layout, int32_t out_dtype, float scale,
                       float offset, void* dst, void* stream);
+/* emb_mask_actions that also tells the HOST when it is done (ABI 5): `flag`, a
+ * 32-bit word in pinned, device-mapped host memory, receives `seq` once every row
+ * has been stored (system-scope release behind the stores).  With `out` in pinned
+ * memory as well this is how the Driver brings the next step's masked actions
+ * (driver.py:72-75) down to its env processes: the host reads one word instead of
+ * recording and waiting for an event.  `counter`: a zeroed 32-bit device word of
+ * the caller's, zero again afterwards; one launch at a time per counter.        */
+int32_t emb_mask_actions_notify(const void* act, void* out, int64_t n, int64_t row_elems,
+                                int32_t dtype, const void* is_last, void* counter, void* flag,
+                                uint32_t seq, void* stream);
+
 /* dst[0 .. bytes) = src[0 .. bytes) by a KERNEL on `stream` (ABI 5).  `src` may be
  * pinned, device-mapped host memory: the Driver brings a piece of its shared
  * observation slab (embodied/core/driver.py:17-25,61-65: what env processes wrote)

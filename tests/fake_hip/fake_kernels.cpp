@@ -217,11 +217,12 @@ hipError_t launch_copy_bytes(const void* src, void* dst, int64_t bytes, hipStrea
 }
 
 hipError_t launch_mask_rows(const void* act, void* out, int64_t n, int64_t row_elems, int dtype,
-                            const uint8_t* is_last, hipStream_t) {
+                            const uint8_t* is_last, hipStream_t, uint32_t*, uint32_t* flag, uint32_t seq) {
   const int64_t rowbytes = row_elems * dtype_size(dtype);
   for (int64_t r = 0; r < n; ++r)
     masked(static_cast<const uint8_t*>(act) + r * rowbytes, nullptr, static_cast<uint8_t*>(out) + r * rowbytes,
            rowbytes, dtype, is_last[r] == 0);
+  if (flag) *flag = seq;
   return hipSuccess;
 }
 

@@ -465,16 +465,18 @@ def test_wide_observations_go_up_in_pieces_and_actions_come_down_by_store(emb, p
         {key: (v.cpu().numpy() if torch.is_tensor(v) else np.array(v)) for key, v in trans.items()}))
     driver.reset(lambda count: 0)
     driver(policy, steps=n * 14)
-    state = (getattr(driver, '_upload_plan', None), getattr(driver, '_acts_by_store', None))
+    state = (getattr(driver, '_upload_plan', None), getattr(driver, '_acts_by_store', None),
+             getattr(driver, '_acts_seq', 0))
     driver.close()
     return log, state
 
   want, _ = run(parallel=False)
-  got, (plan, by_store) = run(parallel=True, device='cuda', envs_per_worker=per_worker, upload_groups=4)
+  got, (plan, by_store, notified) = run(parallel=True, device='cuda', envs_per_worker=per_worker, upload_groups=4)
   assert len(plan) == 4 + 1                                # four pieces of the image key + the narrow keys
   assert [p[:2] for p in plan[:4]] == [(0, 4), (4, 8), (8, 12), (12, 16)]
   assert driverlib._UPLOAD_GROUPS == 2                     # (the default: two pieces, used by the Replay-sink half below)
   assert by_store is True                                  # the stores agreed with a plain copy on the first step
+  assert notified == 14                                    # ... and every step's last store told the host by a word, no event
   assert len(want) == len(got) == 14
   for a, b in zip(want, got):
     assert_same(b, a, f'wide-parallel-{per_worker}')

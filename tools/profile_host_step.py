@@ -33,7 +33,7 @@ for _ in range(iters):
   t = time.perf_counter()
   host = d._acts_on_host
   if host is not None:
-    d._acts_landed.synchronize()
+    d._wait_acts()
     d._acts_on_host = None
   else:
     host = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.acts.items()}
