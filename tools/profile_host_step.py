@@ -48,7 +48,7 @@ for _ in range(iters):
   ended = d._host_flags['is_last']
   if ended.any():
     acts = {k: mask_actions(v, is_last) for k, v in acts.items()}
-  d.acts = {**acts, 'reset': is_last.clone()}
+  d.acts = {**acts, 'reset': is_last if d._rotate() else is_last.clone()}
   t = lap('mask / reset clone', t)
   d._fetch_acts()
   if d._upload_pending == 'unrecorded':        # as Driver._step: the actions' event also covers the uploads
